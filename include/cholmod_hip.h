@@ -1,0 +1,143 @@
+/* cholmod_hip.h -- thin C-ABI shim of the MI355X (gfx950) supernodal Cholesky
+ * engine.  Plain pointers and sizes only; no CHOLMOD structs, no torch types.
+ *
+ * This is the boundary a CHOLMOD maintainer binds: each entry point names the
+ * reference interface it replaces (paths relative to the reference root).
+ * The host layer in include/cholmod.h (cholmod_l_* mirror) is built on exactly
+ * these calls; INTEGRATION.md shows the same calls made from the reference's
+ * own cholmod_super_numeric.c.
+ *
+ * Index type is int64 (the reference's GPU path exists only in the
+ * cholmod_l_* / DLONG build: CHOLMOD/Include/cholmod_internal.h:250-251).
+ * All functions return 0 on success unless stated otherwise.
+ */
+#ifndef CHOLMOD_HIP_H
+#define CHOLMOD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* return codes (engine level; the host layer maps them to Common->status) */
+#define CHOLMOD_HIP_OK            0
+#define CHOLMOD_HIP_NOT_POSDEF    1     /* success, but minor < n            */
+#define CHOLMOD_HIP_NO_DEVICE   (-1)    /* no usable gfx950 device / runtime */
+#define CHOLMOD_HIP_OUT_OF_MEMORY (-2)
+#define CHOLMOD_HIP_INVALID     (-4)
+#define CHOLMOD_HIP_GPU_PROBLEM (-5)    /* a HIP call or kernel failed       */
+
+/* plan flags */
+#define CHOLMOD_HIP_PLAN_DEFAULT   0
+#define CHOLMOD_HIP_GEMM_VALU      1    /* debug: VALU instead of MFMA tiles */
+#define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
+                                           (CPU-side tests of the host logic)       */
+
+typedef struct cholmod_hip_plan cholmod_hip_plan ;  /* opaque, one per symbolic L */
+
+/* replaces cholmod_l_gpu_probe (CHOLMOD/GPU/cholmod_gpu.c:170-205):
+ * returns 1 if a device is usable, 0 otherwise. */
+int cholmod_hip_probe (void) ;
+
+/* replaces cholmod_l_gpu_memorysize (CHOLMOD/GPU/cholmod_gpu.c:71-160):
+ * returns 0 and fills total/available bytes, or 1 if there is no device. */
+int cholmod_hip_memorysize (size_t *total_mem, size_t *available_mem) ;
+
+/* Select the device for this process (one process per GPU). */
+int cholmod_hip_set_device (int device) ;
+
+/* Build the device plan of a supernodal symbolic factor: uploads the index
+ * maps (super/pi/px/s exactly as in cholmod_factor, CHOLMOD/Include/
+ * cholmod_core.h:1673-1798), derives the supernodal etree, its level sets, the
+ * child->parent relative row maps (the reference's RelativeMap,
+ * CHOLMOD/Supernodal/t_cholmod_super_numeric.c:743-750, computed on the device)
+ * and the batched launch schedule.  Replaces r_cholmod_l_gpu_init
+ * (CHOLMOD/GPU/t_cholmod_gpu.c:79-205) and cholmod_l_gpu_allocate
+ * (CHOLMOD/GPU/cholmod_gpu.c:364-486): all device memory for L (xsize doubles)
+ * and for the contribution-block arena is reserved here.
+ * On failure returns NULL and stores a CHOLMOD_HIP_* code in *status. */
+cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px,
+    const int64_t *s, int flags, int *status) ;
+
+void cholmod_hip_plan_destroy (cholmod_hip_plan *plan) ;
+
+/* Numeric factorization  L L' = S + beta*I  of the already permuted,
+ * lower-stored matrix S = tril(P A P') (packed or unpacked CSC on the host:
+ * Snz may be NULL), the whole of cholmod_l_super_numeric's loop
+ * (CHOLMOD/Supernodal/t_cholmod_super_numeric.c:93-1079: assemble, descendant
+ * updates, dpotrf, dtrsm, not-positive-definite protocol :883-968).
+ * The factor stays resident in HBM; if Lx_host != NULL the packed Lx array
+ * (xsize doubles, reference layout) is also copied back.
+ * *minor receives L->minor (== n when positive definite).
+ * Returns CHOLMOD_HIP_OK, CHOLMOD_HIP_NOT_POSDEF, or a negative error. */
+int cholmod_hip_factorize (cholmod_hip_plan *plan, const int64_t *Sp,
+    const int64_t *Si, const int64_t *Snz, const double *Sx, double beta,
+    int quick_return_if_not_posdef, double *Lx_host, int64_t *minor) ;
+
+/* The same in two steps, so that a caller (bench.py) can time the factorization
+ * with the input already resident in HBM: upload S once, refactorize often. */
+int cholmod_hip_upload_matrix (cholmod_hip_plan *plan, const int64_t *Sp,
+    const int64_t *Si, const int64_t *Snz, const double *Sx) ;
+int cholmod_hip_factorize_resident (cholmod_hip_plan *plan, double beta,
+    int quick_return_if_not_posdef, int64_t *minor) ;
+
+/* Copy the device-resident packed Lx (xsize doubles) to the host. */
+int cholmod_hip_download_factor (cholmod_hip_plan *plan, double *Lx_host) ;
+/* Replace the device-resident Lx by host values (e.g. a factor computed
+ * elsewhere), so the device solves can be used with it. */
+int cholmod_hip_upload_factor (cholmod_hip_plan *plan, const double *Lx_host) ;
+
+/* Supernodal triangular solves on the device-resident factor, in place on the
+ * host array X (n-by-nrhs, leading dimension ldx), in the permuted ordering:
+ * replace cholmod_l_super_lsolve / cholmod_l_super_ltsolve
+ * (CHOLMOD/Supernodal/t_cholmod_super_solve.c:14-220, :222-411).
+ * which: 0 = L then L' (both), 1 = L only, 2 = L' only. */
+int cholmod_hip_solve (cholmod_hip_plan *plan, int which, double *X,
+    int64_t nrhs, int64_t ldx) ;
+
+/* Parity hooks: copy derived integer maps back to the host.
+ *  sparent  [nsuper]     supernodal etree (reference :1025)
+ *  level    [nsuper]     height of s in that tree (leaves 0)
+ *  relmap   [ssize - n]  relative row maps, relmap[pi[d]-super[d] + i] = local
+ *                        row in the parent of row i below d's diagonal block */
+int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
+    int64_t *level, int64_t *relmap) ;
+
+/* Statistics of the last factorization / of the plan (doubles):
+ *  [0] device seconds, whole factorization (HIP events on the engine stream)
+ *  [1] executed flops (updates + panel factorizations, as SURVEY.md 8d)
+ *  [2] kernel launches   [3] levels   [4] arena bytes   [5] Lx bytes
+ *  [6] seconds in dense-update kernels   [7] launches of dense-update kernels
+ *  [8] algorithmic flops of dense-update kernels
+ *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
+ *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
+ *  [13] seconds in assemble (memset + A scatter)
+ * Per-class seconds are only collected when profiling is enabled with
+ * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
+#define CHOLMOD_HIP_NSTATS 16
+int cholmod_hip_get_stats (cholmod_hip_plan *plan, double *stats) ;
+int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
+
+/* Dense fp64 C -= A*B' micro-benchmark on the engine's update kernel (used by
+ * bench.py to print the measured MFMA rate next to the 78.6 TFLOP/s spec).
+ * Returns achieved flop/s, or a negative CHOLMOD_HIP_* code. */
+double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
+    int iters, int flags) ;
+
+/* Test hook: run the engine's dense partial factorization on ONE dense front
+ * given on the host (column-major nsrow-by-nsrow, lower; the first nscol
+ * columns are eliminated; on return F holds [L11; L21] in the first nscol
+ * columns and the Schur complement in the rest).  Exercises potrf/trsm/update
+ * kernels without any sparse structure. */
+int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol,
+    int flags, int64_t *info) ;
+
+const char *cholmod_hip_version (void) ;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

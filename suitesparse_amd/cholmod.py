@@ -1,0 +1,346 @@
+"""ctypes binding of libcholmod_amd.so -- the host-side mirror of the reference's
+cholmod_l_* C API (include/cholmod.h) plus the engine shim (include/cholmod_hip.h).
+
+This module is plumbing for tests and bench.py: it declares the C structs,
+loads the in-tree shared library and fails loudly if it is missing.  All
+numeric work happens in the library (HIP engine); nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcholmod_amd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+CHOLMOD_MAXMETHODS = 9
+CHOLMOD_HIP_NSTATS = 16
+
+# constants (include/cholmod.h)
+PATTERN, REAL = 0, 1
+OK, NOT_INSTALLED, OUT_OF_MEMORY, TOO_LARGE, INVALID, GPU_PROBLEM = 0, -1, -2, -3, -4, -5
+NOT_POSDEF = 1
+NATURAL, GIVEN, POSTORDERED = 0, 1, 6
+SIMPLICIAL, AUTO, SUPERNODAL = 0, 1, 2
+SYS_A, SYS_LDLt, SYS_LD, SYS_DLt, SYS_L, SYS_Lt, SYS_D, SYS_P, SYS_Pt = range(9)
+HIP_GEMM_VALU, HIP_PLAN_HOST_ONLY = 1, 2
+
+
+class Method(C.Structure):
+    _fields_ = [("lnz", C.c_double), ("fl", C.c_double), ("ordering", C.c_int)]
+
+
+ERRFUNC = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_int, C.c_char_p)
+
+
+class Common(C.Structure):
+    _fields_ = [
+        ("supernodal", C.c_int), ("supernodal_switch", C.c_double),
+        ("final_asis", C.c_int), ("final_super", C.c_int), ("final_ll", C.c_int),
+        ("final_pack", C.c_int), ("final_monotonic", C.c_int), ("final_resymbol", C.c_int),
+        ("zrelax", C.c_double * 3), ("nrelax", C.c_size_t * 3),
+        ("prefer_upper", C.c_int), ("quick_return_if_not_posdef", C.c_int),
+        ("print", C.c_int), ("nmethods", C.c_int), ("current", C.c_int), ("selected", C.c_int),
+        ("method", Method * (CHOLMOD_MAXMETHODS + 1)),
+        ("postorder", C.c_int), ("try_catch", C.c_int),
+        ("error_handler", ERRFUNC),
+        ("itype", C.c_int), ("dtype", C.c_int), ("status", C.c_int),
+        ("fl", C.c_double), ("lnz", C.c_double), ("anz", C.c_double), ("modfl", C.c_double),
+        ("malloc_count", C.c_size_t), ("memory_usage", C.c_size_t), ("memory_inuse", C.c_size_t),
+        ("nrealloc_col", C.c_double), ("nrealloc_factor", C.c_double), ("ndbounds_hit", C.c_double),
+        ("rowfacfl", C.c_double), ("aatfl", C.c_double),
+        ("called_nd", C.c_int), ("blas_ok", C.c_int),
+        ("useGPU", C.c_int), ("maxGpuMemBytes", C.c_size_t), ("maxGpuMemFraction", C.c_double),
+        ("gpuMemorySize", C.c_size_t), ("gpuKernelTime", C.c_double), ("gpuFlops", C.c_int64),
+        ("gpuNumKernelLaunches", C.c_int), ("devBuffSize", C.c_size_t), ("ibuffer", C.c_int),
+        ("syrkStart", C.c_double),
+        ("cholmod_cpu_gemm_time", C.c_double), ("cholmod_cpu_syrk_time", C.c_double),
+        ("cholmod_cpu_trsm_time", C.c_double), ("cholmod_cpu_potrf_time", C.c_double),
+        ("cholmod_gpu_gemm_time", C.c_double), ("cholmod_gpu_syrk_time", C.c_double),
+        ("cholmod_gpu_trsm_time", C.c_double), ("cholmod_gpu_potrf_time", C.c_double),
+        ("cholmod_assemble_time", C.c_double), ("cholmod_assemble_time2", C.c_double),
+        ("cholmod_cpu_gemm_calls", C.c_size_t), ("cholmod_cpu_syrk_calls", C.c_size_t),
+        ("cholmod_cpu_trsm_calls", C.c_size_t), ("cholmod_cpu_potrf_calls", C.c_size_t),
+        ("cholmod_gpu_gemm_calls", C.c_size_t), ("cholmod_gpu_syrk_calls", C.c_size_t),
+        ("cholmod_gpu_trsm_calls", C.c_size_t), ("cholmod_gpu_potrf_calls", C.c_size_t),
+        ("hip_factor_on_device", C.c_int), ("hip_flags", C.c_int), ("hip_profile", C.c_int),
+    ]
+
+
+class Sparse(C.Structure):
+    _fields_ = [("nrow", C.c_size_t), ("ncol", C.c_size_t), ("nzmax", C.c_size_t),
+                ("p", C.c_void_p), ("i", C.c_void_p), ("nz", C.c_void_p), ("x", C.c_void_p),
+                ("z", C.c_void_p), ("stype", C.c_int), ("itype", C.c_int), ("xtype", C.c_int),
+                ("dtype", C.c_int), ("sorted", C.c_int), ("packed", C.c_int)]
+
+
+class Dense(C.Structure):
+    _fields_ = [("nrow", C.c_size_t), ("ncol", C.c_size_t), ("nzmax", C.c_size_t),
+                ("d", C.c_size_t), ("x", C.c_void_p), ("z", C.c_void_p),
+                ("xtype", C.c_int), ("dtype", C.c_int)]
+
+
+class Factor(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("minor", C.c_size_t),
+                ("Perm", C.c_void_p), ("ColCount", C.c_void_p), ("IPerm", C.c_void_p),
+                ("nzmax", C.c_size_t),
+                ("p", C.c_void_p), ("i", C.c_void_p), ("x", C.c_void_p), ("z", C.c_void_p),
+                ("nz", C.c_void_p), ("next", C.c_void_p), ("prev", C.c_void_p),
+                ("nsuper", C.c_size_t), ("ssize", C.c_size_t), ("xsize", C.c_size_t),
+                ("maxcsize", C.c_size_t), ("maxesize", C.c_size_t),
+                ("super", C.c_void_p), ("pi", C.c_void_p), ("px", C.c_void_p), ("s", C.c_void_p),
+                ("ordering", C.c_int), ("is_ll", C.c_int), ("is_super", C.c_int),
+                ("is_monotonic", C.c_int), ("itype", C.c_int), ("xtype", C.c_int),
+                ("dtype", C.c_int), ("useGPU", C.c_int),
+                ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int)]
+
+
+# every symbol include/cholmod.h and include/cholmod_hip.h declare
+API_SYMBOLS = [
+    "cholmod_l_start", "cholmod_l_finish", "cholmod_l_defaults", "cholmod_l_error",
+    "cholmod_l_malloc", "cholmod_l_calloc", "cholmod_l_free",
+    "cholmod_l_allocate_sparse", "cholmod_l_free_sparse", "cholmod_l_copy_sparse",
+    "cholmod_l_nnz", "cholmod_l_ptranspose", "cholmod_l_transpose",
+    "cholmod_l_allocate_triplet", "cholmod_l_free_triplet", "cholmod_l_triplet_to_sparse",
+    "cholmod_l_allocate_dense", "cholmod_l_zeros", "cholmod_l_ones", "cholmod_l_copy_dense",
+    "cholmod_l_free_dense", "cholmod_l_free_factor",
+    "cholmod_l_read_sparse", "cholmod_l_check_factor", "cholmod_l_check_sparse",
+    "cholmod_l_gpu_stats", "cholmod_l_sdmult", "cholmod_l_norm_dense", "cholmod_l_norm_sparse",
+    "cholmod_l_analyze", "cholmod_l_analyze_p", "cholmod_l_analyze_p2",
+    "cholmod_l_factorize", "cholmod_l_factorize_p", "cholmod_l_solve", "cholmod_l_solve2",
+    "cholmod_l_etree", "cholmod_l_postorder", "cholmod_l_rowcolcounts",
+    "cholmod_l_super_symbolic", "cholmod_l_super_symbolic2", "cholmod_l_super_numeric",
+    "cholmod_l_super_lsolve", "cholmod_l_super_ltsolve",
+    "cholmod_l_gpu_memorysize", "cholmod_l_gpu_probe", "cholmod_l_gpu_deallocate",
+    "cholmod_l_gpu_end", "cholmod_l_gpu_allocate",
+    "cholmod_l_factor_to_host", "cholmod_l_hip_stats", "cholmod_l_refactorize_resident",
+]
+HIP_SYMBOLS = [
+    "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device",
+    "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
+    "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
+    "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
+    "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
+    "cholmod_hip_bench_update_kernel", "cholmod_hip_dense_partial_factor",
+    "cholmod_hip_version",
+]
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the host C layer and the HIP engine for gfx950 (in-tree)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", CSRC, "-s"])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, dbl, sz = C.c_void_p, C.c_int64, C.c_double, C.c_size_t
+    cm = C.POINTER(Common)
+    sp, dn, fc = C.POINTER(Sparse), C.POINTER(Dense), C.POINTER(Factor)
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+    sig("cholmod_l_start", C.c_int, [cm])
+    sig("cholmod_l_finish", C.c_int, [cm])
+    sig("cholmod_l_defaults", C.c_int, [cm])
+    sig("cholmod_l_allocate_sparse", sp, [sz, sz, sz, C.c_int, C.c_int, C.c_int, C.c_int, cm])
+    sig("cholmod_l_free_sparse", C.c_int, [C.POINTER(sp), cm])
+    sig("cholmod_l_copy_sparse", sp, [sp, cm])
+    sig("cholmod_l_nnz", i64, [sp, cm])
+    sig("cholmod_l_ptranspose", sp, [sp, C.c_int, vp, vp, sz, cm])
+    sig("cholmod_l_transpose", sp, [sp, C.c_int, cm])
+    sig("cholmod_l_allocate_dense", dn, [sz, sz, sz, C.c_int, cm])
+    sig("cholmod_l_zeros", dn, [sz, sz, C.c_int, cm])
+    sig("cholmod_l_ones", dn, [sz, sz, C.c_int, cm])
+    sig("cholmod_l_copy_dense", dn, [dn, cm])
+    sig("cholmod_l_free_dense", C.c_int, [C.POINTER(dn), cm])
+    sig("cholmod_l_free_factor", C.c_int, [C.POINTER(fc), cm])
+    sig("cholmod_l_check_factor", C.c_int, [fc, cm])
+    sig("cholmod_l_check_sparse", C.c_int, [sp, cm])
+    sig("cholmod_l_gpu_stats", C.c_int, [cm])
+    sig("cholmod_l_sdmult", C.c_int, [sp, C.c_int, C.POINTER(dbl * 2), C.POINTER(dbl * 2), dn, dn, cm])
+    sig("cholmod_l_norm_dense", dbl, [dn, C.c_int, cm])
+    sig("cholmod_l_norm_sparse", dbl, [sp, C.c_int, cm])
+    sig("cholmod_l_analyze", fc, [sp, cm])
+    sig("cholmod_l_analyze_p", fc, [sp, vp, vp, sz, cm])
+    sig("cholmod_l_analyze_p2", fc, [C.c_int, sp, vp, vp, sz, cm])
+    sig("cholmod_l_factorize", C.c_int, [sp, fc, cm])
+    sig("cholmod_l_factorize_p", C.c_int, [sp, C.POINTER(dbl * 2), vp, sz, fc, cm])
+    sig("cholmod_l_solve", dn, [C.c_int, fc, dn, cm])
+    sig("cholmod_l_etree", C.c_int, [sp, vp, cm])
+    sig("cholmod_l_postorder", i64, [vp, sz, vp, vp, cm])
+    sig("cholmod_l_rowcolcounts", C.c_int, [sp, vp, sz, vp, vp, vp, vp, vp, vp, cm])
+    sig("cholmod_l_super_symbolic", C.c_int, [sp, sp, vp, fc, cm])
+    sig("cholmod_l_super_numeric", C.c_int, [sp, sp, C.POINTER(dbl * 2), fc, cm])
+    sig("cholmod_l_super_lsolve", C.c_int, [fc, dn, dn, cm])
+    sig("cholmod_l_super_ltsolve", C.c_int, [fc, dn, dn, cm])
+    sig("cholmod_l_gpu_memorysize", C.c_int, [C.POINTER(sz), C.POINTER(sz), cm])
+    sig("cholmod_l_gpu_probe", C.c_int, [cm])
+    sig("cholmod_l_gpu_allocate", C.c_int, [cm])
+    sig("cholmod_l_gpu_deallocate", C.c_int, [cm])
+    sig("cholmod_l_factor_to_host", C.c_int, [fc, cm])
+    sig("cholmod_l_hip_stats", C.c_int, [fc, C.POINTER(dbl * CHOLMOD_HIP_NSTATS), cm])
+    sig("cholmod_l_refactorize_resident", C.c_int, [C.POINTER(dbl * 2), fc, cm])
+    sig("cholmod_l_read_sparse", sp, [vp, cm])
+    # engine shim
+    sig("cholmod_hip_probe", C.c_int, [])
+    sig("cholmod_hip_set_device", C.c_int, [C.c_int])
+    sig("cholmod_hip_memorysize", C.c_int, [C.POINTER(sz), C.POINTER(sz)])
+    sig("cholmod_hip_plan_create", vp, [i64, i64, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)])
+    sig("cholmod_hip_plan_destroy", None, [vp])
+    sig("cholmod_hip_factorize", C.c_int, [vp, vp, vp, vp, vp, dbl, C.c_int, vp, C.POINTER(i64)])
+    sig("cholmod_hip_upload_matrix", C.c_int, [vp, vp, vp, vp, vp])
+    sig("cholmod_hip_factorize_resident", C.c_int, [vp, dbl, C.c_int, C.POINTER(i64)])
+    sig("cholmod_hip_download_factor", C.c_int, [vp, vp])
+    sig("cholmod_hip_upload_factor", C.c_int, [vp, vp])
+    sig("cholmod_hip_solve", C.c_int, [vp, C.c_int, vp, i64, i64])
+    sig("cholmod_hip_get_maps", C.c_int, [vp, vp, vp, vp])
+    sig("cholmod_hip_get_stats", C.c_int, [vp, vp])
+    sig("cholmod_hip_set_profiling", C.c_int, [vp, C.c_int])
+    sig("cholmod_hip_bench_update_kernel", dbl, [i64, i64, i64, C.c_int, C.c_int])
+    sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
+    sig("cholmod_hip_version", C.c_char_p, [])
+    _lib = L
+    return L
+
+
+def _view(ptr, n, ctype, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(int(n),))
+
+
+class Session:
+    """One cholmod_common plus convenience wrappers (tests / bench harness)."""
+
+    def __init__(self, supernodal=SUPERNODAL, use_gpu=1, print_level=0, postorder=True,
+                 factor_on_device=False, hip_flags=0):
+        self.L = lib()
+        self.cm = Common()
+        self.L.cholmod_l_start(C.byref(self.cm))
+        self.cm.supernodal = supernodal
+        self.cm.useGPU = use_gpu
+        self.cm.print = print_level
+        self.cm.postorder = int(postorder)
+        self.cm.hip_factor_on_device = int(factor_on_device)
+        self.cm.hip_flags = hip_flags
+        self._keep = []
+
+    @property
+    def status(self):
+        return self.cm.status
+
+    def finish(self):
+        self.L.cholmod_l_finish(C.byref(self.cm))
+
+    # ---- object helpers
+    def sparse(self, n, Ap, Ai, Ax, stype):
+        """Copy numpy CSC arrays into a library-owned cholmod_sparse."""
+        nz = int(Ap[-1])
+        A = self.L.cholmod_l_allocate_sparse(n, n, max(nz, 1), 1, 1, stype, REAL, C.byref(self.cm))
+        if not A:
+            raise MemoryError("cholmod_l_allocate_sparse")
+        a = A.contents
+        _view(a.p, n + 1, C.c_int64, np.int64)[:] = Ap
+        if nz:
+            _view(a.i, nz, C.c_int64, np.int64)[:] = Ai
+            _view(a.x, nz, C.c_double, np.float64)[:] = Ax
+        return A
+
+    def dense(self, arr):
+        arr = np.asarray(arr, dtype=np.float64)
+        n = arr.shape[-1] if arr.ndim > 1 else arr.shape[0]
+        nrhs = arr.shape[0] if arr.ndim > 1 else 1
+        X = self.L.cholmod_l_allocate_dense(n, nrhs, n, REAL, C.byref(self.cm))
+        _view(X.contents.x, n * nrhs, C.c_double, np.float64)[:] = arr.reshape(-1)
+        return X
+
+    def dense_to_numpy(self, X):
+        x = X.contents
+        out = _view(x.x, x.d * x.ncol, C.c_double, np.float64).copy()
+        return out.reshape(x.ncol, x.d)[:, :x.nrow] if x.ncol > 1 else out[:x.nrow]
+
+    def free_sparse(self, A):
+        self.L.cholmod_l_free_sparse(C.byref(A), C.byref(self.cm))
+
+    def free_dense(self, X):
+        self.L.cholmod_l_free_dense(C.byref(X), C.byref(self.cm))
+
+    def free_factor(self, Lf):
+        self.L.cholmod_l_free_factor(C.byref(Lf), C.byref(self.cm))
+
+    # ---- the path
+    def analyze(self, A, perm=None):
+        if perm is None:
+            Lf = self.L.cholmod_l_analyze(A, C.byref(self.cm))
+        else:
+            p = np.ascontiguousarray(perm, dtype=np.int64)
+            Lf = self.L.cholmod_l_analyze_p(A, p.ctypes.data, None, 0, C.byref(self.cm))
+        if not Lf:
+            raise RuntimeError(f"cholmod_l_analyze failed, status {self.cm.status}")
+        return Lf
+
+    def factorize(self, A, Lf, beta=0.0):
+        b = (C.c_double * 2)(beta, 0.0)
+        return self.L.cholmod_l_factorize_p(A, C.byref(b), None, 0, Lf, C.byref(self.cm))
+
+    def refactorize_resident(self, Lf, beta=0.0):
+        b = (C.c_double * 2)(beta, 0.0)
+        return self.L.cholmod_l_refactorize_resident(C.byref(b), Lf, C.byref(self.cm))
+
+    def solve(self, Lf, b, sys=SYS_A):
+        B = self.dense(b)
+        X = self.L.cholmod_l_solve(sys, Lf, B, C.byref(self.cm))
+        self.free_dense(B)
+        if not X:
+            raise RuntimeError(f"cholmod_l_solve failed, status {self.cm.status}")
+        out = self.dense_to_numpy(X)
+        self.free_dense(X)
+        return out
+
+    def hip_stats(self, Lf):
+        s = (C.c_double * CHOLMOD_HIP_NSTATS)()
+        self.L.cholmod_l_hip_stats(Lf, C.byref(s), C.byref(self.cm))
+        return np.array(list(s))
+
+    def set_profiling(self, Lf, on=True):
+        if Lf.contents.hip_plan:
+            self.L.cholmod_hip_set_profiling(Lf.contents.hip_plan, int(on))
+
+
+class FactorView:
+    """numpy views of a cholmod_factor's supernodal fields."""
+
+    def __init__(self, Lf):
+        f = Lf.contents
+        self.n, self.nsuper = int(f.n), int(f.nsuper)
+        self.ssize, self.xsize = int(f.ssize), int(f.xsize)
+        self.maxcsize, self.maxesize, self.minor = int(f.maxcsize), int(f.maxesize), int(f.minor)
+        self.ordering, self.is_super, self.is_ll, self.xtype = f.ordering, f.is_super, f.is_ll, f.xtype
+        self.useGPU = f.useGPU
+        self.Perm = _view(f.Perm, self.n, C.c_int64, np.int64)
+        self.ColCount = _view(f.ColCount, self.n, C.c_int64, np.int64)
+        self.super = _view(f.super, self.nsuper + 1, C.c_int64, np.int64)
+        self.pi = _view(f.pi, self.nsuper + 1, C.c_int64, np.int64)
+        self.px = _view(f.px, self.nsuper + 1, C.c_int64, np.int64)
+        self.s = _view(f.s, self.ssize, C.c_int64, np.int64)
+        self.x = _view(f.x, self.xsize, C.c_double, np.float64) if f.x else None
+        self.hip_plan = f.hip_plan

@@ -1,0 +1,887 @@
+// engine.hip -- host side of the MI355X supernodal Cholesky engine: plan
+// (supernodal etree, level sets, contribution-block arena, batched launch
+// schedule), the runner, and the extern "C" shim declared in
+// include/cholmod_hip.h.  One process drives one GPU; everything runs on one
+// HIP stream owned by the plan.
+#include "kernels.hip.h"
+#include "../../../include/cholmod_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+using namespace sship ;
+
+namespace {
+
+constexpr int NB = PF_NB ;      // inner panel width (potrf / trsm block)
+constexpr int OB = 512 ;        // outer block: trailing updates contract over <= OB columns
+constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
+
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_NKIND } ;
+
+struct Launch {
+    int kind ;
+    int grid ;
+    int ng ;
+    size_t goff ;       // first group (index into the kind's group array)
+    double flops ;      // algorithmic flops (dense kinds)
+    double bytes ;      // algorithmic bytes (extend-add / zero)
+} ;
+
+#define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
+    fprintf (stderr, "cholmod_hip: %s failed: %s (%s:%d)\n", #call, \
+        hipGetErrorString (e_), __FILE__, __LINE__) ; return CHOLMOD_HIP_GPU_PROBLEM ; } } while (0)
+
+// best-fit free-list allocator for the contribution-block arena (plan time)
+struct Arena {
+    std::map<i64, i64> free_by_off ;            // off -> len
+    std::multimap<i64, i64> free_by_len ;       // len -> off
+    i64 top = 0 ;
+    void erase_len (i64 len, i64 off)
+    {
+        auto r = free_by_len.equal_range (len) ;
+        for (auto it = r.first ; it != r.second ; ++it)
+            if (it->second == off) { free_by_len.erase (it) ; return ; }
+    }
+    i64 alloc (i64 len)
+    {
+        if (len == 0) return 0 ;
+        auto it = free_by_len.lower_bound (len) ;
+        if (it != free_by_len.end ())
+        {
+            i64 blen = it->first, off = it->second ;
+            free_by_len.erase (it) ;
+            free_by_off.erase (off) ;
+            if (blen > len)
+            {
+                free_by_off [off + len] = blen - len ;
+                free_by_len.insert ({blen - len, off + len}) ;
+            }
+            return off ;
+        }
+        // grow: merge with a free block that touches the top, if any
+        i64 off = top ;
+        if (!free_by_off.empty ())
+        {
+            auto last = std::prev (free_by_off.end ()) ;
+            if (last->first + last->second == top)
+            {
+                off = last->first ;
+                erase_len (last->second, last->first) ;
+                free_by_off.erase (last) ;
+            }
+        }
+        top = off + len ;
+        return off ;
+    }
+    void release (i64 off, i64 len)
+    {
+        if (len == 0) return ;
+        auto nx = free_by_off.lower_bound (off) ;
+        if (nx != free_by_off.end () && off + len == nx->first)
+        {
+            len += nx->second ;
+            erase_len (nx->second, nx->first) ;
+            nx = free_by_off.erase (nx) ;
+        }
+        if (nx != free_by_off.begin ())
+        {
+            auto pv = std::prev (nx) ;
+            if (pv->first + pv->second == off)
+            {
+                off = pv->first ;
+                len += pv->second ;
+                erase_len (pv->second, pv->first) ;
+                free_by_off.erase (pv) ;
+            }
+        }
+        free_by_off [off] = len ;
+        free_by_len.insert ({len, off}) ;
+    }
+} ;
+
+struct Schedule {
+    std::vector<ZeroGroup> zg ;
+    std::vector<EaGroup> eg ;
+    std::vector<PfGroup> pg ;
+    std::vector<TrGroup> tg ;
+    std::vector<GemmGroup> gg ;
+    std::vector<Launch> launches ;
+} ;
+
+template <typename T> static T *dupload (const std::vector<T> &v, hipError_t &err)
+{
+    T *d = nullptr ;
+    size_t bytes = std::max<size_t> (v.size (), 1) * sizeof (T) ;
+    err = hipMalloc ((void **) &d, bytes) ;
+    if (err != hipSuccess) return nullptr ;
+    if (!v.empty ()) err = hipMemcpy (d, v.data (), v.size () * sizeof (T), hipMemcpyHostToDevice) ;
+    return d ;
+}
+
+} // namespace
+
+struct cholmod_hip_plan {
+    i64 n = 0, nsuper = 0, ssize = 0, xsize = 0 ;
+    int flags = 0 ;
+    bool host_only = false ;
+    std::vector<i64> super, pi, px, Ls ;
+    std::vector<FrontD> fr ;
+    std::vector<i32> level, child, supermap ;
+    std::vector<i32> lvl_ptr, lvl_list ;        // fronts by level
+    i64 relsize = 0, arena = 0 ;
+    int nlevels = 0 ;
+    Schedule sch ;
+    double exec_flops = 0 ;
+    // device
+    hipStream_t stream = nullptr ;
+    i64 *d_Ls = nullptr ;
+    FrontD *d_fr = nullptr ;
+    i32 *d_supermap = nullptr, *d_child = nullptr, *d_relmap = nullptr, *d_info = nullptr ;
+    i32 *d_lvl_list = nullptr ;
+    double *d_Lx = nullptr, *d_cb = nullptr ;
+    ZeroGroup *d_zg = nullptr ; EaGroup *d_eg = nullptr ; PfGroup *d_pg = nullptr ;
+    TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ;
+    // resident input matrix
+    i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
+    i64 s_nz = 0 ; bool s_unpacked = false ;
+    // solve workspace
+    double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
+    i64 *d_perm = nullptr ;
+    // stats
+    bool profiling = false ;
+    double stats [CHOLMOD_HIP_NSTATS] = {0} ;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr ;
+    std::vector<hipEvent_t> evpool ;
+} ;
+
+namespace {
+
+// Append the launches that perform the dense partial factorization of a batch
+// of fronts (all of one etree level): two-level blocked right-looking Cholesky
+// of the first nscol columns of every front [panel | CB].
+static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
+    Schedule &S, bool valu, double &exec_flops)
+{
+    int maxnscol = 0 ;
+    for (int q = 0 ; q < nf ; q++) maxnscol = std::max (maxnscol, fr [ids [q]].nscol) ;
+    auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
+    {
+        for (int pass = 0 ; pass < 2 ; pass++)
+        {
+            std::vector<GemmGroup> &v = pass ? small : big ;
+            if (v.empty ()) continue ;
+            int T = pass ? SMALL : BIG ;
+            Launch L {pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
+            i64 tiles = 0 ;
+            for (auto &G : v)
+            {
+                G.mt = (G.m + T - 1) / T ; G.nt = (G.n + T - 1) / T ;
+                G.tile_start = (i32) tiles ;
+                i64 cnt = G.tri ? (i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt
+                                : (i64) G.mt * G.nt ;
+                tiles += cnt ;
+                double elems = G.tri ? (double) G.n * (G.n + 1) / 2 + (double) (G.m - G.n) * G.n
+                                     : (double) G.m * G.n ;
+                L.flops += 2.0 * elems * G.k ;
+                L.bytes += 16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k ;
+                S.gg.push_back (G) ;
+            }
+            L.grid = (int) tiles ;
+            S.launches.push_back (L) ;
+            v.clear () ;
+        }
+    } ;
+    auto add_update = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small,
+        const FrontD &f, int fid, int r0, int kc, int kk, int m, int ncols, bool to_cb)
+    {
+        // target region: rows r0.., cols r0.. of the front (starts on the diagonal)
+        if (m <= 0 || ncols <= 0 || kk <= 0) return ;
+        GemmGroup G ;
+        memset (&G, 0, sizeof (G)) ;
+        G.a_off = f.psx + r0 + (i64) kc * f.nsrow ;
+        G.b_off = G.a_off ;
+        G.lda = f.nsrow ;
+        if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
+        else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
+        G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
+        bool isbig = !valu && ncols >= BIG && m >= 2 * BIG ;
+        (isbig ? big : small).push_back (G) ;
+    } ;
+    std::vector<GemmGroup> big, small ;
+    for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
+    {
+        for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
+        {
+            // potrf of the diagonal blocks
+            Launch Lp {K_POTRF, 0, 0, S.pg.size (), 0, 0} ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0) continue ;
+                int nb = std::min (NB, f.nscol - i0) ;
+                PfGroup G {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, nb, ids [q], i0} ;
+                S.pg.push_back (G) ;
+                Lp.flops += (double) nb * nb * nb / 3.0 ;
+            }
+            Lp.ng = Lp.grid = (int) (S.pg.size () - Lp.goff) ;
+            if (Lp.ng) S.launches.push_back (Lp) ;
+            // trsm of the rows below
+            Launch Lt {K_TRSM, 0, 0, S.tg.size (), 0, 0} ;
+            int blocks = 0 ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0) continue ;
+                int nb = std::min (NB, f.nscol - i0) ;
+                int m = f.nsrow - (i0 + nb) ;
+                if (m <= 0) continue ;
+                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
+                           f.psx + (i0 + nb) + (i64) i0 * f.nsrow, f.nsrow, m, nb,
+                           ids [q], i0, blocks} ;
+                blocks += (m + TR_ROWS - 1) / TR_ROWS ;
+                S.tg.push_back (G) ;
+                Lt.flops += (double) m * nb * nb ;
+            }
+            Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
+            if (Lt.ng) S.launches.push_back (Lt) ;
+            // inner trailing update, restricted to the outer block column
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0) continue ;
+                int nb = std::min (NB, f.nscol - i0) ;
+                int i1 = i0 + nb ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                add_update (big, small, f, ids [q], i1, i0, nb, f.nsrow - i1, o1 - i1, false) ;
+            }
+            flush_updates (big, small) ;
+        }
+        // outer trailing update: everything right of the outer block column
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= o0) continue ;
+            int o1 = std::min (o0 + OB, f.nscol) ;
+            int kk = o1 - o0 ;
+            add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false) ;
+            add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true) ;
+        }
+        flush_updates (big, small) ;
+    }
+    for (int q = 0 ; q < nf ; q++)
+    {
+        const FrontD &f = fr [ids [q]] ;
+        double c = f.nscol, r = f.ncb ;
+        exec_flops += c * c * c / 3.0 + r * c * c + r * r * c ;
+    }
+}
+
+static int build_host (cholmod_hip_plan *P)
+{
+    i64 n = P->n, nsuper = P->nsuper ;
+    P->fr.resize (nsuper) ;
+    P->supermap.resize (std::max<i64> (n, 1)) ;
+    P->level.assign (nsuper, 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        FrontD &f = P->fr [s] ;
+        memset (&f, 0, sizeof (f)) ;
+        if (P->super [s+1] - P->super [s] <= 0 || P->pi [s+1] - P->pi [s] > INT32_MAX)
+            return CHOLMOD_HIP_INVALID ;
+        f.psx = P->px [s] ; f.psi = P->pi [s] ;
+        f.k1 = (i32) P->super [s] ;
+        f.nscol = (i32) (P->super [s+1] - P->super [s]) ;
+        f.nsrow = (i32) (P->pi [s+1] - P->pi [s]) ;
+        if (f.nsrow < f.nscol) return CHOLMOD_HIP_INVALID ;
+        f.ncb = f.nsrow - f.nscol ;
+        f.rel = P->pi [s] - P->super [s] ;      // compact offset, sum of earlier ncb
+        for (i64 k = P->super [s] ; k < P->super [s+1] ; k++) P->supermap [k] = (i32) s ;
+    }
+    P->relsize = P->ssize - n ;
+    // supernodal etree (reference t_cholmod_super_numeric.c:1025) and levels
+    std::vector<i32> nchild (nsuper, 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        FrontD &f = P->fr [s] ;
+        f.parent = f.ncb > 0 ? P->supermap [P->Ls [f.psi + f.nscol]] : -1 ;
+        if (f.parent >= 0)
+        {
+            if (f.parent <= s) return CHOLMOD_HIP_INVALID ;
+            nchild [f.parent]++ ;
+            P->level [f.parent] = std::max (P->level [f.parent], P->level [s] + 1) ;
+        }
+    }
+    i32 acc = 0 ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        P->fr [s].child_begin = acc ; acc += nchild [s] ; P->fr [s].child_end = P->fr [s].child_begin ;
+    }
+    P->child.assign (std::max<i32> (acc, 1), 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        i32 p = P->fr [s].parent ;
+        if (p >= 0) P->child [P->fr [p].child_end++] = (i32) s ;
+    }
+    int nlev = 0 ;
+    for (i64 s = 0 ; s < nsuper ; s++) nlev = std::max (nlev, P->level [s] + 1) ;
+    P->nlevels = nlev ;
+    P->lvl_ptr.assign (nlev + 1, 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++) P->lvl_ptr [P->level [s] + 1]++ ;
+    for (int l = 0 ; l < nlev ; l++) P->lvl_ptr [l+1] += P->lvl_ptr [l] ;
+    P->lvl_list.assign (std::max<i64> (nsuper, 1), 0) ;
+    {
+        std::vector<i32> pos (P->lvl_ptr.begin (), P->lvl_ptr.end () - 1) ;
+        for (i64 s = 0 ; s < nsuper ; s++) P->lvl_list [pos [P->level [s]]++] = (i32) s ;
+    }
+    // arena: a CB lives from its own level until its parent's level is assembled
+    Arena A ;
+    for (int l = 0 ; l < nlev ; l++)
+    {
+        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
+        {
+            FrontD &f = P->fr [P->lvl_list [q]] ;
+            f.cb = A.alloc ((i64) f.ncb * f.ncb) ;
+        }
+        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
+        {
+            FrontD &f = P->fr [P->lvl_list [q]] ;
+            for (int c = f.child_begin ; c < f.child_end ; c++)
+            {
+                FrontD &g = P->fr [P->child [c]] ;
+                A.release (g.cb, (i64) g.ncb * g.ncb) ;
+            }
+        }
+    }
+    P->arena = A.top ;
+    // launch schedule
+    Schedule &S = P->sch ;
+    bool valu = (P->flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
+    for (int l = 0 ; l < nlev ; l++)
+    {
+        const i32 *ids = P->lvl_list.data () + P->lvl_ptr [l] ;
+        int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
+        Launch Lz {K_ZERO, 0, 0, S.zg.size (), 0, 0} ;
+        int blocks = 0 ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = P->fr [ids [q]] ;
+            i64 len = (i64) f.ncb * f.ncb ;
+            if (len == 0) continue ;
+            S.zg.push_back (ZeroGroup {f.cb, len, blocks, 0}) ;
+            blocks += (int) ((len + ZERO_CHUNK - 1) / ZERO_CHUNK) ;
+            Lz.bytes += 8.0 * len ;
+        }
+        Lz.ng = (int) (S.zg.size () - Lz.goff) ; Lz.grid = blocks ;
+        if (Lz.ng) S.launches.push_back (Lz) ;
+        Launch Le {K_EA, 0, 0, S.eg.size (), 0, 0} ;
+        blocks = 0 ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = P->fr [ids [q]] ;
+            if (f.child_end == f.child_begin) continue ;
+            S.eg.push_back (EaGroup {ids [q], blocks}) ;
+            blocks += (f.nsrow + EA_TW - 1) / EA_TW ;
+            for (int c = f.child_begin ; c < f.child_end ; c++)
+            {
+                double r = P->fr [P->child [c]].ncb ;
+                Le.bytes += (r * (r + 1) / 2) * 24.0 + 4.0 * r ;   // CB read + target RMW + map
+            }
+        }
+        Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
+        if (Le.ng) S.launches.push_back (Le) ;
+        schedule_dense (P->fr, ids, nf, S, valu, P->exec_flops) ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+static void free_device (cholmod_hip_plan *P)
+{
+    void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
+        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm} ;
+    for (void *p : ptrs) if (p) (void) hipFree (p) ;
+    for (auto e : P->evpool) (void) hipEventDestroy (e) ;
+    if (P->ev0) (void) hipEventDestroy (P->ev0) ;
+    if (P->ev1) (void) hipEventDestroy (P->ev1) ;
+    if (P->stream) (void) hipStreamDestroy (P->stream) ;
+}
+
+static int upload_plan (cholmod_hip_plan *P)
+{
+    hipError_t e ;
+    HIPCHK (hipStreamCreate (&P->stream)) ;
+    HIPCHK (hipEventCreate (&P->ev0)) ;
+    HIPCHK (hipEventCreate (&P->ev1)) ;
+    size_t freeb = 0, totalb = 0 ;
+    HIPCHK (hipMemGetInfo (&freeb, &totalb)) ;
+    double need = 8.0 * P->xsize + 8.0 * P->arena + 8.0 * P->ssize + 4.0 * P->relsize
+        + sizeof (GemmGroup) * (double) P->sch.gg.size () + 64.0 * P->nsuper + (double) (64 << 20) ;
+    if (need > (double) freeb)
+    {
+        fprintf (stderr, "cholmod_hip: factor needs %.2f GB of HBM, %.2f GB free\n",
+            need / 1e9, freeb / 1e9) ;
+        return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    }
+    P->d_Ls = dupload (P->Ls, e) ; HIPCHK (e) ;
+    P->d_fr = dupload (P->fr, e) ; HIPCHK (e) ;
+    P->d_supermap = dupload (P->supermap, e) ; HIPCHK (e) ;
+    P->d_child = dupload (P->child, e) ; HIPCHK (e) ;
+    P->d_lvl_list = dupload (P->lvl_list, e) ; HIPCHK (e) ;
+    P->d_zg = dupload (P->sch.zg, e) ; HIPCHK (e) ;
+    P->d_eg = dupload (P->sch.eg, e) ; HIPCHK (e) ;
+    P->d_pg = dupload (P->sch.pg, e) ; HIPCHK (e) ;
+    P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
+    P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
+    if (P->nsuper > 0)
+    {
+        int grid = (int) ((P->nsuper * 64 + 255) / 256) ;
+        hipLaunchKernelGGL (k_relmap, dim3 (grid), dim3 (256), 0, P->stream,
+            (int) P->nsuper, P->d_fr, P->d_Ls, P->d_relmap) ;
+        HIPCHK (hipGetLastError ()) ;
+        HIPCHK (hipStreamSynchronize (P->stream)) ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+static int run_launch (cholmod_hip_plan *P, const Launch &L)
+{
+    hipStream_t st = P->stream ;
+    switch (L.kind)
+    {
+        case K_ZERO:
+            hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
+                P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
+        case K_EA:
+            hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
+                P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb) ; break ;
+        case K_POTRF:
+            hipLaunchKernelGGL (k_potrf, dim3 (L.grid), dim3 (64), 0, st,
+                P->d_pg + L.goff, P->d_Lx, P->d_info) ; break ;
+        case K_TRSM:
+            hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS), 0, st,
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info) ; break ;
+        case K_UPD_BIG:
+            hipLaunchKernelGGL ((k_update<BIG, BIG, BKK, true>), dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ; break ;
+        case K_UPD_SMALL:
+            if (P->flags & CHOLMOD_HIP_GEMM_VALU)
+                hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (L.grid), dim3 (256), 0, st,
+                    P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            else
+                hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, true>), dim3 (L.grid), dim3 (256), 0, st,
+                    P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            break ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+// Run the numeric factorization on the resident S.  Leaves Lx on the device.
+static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *minor)
+{
+    hipStream_t st = P->stream ;
+    if (!P->d_Sp) return CHOLMOD_HIP_INVALID ;
+    bool prof = P->profiling ;
+    size_t nl = P->sch.launches.size () ;
+    if (prof)
+    {
+        while (P->evpool.size () < 2 * (nl + 1))
+        {
+            hipEvent_t e ; HIPCHK (hipEventCreate (&e)) ; P->evpool.push_back (e) ;
+        }
+    }
+    HIPCHK (hipEventRecord (P->ev0, st)) ;
+    if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
+    HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
+    HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
+    if (P->n > 0)
+    {
+        hipLaunchKernelGGL (k_assemble, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+            P->n, P->d_Sp, P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx,
+            P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta) ;
+    }
+    if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
+    for (size_t q = 0 ; q < nl ; q++)
+    {
+        const Launch &L = P->sch.launches [q] ;
+        if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
+        run_launch (P, L) ;
+        if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1) + 1], st)) ;
+    }
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipEventRecord (P->ev1, st)) ;
+    // not-positive-definite protocol (t_cholmod_super_numeric.c:905-968)
+    std::vector<i32> info (std::max<i64> (P->nsuper, 1)) ;
+    HIPCHK (hipMemcpyAsync (info.data (), P->d_info, info.size () * sizeof (i32),
+        hipMemcpyDeviceToHost, st)) ;
+    HIPCHK (hipStreamSynchronize (st)) ;
+    float ms = 0 ;
+    HIPCHK (hipEventElapsedTime (&ms, P->ev0, P->ev1)) ;
+    double *S = P->stats ;
+    for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) S [q] = 0 ;
+    S [0] = ms * 1e-3 ;
+    S [1] = P->exec_flops ;
+    S [2] = (double) nl + 3 ;
+    S [3] = P->nlevels ;
+    S [4] = 8.0 * P->arena ;
+    S [5] = 8.0 * P->xsize ;
+    for (size_t q = 0 ; q < nl ; q++)
+    {
+        const Launch &L = P->sch.launches [q] ;
+        if (L.kind == K_UPD_BIG || L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; }
+        if (L.kind == K_EA) S [10] += L.bytes ;
+    }
+    if (prof)
+    {
+        float t = 0 ;
+        HIPCHK (hipEventElapsedTime (&t, P->evpool [0], P->evpool [1])) ;
+        S [13] = t * 1e-3 ;
+        for (size_t q = 0 ; q < nl ; q++)
+        {
+            const Launch &L = P->sch.launches [q] ;
+            HIPCHK (hipEventElapsedTime (&t, P->evpool [2 * (q + 1)], P->evpool [2 * (q + 1) + 1])) ;
+            double sec = t * 1e-3 ;
+            switch (L.kind)
+            {
+                case K_UPD_BIG: case K_UPD_SMALL: S [6] += sec ; break ;
+                case K_EA: case K_ZERO: S [9] += sec ; break ;
+                case K_POTRF: S [11] += sec ; break ;
+                case K_TRSM: S [12] += sec ; break ;
+            }
+        }
+    }
+    i64 sbad = -1 ;
+    for (i64 s = 0 ; s < P->nsuper ; s++) if (info [s] != 0) { sbad = s ; break ; }
+    *minor = P->n ;
+    if (sbad < 0) return CHOLMOD_HIP_OK ;
+    const FrontD &f = P->fr [sbad] ;
+    *minor = f.k1 + info [sbad] - 1 ;
+    i64 zero_from = P->px [sbad + 1] ;
+    if (info [sbad] == 1 || quick) zero_from = P->px [sbad] ;
+    if (zero_from < P->xsize)
+        HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->xsize - zero_from) * sizeof (double), st)) ;
+    HIPCHK (hipStreamSynchronize (st)) ;
+    return CHOLMOD_HIP_NOT_POSDEF ;
+}
+
+} // namespace
+
+// ============================================================================
+// extern "C" shim
+// ============================================================================
+
+extern "C" {
+
+const char *cholmod_hip_version (void) { return "suitesparse_amd cholmod_hip 0.1 (gfx950)" ; }
+
+int cholmod_hip_probe (void)
+{
+    int cnt = 0 ;
+    if (hipGetDeviceCount (&cnt) != hipSuccess) return 0 ;
+    return cnt > 0 ? 1 : 0 ;
+}
+
+int cholmod_hip_memorysize (size_t *total_mem, size_t *available_mem)
+{
+    if (total_mem) *total_mem = 0 ;
+    if (available_mem) *available_mem = 0 ;
+    if (!cholmod_hip_probe ()) return 1 ;
+    size_t f = 0, t = 0 ;
+    if (hipMemGetInfo (&f, &t) != hipSuccess) return 1 ;
+    if (total_mem) *total_mem = t ;
+    if (available_mem) *available_mem = f ;
+    return 0 ;
+}
+
+int cholmod_hip_set_device (int device)
+{
+    return hipSetDevice (device) == hipSuccess ? CHOLMOD_HIP_OK : CHOLMOD_HIP_NO_DEVICE ;
+}
+
+cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
+    int flags, int *status)
+{
+    int st_local ;
+    if (!status) status = &st_local ;
+    *status = CHOLMOD_HIP_OK ;
+    if (n < 0 || nsuper < 0 || !super || !pi || !px || !s) { *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
+    bool host_only = (flags & CHOLMOD_HIP_PLAN_HOST_ONLY) != 0 ;
+    if (!host_only && !cholmod_hip_probe ()) { *status = CHOLMOD_HIP_NO_DEVICE ; return nullptr ; }
+    cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
+    if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
+    P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
+    P->super.assign (super, super + nsuper + 1) ;
+    P->pi.assign (pi, pi + nsuper + 1) ;
+    P->px.assign (px, px + nsuper + 1) ;
+    P->ssize = pi [nsuper] ; P->xsize = px [nsuper] ;
+    P->Ls.assign (s, s + std::max<i64> (P->ssize, 1)) ;
+    *status = build_host (P) ;
+    if (*status == CHOLMOD_HIP_OK && !host_only) *status = upload_plan (P) ;
+    if (*status != CHOLMOD_HIP_OK)
+    {
+        free_device (P) ; delete P ; return nullptr ;
+    }
+    return P ;
+}
+
+void cholmod_hip_plan_destroy (cholmod_hip_plan *P)
+{
+    if (!P) return ;
+    free_device (P) ;
+    delete P ;
+}
+
+int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int64_t *Si,
+    const int64_t *Snz, const double *Sx)
+{
+    if (!P || P->host_only || !Sp || !Si || !Sx) return CHOLMOD_HIP_INVALID ;
+    i64 n = P->n ;
+    i64 nz = 0 ;
+    if (Snz) { for (i64 j = 0 ; j < n ; j++) nz = std::max<i64> (nz, Sp [j] + Snz [j]) ; }
+    else nz = Sp [n] ;
+    if (nz > P->s_nz || !P->d_Sp)
+    {
+        if (P->d_Sp) { (void) hipFree (P->d_Sp) ; (void) hipFree (P->d_Si) ; (void) hipFree (P->d_Sx) ; (void) hipFree (P->d_Snz) ; }
+        P->d_Sp = P->d_Si = P->d_Snz = nullptr ; P->d_Sx = nullptr ;
+        HIPCHK (hipMalloc ((void **) &P->d_Sp, (n + 1) * sizeof (i64))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_Snz, std::max<i64> (n, 1) * sizeof (i64))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_Si, std::max<i64> (nz, 1) * sizeof (i64))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_Sx, std::max<i64> (nz, 1) * sizeof (double))) ;
+        P->s_nz = nz ;
+    }
+    HIPCHK (hipMemcpyAsync (P->d_Sp, Sp, (n + 1) * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
+    if (Snz) HIPCHK (hipMemcpyAsync (P->d_Snz, Snz, n * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
+    if (nz) HIPCHK (hipMemcpyAsync (P->d_Si, Si, nz * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
+    if (nz) HIPCHK (hipMemcpyAsync (P->d_Sx, Sx, nz * sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    P->s_unpacked = (Snz != nullptr) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_factorize_resident (cholmod_hip_plan *P, double beta,
+    int quick_return_if_not_posdef, int64_t *minor)
+{
+    if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
+    i64 m = P->n ;
+    int rc = run_factorize (P, beta, quick_return_if_not_posdef, &m) ;
+    if (minor) *minor = m ;
+    return rc ;
+}
+
+int cholmod_hip_download_factor (cholmod_hip_plan *P, double *Lx_host)
+{
+    if (!P || P->host_only || !Lx_host) return CHOLMOD_HIP_INVALID ;
+    HIPCHK (hipMemcpy (Lx_host, P->d_Lx, P->xsize * sizeof (double), hipMemcpyDeviceToHost)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_upload_factor (cholmod_hip_plan *P, const double *Lx_host)
+{
+    if (!P || P->host_only || !Lx_host) return CHOLMOD_HIP_INVALID ;
+    HIPCHK (hipMemcpy (P->d_Lx, Lx_host, P->xsize * sizeof (double), hipMemcpyHostToDevice)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_factorize (cholmod_hip_plan *P, const int64_t *Sp, const int64_t *Si,
+    const int64_t *Snz, const double *Sx, double beta, int quick_return_if_not_posdef,
+    double *Lx_host, int64_t *minor)
+{
+    int rc = cholmod_hip_upload_matrix (P, Sp, Si, Snz, Sx) ;
+    if (rc != CHOLMOD_HIP_OK) return rc ;
+    rc = cholmod_hip_factorize_resident (P, beta, quick_return_if_not_posdef, minor) ;
+    if (rc < 0) return rc ;
+    if (Lx_host)
+    {
+        int rc2 = cholmod_hip_download_factor (P, Lx_host) ;
+        if (rc2 != CHOLMOD_HIP_OK) return rc2 ;
+    }
+    return rc ;
+}
+
+int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, int64_t ldx)
+{
+    if (!P || P->host_only || !X || nrhs < 0 || ldx < P->n) return CHOLMOD_HIP_INVALID ;
+    if (nrhs == 0 || P->n == 0) return CHOLMOD_HIP_OK ;
+    i64 need = ldx * nrhs ;
+    if (need > P->x_cap)
+    {
+        if (P->d_X) (void) hipFree (P->d_X) ;
+        P->d_X = nullptr ;
+        HIPCHK (hipMalloc ((void **) &P->d_X, need * sizeof (double))) ;
+        P->x_cap = need ;
+    }
+    hipStream_t st = P->stream ;
+    HIPCHK (hipMemcpyAsync (P->d_X, X, need * sizeof (double), hipMemcpyHostToDevice, st)) ;
+    if (which == 0 || which == 1)
+    {
+        for (int l = 0 ; l < P->nlevels ; l++)
+        {
+            int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
+            hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
+                P->d_lvl_list + P->lvl_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+        }
+    }
+    if (which == 0 || which == 2)
+    {
+        for (int l = P->nlevels - 1 ; l >= 0 ; l--)
+        {
+            int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
+            hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
+                P->d_lvl_list + P->lvl_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+        }
+    }
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipMemcpyAsync (X, P->d_X, need * sizeof (double), hipMemcpyDeviceToHost, st)) ;
+    HIPCHK (hipStreamSynchronize (st)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_get_maps (cholmod_hip_plan *P, int64_t *sparent, int64_t *level, int64_t *relmap)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    for (i64 s = 0 ; s < P->nsuper ; s++)
+    {
+        if (sparent) sparent [s] = P->fr [s].parent ;
+        if (level) level [s] = P->level [s] ;
+    }
+    if (relmap)
+    {
+        if (P->host_only) return CHOLMOD_HIP_NO_DEVICE ;
+        std::vector<i32> tmp (std::max<i64> (P->relsize, 1)) ;
+        HIPCHK (hipMemcpy (tmp.data (), P->d_relmap, tmp.size () * sizeof (i32), hipMemcpyDeviceToHost)) ;
+        // fronts without a parent have no entries; the compact layout has none either
+        for (i64 q = 0 ; q < P->relsize ; q++) relmap [q] = tmp [q] ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
+{
+    if (!P || !stats) return CHOLMOD_HIP_INVALID ;
+    P->stats [1] = P->exec_flops ;
+    P->stats [2] = (double) P->sch.launches.size () + 3 ;
+    P->stats [3] = P->nlevels ;
+    P->stats [4] = 8.0 * P->arena ;
+    P->stats [5] = 8.0 * P->xsize ;
+    for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_set_profiling (cholmod_hip_plan *P, int on)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    P->profiling = on != 0 ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, int flags,
+    int64_t *info_out)
+{
+    if (!F || nsrow <= 0 || nscol <= 0 || nscol > nsrow) return CHOLMOD_HIP_INVALID ;
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    FrontD f ;
+    memset (&f, 0, sizeof (f)) ;
+    f.nscol = (i32) nscol ; f.nsrow = (i32) nsrow ; f.ncb = (i32) (nsrow - nscol) ; f.parent = -1 ;
+    std::vector<FrontD> fr (1, f) ;
+    Schedule S ;
+    i32 id = 0 ;
+    double fl = 0 ;
+    schedule_dense (fr, &id, 1, S, (flags & CHOLMOD_HIP_GEMM_VALU) != 0, fl) ;
+    cholmod_hip_plan P ;
+    P.flags = flags ;
+    hipError_t e ;
+    HIPCHK (hipStreamCreate (&P.stream)) ;
+    i64 ncb = nsrow - nscol ;
+    HIPCHK (hipMalloc ((void **) &P.d_Lx, nsrow * nscol * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P.d_cb, std::max<i64> (ncb * ncb, 1) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P.d_info, sizeof (i32))) ;
+    HIPCHK (hipMemset (P.d_info, 0, sizeof (i32))) ;
+    P.d_pg = dupload (S.pg, e) ; HIPCHK (e) ;
+    P.d_tg = dupload (S.tg, e) ; HIPCHK (e) ;
+    P.d_gg = dupload (S.gg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
+    if (ncb > 0)
+        HIPCHK (hipMemcpy2D (P.d_cb, ncb * sizeof (double), F + nscol + nscol * nsrow,
+            nsrow * sizeof (double), ncb * sizeof (double), ncb, hipMemcpyHostToDevice)) ;
+    for (const Launch &L : S.launches) run_launch (&P, L) ;
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipStreamSynchronize (P.stream)) ;
+    HIPCHK (hipMemcpy (F, P.d_Lx, nsrow * nscol * sizeof (double), hipMemcpyDeviceToHost)) ;
+    if (ncb > 0)
+        HIPCHK (hipMemcpy2D (F + nscol + nscol * nsrow, nsrow * sizeof (double), P.d_cb,
+            ncb * sizeof (double), ncb * sizeof (double), ncb, hipMemcpyDeviceToHost)) ;
+    i32 inf = 0 ;
+    HIPCHK (hipMemcpy (&inf, P.d_info, sizeof (i32), hipMemcpyDeviceToHost)) ;
+    if (info_out) *info_out = inf ;
+    free_device (&P) ;
+    P.stream = nullptr ; P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
+    P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ;
+    return CHOLMOD_HIP_OK ;
+}
+
+double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int iters, int flags)
+{
+    if (m <= 0 || n <= 0 || k <= 0 || iters <= 0) return CHOLMOD_HIP_INVALID ;
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    // A: m x k, B: n x k (both ld = max(m,n)), C: m x n, all in one "Lx" buffer
+    i64 ld = std::max (m, n) ;
+    i64 a_off = 0, b_off = ld * k, c_off = 2 * ld * k ;
+    i64 total = c_off + m * n ;
+    double *d = nullptr ;
+    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    std::vector<double> h (total) ;
+    unsigned long long sdd = 88172645463325252ull ;
+    for (i64 q = 0 ; q < total ; q++)
+    {
+        sdd ^= sdd << 13 ; sdd ^= sdd >> 7 ; sdd ^= sdd << 17 ;
+        h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
+    }
+    (void) hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice) ;
+    bool small = (flags & 4) != 0 ;
+    int T = small ? SMALL : BIG ;
+    GemmGroup G ;
+    memset (&G, 0, sizeof (G)) ;
+    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
+    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ;
+    G.mt = (i32) ((m + T - 1) / T) ; G.nt = (i32) ((n + T - 1) / T) ;
+    GemmGroup *dg = nullptr ;
+    (void) hipMalloc ((void **) &dg, sizeof (G)) ;
+    (void) hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice) ;
+    int grid = G.mt * G.nt ;
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    auto launch = [&] ()
+    {
+        if (flags & CHOLMOD_HIP_GEMM_VALU)
+            hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (small)
+            hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else
+            hipLaunchKernelGGL ((k_update<BIG, BIG, BKK, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+    } ;
+    launch () ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    for (int it = 0 ; it < iters ; it++) launch () ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    hipError_t err = hipGetLastError () ;
+    (void) hipFree (d) ; (void) hipFree (dg) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    return 2.0 * (double) m * n * k * iters / (ms * 1e-3) ;
+}
+
+} // extern "C"

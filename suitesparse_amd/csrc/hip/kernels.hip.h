@@ -1,0 +1,596 @@
+// kernels.hip.h -- gfx950 device kernels of the supernodal Cholesky engine.
+//
+// The engine is a level-scheduled multifrontal formulation of the reference's
+// left-looking loop (CHOLMOD/Supernodal/t_cholmod_super_numeric.c:279-1048):
+// each supernode s owns a dense front  F_s = [ panel | contribution block ]
+//   panel  = the nsrow x nscol block of the packed Lx array (reference layout,
+//            CHOLMOD/Include/cholmod_core.h:1673-1798), factored in place;
+//   CB_s   = (nsrow-nscol)^2 Schur contribution, kept in an HBM arena and
+//            extend-added into the parent front through the relative row map
+//            (the reference's RelativeMap, :743-750, and scatter, :756-772).
+// The sum of all CB-borne updates into a front equals the sum of the
+// reference's per-descendant dsyrk/dgemm updates (:682-717); the order of
+// summation differs, hence parity is to 1e-12, not bitwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef long long i64;
+typedef int i32;
+
+namespace sship {
+
+// ---- device-side descriptors ------------------------------------------------
+
+struct FrontD {
+    i64 psx;        // offset of the panel in Lx            (L->px[s])
+    i64 psi;        // offset of the row list in Ls         (L->pi[s])
+    i64 cb;         // offset of the contribution block in the arena
+    i64 rel;        // offset of this front's child->parent relative map
+    i32 k1;         // first column                         (L->super[s])
+    i32 nscol, nsrow, ncb;
+    i32 parent;     // supernodal etree parent or -1
+    i32 child_begin, child_end;   // range in the child index array
+    i32 pad;
+};
+
+struct EaGroup { i32 front; i32 blk_start; };           // extend-add
+struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
+struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
+struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
+                 i32 col0; i32 blk_start; };
+struct GemmGroup {
+    i64 a_off, b_off, c_off;    // a/b index Lx; c indexes Lx or the CB arena
+    i32 lda, ldc;
+    i32 m, n, k;                // target region m x n, contraction length k
+    i32 tri;                    // 1: region starts on the diagonal (row0==col0):
+                                //    only tiles with I>=J, and i>=j inside
+    i32 c_in_cb;                // 1: C lives in the CB arena
+    i32 tile_start;             // first tile of this group in the launch
+    i32 mt, nt;                 // tile grid
+    i32 front;
+    i32 pad;
+};
+
+// Contribution blocks are stored as full squares, ld = ncb (lower part used).
+
+__device__ __forceinline__ int lower_bound_i32 (const i32 *a, int n, int v)
+{
+    int lo = 0, hi = n ;
+    while (lo < hi) { int mid = (lo + hi) >> 1 ; if (a [mid] < v) lo = mid + 1 ; else hi = mid ; }
+    return lo ;
+}
+
+template <typename G>
+__device__ __forceinline__ int find_group (const G *g, int ng, int b, i32 G::*start)
+{
+    int lo = 0, hi = ng - 1 ;
+    while (lo < hi)
+    {
+        int mid = (lo + hi + 1) >> 1 ;
+        if (g [mid].*start <= b) lo = mid ; else hi = mid - 1 ;
+    }
+    return lo ;
+}
+
+// ---- one-time: child -> parent relative row maps ---------------------------
+// relmap[rel_d + i] = position of row Ls[pi_d + nscol_d + i] in the parent's
+// row list; the reference builds the same numbers through Map[] at
+// t_cholmod_super_numeric.c:326-333 and :743-750.  One wave per child, lanes
+// stride the rows ("gather" of sorted lists by binary search).
+__global__ void __launch_bounds__(256) k_relmap (int nsuper, const FrontD *fr,
+    const i64 *Ls, i32 *relmap)
+{
+    int wave = (blockIdx.x * 256 + threadIdx.x) >> 6 ;
+    int lane = threadIdx.x & 63 ;
+    if (wave >= nsuper) return ;
+    FrontD d = fr [wave] ;
+    if (d.parent < 0 || d.ncb == 0) return ;
+    FrontD p = fr [d.parent] ;
+    const i64 *prow = Ls + p.psi ;
+    const i64 *drow = Ls + d.psi + d.nscol ;
+    for (int i = lane ; i < d.ncb ; i += 64)
+    {
+        i64 r = drow [i] ;
+        int lo = 0, hi = p.nsrow ;
+        while (lo < hi) { int mid = (lo + hi) >> 1 ; if (prow [mid] < r) lo = mid + 1 ; else hi = mid ; }
+        relmap [d.rel + i] = lo ;
+    }
+}
+
+// ---- assemble A into the panels ---------------------------------------------
+// reference: t_cholmod_super_numeric.c:353-431 (ASSIGN semantics, entries not
+// in the symbolic pattern are dropped, beta added to the diagonal).
+__global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
+    const i64 *Snz, const i64 *Si, const double *Sx, const i32 *supermap,
+    const FrontD *fr, const i64 *Ls, double *Lx, double beta)
+{
+    i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (k >= n) return ;
+    const FrontD &f = fr [supermap [k]] ;
+    i64 psx = f.psx, psi = f.psi ;
+    int nsrow = f.nsrow, k1 = f.k1 ;
+    const i64 *rows = Ls + psi ;
+    double *col = Lx + psx + (i64) (k - k1) * nsrow ;
+    i64 p = Sp [k], pend = Snz ? p + Snz [k] : Sp [k+1] ;
+    for ( ; p < pend ; p++)
+    {
+        i64 i = Si [p] ;
+        if (i < k) continue ;
+        int lo = 0, hi = nsrow ;
+        while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows [mid] < i) lo = mid + 1 ; else hi = mid ; }
+        if (lo < nsrow && rows [lo] == i) col [lo] = Sx [p] ;
+    }
+    if (beta != 0.0) col [k - k1] += beta ;
+}
+
+// ---- zero the contribution blocks of a level --------------------------------
+#define ZERO_CHUNK 8192
+__global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, double *CB)
+{
+    int gi = find_group (g, ng, (int) blockIdx.x, &ZeroGroup::blk_start) ;
+    ZeroGroup G = g [gi] ;
+    i64 base = (i64) (blockIdx.x - G.blk_start) * ZERO_CHUNK ;
+    i64 end = base + ZERO_CHUNK ; if (end > G.len) end = G.len ;
+    double *dst = CB + G.off ;
+    for (i64 e = base + threadIdx.x ; e < end ; e += 256) dst [e] = 0.0 ;
+}
+
+// ---- extend-add: pull the children's contribution blocks into a front -------
+// One workgroup owns EA_TW consecutive target columns of the parent front and
+// visits every child; wave w owns the target columns == w (mod 4), so no two
+// waves ever touch the same entry and no atomics are needed.  Reads of a child
+// CB column are contiguous (coalesced); the target rows follow the relative
+// map.  reference scatter: t_cholmod_super_numeric.c:756-772.
+#define EA_TW 16
+__global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
+    const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB)
+{
+    int gi = find_group (g, ng, (int) blockIdx.x, &EaGroup::blk_start) ;
+    const FrontD &P = fr [g [gi].front] ;
+    int c0 = ((int) blockIdx.x - g [gi].blk_start) * EA_TW ;
+    int c1 = c0 + EA_TW ;
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
+    i64 Ppsx = P.psx, Pcb = P.cb ;
+    int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
+    int cb = P.child_begin, ce = P.child_end ;
+    for (int ci = cb ; ci < ce ; ci++)
+    {
+        const FrontD &Cc = fr [child [ci]] ;
+        const i32 *rm = relmap + Cc.rel ;
+        int nc = Cc.ncb ;
+        const double *src = CB + Cc.cb ;
+        int j0 = lower_bound_i32 (rm, nc, c0) ;
+        int j1 = lower_bound_i32 (rm, nc, c1) ;
+        for (int j = j0 ; j < j1 ; j++)
+        {
+            int tc = rm [j] ;
+            if ((tc & 3) != wave) continue ;
+            double *dst ;
+            int roff ;
+            if (tc < Pnscol) { dst = Lx + Ppsx + (i64) tc * Pnsrow ; roff = 0 ; }
+            else { dst = CB + Pcb + (i64) (tc - Pnscol) * Pncb ; roff = Pnscol ; }
+            const double *sc = src + (i64) j * nc ;
+            for (int i = j + lane ; i < nc ; i += 64)
+                dst [rm [i] - roff] += sc [i] ;
+        }
+    }
+}
+
+// ---- diagonal-block Cholesky (nb <= 64), one wave per block ----------------
+// LAPACK dpotrf("L") semantics on the nb x nb block (reference call
+// t_cholmod_super_numeric.c:864-867): the first pivot <= 0 stops the
+// factorization and is reported 1-based, relative to the front, in info[front];
+// NaN pivots do not stop it (:907-908).  After a failure every remaining
+// column of this front is written as zero (:889-895, :926-931).
+#define PF_NB 64
+__global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32 *info)
+{
+    __shared__ double T [PF_NB][PF_NB + 1] ;
+    PfGroup G = g [blockIdx.x] ;
+    double *A = Lx + G.off ;
+    int nb = G.nb, lda = G.lda, lane = threadIdx.x ;
+    if (info [G.front] != 0)
+    {
+        for (int j = 0 ; j < nb ; j++)
+            if (lane >= j && lane < nb) A [lane + (i64) j * lda] = 0.0 ;
+        return ;
+    }
+    for (int j = 0 ; j < nb ; j++)
+        if (lane < nb) T [lane][j] = A [lane + (i64) j * lda] ;
+    __syncthreads () ;
+    int fail = -1 ;
+    for (int j = 0 ; j < nb ; j++)
+    {
+        double v = 0.0 ;
+        if (lane >= j && lane < nb)
+        {
+            v = T [lane][j] ;
+            for (int k = 0 ; k < j ; k++) v -= T [lane][k] * T [j][k] ;
+        }
+        double d = __shfl (v, j) ;
+        if (d <= 0.0) { fail = j ; break ; }
+        double r = sqrt (d) ;
+        if (lane == j) T [lane][j] = r ;
+        else if (lane > j && lane < nb) T [lane][j] = v / r ;
+        __syncthreads () ;
+    }
+    if (fail >= 0)
+    {
+        if (lane == 0) info [G.front] = G.col0 + fail + 1 ;
+        for (int j = fail ; j < nb ; j++)
+            if (lane < nb) T [lane][j] = 0.0 ;
+    }
+    __syncthreads () ;
+    for (int j = 0 ; j < nb ; j++)
+        if (lane >= j && lane < nb) A [lane + (i64) j * lda] = T [lane][j] ;
+}
+
+// ---- panel triangular solve: B := B * inv(L11)' , one thread per row --------
+// dtrsm("R","L","C","N") of the reference (:997-1002).  L11 (nb <= 64) is
+// staged in LDS and broadcast; each thread keeps its row of B in registers.
+// Columns at or beyond a failed pivot are written as zero.
+#define TR_ROWS 128
+#define TR_CW 8
+__global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
+    double *Lx, const i32 *info)
+{
+    // Lt[k][j] = L11(j,k): for a fixed earlier column k the multipliers of a
+    // group of TR_CW target columns are contiguous (one broadcast LDS line)
+    __shared__ double Lt [PF_NB * PF_NB] ;
+    int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
+    TrGroup G = g [gi] ;
+    int nb = G.nb, lda = G.lda ;
+    int nbp = (nb + TR_CW - 1) / TR_CW * TR_CW ;
+    const double *L11 = Lx + G.l_off ;
+    int inf = info [G.front] ;
+    int nvalid = nb ;
+    if (inf != 0)
+    {
+        nvalid = inf - 1 - G.col0 ;
+        if (nvalid < 0) nvalid = 0 ;
+        if (nvalid > nb) nvalid = nb ;
+    }
+    // stage L11', identity-padded to a multiple of TR_CW and beyond a failed
+    // pivot (so the unrolled solve never divides by a zeroed diagonal)
+    for (int e = threadIdx.x ; e < nbp * nbp ; e += TR_ROWS)
+    {
+        int j = e % nbp, k = e / nbp ;      // L11(j,k), j >= k
+        double v = (j == k) ? 1.0 : 0.0 ;
+        if (j < nvalid && k <= j) v = L11 [j + (i64) k * lda] ;
+        Lt [k * PF_NB + j] = v ;
+    }
+    __syncthreads () ;
+    int row = ((int) blockIdx.x - G.blk_start) * TR_ROWS + threadIdx.x ;
+    if (row >= G.m) return ;
+    double *B = Lx + G.b_off + row ;
+    for (int jb = 0 ; jb < nbp ; jb += TR_CW)
+    {
+        double xb [TR_CW] ;
+#pragma unroll
+        for (int c = 0 ; c < TR_CW ; c++)
+            xb [c] = (jb + c < nb) ? B [(i64) (jb + c) * lda] : 0.0 ;
+        for (int k = 0 ; k < jb ; k++)
+        {
+            double xk = B [(i64) k * lda] ;         // solved in an earlier group
+            const double *lt = Lt + k * PF_NB + jb ;
+#pragma unroll
+            for (int c = 0 ; c < TR_CW ; c++) xb [c] -= xk * lt [c] ;
+        }
+#pragma unroll
+        for (int c = 0 ; c < TR_CW ; c++)
+        {
+            double v = xb [c] ;
+#pragma unroll
+            for (int d = 0 ; d < c ; d++) v -= xb [d] * Lt [(jb + d) * PF_NB + jb + c] ;
+            xb [c] = v / Lt [(jb + c) * PF_NB + jb + c] ;
+        }
+#pragma unroll
+        for (int c = 0 ; c < TR_CW ; c++)
+            if (jb + c < nb) B [(i64) (jb + c) * lda] = (jb + c < nvalid) ? xb [c] : 0.0 ;
+    }
+}
+
+// ---- dense update  C -= A * B'  (fp64 MFMA 16x16x4 tiles) -------------------
+// The contraction the reference performs with dsyrk/dgemm per descendant
+// (:682-717) and LAPACK performs inside dpotrf.  A and B are row blocks of the
+// same packed panel (leading dimension lda), C is a region of a panel or of a
+// contribution block.  One workgroup (4 waves, 2x2) owns a BM x BN tile of C;
+// A/B k-slabs of BK columns are staged in LDS k-major with a 16-double pad so
+// the 16x4 MFMA operand reads are bank-conflict free; the next slab is
+// prefetched into registers while the current one feeds the matrix cores.
+// The MFMA is issued as D' = Bfrag x Afrag so that a lane holds C(i0+(l&15),
+// j0+(l>>4)+4r): consecutive lanes then touch consecutive rows of a column of
+// the column-major target and the read-modify-write is coalesced.
+typedef double d4 __attribute__((ext_vector_type(4))) ;
+
+__device__ __forceinline__ void decode_tile (const GemmGroup &G, int t, int &I, int &J)
+{
+    if (!G.tri) { I = t % G.mt ; J = t / G.mt ; return ; }
+    // rows I < nt hold I+1 tiles (triangle), rows I >= nt hold nt tiles
+    i64 ntri = (i64) G.nt * (G.nt + 1) / 2 ;
+    if (t < ntri)
+    {
+        int r = (int) ((sqrt (8.0 * (double) t + 1.0) - 1.0) * 0.5) ;
+        while ((i64) (r + 1) * (r + 2) / 2 <= t) r++ ;
+        while ((i64) r * (r + 1) / 2 > t) r-- ;
+        I = r ; J = t - (int) ((i64) r * (r + 1) / 2) ;
+    }
+    else
+    {
+        int u = t - (int) ntri ;
+        I = G.nt + u / G.nt ; J = u % G.nt ;
+    }
+}
+
+template <int BM, int BN, int BK, bool USE_MFMA>
+__global__ void __launch_bounds__(256) k_update (const GemmGroup *g, int ng,
+    double *Lx, double *CB)
+{
+    constexpr int LDT = BM + 16 ;           // k-major LDS row stride (A), see above
+    constexpr int LDU = BN + 16 ;
+    constexpr int WM = BM / 2, WN = BN / 2 ; // per-wave tile
+    constexpr int TI = WM / 16, TJ = WN / 16 ;
+    constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256 ;
+    __shared__ double As [BK * LDT] ;
+    __shared__ double Bs [BK * LDU] ;
+
+    int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
+    GemmGroup G = g [gi] ;
+    int I, J ;
+    decode_tile (G, (int) blockIdx.x - G.tile_start, I, J) ;
+    int row0 = I * BM, col0 = J * BN ;
+    int mrem = G.m - row0, nrem = G.n - col0 ;      // valid rows / cols in tile
+    const double *A = Lx + G.a_off + row0 ;
+    const double *B = Lx + G.b_off + col0 ;
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    int lda = G.lda, K = G.k ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    int wm = wave & 1, wn = wave >> 1 ;
+
+    double ra [NA], rb [NB_] ;
+    auto gload = [&] (int k0)
+    {
+#pragma unroll
+        for (int q = 0 ; q < NA ; q++)
+        {
+            int idx = tid + 256 * q ;
+            int i = idx % BM, k = idx / BM ;
+            ra [q] = (i < mrem && k0 + k < K) ? A [i + (i64) (k0 + k) * lda] : 0.0 ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < NB_ ; q++)
+        {
+            int idx = tid + 256 * q ;
+            int j = idx % BN, k = idx / BN ;
+            rb [q] = (j < nrem && k0 + k < K) ? B [j + (i64) (k0 + k) * lda] : 0.0 ;
+        }
+    } ;
+    auto lstore = [&] ()
+    {
+#pragma unroll
+        for (int q = 0 ; q < NA ; q++)
+        {
+            int idx = tid + 256 * q ;
+            As [(idx / BM) * LDT + (idx % BM)] = ra [q] ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < NB_ ; q++)
+        {
+            int idx = tid + 256 * q ;
+            Bs [(idx / BN) * LDU + (idx % BN)] = rb [q] ;
+        }
+    } ;
+
+    if constexpr (USE_MFMA)
+    {
+        d4 acc [TI][TJ] ;
+#pragma unroll
+        for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++) acc [a][b] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+        gload (0) ;
+        for (int k0 = 0 ; k0 < K ; k0 += BK)
+        {
+            __syncthreads () ;
+            lstore () ;
+            __syncthreads () ;
+            if (k0 + BK < K) gload (k0 + BK) ;
+#pragma unroll
+            for (int kk = 0 ; kk < BK ; kk += 4)
+            {
+                double af [TI], bf [TJ] ;
+                int kr = kk + (lane >> 4) ;
+#pragma unroll
+                for (int a = 0 ; a < TI ; a++)
+                    af [a] = As [kr * LDT + wm * WM + a * 16 + (lane & 15)] ;
+#pragma unroll
+                for (int b = 0 ; b < TJ ; b++)
+                    bf [b] = Bs [kr * LDU + wn * WN + b * 16 + (lane & 15)] ;
+#pragma unroll
+                for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+                    for (int b = 0 ; b < TJ ; b++)
+                        acc [a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64 (
+                            bf [b], af [a], acc [a][b], 0, 0, 0) ;
+            }
+        }
+        // lane holds C(i, j) with i = .. + (lane&15), j = .. + (lane>>4) + 4r
+#pragma unroll
+        for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int i = wm * WM + a * 16 + (lane & 15) ;
+                    int j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
+                    if (i < mrem && j < nrem && (!G.tri || row0 + i >= col0 + j))
+                        C [i + (i64) j * G.ldc] -= acc [a][b][r] ;
+                }
+    }
+    else
+    {
+        // VALU reference path (debug / cross-check of the MFMA operand maps):
+        // thread (ti,tj) of a 16x16 grid owns a (BM/16) x (BN/16) sub-tile.
+        constexpr int RM = BM / 16, RN = BN / 16 ;
+        double acc [RM][RN] ;
+#pragma unroll
+        for (int a = 0 ; a < RM ; a++)
+#pragma unroll
+            for (int b = 0 ; b < RN ; b++) acc [a][b] = 0.0 ;
+        int ti = tid & 15, tj = tid >> 4 ;
+        gload (0) ;
+        for (int k0 = 0 ; k0 < K ; k0 += BK)
+        {
+            __syncthreads () ;
+            lstore () ;
+            __syncthreads () ;
+            if (k0 + BK < K) gload (k0 + BK) ;
+#pragma unroll
+            for (int kk = 0 ; kk < BK ; kk++)
+            {
+                double af [RM], bf [RN] ;
+#pragma unroll
+                for (int a = 0 ; a < RM ; a++) af [a] = As [kk * LDT + ti + 16 * a] ;
+#pragma unroll
+                for (int b = 0 ; b < RN ; b++) bf [b] = Bs [kk * LDU + tj + 16 * b] ;
+#pragma unroll
+                for (int a = 0 ; a < RM ; a++)
+#pragma unroll
+                    for (int b = 0 ; b < RN ; b++) acc [a][b] += af [a] * bf [b] ;
+            }
+        }
+#pragma unroll
+        for (int a = 0 ; a < RM ; a++)
+#pragma unroll
+            for (int b = 0 ; b < RN ; b++)
+            {
+                int i = ti + 16 * a, j = tj + 16 * b ;
+                if (i < mrem && j < nrem && (!G.tri || row0 + i >= col0 + j))
+                    C [i + (i64) j * G.ldc] -= acc [a][b] ;
+            }
+    }
+}
+
+// ---- triangular solves with the device-resident factor (nrhs columns) -------
+// Level-scheduled restatement of cholmod_l_super_lsolve / _ltsolve
+// (t_cholmod_super_solve.c:14-220, :222-411).  One workgroup per supernode of
+// the level.  Forward: x1 = L1 \ x1 ; X[Ls2] -= L2 * x1 (children of one parent
+// may hit the same rows, hence the atomic add).  Backward: x1 = L1' \ (x1 -
+// L2' * X[Ls2]) needs no atomics.
+__global__ void __launch_bounds__(256) k_lsolve (const i32 *fronts,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
+{
+    __shared__ double xb [64] ;
+    const FrontD &f = fr [fronts [blockIdx.x]] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    int lane = tid & 63, wave = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    for (int r = 0 ; r < nrhs ; r++)
+    {
+        double *x = X + (i64) r * ldx ;
+        for (int jb = 0 ; jb < nscol ; jb += 64)
+        {
+            int nb = nscol - jb < 64 ? nscol - jb : 64 ;
+            if (wave == 0)
+            {
+                // dtrsv("L","N","N") on the 64-wide diagonal block, one wave
+                double xv = (lane < nb) ? x [k1 + jb + lane] : 0.0 ;
+                for (int j = 0 ; j < nb ; j++)
+                {
+                    double xj = __shfl (xv, j) / L [(jb + j) + (i64) (jb + j) * nsrow] ;
+                    if (lane == j) xv = xj ;
+                    else if (lane > j && lane < nb)
+                        xv -= L [(jb + lane) + (i64) (jb + j) * nsrow] * xj ;
+                }
+                xb [lane] = xv ;
+                if (lane < nb) x [k1 + jb + lane] = xv ;
+            }
+            __syncthreads () ;
+            for (int i = jb + nb + tid ; i < nscol ; i += 256)
+            {
+                double acc = 0.0 ;
+                for (int j = 0 ; j < nb ; j++) acc += L [i + (i64) (jb + j) * nsrow] * xb [j] ;
+                x [k1 + i] -= acc ;
+            }
+            __syncthreads () ;
+        }
+        // dgemv: X[rows2] -= L2 * x1 ; siblings share ancestor rows -> atomic
+        for (int i = nscol + tid ; i < nsrow ; i += 256)
+        {
+            double acc = 0.0 ;
+            for (int j = 0 ; j < nscol ; j++) acc += L [i + (i64) j * nsrow] * x [k1 + j] ;
+            atomicAdd (&x [rows [i]], -acc) ;
+        }
+        __syncthreads () ;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ltsolve (const i32 *fronts,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
+{
+    __shared__ double xb [64] ;
+    const FrontD &f = fr [fronts [blockIdx.x]] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    int lane = tid & 63, wave = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    for (int r = 0 ; r < nrhs ; r++)
+    {
+        double *x = X + (i64) r * ldx ;
+        // dgemv("C"): x1 -= L2' * X[rows2]; one wave per column
+        for (int j = wave ; j < nscol ; j += 4)
+        {
+            double acc = 0.0 ;
+            for (int i = nscol + lane ; i < nsrow ; i += 64)
+                acc += L [i + (i64) j * nsrow] * x [rows [i]] ;
+            for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
+            if (lane == 0) x [k1 + j] -= acc ;
+        }
+        __syncthreads () ;
+        // dtrsv("L","C","N") by 64-wide blocks from the bottom
+        int last = ((nscol - 1) / 64) * 64 ;
+        for (int jb = last ; jb >= 0 ; jb -= 64)
+        {
+            int nb = nscol - jb < 64 ? nscol - jb : 64 ;
+            for (int jj = wave ; jj < nb ; jj += 4)
+            {
+                int j = jb + jj ;
+                double acc = 0.0 ;
+                for (int i = jb + nb + lane ; i < nscol ; i += 64)
+                    acc += L [i + (i64) j * nsrow] * x [k1 + i] ;
+                for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
+                if (lane == 0) xb [jj] = x [k1 + j] - acc ;
+            }
+            __syncthreads () ;
+            if (wave == 0)
+            {
+                double xv = (lane < nb) ? xb [lane] : 0.0 ;
+                for (int j = nb - 1 ; j >= 0 ; j--)
+                {
+                    double xj = __shfl (xv, j) / L [(jb + j) + (i64) (jb + j) * nsrow] ;
+                    if (lane == j) xv = xj ;
+                    else if (lane < j)
+                        xv -= L [(jb + j) + (i64) (jb + lane) * nsrow] * xj ;
+                }
+                if (lane < nb) x [k1 + jb + lane] = xv ;
+            }
+            __syncthreads () ;
+        }
+    }
+}
+
+// gather / scatter by the fill-reducing permutation (cholmod_solve.c:105,:322)
+__global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
+    int inverse)
+{
+    i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (k >= n) return ;
+    if (inverse) dst [perm [k]] = src [k] ; else dst [k] = src [perm [k]] ;
+}
+
+// plain dense C -= A*B' wrapper data for the micro-benchmark uses k_update too.
+
+} // namespace sship

@@ -1,0 +1,677 @@
+/* analyze.c -- symbolic analysis of the host layer: elimination tree, weighted
+ * postorder, column counts, cholmod_l_analyze[_p|_p2] and the supernodal
+ * symbolic factorization.  Integer-only host code; the index maps it produces
+ * (super / pi / px / s / maxcsize / maxesize) are contractual: bit-exact with
+ * the reference's useGPU==0 partition (SURVEY.md finding 3 -- no device-buffer
+ * driven supernode splits are applied here, unlike the reference's GPU branch
+ * at CHOLMOD/Supernodal/cholmod_super_symbolic.c:422-429, :582-592).
+ *
+ * Reference files: CHOLMOD/Cholesky/cholmod_etree.c, cholmod_postorder.c,
+ * cholmod_rowcolcounts.c, cholmod_analyze.c; CHOLMOD/Supernodal/
+ * cholmod_super_symbolic.c. */
+#include "host_internal.h"
+
+/* ---- elimination tree ------------------------------------------------------------ */
+
+/* Liu's algorithm with path compression over an upper-stored pattern
+ * (reference Cholesky/cholmod_etree.c:81-223, stype > 0 branch). */
+int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent)
+{
+    Int *anc = malloc ((n > 0 ? n : 1) * sizeof (Int)) ;
+    if (!anc) return FALSE ;
+    for (Int j = 0 ; j < n ; j++) { Parent [j] = EMPTY ; anc [j] = EMPTY ; }
+    for (Int j = 0 ; j < n ; j++)
+    {
+        for (Int p = Up [j] ; p < Up [j+1] ; p++)
+        {
+            Int i = Ui [p] ;
+            /* climb from i towards the root, hanging every visited root under j */
+            while (i < j)
+            {
+                Int up = anc [i] ;
+                anc [i] = j ;
+                if (up == EMPTY) { Parent [i] = j ; break ; }
+                if (up == j) break ;
+                i = up ;
+            }
+        }
+    }
+    free (anc) ;
+    return TRUE ;
+}
+
+int cholmod_l_etree (cholmod_sparse *A, SuiteSparse_long *Parent, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (A, FALSE) ;
+    RETURN_IF_NULL (Parent, FALSE) ;
+    Common->status = CHOLMOD_OK ;
+    if (A->stype < 0) { ERROR (CHOLMOD_INVALID, "symmetric lower not supported") ; return FALSE ; }
+    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "etree(A'A) not built") ; return FALSE ; }
+    if (!A->packed) { ERROR (CHOLMOD_NOT_INSTALLED, "unpacked etree input not built") ; return FALSE ; }
+    if (!ssamd_etree_upper ((Int) A->ncol, A->p, A->i, Parent))
+    { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return FALSE ; }
+    return TRUE ;
+}
+
+/* ---- postorder --------------------------------------------------------------------- */
+
+/* Children are visited in increasing weight, ties in increasing node number
+ * (no weights: increasing node number); roots in increasing node number.
+ * This is the visiting order the reference obtains from its bucket lists
+ * (Cholesky/cholmod_postorder.c:185-260) and non-recursive dfs (:60-94).
+ * work3n: 3n Ints. */
+Int ssamd_postorder (Int n, const Int *Parent, const Int *Weight, Int *Post, Int *work)
+{
+    Int *first_child = work, *sibling = work + n, *stack = work + 2*n ;
+    for (Int j = 0 ; j < n ; j++) first_child [j] = EMPTY ;
+    if (!Weight)
+    {
+        for (Int j = n - 1 ; j >= 0 ; j--)
+        {
+            Int p = Parent [j] ;
+            if (p >= 0 && p < n) { sibling [j] = first_child [p] ; first_child [p] = j ; }
+        }
+    }
+    else
+    {
+        /* counting sort of the nodes by clamped weight (stable in node number),
+         * then push them on their parents' lists from heaviest to lightest so
+         * that every list ends up lightest-first */
+        Int *bucket = stack ;                   /* n counters, reused as stack later */
+        Int *order = malloc ((n > 0 ? n : 1) * sizeof (Int)) ;
+        if (!order) return EMPTY ;
+        for (Int w = 0 ; w < n ; w++) bucket [w] = 0 ;
+        for (Int j = 0 ; j < n ; j++)
+        {
+            Int w = Weight [j] ; if (w < 0) w = 0 ; if (w > n - 1) w = n - 1 ;
+            bucket [w]++ ;
+        }
+        Int run = 0 ;
+        for (Int w = 0 ; w < n ; w++) { Int c = bucket [w] ; bucket [w] = run ; run += c ; }
+        for (Int j = 0 ; j < n ; j++)
+        {
+            Int w = Weight [j] ; if (w < 0) w = 0 ; if (w > n - 1) w = n - 1 ;
+            order [bucket [w]++] = j ;
+        }
+        for (Int q = n - 1 ; q >= 0 ; q--)
+        {
+            Int j = order [q] ;
+            Int p = Parent [j] ;
+            if (p >= 0 && p < n) { sibling [j] = first_child [p] ; first_child [p] = j ; }
+        }
+        free (order) ;
+    }
+    Int k = 0 ;
+    for (Int r = 0 ; r < n ; r++)
+    {
+        if (Parent [r] != EMPTY) continue ;
+        Int top = 0 ;
+        stack [0] = r ;
+        while (top >= 0)
+        {
+            Int node = stack [top] ;
+            Int c = first_child [node] ;
+            if (c == EMPTY) { Post [k++] = node ; top-- ; }
+            else { first_child [node] = sibling [c] ; stack [++top] = c ; }
+        }
+    }
+    return k ;
+}
+
+SuiteSparse_long cholmod_l_postorder (SuiteSparse_long *Parent, size_t n,
+    SuiteSparse_long *Weight, SuiteSparse_long *Post, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (EMPTY) ;
+    RETURN_IF_NULL (Parent, EMPTY) ;
+    RETURN_IF_NULL (Post, EMPTY) ;
+    Common->status = CHOLMOD_OK ;
+    Int *work = cholmod_l_malloc (3 * n + 1, sizeof (Int), Common) ;
+    if (!work) return EMPTY ;
+    Int k = ssamd_postorder ((Int) n, Parent, Weight, Post, work) ;
+    cholmod_l_free (3 * n + 1, sizeof (Int), work, Common) ;
+    if (k == EMPTY) ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ;
+    return k ;
+}
+
+/* ---- column counts ------------------------------------------------------------------ */
+
+/* Gilbert-Ng-Peyton skeleton algorithm on a lower-stored pattern (column j
+ * holds the rows i >= j of the symmetric matrix).  Produces the counts the
+ * reference computes at Cholesky/cholmod_rowcolcounts.c:184-533 (diagonal
+ * included).  work5n: 5n Ints. */
+void ssamd_colcounts (Int n, const Int *Lp, const Int *Li, const Int *Parent, const Int *Post,
+    Int *ColCount, Int *work)
+{
+    Int *first = work, *maxfirst = work + n, *prevleaf = work + 2*n, *setroot = work + 3*n ;
+    Int *delta = ColCount ;
+    for (Int j = 0 ; j < n ; j++) { first [j] = EMPTY ; maxfirst [j] = EMPTY ; prevleaf [j] = EMPTY ; setroot [j] = j ; }
+    for (Int k = 0 ; k < n ; k++)
+    {
+        Int j = Post [k] ;
+        delta [j] = (first [j] == EMPTY) ? 1 : 0 ;         /* 1 for a leaf of the etree */
+        for ( ; j != EMPTY && first [j] == EMPTY ; j = Parent [j]) first [j] = k ;
+    }
+    for (Int k = 0 ; k < n ; k++)
+    {
+        Int j = Post [k] ;
+        if (Parent [j] != EMPTY) delta [Parent [j]]-- ;
+        for (Int p = Lp [j] ; p < Lp [j+1] ; p++)
+        {
+            Int i = Li [p] ;
+            if (i <= j || first [j] <= maxfirst [i]) continue ;  /* j not a leaf of row subtree i */
+            maxfirst [i] = first [j] ;
+            Int jprev = prevleaf [i] ;
+            prevleaf [i] = j ;
+            delta [j]++ ;
+            if (jprev != EMPTY)
+            {
+                /* least common ancestor of the previous leaf and j */
+                Int q = jprev ;
+                while (q != setroot [q]) q = setroot [q] ;
+                for (Int s = jprev ; s != q ; ) { Int nx = setroot [s] ; setroot [s] = q ; s = nx ; }
+                delta [q]-- ;
+            }
+        }
+        if (Parent [j] != EMPTY) setroot [j] = Parent [j] ;
+    }
+    for (Int j = 0 ; j < n ; j++)
+        if (Parent [j] != EMPTY) ColCount [Parent [j]] += ColCount [j] ;
+}
+
+int cholmod_l_rowcolcounts (cholmod_sparse *A, SuiteSparse_long *fset, size_t fsize,
+    SuiteSparse_long *Parent, SuiteSparse_long *Post, SuiteSparse_long *RowCount,
+    SuiteSparse_long *ColCount, SuiteSparse_long *First, SuiteSparse_long *Level,
+    cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (A, FALSE) ;
+    RETURN_IF_NULL (Parent, FALSE) ;
+    RETURN_IF_NULL (Post, FALSE) ;
+    RETURN_IF_NULL (ColCount, FALSE) ;
+    (void) fset ; (void) fsize ;
+    Common->status = CHOLMOD_OK ;
+    if (A->stype > 0) { ERROR (CHOLMOD_INVALID, "symmetric upper not supported") ; return FALSE ; }
+    if (A->stype == 0 || !A->packed) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' counts not built") ; return FALSE ; }
+    Int n = (Int) A->nrow ;
+    Int *work = cholmod_l_malloc (5 * (size_t) n + 1, sizeof (Int), Common) ;
+    if (!work) return FALSE ;
+    ssamd_colcounts (n, A->p, A->i, Parent, Post, ColCount, work) ;
+    if (First) for (Int j = 0 ; j < n ; j++) First [j] = work [j] ;
+    if (Level)
+    {
+        for (Int k = n - 1 ; k >= 0 ; k--)
+        {
+            Int j = Post [k] ;
+            Level [j] = (Parent [j] == EMPTY) ? 0 : Level [Parent [j]] + 1 ;
+        }
+    }
+    if (RowCount)
+    {
+        /* nnz in row i of L = size of the row subtree; recount with marking
+         * (only used for statistics, O(nnz(L))) */
+        Int *mark = work ;
+        for (Int i = 0 ; i < n ; i++) { RowCount [i] = 1 ; mark [i] = EMPTY ; }
+        cholmod_sparse *U = cholmod_l_ptranspose (A, 0, NULL, NULL, 0, Common) ;
+        if (U)
+        {
+            Int *Up = U->p, *Ui = U->i ;
+            for (Int i = 0 ; i < n ; i++)
+            {
+                mark [i] = i ;
+                for (Int p = Up [i] ; p < Up [i+1] ; p++)
+                    for (Int k = Ui [p] ; k < i && mark [k] != i ; k = Parent [k]) { RowCount [i]++ ; mark [k] = i ; }
+            }
+            cholmod_l_free_sparse (&U, Common) ;
+        }
+    }
+    double fl = 0, lnz = 0 ;
+    for (Int j = 0 ; j < n ; j++) { double c = (double) ColCount [j] ; fl += c * c ; lnz += c ; }
+    Common->fl = fl ; Common->lnz = lnz ;       /* rowcolcounts.c:517-528 */
+    cholmod_l_free (5 * (size_t) n + 1, sizeof (Int), work, Common) ;
+    return TRUE ;
+}
+
+/* ---- supernodal symbolic ---------------------------------------------------------------- */
+
+/* resolve Common->useGPU == EMPTY from CHOLMOD_USE_GPU as the reference does
+ * (Supernodal/cholmod_super_symbolic.c:257-296); unlike the reference an unset
+ * variable selects the GPU, because the HIP engine is this library's only
+ * numeric path. */
+int ssamd_resolve_use_gpu (cholmod_common *Common)
+{
+    if (Common->useGPU == EMPTY)
+    {
+        const char *e = getenv ("CHOLMOD_USE_GPU") ;
+        Common->useGPU = (e && atoi (e) == 0 && e [0] != '\0') ? 0 : 1 ;
+        const char *b = getenv ("CHOLMOD_GPU_MEM_BYTES") ;
+        if (b) Common->maxGpuMemBytes = (size_t) strtoull (b, NULL, 10) ;
+        const char *f = getenv ("CHOLMOD_GPU_MEM_FRACTION") ;
+        if (f) Common->maxGpuMemFraction = atof (f) ;
+    }
+    return Common->useGPU ;
+}
+
+typedef struct
+{
+    Int first ;     /* leading column */
+    Int ncols ;
+    Int lead_nz ;   /* entries in the leading column (= rows of the supernode) */
+    Int zeros ;     /* explicit zeros accumulated by amalgamation */
+    Int into ;      /* supernode this one has been merged into, or EMPTY */
+    Int tparent ;   /* parent in the fundamental supernodal etree */
+} fsnode ;
+
+static Int live_ancestor (fsnode *F, Int s)
+{
+    Int r = F [s].tparent ;
+    while (F [r].into != EMPTY) r = F [r].into ;
+    /* path compression: everything on the way now points at the live node */
+    for (Int q = F [s].tparent ; F [q].into != EMPTY ; )
+    {
+        Int nx = F [q].into ;
+        F [q].into = r ;
+        q = nx ;
+    }
+    return r ;
+}
+
+int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *Fm,
+    SuiteSparse_long *Parent, cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (A, FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    RETURN_IF_NULL (Parent, FALSE) ;
+    (void) Fm ;
+    if (A->stype < 0) { ERROR (CHOLMOD_INVALID, "symmetric lower not supported") ; return FALSE ; }
+    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' supernodal analysis not built") ; return FALSE ; }
+    if (L->is_super || L->xtype != CHOLMOD_PATTERN)
+    { ERROR (CHOLMOD_INVALID, "L must be symbolic on input") ; return FALSE ; }
+    if (!A->packed) { ERROR (CHOLMOD_NOT_INSTALLED, "unpacked input not built") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    Int n = (Int) A->nrow ;
+    const Int *Up = A->p, *Ui = A->i ;
+    const Int *ColCount = L->ColCount ;
+
+    /* GPU selection only (no memory pools are cut here; the engine reserves HBM
+     * when the plan is created at the first numeric factorization) */
+    if (for_whom == CHOLMOD_ANALYZE_FOR_CHOLESKY && ssamd_resolve_use_gpu (Common) == 1)
+        L->useGPU = cholmod_l_gpu_probe (Common) ;
+    else
+        L->useGPU = 0 ;
+
+    double zr [3] ;
+    for (int t = 0 ; t < 3 ; t++) zr [t] = isnan (Common->zrelax [t]) ? 0 : Common->zrelax [t] ;
+    Int nr0 = (Int) Common->nrelax [0], nr1 = (Int) Common->nrelax [1], nr2 = (Int) Common->nrelax [2] ;
+
+    fsnode *F = cholmod_l_malloc (n + 1, sizeof (fsnode), Common) ;
+    Int *col2s = cholmod_l_malloc (n + 1, sizeof (Int), Common) ;
+    Int *kids = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
+    if (!F || !col2s || !kids)
+    {
+        if (F) cholmod_l_free (n + 1, sizeof (fsnode), F, Common) ;
+        if (col2s) cholmod_l_free (n + 1, sizeof (Int), col2s, Common) ;
+        if (kids) cholmod_l_free (n + 1, sizeof (Int), kids, Common) ;
+        return FALSE ;
+    }
+    /* fundamental supernodes: column j continues the supernode of j-1 iff j is
+     * the only child of... precisely the three tests of :416-435 */
+    for (Int j = 0 ; j < n ; j++) if (Parent [j] != EMPTY) kids [Parent [j]]++ ;
+    Int nf = 0 ;
+    for (Int j = 0 ; j < n ; j++)
+    {
+        int chain = j > 0 && Parent [j-1] == j && ColCount [j-1] == ColCount [j] + 1 && kids [j] <= 1 ;
+        if (!chain)
+        {
+            F [nf].first = j ; F [nf].ncols = 0 ; F [nf].lead_nz = ColCount [j] ;
+            F [nf].zeros = 0 ; F [nf].into = EMPTY ;
+            nf++ ;
+        }
+        F [nf-1].ncols++ ;
+        col2s [j] = nf - 1 ;
+    }
+    for (Int s = 0 ; s < nf ; s++)
+    {
+        Int last = F [s].first + F [s].ncols - 1 ;
+        F [s].tparent = (Parent [last] == EMPTY) ? EMPTY : col2s [Parent [last]] ;
+    }
+    /* relaxed amalgamation, right to left (:478-602) */
+    for (Int s = nf - 2 ; s >= 0 ; s--)
+    {
+        if (F [s].tparent == EMPTY) continue ;
+        if (live_ancestor (F, s) != s + 1) continue ;
+        fsnode *a = &F [s], *b = &F [s+1] ;
+        Int ns = a->ncols + b->ncols ;
+        Int zeros = b->zeros ;
+        int merge ;
+        if (ns <= nr0)
+        {
+            merge = TRUE ;      /* tiny: merged without counting its new zeros (:530-534) */
+        }
+        else
+        {
+            double lnz0 = (double) a->lead_nz, lnz1 = (double) b->lead_nz ;
+            double xnew = a->ncols * (lnz1 + a->ncols - lnz0) ;
+            if (xnew == 0)
+            {
+                merge = TRUE ;
+            }
+            else
+            {
+                double xns = (double) ns ;
+                double xsize = (xns * (xns + 1) / 2) + xns * (lnz1 - b->ncols) ;
+                double z = (((double) zeros) + xnew) / xsize ;
+                zeros += a->ncols * (b->lead_nz + a->ncols - a->lead_nz) ;
+                merge = ((ns <= nr1 && z < zr [0]) || (ns <= nr2 && z < zr [1]) || (z < zr [2]))
+                    && (xsize < (double) INT64_MAX / sizeof (double)) ;
+            }
+        }
+        if (merge)
+        {
+            a->zeros = zeros ;
+            b->into = s ;
+            a->lead_nz = a->ncols + b->lead_nz ;
+            a->ncols = ns ;
+        }
+    }
+    /* relaxed supernodes and their sizes (:612-699) */
+    Int nsuper = 0 ;
+    for (Int s = 0 ; s < nf ; s++) if (F [s].into == EMPTY) nsuper++ ;
+    Int *Super = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *Lpi = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *Lpx = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *Sparent = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *fill = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *seen = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    Int *Ls = NULL ;
+    Int ssize = 0, xsize = 0 ;
+    int ok = Super && Lpi && Lpx && Sparent && fill && seen ;
+    if (ok)
+    {
+        double xx = 0 ;
+        Int q = 0 ;
+        for (Int s = 0 ; s < nf ; s++)
+        {
+            if (F [s].into != EMPTY) continue ;
+            Super [q] = F [s].first ;
+            Lpi [q] = ssize ; Lpx [q] = xsize ;
+            ssize += F [s].lead_nz ;
+            xsize += F [s].ncols * F [s].lead_nz ;
+            xx += (double) F [s].ncols * (double) F [s].lead_nz ;
+            if (ssize < 0 || xx > (double) INT64_MAX)
+            {
+                ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
+                ok = FALSE ;
+                break ;
+            }
+            q++ ;
+        }
+        if (ok)
+        {
+            Super [nsuper] = n ; Lpi [nsuper] = ssize ; Lpx [nsuper] = xsize ;
+            for (Int s = 0 ; s < nsuper ; s++)
+                for (Int k = Super [s] ; k < Super [s+1] ; k++) col2s [k] = s ;
+            for (Int s = 0 ; s < nsuper ; s++)
+            {
+                Int par = Parent [Super [s+1] - 1] ;
+                Sparent [s] = (par == EMPTY) ? EMPTY : col2s [par] ;
+            }
+            Ls = cholmod_l_malloc (ssize > 1 ? ssize : 1, sizeof (Int), Common) ;
+            ok = Ls != NULL ;
+        }
+    }
+    if (ok)
+    {
+        /* row structure: own columns first, then for every column k the
+         * supernodes on the etree paths from the supernodes of A(0:k1-1,k) up
+         * to s receive row k (:786-835).  Lists come out strictly ascending. */
+        Ls [0] = 0 ;
+        for (Int s = 0 ; s < nsuper ; s++) { fill [s] = Lpi [s] ; seen [s] = EMPTY ; }
+        for (Int s = 0 ; s < nsuper ; s++)
+        {
+            Int k1 = Super [s], k2 = Super [s+1] ;
+            for (Int k = k1 ; k < k2 ; k++) Ls [fill [s]++] = k ;
+            for (Int k = k1 ; k < k2 ; k++)
+            {
+                seen [s] = k ;          /* stamps are column numbers: unique per k */
+                for (Int p = Up [k] ; p < Up [k+1] ; p++)
+                {
+                    Int i = Ui [p] ;
+                    if (i >= k1) { if (A->sorted) break ; else continue ; }
+                    for (Int t = col2s [i] ; seen [t] != k ; t = Sparent [t])
+                    {
+                        Ls [fill [t]++] = k ;
+                        seen [t] = k ;
+                    }
+                }
+            }
+        }
+        for (Int s = 0 ; s < nsuper && ok ; s++) if (fill [s] != Lpi [s+1]) ok = FALSE ;
+        if (!ok) ERROR (CHOLMOD_INVALID, "invalid symbolic structure (ColCount/Parent mismatch)") ;
+    }
+    Int maxcsize = 1, maxesize = 1 ;
+    if (ok)
+    {
+        /* largest update matrix / largest set of rows below a diagonal block
+         * (:907-948): runs of rows belonging to one ancestor supernode */
+        for (Int d = 0 ; d < nsuper ; d++)
+        {
+            Int nscol = Super [d+1] - Super [d] ;
+            Int p = Lpi [d] + nscol, pend = Lpi [d+1] ;
+            if (pend - p > maxesize) maxesize = pend - p ;
+            while (p < pend)
+            {
+                Int t = col2s [Ls [p]] ;
+                Int q = p ;
+                while (q < pend && col2s [Ls [q]] == t) q++ ;
+                Int csize = (pend - p) * (q - p) ;
+                if (csize > maxcsize) maxcsize = csize ;
+                p = q ;
+            }
+        }
+        L->nsuper = nsuper ;
+        L->ssize = ssize > 1 ? ssize : 1 ;
+        L->xsize = xsize > 1 ? xsize : 1 ;
+        L->maxcsize = maxcsize ; L->maxesize = maxesize ;
+        L->super = Super ; L->pi = Lpi ; L->px = Lpx ; L->s = Ls ;
+        L->is_super = TRUE ; L->is_ll = TRUE ; L->xtype = CHOLMOD_PATTERN ;
+        L->minor = n ;
+    }
+    else
+    {
+        if (Super) cholmod_l_free (nsuper + 1, sizeof (Int), Super, Common) ;
+        if (Lpi) cholmod_l_free (nsuper + 1, sizeof (Int), Lpi, Common) ;
+        if (Lpx) cholmod_l_free (nsuper + 1, sizeof (Int), Lpx, Common) ;
+        if (Ls) cholmod_l_free (ssize > 1 ? ssize : 1, sizeof (Int), Ls, Common) ;
+    }
+    if (Sparent) cholmod_l_free (nsuper + 1, sizeof (Int), Sparent, Common) ;
+    if (fill) cholmod_l_free (nsuper + 1, sizeof (Int), fill, Common) ;
+    if (seen) cholmod_l_free (nsuper + 1, sizeof (Int), seen, Common) ;
+    cholmod_l_free (n + 1, sizeof (fsnode), F, Common) ;
+    cholmod_l_free (n + 1, sizeof (Int), col2s, Common) ;
+    cholmod_l_free (n + 1, sizeof (Int), kids, Common) ;
+    return ok ;
+}
+
+int cholmod_l_super_symbolic (cholmod_sparse *A, cholmod_sparse *F, SuiteSparse_long *Parent,
+    cholmod_factor *L, cholmod_common *Common)
+{
+    return cholmod_l_super_symbolic2 (CHOLMOD_ANALYZE_FOR_CHOLESKY, A, F, Parent, L, Common) ;
+}
+
+/* ---- analyze -------------------------------------------------------------------------------- */
+
+static cholmod_factor *new_symbolic_factor (Int n, cholmod_common *Common)
+{
+    cholmod_factor *L = cholmod_l_calloc (1, sizeof (cholmod_factor), Common) ;
+    if (!L) return NULL ;
+    L->n = n ; L->minor = n ;
+    L->is_ll = FALSE ; L->is_super = FALSE ; L->is_monotonic = TRUE ;
+    L->itype = CHOLMOD_LONG ; L->xtype = CHOLMOD_PATTERN ; L->dtype = CHOLMOD_DOUBLE ;
+    L->ordering = CHOLMOD_NATURAL ;
+    L->Perm = cholmod_l_malloc (n, sizeof (Int), Common) ;
+    L->ColCount = cholmod_l_malloc (n, sizeof (Int), Common) ;
+    if (!L->Perm || !L->ColCount) { cholmod_l_free_factor (&L, Common) ; return NULL ; }
+    Int *P = L->Perm, *C = L->ColCount ;
+    for (Int j = 0 ; j < n ; j++) { P [j] = j ; C [j] = 1 ; }
+    return L ;
+}
+
+/* upper- and lower-stored patterns of P A P' */
+static int permuted_patterns (cholmod_sparse *A, Int *Perm, cholmod_sparse **U, cholmod_sparse **Lw,
+    cholmod_common *Common)
+{
+    *U = NULL ; *Lw = NULL ;
+    if (A->stype > 0)
+    {
+        *Lw = cholmod_l_ptranspose (A, 0, Perm, NULL, 0, Common) ;
+        if (*Lw) *U = cholmod_l_ptranspose (*Lw, 0, NULL, NULL, 0, Common) ;
+    }
+    else
+    {
+        *U = cholmod_l_ptranspose (A, 0, Perm, NULL, 0, Common) ;
+        if (*U) *Lw = cholmod_l_ptranspose (*U, 0, NULL, NULL, 0, Common) ;
+    }
+    if (!*U || !*Lw)
+    {
+        cholmod_l_free_sparse (U, Common) ;
+        cholmod_l_free_sparse (Lw, Common) ;
+        return FALSE ;
+    }
+    return TRUE ;
+}
+
+/* reference: Cholesky/cholmod_analyze.c:401-935.  Orderings available in this
+ * build: the user's permutation (CHOLMOD_GIVEN) and the natural ordering; the
+ * ordering packages (AMD, COLAMD, METIS/NESDIS) are out of scope, so the
+ * "try several methods, keep the sparsest" loop (:569-804) reduces to the one
+ * candidate at hand.  Then etree, column counts, weighted postorder composed
+ * into L->Perm (:855-906) and the supernodal symbolic factorization (:913-931). */
+cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSparse_long *UserPerm,
+    SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (A, NULL) ;
+    (void) fset ; (void) fsize ;
+    Common->status = CHOLMOD_OK ;
+    if (A->stype == 0)
+    {
+        ERROR (CHOLMOD_NOT_INSTALLED, "analysis of A*A' (stype 0) not built") ;
+        return NULL ;
+    }
+    if (A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "matrix invalid") ; return NULL ; }
+    if (Common->supernodal == CHOLMOD_SIMPLICIAL)
+    {
+        ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built (supernodal only)") ;
+        return NULL ;
+    }
+    Int n = (Int) A->nrow ;
+    cholmod_sparse *Apk = NULL ;
+    if (!A->packed) { Apk = cholmod_l_copy_sparse (A, Common) ; }
+    if (!A->packed)
+    {
+        /* pack a private copy so the transposes can assume packed input */
+        if (!Apk) return NULL ;
+        Int *p = Apk->p, *nzc = Apk->nz, *ii = Apk->i ; double *xx = Apk->x ;
+        Int dst = 0 ;
+        for (Int j = 0 ; j < n ; j++)
+        {
+            Int s = p [j], e = s + nzc [j] ;
+            p [j] = dst ;
+            for (Int q = s ; q < e ; q++) { ii [dst] = ii [q] ; if (xx) xx [dst] = xx [q] ; dst++ ; }
+        }
+        p [n] = dst ;
+        cholmod_l_free (Apk->ncol > 0 ? Apk->ncol : 1, sizeof (Int), Apk->nz, Common) ;
+        Apk->nz = NULL ; Apk->packed = TRUE ;
+        A = Apk ;
+    }
+    cholmod_factor *L = new_symbolic_factor (n, Common) ;
+    Int *Parent = cholmod_l_malloc (n + 1, sizeof (Int), Common) ;
+    Int *Post = cholmod_l_malloc (n + 1, sizeof (Int), Common) ;
+    Int *work = cholmod_l_malloc (5 * (size_t) n + 1, sizeof (Int), Common) ;
+    cholmod_sparse *U = NULL, *Lw = NULL ;
+    int ok = L && Parent && Post && work ;
+    if (ok)
+    {
+        Int *Perm = L->Perm ;
+        if (UserPerm)
+        {
+            /* validate (reference cholmod_analyze.c:617-635 via check_perm) */
+            for (Int k = 0 ; k < n ; k++) work [k] = 0 ;
+            for (Int k = 0 ; k < n && ok ; k++)
+            {
+                Int j = UserPerm [k] ;
+                if (j < 0 || j >= n || work [j]) ok = FALSE ; else work [j] = 1 ;
+            }
+            if (!ok) ERROR (CHOLMOD_INVALID, "invalid UserPerm") ;
+            else for (Int k = 0 ; k < n ; k++) Perm [k] = UserPerm [k] ;
+            L->ordering = CHOLMOD_GIVEN ;
+        }
+        else L->ordering = CHOLMOD_NATURAL ;
+    }
+    ok = ok && permuted_patterns (A, L->Perm, &U, &Lw, Common) ;
+    if (ok)
+    {
+        Int *Perm = L->Perm, *ColCount = L->ColCount ;
+        ok = ssamd_etree_upper (n, U->p, U->i, Parent)
+            && ssamd_postorder (n, Parent, NULL, Post, work) == n ;
+        if (ok) ssamd_colcounts (n, Lw->p, Lw->i, Parent, Post, ColCount, work) ;
+        if (ok)
+        {
+            double fl = 0, lnz = 0 ;
+            for (Int j = 0 ; j < n ; j++) { double c = (double) ColCount [j] ; fl += c * c ; lnz += c ; }
+            Common->fl = fl ; Common->lnz = lnz ;
+            Common->anz = (double) ((Int *) U->p) [n] ;
+            Common->method [0].fl = fl ; Common->method [0].lnz = lnz ;
+            Common->selected = 0 ;
+        }
+        if (ok && Common->postorder)
+        {
+            if (ssamd_postorder (n, Parent, ColCount, Post, work) == n)
+            {
+                Int *tmp = work, *inv = work + n ;
+                for (Int k = 0 ; k < n ; k++) tmp [k] = Perm [Post [k]] ;
+                for (Int k = 0 ; k < n ; k++) Perm [k] = tmp [k] ;
+                for (Int k = 0 ; k < n ; k++) tmp [k] = ColCount [Post [k]] ;
+                for (Int k = 0 ; k < n ; k++) ColCount [k] = tmp [k] ;
+                for (Int k = 0 ; k < n ; k++) inv [Post [k]] = k ;
+                for (Int c = 0 ; c < n ; c++)
+                {
+                    Int op = Parent [Post [c]] ;
+                    tmp [c] = (op == EMPTY) ? EMPTY : inv [op] ;
+                }
+                for (Int k = 0 ; k < n ; k++) Parent [k] = tmp [k] ;
+                if (L->ordering == CHOLMOD_NATURAL) L->ordering = CHOLMOD_POSTORDERED ;
+                cholmod_l_free_sparse (&U, Common) ;
+                cholmod_l_free_sparse (&Lw, Common) ;
+                ok = permuted_patterns (A, Perm, &U, &Lw, Common) ;
+            }
+        }
+    }
+    if (ok) ok = cholmod_l_super_symbolic2 (for_whom, U, NULL, Parent, L, Common) ;
+    cholmod_l_free_sparse (&U, Common) ;
+    cholmod_l_free_sparse (&Lw, Common) ;
+    if (Parent) cholmod_l_free (n + 1, sizeof (Int), Parent, Common) ;
+    if (Post) cholmod_l_free (n + 1, sizeof (Int), Post, Common) ;
+    if (work) cholmod_l_free (5 * (size_t) n + 1, sizeof (Int), work, Common) ;
+    if (Apk) cholmod_l_free_sparse (&Apk, Common) ;
+    if (!ok)
+    {
+        if (Common->status == CHOLMOD_OK) ERROR (CHOLMOD_OUT_OF_MEMORY, "analyze failed") ;
+        cholmod_l_free_factor (&L, Common) ;
+        return NULL ;
+    }
+    return L ;
+}
+
+cholmod_factor *cholmod_l_analyze_p (cholmod_sparse *A, SuiteSparse_long *UserPerm,
+    SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
+{
+    return cholmod_l_analyze_p2 (CHOLMOD_ANALYZE_FOR_CHOLESKY, A, UserPerm, fset, fsize, Common) ;
+}
+
+cholmod_factor *cholmod_l_analyze (cholmod_sparse *A, cholmod_common *Common)
+{
+    return cholmod_l_analyze_p2 (CHOLMOD_ANALYZE_FOR_CHOLESKY, A, NULL, NULL, 0, Common) ;
+}

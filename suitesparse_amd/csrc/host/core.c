@@ -1,0 +1,529 @@
+/* core.c -- objects, memory and permuted transposes of the host layer.
+ * Mirrors the part of the reference's Core module that the supernodal path
+ * uses (reference files: CHOLMOD/Core/cholmod_common.c, cholmod_memory.c,
+ * cholmod_sparse.c, cholmod_dense.c, cholmod_triplet.c, cholmod_transpose.c,
+ * cholmod_factor.c, cholmod_error.c).  64-bit indices, real double only. */
+#include "host_internal.h"
+
+/* ---- error / common ----------------------------------------------------------- */
+
+/* reference: Core/cholmod_error.c:31-81 */
+int cholmod_l_error (int status, const char *file, int line, const char *message,
+    cholmod_common *Common)
+{
+    if (!Common) return FALSE ;
+    Common->status = status ;
+    if (!Common->try_catch)
+    {
+        if (Common->print > 1 && status != CHOLMOD_OK)
+        {
+            fprintf (stderr, "CHOLMOD %s: %s (file %s line %d)\n",
+                status < 0 ? "error" : "warning", message ? message : "", file ? file : "?", line) ;
+        }
+        if (Common->error_handler) Common->error_handler (status, file, line, message) ;
+    }
+    return TRUE ;
+}
+
+/* reference: Core/cholmod_common.c:244-330 */
+int cholmod_l_defaults (cholmod_common *Common)
+{
+    if (!Common) return FALSE ;
+    Common->final_asis = TRUE ; Common->final_super = TRUE ; Common->final_ll = FALSE ;
+    Common->final_pack = TRUE ; Common->final_monotonic = TRUE ; Common->final_resymbol = FALSE ;
+    Common->supernodal = CHOLMOD_AUTO ;
+    Common->supernodal_switch = 40 ;
+    Common->nrelax [0] = 4 ; Common->nrelax [1] = 16 ; Common->nrelax [2] = 48 ;
+    Common->zrelax [0] = 0.8 ; Common->zrelax [1] = 0.1 ; Common->zrelax [2] = 0.05 ;
+    Common->prefer_upper = TRUE ;
+    Common->quick_return_if_not_posdef = FALSE ;
+    Common->print = 3 ;
+    Common->nmethods = 0 ;
+    Common->current = 0 ; Common->selected = 0 ;
+    for (int i = 0 ; i <= CHOLMOD_MAXMETHODS ; i++)
+    {
+        Common->method [i].ordering = CHOLMOD_AMD ;
+        Common->method [i].fl = EMPTY ;
+        Common->method [i].lnz = EMPTY ;
+    }
+    Common->method [0].ordering = CHOLMOD_GIVEN ;
+    Common->method [1].ordering = CHOLMOD_AMD ;
+    Common->method [2].ordering = CHOLMOD_METIS ;
+    Common->postorder = TRUE ;
+    Common->useGPU = EMPTY ;
+    return TRUE ;
+}
+
+/* reference: Core/cholmod_common.c:58-242 (useGPU = EMPTY for the long build :371) */
+int cholmod_l_start (cholmod_common *Common)
+{
+    if (!Common) return FALSE ;
+    memset (Common, 0, sizeof (cholmod_common)) ;
+    Common->itype = CHOLMOD_LONG ;
+    Common->dtype = CHOLMOD_DOUBLE ;
+    cholmod_l_defaults (Common) ;
+    Common->try_catch = FALSE ;
+    Common->error_handler = NULL ;
+    Common->status = CHOLMOD_OK ;
+    Common->blas_ok = TRUE ;
+    Common->fl = EMPTY ; Common->lnz = EMPTY ; Common->anz = EMPTY ; Common->modfl = EMPTY ;
+    Common->maxGpuMemFraction = 0.0 ;
+    Common->maxGpuMemBytes = 0 ;
+    return TRUE ;
+}
+
+/* reference: Core/cholmod_common.c:415-420 (frees workspace; none is cached here) */
+int cholmod_l_finish (cholmod_common *Common)
+{
+    if (!Common) return FALSE ;
+    cholmod_l_gpu_deallocate (Common) ;
+    return TRUE ;
+}
+
+/* ---- memory (reference: Core/cholmod_memory.c:111-230) ------------------------- */
+
+void *cholmod_l_malloc (size_t n, size_t size, cholmod_common *Common)
+{
+    if (!Common) return NULL ;
+    if (size == 0) { ERROR (CHOLMOD_INVALID, "sizeof(item) must be > 0") ; return NULL ; }
+    if (n >= (SIZE_MAX / size) || n >= (size_t) INT64_MAX / size)
+    {
+        ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
+        return NULL ;
+    }
+    void *p = malloc ((n > 0 ? n : 1) * size) ;
+    if (!p) { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return NULL ; }
+    Common->malloc_count++ ;
+    Common->memory_inuse += n * size ;
+    if (Common->memory_inuse > Common->memory_usage) Common->memory_usage = Common->memory_inuse ;
+    return p ;
+}
+
+void *cholmod_l_calloc (size_t n, size_t size, cholmod_common *Common)
+{
+    void *p = cholmod_l_malloc (n, size, Common) ;
+    if (p) memset (p, 0, (n > 0 ? n : 1) * size) ;
+    return p ;
+}
+
+void *cholmod_l_free (size_t n, size_t size, void *p, cholmod_common *Common)
+{
+    if (!Common) return NULL ;
+    if (p)
+    {
+        free (p) ;
+        Common->malloc_count-- ;
+        Common->memory_inuse -= n * size ;
+    }
+    return NULL ;
+}
+
+/* ---- sparse (reference: Core/cholmod_sparse.c) --------------------------------- */
+
+cholmod_sparse *cholmod_l_allocate_sparse (size_t nrow, size_t ncol, size_t nzmax,
+    int sorted, int packed, int stype, int xtype, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    if (stype != 0 && nrow != ncol)
+    {
+        ERROR (CHOLMOD_INVALID, "rectangular matrix with stype != 0 invalid") ;
+        return NULL ;
+    }
+    if (xtype != CHOLMOD_PATTERN && xtype != CHOLMOD_REAL)
+    {
+        ERROR (CHOLMOD_INVALID, "xtype invalid (only pattern and real are built)") ;
+        return NULL ;
+    }
+    Common->status = CHOLMOD_OK ;
+    cholmod_sparse *A = cholmod_l_calloc (1, sizeof (cholmod_sparse), Common) ;
+    if (!A) return NULL ;
+    nzmax = nzmax > 1 ? nzmax : 1 ;
+    A->nrow = nrow ; A->ncol = ncol ; A->nzmax = nzmax ;
+    A->packed = packed ; A->stype = stype ;
+    A->itype = CHOLMOD_LONG ; A->xtype = xtype ; A->dtype = CHOLMOD_DOUBLE ;
+    A->sorted = (nrow <= 1) ? TRUE : sorted ;
+    A->p = cholmod_l_calloc (ncol + 1, sizeof (Int), Common) ;
+    if (!packed) A->nz = cholmod_l_calloc (ncol > 0 ? ncol : 1, sizeof (Int), Common) ;
+    A->i = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
+    if (xtype == CHOLMOD_REAL) A->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    if (Common->status < CHOLMOD_OK) { cholmod_l_free_sparse (&A, Common) ; return NULL ; }
+    return A ;
+}
+
+int cholmod_l_free_sparse (cholmod_sparse **AH, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    if (!AH || !*AH) return TRUE ;
+    cholmod_sparse *A = *AH ;
+    cholmod_l_free (A->ncol + 1, sizeof (Int), A->p, Common) ;
+    if (A->nz) cholmod_l_free (A->ncol > 0 ? A->ncol : 1, sizeof (Int), A->nz, Common) ;
+    cholmod_l_free (A->nzmax, sizeof (Int), A->i, Common) ;
+    if (A->x) cholmod_l_free (A->nzmax, sizeof (double), A->x, Common) ;
+    cholmod_l_free (1, sizeof (cholmod_sparse), A, Common) ;
+    *AH = NULL ;
+    return TRUE ;
+}
+
+SuiteSparse_long cholmod_l_nnz (cholmod_sparse *A, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (EMPTY) ;
+    RETURN_IF_NULL (A, EMPTY) ;
+    Int *Ap = A->p, *Anz = A->nz ;
+    if (A->packed) return Ap [A->ncol] ;
+    Int nz = 0 ;
+    for (size_t j = 0 ; j < A->ncol ; j++) nz += Anz [j] > 0 ? Anz [j] : 0 ;
+    return nz ;
+}
+
+cholmod_sparse *cholmod_l_copy_sparse (cholmod_sparse *A, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (A, NULL) ;
+    cholmod_sparse *C = cholmod_l_allocate_sparse (A->nrow, A->ncol, A->nzmax, A->sorted,
+        A->packed, A->stype, A->xtype, Common) ;
+    if (!C) return NULL ;
+    memcpy (C->p, A->p, (A->ncol + 1) * sizeof (Int)) ;
+    if (!A->packed) memcpy (C->nz, A->nz, A->ncol * sizeof (Int)) ;
+    Int *Ap = A->p, *Anz = A->nz ;
+    for (size_t j = 0 ; j < A->ncol ; j++)
+    {
+        Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+        if (pend > p)
+        {
+            memcpy ((Int *) C->i + p, (Int *) A->i + p, (pend - p) * sizeof (Int)) ;
+            if (A->x) memcpy ((double *) C->x + p, (double *) A->x + p, (pend - p) * sizeof (double)) ;
+        }
+    }
+    return C ;
+}
+
+/* ---- transposes (reference: Core/cholmod_transpose.c:871-1139) ----------------- */
+
+/* Symmetric case: C = A(p,p)' with the other triangle stored (stype flips).
+ * An entry of the stored triangle of A at (i,j) moves to (Pinv[i], Pinv[j]),
+ * is reflected into the triangle C stores, and the columns of C come out
+ * sorted (two bucket passes).  Unsymmetric case: plain transpose (Perm/fset
+ * are not supported for stype == 0 in this build). */
+cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse_long *Perm,
+    SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (A, NULL) ;
+    (void) fsize ;
+    Common->status = CHOLMOD_OK ;
+    Int n = (Int) A->nrow, ncol = (Int) A->ncol ;
+    Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
+    double *Ax = A->x ;
+    int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
+    if (A->stype == 0)
+    {
+        if (Perm || fset)
+        {
+            ERROR (CHOLMOD_NOT_INSTALLED, "permuted unsymmetric transpose not built") ;
+            return NULL ;
+        }
+        Int nz = cholmod_l_nnz (A, Common) ;
+        cholmod_sparse *C = cholmod_l_allocate_sparse (ncol, n, nz, TRUE, TRUE, 0, xtype, Common) ;
+        if (!C) return NULL ;
+        Int *Cp = C->p, *Ci = C->i ;
+        double *Cx = C->x ;
+        Int *w = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
+        if (!w) { cholmod_l_free_sparse (&C, Common) ; return NULL ; }
+        for (Int j = 0 ; j < ncol ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++) w [Ai [p]]++ ;
+        }
+        Cp [0] = 0 ;
+        for (Int i = 0 ; i < n ; i++) { Cp [i+1] = Cp [i] + w [i] ; w [i] = Cp [i] ; }
+        for (Int j = 0 ; j < ncol ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int q = w [Ai [p]]++ ;
+                Ci [q] = j ;
+                if (xtype == CHOLMOD_REAL) Cx [q] = Ax [p] ;
+            }
+        }
+        cholmod_l_free (n + 1, sizeof (Int), w, Common) ;
+        return C ;
+    }
+    /* symmetric */
+    int upper_in = A->stype > 0 ;
+    int upper_out = !upper_in ;
+    Int *Pinv = NULL ;
+    if (Perm)
+    {
+        Pinv = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
+        if (!Pinv) return NULL ;
+        for (Int k = 0 ; k < n ; k++) Pinv [k] = EMPTY ;
+        for (Int k = 0 ; k < n ; k++)
+        {
+            Int j = Perm [k] ;
+            if (j < 0 || j >= n || Pinv [j] != EMPTY)
+            {
+                cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
+                ERROR (CHOLMOD_INVALID, "invalid permutation") ;
+                return NULL ;
+            }
+            Pinv [j] = k ;
+        }
+    }
+    /* pass 1: count entries per output column and per output row */
+    Int *colcnt = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
+    Int *rowptr = cholmod_l_calloc (n + 2, sizeof (Int), Common) ;
+    Int nz = 0 ;
+    if (colcnt && rowptr)
+    {
+        for (Int j = 0 ; j < n ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int i = Ai [p] ;
+                if (upper_in ? (i > j) : (i < j)) continue ;    /* ignored triangle */
+                Int r = Pinv ? Pinv [i] : i, c = Pinv ? Pinv [j] : j ;
+                Int lo = r < c ? r : c, hi = r < c ? c : r ;
+                colcnt [upper_out ? hi : lo]++ ;
+                rowptr [(upper_out ? lo : hi) + 1]++ ;
+                nz++ ;
+            }
+        }
+    }
+    cholmod_sparse *C = (colcnt && rowptr) ? cholmod_l_allocate_sparse (n, n, nz, TRUE, TRUE,
+        upper_out ? 1 : -1, xtype, Common) : NULL ;
+    Int *erow = C ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) : NULL ;
+    Int *ecol = C ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) : NULL ;
+    double *eval = (C && xtype == CHOLMOD_REAL) ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (double), Common) : NULL ;
+    if (C && erow && ecol && (xtype != CHOLMOD_REAL || eval))
+    {
+        /* pass 2: bucket by output row so that pass 3 emits sorted columns */
+        for (Int i = 0 ; i < n ; i++) rowptr [i+1] += rowptr [i] ;
+        for (Int j = 0 ; j < n ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int i = Ai [p] ;
+                if (upper_in ? (i > j) : (i < j)) continue ;
+                Int r = Pinv ? Pinv [i] : i, c = Pinv ? Pinv [j] : j ;
+                Int lo = r < c ? r : c, hi = r < c ? c : r ;
+                Int row = upper_out ? lo : hi, col = upper_out ? hi : lo ;
+                Int q = rowptr [row]++ ;
+                erow [q] = row ; ecol [q] = col ;
+                if (eval) eval [q] = Ax [p] ;
+            }
+        }
+        Int *Cp = C->p, *Ci = C->i ;
+        double *Cx = C->x ;
+        Cp [0] = 0 ;
+        for (Int j = 0 ; j < n ; j++) { Cp [j+1] = Cp [j] + colcnt [j] ; colcnt [j] = Cp [j] ; }
+        for (Int q = 0 ; q < nz ; q++)
+        {
+            Int dst = colcnt [ecol [q]]++ ;
+            Ci [dst] = erow [q] ;
+            if (eval) Cx [dst] = eval [q] ;
+        }
+    }
+    else if (C) cholmod_l_free_sparse (&C, Common) ;
+    if (eval) cholmod_l_free (nz > 0 ? nz : 1, sizeof (double), eval, Common) ;
+    if (ecol) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), ecol, Common) ;
+    if (erow) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), erow, Common) ;
+    if (rowptr) cholmod_l_free (n + 2, sizeof (Int), rowptr, Common) ;
+    if (colcnt) cholmod_l_free (n + 1, sizeof (Int), colcnt, Common) ;
+    if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
+    return C ;
+}
+
+cholmod_sparse *cholmod_l_transpose (cholmod_sparse *A, int values, cholmod_common *Common)
+{
+    return cholmod_l_ptranspose (A, values, NULL, NULL, 0, Common) ;
+}
+
+/* ---- triplet (reference: Core/cholmod_triplet.c) ------------------------------- */
+
+cholmod_triplet *cholmod_l_allocate_triplet (size_t nrow, size_t ncol, size_t nzmax,
+    int stype, int xtype, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    if (xtype != CHOLMOD_PATTERN && xtype != CHOLMOD_REAL)
+    {
+        ERROR (CHOLMOD_INVALID, "xtype invalid") ;
+        return NULL ;
+    }
+    Common->status = CHOLMOD_OK ;
+    cholmod_triplet *T = cholmod_l_calloc (1, sizeof (cholmod_triplet), Common) ;
+    if (!T) return NULL ;
+    nzmax = nzmax > 1 ? nzmax : 1 ;
+    T->nrow = nrow ; T->ncol = ncol ; T->nzmax = nzmax ; T->nnz = 0 ;
+    T->stype = stype ; T->itype = CHOLMOD_LONG ; T->xtype = xtype ; T->dtype = CHOLMOD_DOUBLE ;
+    T->i = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
+    T->j = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
+    if (xtype == CHOLMOD_REAL) T->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    if (Common->status < CHOLMOD_OK) { cholmod_l_free_triplet (&T, Common) ; return NULL ; }
+    return T ;
+}
+
+int cholmod_l_free_triplet (cholmod_triplet **TH, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    if (!TH || !*TH) return TRUE ;
+    cholmod_triplet *T = *TH ;
+    cholmod_l_free (T->nzmax, sizeof (Int), T->i, Common) ;
+    cholmod_l_free (T->nzmax, sizeof (Int), T->j, Common) ;
+    if (T->x) cholmod_l_free (T->nzmax, sizeof (double), T->x, Common) ;
+    cholmod_l_free (1, sizeof (cholmod_triplet), T, Common) ;
+    *TH = NULL ;
+    return TRUE ;
+}
+
+/* Duplicates are summed; for stype != 0 entries in the ignored triangle are
+ * transposed into the stored one (reference Core/cholmod_triplet.c:266-270:
+ * "entries in the wrong triangle are transposed").  Output columns sorted. */
+cholmod_sparse *cholmod_l_triplet_to_sparse (cholmod_triplet *T, size_t nzmax,
+    cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (T, NULL) ;
+    Common->status = CHOLMOD_OK ;
+    Int nrow = (Int) T->nrow, ncol = (Int) T->ncol, nz = (Int) T->nnz ;
+    Int *Ti = T->i, *Tj = T->j ;
+    double *Tx = T->x ;
+    if (T->stype != 0 && nrow != ncol) { ERROR (CHOLMOD_INVALID, "matrix invalid") ; return NULL ; }
+    for (Int k = 0 ; k < nz ; k++)
+        if (Ti [k] < 0 || Ti [k] >= nrow || Tj [k] < 0 || Tj [k] >= ncol)
+        { ERROR (CHOLMOD_INVALID, "index out of range") ; return NULL ; }
+    /* sort by (col,row) with two stable bucket passes */
+    Int *r1 = cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) ;   /* order after row pass */
+    Int *cnt = cholmod_l_calloc ((nrow > ncol ? nrow : ncol) + 2, sizeof (Int), Common) ;
+    Int *r2 = cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) ;
+    if (!r1 || !cnt || !r2)
+    {
+        if (r1) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), r1, Common) ;
+        if (r2) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), r2, Common) ;
+        if (cnt) cholmod_l_free ((nrow > ncol ? nrow : ncol) + 2, sizeof (Int), cnt, Common) ;
+        return NULL ;
+    }
+#define TROW(k) ((T->stype > 0 && Ti [k] > Tj [k]) || (T->stype < 0 && Ti [k] < Tj [k]) ? Tj [k] : Ti [k])
+#define TCOL(k) ((T->stype > 0 && Ti [k] > Tj [k]) || (T->stype < 0 && Ti [k] < Tj [k]) ? Ti [k] : Tj [k])
+    for (Int k = 0 ; k < nz ; k++) cnt [TROW (k) + 1]++ ;
+    for (Int i = 0 ; i < nrow ; i++) cnt [i+1] += cnt [i] ;
+    for (Int k = 0 ; k < nz ; k++) r1 [cnt [TROW (k)]++] = k ;
+    memset (cnt, 0, ((nrow > ncol ? nrow : ncol) + 2) * sizeof (Int)) ;
+    for (Int k = 0 ; k < nz ; k++) cnt [TCOL (k) + 1]++ ;
+    for (Int j = 0 ; j < ncol ; j++) cnt [j+1] += cnt [j] ;
+    for (Int q = 0 ; q < nz ; q++) { Int k = r1 [q] ; r2 [cnt [TCOL (k)]++] = k ; }
+    /* count distinct */
+    Int nd = 0 ;
+    for (Int q = 0 ; q < nz ; q++)
+    {
+        Int k = r2 [q] ;
+        if (q == 0 || TROW (k) != TROW (r2 [q-1]) || TCOL (k) != TCOL (r2 [q-1])) nd++ ;
+    }
+    size_t cap = (size_t) nd > nzmax ? (size_t) nd : nzmax ;
+    cholmod_sparse *A = cholmod_l_allocate_sparse (nrow, ncol, cap, TRUE, TRUE, T->stype,
+        T->xtype == CHOLMOD_REAL ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+    if (A)
+    {
+        Int *Ap = A->p, *Ai = A->i ;
+        double *Ax = A->x ;
+        Int dst = -1 ;
+        for (Int j = 0 ; j <= ncol ; j++) Ap [j] = 0 ;
+        for (Int q = 0 ; q < nz ; q++)
+        {
+            Int k = r2 [q] ;
+            Int r = TROW (k), c = TCOL (k) ;
+            if (q == 0 || r != TROW (r2 [q-1]) || c != TCOL (r2 [q-1]))
+            {
+                dst++ ;
+                Ai [dst] = r ;
+                if (Ax) Ax [dst] = 0 ;
+                Ap [c+1]++ ;
+            }
+            if (Ax) Ax [dst] += Tx [k] ;
+        }
+        for (Int j = 0 ; j < ncol ; j++) Ap [j+1] += Ap [j] ;
+    }
+#undef TROW
+#undef TCOL
+    cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), r1, Common) ;
+    cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), r2, Common) ;
+    cholmod_l_free ((nrow > ncol ? nrow : ncol) + 2, sizeof (Int), cnt, Common) ;
+    return A ;
+}
+
+/* ---- dense (reference: Core/cholmod_dense.c) ----------------------------------- */
+
+cholmod_dense *cholmod_l_allocate_dense (size_t nrow, size_t ncol, size_t d, int xtype,
+    cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    if (d < nrow) { ERROR (CHOLMOD_INVALID, "leading dimension invalid") ; return NULL ; }
+    if (xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "xtype invalid") ; return NULL ; }
+    Common->status = CHOLMOD_OK ;
+    cholmod_dense *X = cholmod_l_calloc (1, sizeof (cholmod_dense), Common) ;
+    if (!X) return NULL ;
+    size_t nzmax = d * ncol ; nzmax = nzmax > 1 ? nzmax : 1 ;
+    X->nrow = nrow ; X->ncol = ncol ; X->nzmax = nzmax ; X->d = d ;
+    X->xtype = xtype ; X->dtype = CHOLMOD_DOUBLE ;
+    X->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    if (!X->x) { cholmod_l_free (1, sizeof (cholmod_dense), X, Common) ; return NULL ; }
+    return X ;
+}
+
+cholmod_dense *cholmod_l_zeros (size_t nrow, size_t ncol, int xtype, cholmod_common *Common)
+{
+    cholmod_dense *X = cholmod_l_allocate_dense (nrow, ncol, nrow, xtype, Common) ;
+    if (X) memset (X->x, 0, X->nzmax * sizeof (double)) ;
+    return X ;
+}
+
+cholmod_dense *cholmod_l_ones (size_t nrow, size_t ncol, int xtype, cholmod_common *Common)
+{
+    cholmod_dense *X = cholmod_l_allocate_dense (nrow, ncol, nrow, xtype, Common) ;
+    if (X) { double *x = X->x ; for (size_t k = 0 ; k < X->nzmax ; k++) x [k] = 1.0 ; }
+    return X ;
+}
+
+cholmod_dense *cholmod_l_copy_dense (cholmod_dense *X, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (X, NULL) ;
+    cholmod_dense *Y = cholmod_l_allocate_dense (X->nrow, X->ncol, X->d, X->xtype, Common) ;
+    if (Y) memcpy (Y->x, X->x, X->d * X->ncol * sizeof (double)) ;
+    return Y ;
+}
+
+int cholmod_l_free_dense (cholmod_dense **XH, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    if (!XH || !*XH) return TRUE ;
+    cholmod_dense *X = *XH ;
+    cholmod_l_free (X->nzmax, sizeof (double), X->x, Common) ;
+    cholmod_l_free (1, sizeof (cholmod_dense), X, Common) ;
+    *XH = NULL ;
+    return TRUE ;
+}
+
+/* ---- factor (reference: Core/cholmod_factor.c:160-228 free_factor) ------------- */
+
+int cholmod_l_free_factor (cholmod_factor **LH, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    if (!LH || !*LH) return TRUE ;
+    cholmod_factor *L = *LH ;
+    size_t n = L->n ;
+    if (L->hip_plan) { cholmod_hip_plan_destroy ((cholmod_hip_plan *) L->hip_plan) ; L->hip_plan = NULL ; }
+    cholmod_l_free (n, sizeof (Int), L->Perm, Common) ;
+    cholmod_l_free (n, sizeof (Int), L->ColCount, Common) ;
+    if (L->IPerm) cholmod_l_free (n, sizeof (Int), L->IPerm, Common) ;
+    if (L->super) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->super, Common) ;
+    if (L->pi) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->pi, Common) ;
+    if (L->px) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->px, Common) ;
+    if (L->s) cholmod_l_free (L->ssize, sizeof (Int), L->s, Common) ;
+    if (L->x) cholmod_l_free (L->xsize, sizeof (double), L->x, Common) ;
+    cholmod_l_free (1, sizeof (cholmod_factor), L, Common) ;
+    *LH = NULL ;
+    return TRUE ;
+}

@@ -1,0 +1,40 @@
+/* host_internal.h -- shared declarations of the host C layer. */
+#ifndef SSAMD_HOST_INTERNAL_H
+#define SSAMD_HOST_INTERNAL_H
+
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/cholmod.h"
+#include "../../../include/cholmod_hip.h"
+
+typedef SuiteSparse_long Int ;
+#define EMPTY (-1)
+
+#define ERROR(status, msg) cholmod_l_error (status, __FILE__, __LINE__, msg, Common)
+
+#define RETURN_IF_NULL_COMMON(result) \
+    do { if (Common == NULL) return (result) ; \
+         if (Common->itype != CHOLMOD_LONG || Common->dtype != CHOLMOD_DOUBLE) \
+         { Common->status = CHOLMOD_INVALID ; return (result) ; } } while (0)
+
+#define RETURN_IF_NULL(A, result) \
+    do { if ((A) == NULL) { \
+             if (Common->status != CHOLMOD_OUT_OF_MEMORY) { ERROR (CHOLMOD_INVALID, "argument missing") ; } \
+             return (result) ; } } while (0)
+
+/* analyze.c */
+int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent) ;
+Int ssamd_postorder (Int n, const Int *Parent, const Int *Weight, Int *Post, Int *work3n) ;
+void ssamd_colcounts (Int n, const Int *Lp, const Int *Li, const Int *Parent, const Int *Post,
+    Int *ColCount, Int *work5n) ;
+
+/* numeric.c */
+int ssamd_resolve_use_gpu (cholmod_common *Common) ;
+int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common) ;
+
+#endif

@@ -1,0 +1,360 @@
+/* numeric.c -- cholmod_l_factorize / cholmod_l_super_numeric / cholmod_l_solve
+ * and the cholmod_l_gpu_* entry points of the host layer.  All arithmetic is
+ * done by the HIP engine behind include/cholmod_hip.h; this file only checks
+ * arguments, permutes the input (ptranspose), moves vectors and maps engine
+ * return codes to Common->status.  There is deliberately no CPU BLAS path.
+ *
+ * Reference files: CHOLMOD/Cholesky/cholmod_factorize.c, cholmod_solve.c;
+ * CHOLMOD/Supernodal/cholmod_super_numeric.c, cholmod_super_solve.c;
+ * CHOLMOD/GPU/cholmod_gpu.c. */
+#include "host_internal.h"
+
+/* ---- GPU entry points (reference CHOLMOD/GPU/cholmod_gpu.c:71-486) ---------------- */
+
+int cholmod_l_gpu_memorysize (size_t *total_mem, size_t *available_mem, cholmod_common *Common)
+{
+    if (total_mem) *total_mem = 0 ;
+    if (available_mem) *available_mem = 0 ;
+    if (!Common) return 1 ;
+    return cholmod_hip_memorysize (total_mem, available_mem) ;
+}
+
+int cholmod_l_gpu_probe (cholmod_common *Common)
+{
+    if (!Common) return 0 ;
+    if (!cholmod_hip_probe ()) return 0 ;
+    size_t t = 0, a = 0 ;
+    if (cholmod_hip_memorysize (&t, &a) == 0) Common->gpuMemorySize = a ;
+    return 1 ;
+}
+
+/* The reference carves Common->dev_mempool / host_pinned_mempool here
+ * (cholmod_gpu.c:364-486).  The HIP engine keeps L itself resident and sizes
+ * its HBM reservation per symbolic factor (cholmod_hip_plan_create), so these
+ * two calls only validate that a device exists.  0 = ok, as in the reference. */
+int cholmod_l_gpu_allocate (cholmod_common *Common)
+{
+    if (!Common) return 1 ;
+    return cholmod_hip_probe () ? 0 : 1 ;
+}
+
+int cholmod_l_gpu_deallocate (cholmod_common *Common)
+{
+    if (!Common) return 1 ;
+    return 0 ;
+}
+
+void cholmod_l_gpu_end (cholmod_common *Common)
+{
+    (void) Common ;
+}
+
+/* ---- plan management ------------------------------------------------------------------ */
+
+static int map_hip_status (int rc, cholmod_common *Common, const char *what)
+{
+    switch (rc)
+    {
+        case CHOLMOD_HIP_OK: return TRUE ;
+        case CHOLMOD_HIP_NOT_POSDEF: return TRUE ;
+        case CHOLMOD_HIP_OUT_OF_MEMORY: ERROR (CHOLMOD_OUT_OF_MEMORY, what) ; return FALSE ;
+        case CHOLMOD_HIP_INVALID: ERROR (CHOLMOD_INVALID, what) ; return FALSE ;
+        case CHOLMOD_HIP_NO_DEVICE:
+            ERROR (CHOLMOD_GPU_PROBLEM, "no usable HIP device: the numeric factorization of this "
+                "library runs only on the GPU engine") ;
+            return FALSE ;
+        default: ERROR (CHOLMOD_GPU_PROBLEM, what) ; return FALSE ;
+    }
+}
+
+int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
+{
+    if (L->hip_plan) return TRUE ;
+    int st = 0 ;
+    cholmod_hip_plan *P = cholmod_hip_plan_create ((int64_t) L->n, (int64_t) L->nsuper,
+        L->super, L->pi, L->px, L->s, Common->hip_flags, &st) ;
+    if (!P) return map_hip_status (st ? st : CHOLMOD_HIP_GPU_PROBLEM, Common, "HIP plan creation failed") ;
+    L->hip_plan = P ;
+    return TRUE ;
+}
+
+static void absorb_stats (cholmod_factor *L, cholmod_common *Common)
+{
+    double s [CHOLMOD_HIP_NSTATS] ;
+    if (cholmod_hip_get_stats ((cholmod_hip_plan *) L->hip_plan, s) != CHOLMOD_HIP_OK) return ;
+    /* keep the reference's counters meaningful (cholmod_core.h:1004-1024): the
+     * engine's dense updates play the role of the dsyrk+dgemm calls */
+    Common->gpuKernelTime = s [0] ;
+    Common->gpuFlops = (SuiteSparse_long) s [1] ;
+    Common->gpuNumKernelLaunches = (int) s [2] ;
+    Common->cholmod_gpu_syrk_time = s [6] ;
+    Common->cholmod_gpu_syrk_calls = (size_t) s [7] ;
+    Common->cholmod_gpu_gemm_time = 0 ; Common->cholmod_gpu_gemm_calls = 0 ;
+    Common->cholmod_gpu_potrf_time = s [11] ;
+    Common->cholmod_gpu_trsm_time = s [12] ;
+    Common->cholmod_assemble_time = s [13] ;
+    Common->cholmod_assemble_time2 = s [9] ;
+    Common->cholmod_cpu_gemm_time = Common->cholmod_cpu_syrk_time = 0 ;
+    Common->cholmod_cpu_trsm_time = Common->cholmod_cpu_potrf_time = 0 ;
+    Common->cholmod_cpu_gemm_calls = Common->cholmod_cpu_syrk_calls = 0 ;
+    Common->cholmod_cpu_trsm_calls = Common->cholmod_cpu_potrf_calls = 0 ;
+}
+
+/* ---- cholmod_l_super_numeric ------------------------------------------------------------ */
+
+static int finish_numeric (int rc, int64_t minor, cholmod_factor *L, cholmod_common *Common)
+{
+    if (rc < 0) return map_hip_status (rc, Common, "HIP factorization failed") ;
+    L->xtype = CHOLMOD_REAL ;
+    L->dtype = CHOLMOD_DOUBLE ;
+    L->is_ll = TRUE ;
+    L->minor = (size_t) minor ;
+    L->hip_on_device = TRUE ;
+    L->hip_host_valid = FALSE ;
+    if (!Common->hip_factor_on_device)
+    {
+        if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
+        if (!L->x) return FALSE ;
+        int r2 = cholmod_hip_download_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
+        if (r2 != CHOLMOD_HIP_OK) return map_hip_status (r2, Common, "factor download failed") ;
+        L->hip_host_valid = TRUE ;
+    }
+    absorb_stats (L, Common) ;
+    if (rc == CHOLMOD_HIP_NOT_POSDEF)
+        ERROR (CHOLMOD_NOT_POSDEF, "matrix not positive definite") ;
+    return TRUE ;     /* TRUE also when not positive definite, as the reference */
+}
+
+/* reference: Supernodal/cholmod_super_numeric.c:97-308.  A must be the
+ * permuted matrix in symmetric-lower form (stype < 0). */
+int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [2],
+    cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    RETURN_IF_NULL (A, FALSE) ;
+    (void) F ;
+    if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "A must be real") ; return FALSE ; }
+    if (L->xtype != CHOLMOD_PATTERN && L->xtype != CHOLMOD_REAL)
+    { ERROR (CHOLMOD_INVALID, "invalid xtype of L") ; return FALSE ; }
+    if (A->stype > 0) { ERROR (CHOLMOD_INVALID, "symmetric upper case not supported") ; return FALSE ; }
+    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "unsymmetric (A*F) case not built") ; return FALSE ; }
+    if (A->nrow != A->ncol || A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
+    if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    if (ssamd_resolve_use_gpu (Common) != 1)
+    {
+        ERROR (CHOLMOD_NOT_INSTALLED, "Common->useGPU is 0, but this library has no CPU BLAS path; "
+            "set Common->useGPU = 1 (or CHOLMOD_USE_GPU=1)") ;
+        return FALSE ;
+    }
+    if (!ssamd_ensure_plan (L, Common)) return FALSE ;
+    double b = beta ? beta [0] : 0.0 ;
+    int64_t minor = (int64_t) L->n ;
+    int rc = cholmod_hip_factorize ((cholmod_hip_plan *) L->hip_plan, A->p, A->i,
+        A->packed ? NULL : A->nz, A->x, b, Common->quick_return_if_not_posdef, NULL, &minor) ;
+    return finish_numeric (rc, minor, L, Common) ;
+}
+
+int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    if (!L->hip_plan) { ERROR (CHOLMOD_INVALID, "no resident matrix") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    int64_t minor = (int64_t) L->n ;
+    int rc = cholmod_hip_factorize_resident ((cholmod_hip_plan *) L->hip_plan, beta ? beta [0] : 0.0,
+        Common->quick_return_if_not_posdef, &minor) ;
+    return finish_numeric (rc, minor, L, Common) ;
+}
+
+/* ---- cholmod_l_factorize ---------------------------------------------------------------- */
+
+/* reference: Cholesky/cholmod_factorize.c:97-300, supernodal symmetric branch
+ * (:177-288): S = tril(P A P') by one permuted transpose when A is stored
+ * upper (:225-232) or two when it is stored lower (:233-244). */
+int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long *fset, size_t fsize,
+    cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (A, FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    (void) fset ; (void) fsize ;
+    if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "A must be real") ; return FALSE ; }
+    if (A->nrow != L->n || A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
+    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' factorization not built") ; return FALSE ; }
+    if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    cholmod_sparse *S = NULL, *A1 = NULL ;
+    int natural = (L->ordering == CHOLMOD_NATURAL) ;
+    Int *Perm = natural ? NULL : (Int *) L->Perm ;
+    if (A->stype > 0)
+    {
+        S = cholmod_l_ptranspose (A, 2, Perm, NULL, 0, Common) ;
+    }
+    else if (natural && A->packed)
+    {
+        S = A ;
+    }
+    else
+    {
+        A1 = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, Common) ;
+        if (A1) S = cholmod_l_ptranspose (A1, 2, Perm, NULL, 0, Common) ;
+        cholmod_l_free_sparse (&A1, Common) ;
+    }
+    if (!S) return FALSE ;
+    double zero [2] = {0, 0} ;
+    int ok = cholmod_l_super_numeric (S, NULL, beta ? beta : zero, L, Common) ;
+    if (S != A) cholmod_l_free_sparse (&S, Common) ;
+    return ok ;
+}
+
+int cholmod_l_factorize (cholmod_sparse *A, cholmod_factor *L, cholmod_common *Common)
+{
+    double zero [2] = {0, 0} ;
+    return cholmod_l_factorize_p (A, zero, NULL, 0, L, Common) ;
+}
+
+int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    if (L->hip_host_valid) return TRUE ;
+    if (!L->hip_plan || !L->hip_on_device) { ERROR (CHOLMOD_INVALID, "no numeric factor") ; return FALSE ; }
+    if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
+    if (!L->x) return FALSE ;
+    int rc = cholmod_hip_download_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
+    if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "factor download failed") ;
+    L->hip_host_valid = TRUE ;
+    return TRUE ;
+}
+
+int cholmod_l_hip_stats (cholmod_factor *L, double *stats, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    RETURN_IF_NULL (stats, FALSE) ;
+    if (!L->hip_plan) { ERROR (CHOLMOD_INVALID, "no plan") ; return FALSE ; }
+    return cholmod_hip_get_stats ((cholmod_hip_plan *) L->hip_plan, stats) == CHOLMOD_HIP_OK ;
+}
+
+/* ---- triangular solves ---------------------------------------------------------------------- */
+
+/* make sure the device holds the numeric values the caller sees in L->x */
+static int factor_on_device (cholmod_factor *L, cholmod_common *Common)
+{
+    if (L->xtype != CHOLMOD_REAL || !L->is_super)
+    { ERROR (CHOLMOD_INVALID, "L must be a numeric supernodal factor") ; return FALSE ; }
+    if (!ssamd_ensure_plan (L, Common)) return FALSE ;
+    if (!L->hip_on_device)
+    {
+        if (!L->x) { ERROR (CHOLMOD_INVALID, "L has no values") ; return FALSE ; }
+        int rc = cholmod_hip_upload_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
+        if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "factor upload failed") ;
+        L->hip_on_device = TRUE ;
+    }
+    return TRUE ;
+}
+
+static int super_solve (int which, cholmod_factor *L, cholmod_dense *X, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    RETURN_IF_NULL (X, FALSE) ;
+    if (X->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "X must be real") ; return FALSE ; }
+    if (X->nrow != L->n || X->d < X->nrow) { ERROR (CHOLMOD_INVALID, "X and L dimensions must match") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    if (!factor_on_device (L, Common)) return FALSE ;
+    int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, X->x, (int64_t) X->ncol, (int64_t) X->d) ;
+    if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "HIP solve failed") ;
+    return Common->blas_ok ;
+}
+
+/* reference: Supernodal/cholmod_super_solve.c:43-134 / :136-231.  E (workspace
+ * in the reference) is accepted and ignored. */
+int cholmod_l_super_lsolve (cholmod_factor *L, cholmod_dense *X, cholmod_dense *E, cholmod_common *Common)
+{
+    (void) E ;
+    return super_solve (1, L, X, Common) ;
+}
+
+int cholmod_l_super_ltsolve (cholmod_factor *L, cholmod_dense *X, cholmod_dense *E, cholmod_common *Common)
+{
+    (void) E ;
+    return super_solve (2, L, X, Common) ;
+}
+
+/* reference: Cholesky/cholmod_solve.c:946-1030 and the supernodal branch of
+ * solve2 (:1541-1580): Y = P B, L solves, X = P' Y.  LL' factors only, so the
+ * LDL' system codes collapse as in the reference (D = I). */
+cholmod_dense *cholmod_l_solve (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_common *Common)
+{
+    cholmod_dense *X = NULL ;
+    if (!cholmod_l_solve2 (sys, L, B, NULL, &X, NULL, NULL, NULL, Common))
+        cholmod_l_free_dense (&X, Common) ;
+    return X ;
+}
+
+int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_sparse *Bset,
+    cholmod_dense **X_Handle, cholmod_sparse **Xset_Handle, cholmod_dense **Y_Handle,
+    cholmod_dense **E_Handle, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    RETURN_IF_NULL (B, FALSE) ;
+    RETURN_IF_NULL (X_Handle, FALSE) ;
+    (void) Xset_Handle ; (void) Y_Handle ; (void) E_Handle ;
+    if (Bset) { ERROR (CHOLMOD_NOT_INSTALLED, "sparse right-hand-side subsets not built") ; return FALSE ; }
+    if (sys < CHOLMOD_A || sys > CHOLMOD_Pt) { ERROR (CHOLMOD_INVALID, "invalid system") ; return FALSE ; }
+    if (B->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "B must be real") ; return FALSE ; }
+    if (B->d < L->n || B->nrow != L->n) { ERROR (CHOLMOD_INVALID, "dimensions of L and B do not match") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    Int n = (Int) L->n, nrhs = (Int) B->ncol ;
+    cholmod_dense *X = *X_Handle ;
+    if (!X || X->nrow != (size_t) n || X->ncol != (size_t) nrhs || X->xtype != CHOLMOD_REAL)
+    {
+        cholmod_l_free_dense (X_Handle, Common) ;
+        X = cholmod_l_allocate_dense (n, nrhs, n, CHOLMOD_REAL, Common) ;
+        if (!X) return FALSE ;
+        *X_Handle = X ;
+    }
+    const Int *Perm = L->Perm ;
+    double *Bx = B->x, *Xx = X->x ;
+    Int dB = (Int) B->d, dX = (Int) X->d ;
+    if (sys == CHOLMOD_P)
+    {
+        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Bx [Perm [k] + r*dB] ;
+        return TRUE ;
+    }
+    if (sys == CHOLMOD_Pt)
+    {
+        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [Perm [k] + r*dX] = Bx [k + r*dB] ;
+        return TRUE ;
+    }
+    if (sys == CHOLMOD_D)
+    {
+        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Bx [k + r*dB] ;
+        return TRUE ;
+    }
+    int which = (sys == CHOLMOD_A || sys == CHOLMOD_LDLt) ? 0
+              : (sys == CHOLMOD_L || sys == CHOLMOD_LD) ? 1 : 2 ;
+    if (!factor_on_device (L, Common)) return FALSE ;
+    cholmod_dense *Y = cholmod_l_allocate_dense (n, nrhs, n, CHOLMOD_REAL, Common) ;
+    if (!Y) return FALSE ;
+    double *Yx = Y->x ;
+    if (sys == CHOLMOD_A)
+        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [Perm [k] + r*dB] ;
+    else
+        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [k + r*dB] ;
+    int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, Yx, nrhs, n) ;
+    int ok = (rc == CHOLMOD_HIP_OK) ? TRUE : map_hip_status (rc, Common, "HIP solve failed") ;
+    if (ok)
+    {
+        if (sys == CHOLMOD_A)
+            for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [Perm [k] + r*dX] = Yx [k + r*n] ;
+        else
+            for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Yx [k + r*n] ;
+    }
+    cholmod_l_free_dense (&Y, Common) ;
+    return ok ;
+}
