@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- factorize GFLOP/s of the supernodal Cholesky hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE
+JSON line from rank 0.  A "step" is one numeric factorization
+(cholmod_l_factorize's device part: assemble + all fronts) of the workload with
+the permuted input matrix already resident in HBM.  Metric = Common->fl / t,
+fl = sum_j ColCount[j]^2 (reference CHOLMOD/Cholesky/cholmod_rowcolcounts.c:
+517-528, demo convention CHOLMOD/Demo/cholmod_l_demo.c:691-692).
+
+N=1 workload: BASELINE.json configs[1], 3D 7-point Poisson 100^3 under geometric
+nested dissection.  N>1 (round 1): the etree-subtree partition
+is not built yet, so every rank factorizes its own replica ("replicas only",
+see DESIGN.md) and the value is the aggregate over ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6        # MI355X spec, dense fp64 matrix
+
+
+def build_workload(name, m):
+    from suitesparse_amd import generators as G
+    if name == "poisson3d":
+        n, Ap, Ai, Ax = G.poisson3d(m)
+        return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, m, 4), f"poisson3d_{m}^3_geometricND_leaf4"
+    if name == "poisson2d":
+        n, Ap, Ai, Ax = G.poisson2d(m)
+        return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, 1, 4), f"poisson2d_{m}^2_geometricND_leaf4"
+    if name == "box3d":
+        n, Ap, Ai, Ax = G.box_stencil3d(m, 3)
+        return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, m, 4), f"box_stencil_r3_{m}^3_geometricND_leaf4"
+    raise ValueError(name)
+
+
+def cpu_baseline(sample_m):
+    """Oracle (CPU restatement of the reference loop) timed on the host cores on a
+    bounded sample of the same workload family."""
+    from oracle.oracle import OracleFactor, bind_blas
+    from suitesparse_amd import generators as G
+    blas = bind_blas()
+    n, Ap, Ai, Ax = G.poisson3d(sample_m)
+    perm = G.geometric_nd(sample_m, sample_m, sample_m, 4)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    t0 = time.perf_counter()
+    st = O.factorize(Ax)
+    dt = time.perf_counter() - t0
+    assert st == 0
+    cores = os.cpu_count() if blas else 1
+    return {"value": O.fl / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"poisson3d {sample_m}^3 geometric ND, one factorization, fl={O.fl:.3e}, "
+                      f"{dt:.2f} s, BLAS={blas or 'built-in C kernels'}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="poisson3d")
+    ap.add_argument("--m", type=int, default=100)
+    ap.add_argument("--cpu-sample-m", type=int, default=56)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also solve and print the residual")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from suitesparse_amd import cholmod as ch
+    lib = ch.lib()
+    if lib.cholmod_hip_probe() != 1:
+        raise RuntimeError("bench.py needs a HIP device; there is no CPU path to measure")
+    lib.cholmod_hip_set_device(local_rank)
+
+    t0 = time.perf_counter()
+    n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, args.m)
+    t_gen = time.perf_counter() - t0
+    S = ch.Session(factor_on_device=True)
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    t0 = time.perf_counter()
+    Lf = S.analyze(A, perm)
+    t_analyze = time.perf_counter() - t0
+    fl = S.cm.fl
+    fv = ch.FactorView(Lf)
+    # first factorization: builds the plan, uploads S (H2D, outside the timed region)
+    t0 = time.perf_counter()
+    ok = S.factorize(A, Lf)
+    t_first = time.perf_counter() - t0
+    assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+
+    def barrier():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup - 1, 0)):
+        assert S.refactorize_resident(Lf) == 1
+    barrier()
+    t0 = time.perf_counter()
+    dev_s = 0.0
+    for _ in range(args.steps):
+        assert S.refactorize_resident(Lf) == 1     # synchronises the engine stream
+        dev_s += S.hip_stats(Lf)[0]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = S.hip_stats(Lf)
+    exec_flops = stats[1]
+
+    # roofline of the dominant kernel (128x128 fp64-MFMA update): one extra,
+    # untimed factorization with HIP events around every launch
+    roof = None
+    if not args.no_profile_pass:
+        S.set_profiling(Lf, True)
+        assert S.refactorize_resident(Lf) == 1
+        ps = S.hip_stats(Lf)
+        S.set_profiling(Lf, False)
+        if ps[6] > 0:
+            ach = ps[8] / ps[6] / 1e12
+            roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "k_update<128,128,16,mfma>", "launches": int(ps[7]),
+                    "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
+                    "seconds_by_class": {"update128": ps[6], "update64": ps[14], "extend_add+zero": ps[9],
+                                         "potrf": ps[11], "trsm": ps[12], "assemble": ps[13],
+                                         "total_profiled": ps[0]}}
+
+    resid = None
+    if args.check:
+        from suitesparse_amd import generators as G
+        b = G.demo_rhs(n)
+        x = S.solve(Lf, b)
+        r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
+        resid = float(np.linalg.norm(r) / np.linalg.norm(b))
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.cpu_sample_m)
+        mf = lib.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
+        value = fl * args.steps * world / elapsed / 1e9
+        line = {
+            "metric": "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)",
+            "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wname, "n": int(n), "nnz_lower": int(Ap[-1]),
+                       "fl": fl, "executed_flops": exec_flops, "nsuper": fv.nsuper,
+                       "Lx_GB": 8e-9 * fv.xsize, "arena_GB": 1e-9 * stats[4],
+                       "levels": int(stats[3]), "launches_per_step": int(stats[2]),
+                       "parallelism": "1 GPU" if world == 1 else f"{world} replicas (no subtree split yet)",
+                       "input": "S=tril(PAP') resident in HBM; factor left in HBM"},
+            "pct_fp64_mfma_peak": 100.0 * value / world / (1e3 * FP64_MFMA_PEAK_TFLOPS),
+            "device_ms_per_step": 1e3 * dev_s / args.steps,
+            "measured_update_kernel_TFLOPs_8192x8192x512": mf / 1e12 if mf > 0 else None,
+            "roofline": roof, "cpu_baseline": cpu,
+            "host_seconds": {"generate": t_gen, "analyze": t_analyze, "first_factorize_incl_plan_h2d": t_first},
+        }
+        if resid is not None:
+            line["residual_2norm"] = resid
+        print(json.dumps(line))
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -110,8 +110,9 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *  [0] device seconds, whole factorization (HIP events on the engine stream)
  *  [1] executed flops (updates + panel factorizations, as SURVEY.md 8d)
  *  [2] kernel launches   [3] levels   [4] arena bytes   [5] Lx bytes
- *  [6] seconds in dense-update kernels   [7] launches of dense-update kernels
- *  [8] algorithmic flops of dense-update kernels
+ *  [6] seconds in the 128x128 dense-update kernel   [7] its launches
+ *  [8] its algorithmic flops (2*k per updated lower-trapezoid entry)
+ *  [14] seconds in the 64x64 dense-update kernel    [15] its algorithmic flops
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)

@@ -537,7 +537,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_BIG || L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; }
+        if (L.kind == K_UPD_BIG) { S [7] += 1 ; S [8] += L.flops ; }
+        if (L.kind == K_UPD_SMALL) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
     if (prof)
@@ -552,7 +553,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             double sec = t * 1e-3 ;
             switch (L.kind)
             {
-                case K_UPD_BIG: case K_UPD_SMALL: S [6] += sec ; break ;
+                case K_UPD_BIG: S [6] += sec ; break ;
+                case K_UPD_SMALL: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;

@@ -87,7 +87,7 @@ static void absorb_stats (cholmod_factor *L, cholmod_common *Common)
     Common->gpuKernelTime = s [0] ;
     Common->gpuFlops = (SuiteSparse_long) s [1] ;
     Common->gpuNumKernelLaunches = (int) s [2] ;
-    Common->cholmod_gpu_syrk_time = s [6] ;
+    Common->cholmod_gpu_syrk_time = s [6] + s [14] ;
     Common->cholmod_gpu_syrk_calls = (size_t) s [7] ;
     Common->cholmod_gpu_gemm_time = 0 ; Common->cholmod_gpu_gemm_calls = 0 ;
     Common->cholmod_gpu_potrf_time = s [11] ;
