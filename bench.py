@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--check", action="store_true", help="also solve and print the residual")
+    ap.add_argument("--hip-flags", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,7 +96,7 @@ def main():
     t0 = time.perf_counter()
     n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, args.m)
     t_gen = time.perf_counter() - t0
-    S = ch.Session(factor_on_device=True)
+    S = ch.Session(factor_on_device=True, hip_flags=args.hip_flags)
     A = S.sparse(n, Ap, Ai, Ax, stype)
     t0 = time.perf_counter()
     Lf = S.analyze(A, perm)
@@ -132,7 +133,7 @@ def main():
     stats = S.hip_stats(Lf)
     exec_flops = stats[1]
 
-    # roofline of the dominant kernel (128x128 fp64-MFMA update): one extra,
+    # roofline of the dominant kernel (64x64-tile fp64-MFMA update): one extra,
     # untimed factorization with HIP events around every launch
     roof = None
     if not args.no_profile_pass:
@@ -144,9 +145,9 @@ def main():
             ach = ps[8] / ps[6] / 1e12
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "kernel": "k_update<128,128,16,mfma>", "launches": int(ps[7]),
+                    "kernel": "k_update2<64,64,16,2,false>", "launches": int(ps[7]),
                     "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
-                    "seconds_by_class": {"update128": ps[6], "update64": ps[14], "extend_add+zero": ps[9],
+                    "seconds_by_class": {"update64": ps[6], "update128": ps[14], "extend_add+zero": ps[9],
                                          "potrf": ps[11], "trsm": ps[12], "assemble": ps[13],
                                          "total_profiled": ps[0]}}
 
@@ -163,6 +164,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_m)
         mf = lib.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
+        mpeak = lib.cholmod_hip_bench_mfma_peak(2, 20000)
         value = fl * args.steps * world / elapsed / 1e9
         line = {
             "metric": "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)",
@@ -179,6 +181,7 @@ def main():
             "pct_fp64_mfma_peak": 100.0 * value / world / (1e3 * FP64_MFMA_PEAK_TFLOPS),
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "measured_update_kernel_TFLOPs_8192x8192x512": mf / 1e12 if mf > 0 else None,
+            "measured_mfma_f64_16x16x4_issue_peak_TFLOPs": mpeak / 1e12 if mpeak > 0 else None,
             "roofline": roof, "cpu_baseline": cpu,
             "host_seconds": {"generate": t_gen, "analyze": t_analyze, "first_factorize_incl_plan_h2d": t_first},
         }

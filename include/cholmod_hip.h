@@ -32,6 +32,10 @@ extern "C" {
 /* plan flags */
 #define CHOLMOD_HIP_PLAN_DEFAULT   0
 #define CHOLMOD_HIP_GEMM_VALU      1    /* debug: VALU instead of MFMA tiles */
+#define CHOLMOD_HIP_TILE128         4    /* tuning: 128x128 update tiles on big regions
+                                           (default: 64x64 everywhere, which fills the
+                                           256 CUs on mid-size fronts)               */
+#define CHOLMOD_HIP_NO_LOOKAHEAD    8    /* tuning: single stream, no panel look-ahead */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 
@@ -110,9 +114,10 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *  [0] device seconds, whole factorization (HIP events on the engine stream)
  *  [1] executed flops (updates + panel factorizations, as SURVEY.md 8d)
  *  [2] kernel launches   [3] levels   [4] arena bytes   [5] Lx bytes
- *  [6] seconds in the 128x128 dense-update kernel   [7] its launches
+ *  [6] seconds in the 64x64 dense-update kernel   [7] its launches
  *  [8] its algorithmic flops (2*k per updated lower-trapezoid entry)
- *  [14] seconds in the 64x64 dense-update kernel    [15] its algorithmic flops
+ *  [14] seconds in the 128x128 dense-update kernel (CHOLMOD_HIP_TILE128 only)
+ *  [15] its algorithmic flops
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)
@@ -127,6 +132,14 @@ int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
  * Returns achieved flop/s, or a negative CHOLMOD_HIP_* code. */
 double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
     int iters, int flags) ;
+
+/* Issue-bound v_mfma_f64_16x16x4_f64 loop without memory traffic: the measured
+ * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */
+double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
+
+/* Tuning probe: waves 0,1 of every block run the MFMA loop, waves 2,3 a
+ * v_fma_f64 loop; returns the seconds the launch took. */
+double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu) ;
 
 /* Test hook: run the engine's dense partial factorization on ONE dense front
  * given on the host (column-major nsrow-by-nsrow, lower; the first nscol

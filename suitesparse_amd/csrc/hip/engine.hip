@@ -22,7 +22,7 @@ constexpr int NB = PF_NB ;      // inner panel width (potrf / trsm block)
 constexpr int OB = 512 ;        // outer block: trailing updates contract over <= OB columns
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -31,6 +31,9 @@ struct Launch {
     size_t goff ;       // first group (index into the kind's group array)
     double flops ;      // algorithmic flops (dense kinds)
     double bytes ;      // algorithmic bytes (extend-add / zero)
+    int stream = 0 ;    // 0 = main, 1 = look-ahead (panel) stream
+    int wait_ev = -1 ;  // event this launch's stream waits for first
+    int rec_ev = -1 ;   // event recorded on its stream right after it
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -112,6 +115,7 @@ struct Schedule {
     std::vector<TrGroup> tg ;
     std::vector<GemmGroup> gg ;
     std::vector<Launch> launches ;
+    int nevents = 0 ;
 } ;
 
 template <typename T> static T *dupload (const std::vector<T> &v, hipError_t &err)
@@ -139,7 +143,9 @@ struct cholmod_hip_plan {
     Schedule sch ;
     double exec_flops = 0 ;
     // device
-    hipStream_t stream = nullptr ;
+    hipStream_t stream = nullptr ;          // main stream
+    hipStream_t stream2 = nullptr ;         // look-ahead (panel) stream
+    std::vector<hipEvent_t> sync_ev ;       // schedule events (no timing)
     i64 *d_Ls = nullptr ;
     FrontD *d_fr = nullptr ;
     i32 *d_supermap = nullptr, *d_child = nullptr, *d_relmap = nullptr, *d_info = nullptr ;
@@ -166,8 +172,10 @@ namespace {
 // of fronts (all of one etree level): two-level blocked right-looking Cholesky
 // of the first nscol columns of every front [panel | CB].
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
-    Schedule &S, bool valu, double &exec_flops)
+    Schedule &S, int flags, double &exec_flops)
 {
+    bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
+    bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
     int maxnscol = 0 ;
     for (int q = 0 ; q < nf ; q++) maxnscol = std::max (maxnscol, fr [ids [q]].nscol) ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
@@ -210,12 +218,50 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
         else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
-        bool isbig = !valu && ncols >= BIG && m >= 2 * BIG ;
+        bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
     std::vector<GemmGroup> big, small ;
+    // Look-ahead (levels whose fronts span several outer blocks): the panel
+    // work of block ob+1 (potrf/trsm/inner updates, a handful of workgroups on
+    // the critical path) runs on a second stream while the big trailing update
+    // of block ob still occupies the chip.  The outer update is split in
+    //   U_next(ob): target = the next outer block column only   (panel stream)
+    //   U_rest(ob): target = everything right of it, incl. CB   (main stream)
+    // Emission order P(0) U_next(0) U_rest(0) P(1) ... is also a valid serial
+    // order, which is what the profiling mode uses.
+    bool lookahead = !(flags & CHOLMOD_HIP_NO_LOOKAHEAD) && maxnscol > OB ;
+    int cur_stream = 0, pend_wait = -1 ;
+    size_t mark = S.launches.size () ;
+    auto tag_new = [&] ()
+    {
+        // stamp the launches emitted since `mark` with the current stream; the
+        // first of them carries the pending wait
+        for (size_t q = mark ; q < S.launches.size () ; q++)
+        {
+            S.launches [q].stream = cur_stream ;
+            if (pend_wait >= 0) { S.launches [q].wait_ev = pend_wait ; pend_wait = -1 ; }
+        }
+        mark = S.launches.size () ;
+    } ;
+    auto record_last = [&] () -> int
+    {
+        if (S.launches.size () == 0) return -1 ;
+        if (S.launches.back ().rec_ev < 0) S.launches.back ().rec_ev = S.nevents++ ;
+        return S.launches.back ().rec_ev ;
+    } ;
+    int ev_fork = -1, ev_rest_prev = -1, ev_side_last = -1 ;
+    if (lookahead && !S.launches.empty ())
+    {
+        // everything before this level's dense phase is on the main stream
+        if (S.launches.back ().rec_ev < 0) S.launches.back ().rec_ev = S.nevents++ ;
+        ev_fork = S.launches.back ().rec_ev ;
+    }
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
+        // ---- P(ob): panel factorization of the outer block column ----------
+        cur_stream = lookahead ? 1 : 0 ;
+        if (lookahead && o0 == 0) pend_wait = ev_fork ;
         for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
         {
             // potrf of the diagonal blocks
@@ -262,17 +308,72 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
             flush_updates (big, small) ;
         }
-        // outer trailing update: everything right of the outer block column
+        tag_new () ;
+        int ev_panel = lookahead ? record_last () : -1 ;
+        if (!lookahead)
+        {
+            // outer trailing update: everything right of the outer block column
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= o0) continue ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                int kk = o1 - o0 ;
+                add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false) ;
+                add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true) ;
+            }
+            flush_updates (big, small) ;
+            tag_new () ;
+            continue ;
+        }
+        // ---- U_next(ob) on the panel stream, after U_rest(ob-1) --------------
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= o0) continue ;
             int o1 = std::min (o0 + OB, f.nscol) ;
+            int o2 = std::min (o1 + OB, f.nscol) ;
+            add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, o2 - o1, false) ;
+        }
+        pend_wait = ev_rest_prev ;
+        flush_updates (big, small) ;
+        tag_new () ;
+        pend_wait = -1 ;
+        if (S.launches.size () > 0 && S.launches.back ().stream == 1) ev_side_last = -2 ;
+        // ---- U_rest(ob) on the main stream, after P(ob) ----------------------
+        cur_stream = 0 ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= o0) continue ;
+            int o1 = std::min (o0 + OB, f.nscol) ;
+            int o2 = std::min (o1 + OB, f.nscol) ;
             int kk = o1 - o0 ;
-            add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false) ;
+            add_update (big, small, f, ids [q], o2, o0, kk, f.nsrow - o2, f.nscol - o2, false) ;
             add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true) ;
         }
+        pend_wait = ev_panel ;
+        size_t before = S.launches.size () ;
         flush_updates (big, small) ;
+        tag_new () ;
+        pend_wait = -1 ;
+        if (S.launches.size () > before) ev_rest_prev = record_last () ;
+    }
+    if (lookahead)
+    {
+        // join: the main stream must not run ahead of the panel stream's tail
+        int last_side = -1 ;
+        for (size_t q = S.launches.size () ; q-- > 0 ; )
+            if (S.launches [q].stream == 1) { last_side = (int) q ; break ; }
+        if (last_side >= 0)
+        {
+            int e = S.launches [last_side].rec_ev ;
+            if (e < 0) { e = S.nevents++ ; S.launches [last_side].rec_ev = e ; }
+            S.launches.push_back (Launch {K_JOIN, 0, 0, 0, 0, 0}) ;
+            S.launches.back ().stream = 0 ;
+            S.launches.back ().wait_ev = e ;
+        }
+        (void) ev_side_last ;
     }
     for (int q = 0 ; q < nf ; q++)
     {
@@ -361,7 +462,6 @@ static int build_host (cholmod_hip_plan *P)
     P->arena = A.top ;
     // launch schedule
     Schedule &S = P->sch ;
-    bool valu = (P->flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     for (int l = 0 ; l < nlev ; l++)
     {
         const i32 *ids = P->lvl_list.data () + P->lvl_ptr [l] ;
@@ -395,7 +495,7 @@ static int build_host (cholmod_hip_plan *P)
         }
         Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
         if (Le.ng) S.launches.push_back (Le) ;
-        schedule_dense (P->fr, ids, nf, S, valu, P->exec_flops) ;
+        schedule_dense (P->fr, ids, nf, S, P->flags, P->exec_flops) ;
     }
     return CHOLMOD_HIP_OK ;
 }
@@ -407,6 +507,8 @@ static void free_device (cholmod_hip_plan *P)
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
+    for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
+    if (P->stream2) (void) hipStreamDestroy (P->stream2) ;
     if (P->ev0) (void) hipEventDestroy (P->ev0) ;
     if (P->ev1) (void) hipEventDestroy (P->ev1) ;
     if (P->stream) (void) hipStreamDestroy (P->stream) ;
@@ -416,6 +518,13 @@ static int upload_plan (cholmod_hip_plan *P)
 {
     hipError_t e ;
     HIPCHK (hipStreamCreate (&P->stream)) ;
+    HIPCHK (hipStreamCreate (&P->stream2)) ;
+    for (int q = 0 ; q < P->sch.nevents ; q++)
+    {
+        hipEvent_t e ;
+        HIPCHK (hipEventCreateWithFlags (&e, hipEventDisableTiming)) ;
+        P->sync_ev.push_back (e) ;
+    }
     HIPCHK (hipEventCreate (&P->ev0)) ;
     HIPCHK (hipEventCreate (&P->ev1)) ;
     size_t freeb = 0, totalb = 0 ;
@@ -453,11 +562,13 @@ static int upload_plan (cholmod_hip_plan *P)
     return CHOLMOD_HIP_OK ;
 }
 
-static int run_launch (cholmod_hip_plan *P, const Launch &L)
+static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
-    hipStream_t st = P->stream ;
+    hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
+    if (!serial && L.wait_ev >= 0) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     switch (L.kind)
     {
+        case K_JOIN: break ;
         case K_ZERO:
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
@@ -471,17 +582,19 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L)
             hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS), 0, st,
                 P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info) ; break ;
         case K_UPD_BIG:
-            hipLaunchKernelGGL ((k_update<BIG, BIG, BKK, true>), dim3 (L.grid), dim3 (256), 0, st,
-                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ; break ;
+            hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            break ;
         case K_UPD_SMALL:
             if (P->flags & CHOLMOD_HIP_GEMM_VALU)
                 hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (L.grid), dim3 (256), 0, st,
                     P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             else
-                hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, true>), dim3 (L.grid), dim3 (256), 0, st,
+                hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                     P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
     }
+    if (!serial && L.rec_ev >= 0) HIPCHK (hipEventRecord (P->sync_ev [L.rec_ev], st)) ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -514,7 +627,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     {
         const Launch &L = P->sch.launches [q] ;
         if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
-        run_launch (P, L) ;
+        { int rl = run_launch (P, L, prof) ; if (rl != CHOLMOD_HIP_OK) return rl ; }
         if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1) + 1], st)) ;
     }
     HIPCHK (hipGetLastError ()) ;
@@ -537,8 +650,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_BIG) { S [7] += 1 ; S [8] += L.flops ; }
-        if (L.kind == K_UPD_SMALL) { S [15] += L.flops ; }
+        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; }
+        if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
     if (prof)
@@ -553,8 +666,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             double sec = t * 1e-3 ;
             switch (L.kind)
             {
-                case K_UPD_BIG: S [6] += sec ; break ;
-                case K_UPD_SMALL: S [14] += sec ; break ;
+                case K_UPD_SMALL: S [6] += sec ; break ;
+                case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
@@ -798,11 +911,18 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     Schedule S ;
     i32 id = 0 ;
     double fl = 0 ;
-    schedule_dense (fr, &id, 1, S, (flags & CHOLMOD_HIP_GEMM_VALU) != 0, fl) ;
+    schedule_dense (fr, &id, 1, S, flags, fl) ;
     cholmod_hip_plan P ;
     P.flags = flags ;
     hipError_t e ;
     HIPCHK (hipStreamCreate (&P.stream)) ;
+    HIPCHK (hipStreamCreate (&P.stream2)) ;
+    for (int q = 0 ; q < S.nevents ; q++)
+    {
+        hipEvent_t ev ;
+        HIPCHK (hipEventCreateWithFlags (&ev, hipEventDisableTiming)) ;
+        P.sync_ev.push_back (ev) ;
+    }
     i64 ncb = nsrow - nscol ;
     HIPCHK (hipMalloc ((void **) &P.d_Lx, nsrow * nscol * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P.d_cb, std::max<i64> (ncb * ncb, 1) * sizeof (double))) ;
@@ -815,8 +935,10 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     if (ncb > 0)
         HIPCHK (hipMemcpy2D (P.d_cb, ncb * sizeof (double), F + nscol + nscol * nsrow,
             nsrow * sizeof (double), ncb * sizeof (double), ncb, hipMemcpyHostToDevice)) ;
-    for (const Launch &L : S.launches) run_launch (&P, L) ;
+    HIPCHK (hipDeviceSynchronize ()) ;       // uploads above used the null stream
+    for (const Launch &L : S.launches) run_launch (&P, L, false) ;
     HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipStreamSynchronize (P.stream2)) ;
     HIPCHK (hipStreamSynchronize (P.stream)) ;
     HIPCHK (hipMemcpy (F, P.d_Lx, nsrow * nscol * sizeof (double), hipMemcpyDeviceToHost)) ;
     if (ncb > 0)
@@ -826,7 +948,8 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     HIPCHK (hipMemcpy (&inf, P.d_info, sizeof (i32), hipMemcpyDeviceToHost)) ;
     if (info_out) *info_out = inf ;
     free_device (&P) ;
-    P.stream = nullptr ; P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
+    P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
+    P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
     P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
@@ -849,7 +972,7 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
         h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
     }
     (void) hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice) ;
-    bool small = (flags & 4) != 0 ;
+    bool small = (flags & CHOLMOD_HIP_TILE128) == 0 ;
     int T = small ? SMALL : BIG ;
     GemmGroup G ;
     memset (&G, 0, sizeof (G)) ;
@@ -867,9 +990,9 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
         if (flags & CHOLMOD_HIP_GEMM_VALU)
             hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (small)
-            hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else
-            hipLaunchKernelGGL ((k_update<BIG, BIG, BKK, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+            hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
     } ;
     launch () ;
     (void) hipDeviceSynchronize () ;
@@ -884,6 +1007,58 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
     if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
     return 2.0 * (double) m * n * k * iters / (ms * 1e-3) ;
+}
+
+/* mixed MFMA+VALU issue test: returns seconds; flops are computed by the caller */
+double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    int blocks = 256 * blocks_per_cu ;
+    double *d = nullptr ;
+    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    hipLaunchKernelGGL (k_mixed_peak, dim3 (blocks), dim3 (256), 0, 0, d, 4, 4) ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    hipLaunchKernelGGL (k_mixed_peak, dim3 (blocks), dim3 (256), 0, 0, d, it_mfma, it_valu) ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    (void) hipFree (d) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    return ms * 1e-3 ;
+}
+
+double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    bool valu = waves_per_simd < 0 ;            // negative: fp64 VALU FMA loop instead
+    if (valu) waves_per_simd = -waves_per_simd ;
+    if (waves_per_simd < 1) waves_per_simd = 1 ;
+    if (iters < 1) iters = 1 ;
+    int blocks = 256 * waves_per_simd ;         // 256 CUs x (4 waves per block = 1 per SIMD)
+    double *d = nullptr ;
+    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
+    else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
+    else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    hipError_t err = hipGetLastError () ;
+    (void) hipFree (d) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    if (valu) return (double) blocks * 256.0 * iters * 16.0 * 2.0 / (ms * 1e-3) ;
+    return (double) blocks * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) ;
 }
 
 } // extern "C"

@@ -184,9 +184,25 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
 // NaN pivots do not stop it (:907-908).  After a failure every remaining
 // column of this front is written as zero (:889-895, :926-931).
 #define PF_NB 64
+#define PF_LD 66            /* even (16-B aligned pairs) and conflict-free for b128 */
+#define PF_CW 8             /* columns eliminated per group */
+// One wave, lane = row.  The block is processed in groups of PF_CW columns:
+//  (1) left-looking update of the lane's PF_CW entries by all earlier columns
+//      (PF_CW independent FMA chains; own row read contiguously from T, the
+//      multipliers L(jb..jb+7,k) read as one broadcast line from the k-major
+//      copy Tt);
+//  (2) the PF_CW x PF_CW diagonal block is factored redundantly by every lane
+//      in registers (no cross-lane traffic), (3) each lane solves its own row
+//      against it.  Two barriers per group instead of one per column.
+// The block is identity-padded to a multiple of PF_CW, so nb < 64 needs no
+// special cases.
 __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32 *info)
 {
-    __shared__ double T [PF_NB][PF_NB + 1] ;
+    __shared__ __attribute__((aligned(16))) double T [PF_NB * PF_LD] ;   // T[i][k] = L(i,k)
+    __shared__ __attribute__((aligned(16))) double Tt [PF_NB * PF_NB] ;  // Tt[k][i] = L(i,k)
+    // latency-critical single wave: outrank the MFMA update waves it may share
+    // a SIMD with when the look-ahead stream overlaps it with a trailing update
+    __builtin_amdgcn_s_setprio (3) ;
     PfGroup G = g [blockIdx.x] ;
     double *A = Lx + G.off ;
     int nb = G.nb, lda = G.lda, lane = threadIdx.x ;
@@ -196,48 +212,135 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
             if (lane >= j && lane < nb) A [lane + (i64) j * lda] = 0.0 ;
         return ;
     }
-    for (int j = 0 ; j < nb ; j++)
-        if (lane < nb) T [lane][j] = A [lane + (i64) j * lda] ;
+    int nbp = (nb + PF_CW - 1) / PF_CW * PF_CW ;
+    {
+        // stage the block: 8 independent column loads in flight per step
+        int li = lane < nb ? lane : nb - 1 ;
+        for (int j0 = 0 ; j0 < nbp ; j0 += 8)
+        {
+            double tmp [8] ;
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                int j = j0 + c < nb ? j0 + c : nb - 1 ;
+                tmp [c] = A [li + (i64) j * lda] ;
+            }
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                int j = j0 + c ;
+                double v = (lane < nb && j < nb) ? tmp [c] : (lane == j ? 1.0 : 0.0) ;
+                T [lane * PF_LD + j] = v ;
+            }
+        }
+    }
     __syncthreads () ;
     int fail = -1 ;
-    for (int j = 0 ; j < nb ; j++)
+    for (int jb = 0 ; jb < nbp ; jb += PF_CW)
     {
-        double v = 0.0 ;
-        if (lane >= j && lane < nb)
+        double a [PF_CW] ;
+#pragma unroll
+        for (int c = 0 ; c < PF_CW ; c++) a [c] = T [lane * PF_LD + jb + c] ;
+        for (int k = 0 ; k < jb ; k += 4)
         {
-            v = T [lane][j] ;
-            for (int k = 0 ; k < j ; k++) v -= T [lane][k] * T [j][k] ;
+            double x [4] ;
+#pragma unroll
+            for (int u = 0 ; u < 4 ; u++) x [u] = T [lane * PF_LD + k + u] ;
+#pragma unroll
+            for (int u = 0 ; u < 4 ; u++)
+            {
+                const double *lt = Tt + (k + u) * PF_NB + jb ;
+#pragma unroll
+                for (int c = 0 ; c < PF_CW ; c++) a [c] -= x [u] * lt [c] ;
+            }
         }
-        double d = __shfl (v, j) ;
-        if (d <= 0.0) { fail = j ; break ; }
-        double r = sqrt (d) ;
-        if (lane == j) T [lane][j] = r ;
-        else if (lane > j && lane < nb) T [lane][j] = v / r ;
+#pragma unroll
+        for (int c = 0 ; c < PF_CW ; c++) T [lane * PF_LD + jb + c] = a [c] ;
         __syncthreads () ;
+        // diagonal block, lower part, same values in every lane
+        double D [PF_CW][PF_CW], rinv [PF_CW] ;
+#pragma unroll
+        for (int r = 0 ; r < PF_CW ; r++)
+#pragma unroll
+            for (int c = 0 ; c <= r ; c++) D [r][c] = T [(jb + r) * PF_LD + jb + c] ;
+#pragma unroll
+        for (int c = 0 ; c < PF_CW ; c++)
+        {
+            if (fail < 0)
+            {
+                double d = D [c][c] ;
+                if (d <= 0.0) fail = jb + c ;
+                else
+                {
+                    double r = sqrt (d) ;
+                    double ri = 1.0 / r ;
+                    D [c][c] = r ; rinv [c] = ri ;
+#pragma unroll
+                    for (int r2 = c + 1 ; r2 < PF_CW ; r2++) D [r2][c] *= ri ;
+#pragma unroll
+                    for (int c2 = c + 1 ; c2 < PF_CW ; c2++)
+#pragma unroll
+                        for (int r2 = c2 ; r2 < PF_CW ; r2++) D [r2][c2] -= D [r2][c] * D [c2][c] ;
+                }
+            }
+            if (fail >= 0) { rinv [c] = 0.0 ; }
+        }
+        // own row against the factored diagonal block
+        double x [PF_CW] ;
+#pragma unroll
+        for (int c = 0 ; c < PF_CW ; c++)
+        {
+            double v = a [c] ;
+#pragma unroll
+            for (int e = 0 ; e < c ; e++) v -= x [e] * D [c][e] ;
+            x [c] = v * rinv [c] ;
+            if (lane == jb + c) x [c] = D [c][c] ;
+            if (fail >= 0 && jb + c >= fail) x [c] = 0.0 ;
+        }
+#pragma unroll
+        for (int c = 0 ; c < PF_CW ; c++)
+        {
+            T [lane * PF_LD + jb + c] = x [c] ;
+            Tt [(jb + c) * PF_NB + lane] = x [c] ;
+        }
+        __syncthreads () ;
+        if (fail >= 0) break ;
     }
     if (fail >= 0)
     {
         if (lane == 0) info [G.front] = G.col0 + fail + 1 ;
-        for (int j = fail ; j < nb ; j++)
-            if (lane < nb) T [lane][j] = 0.0 ;
+        for (int j = fail ; j < nb ; j++) T [lane * PF_LD + j] = 0.0 ;
     }
     __syncthreads () ;
-    for (int j = 0 ; j < nb ; j++)
-        if (lane >= j && lane < nb) A [lane + (i64) j * lda] = T [lane][j] ;
+    for (int j0 = 0 ; j0 < nb ; j0 += 8)
+    {
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++)
+        {
+            int j = j0 + c ;
+            if (j < nb && lane >= j && lane < nb) A [lane + (i64) j * lda] = T [lane * PF_LD + j] ;
+        }
+    }
 }
 
 // ---- panel triangular solve: B := B * inv(L11)' , one thread per row --------
-// dtrsm("R","L","C","N") of the reference (:997-1002).  L11 (nb <= 64) is
-// staged in LDS and broadcast; each thread keeps its row of B in registers.
-// Columns at or beyond a failed pivot are written as zero.
-#define TR_ROWS 128
+// dtrsm("R","L","C","N") of the reference (:997-1002).  L11' (nb <= 64) is
+// staged in LDS; a thread solves its row in groups of TR_CW columns held in
+// registers: the contribution of earlier column groups comes from LDS copies of
+// the solved values (column-major over the workgroup's rows: conflict-free) and
+// a broadcast line of L11', the TR_CW x TR_CW diagonal block is applied through
+// its explicit inverse (computed once per workgroup, one lane per column), so
+// no division sits on the per-row dependency chain.  Columns at or beyond a
+// failed pivot are written as zero.
+#define TR_ROWS 64
 #define TR_CW 8
 __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
     double *Lx, const i32 *info)
 {
-    // Lt[k][j] = L11(j,k): for a fixed earlier column k the multipliers of a
-    // group of TR_CW target columns are contiguous (one broadcast LDS line)
-    __shared__ double Lt [PF_NB * PF_NB] ;
+    __shared__ __attribute__((aligned(16))) double Lt [PF_NB * PF_NB] ;  // Lt[k][j] = L11(j,k)
+    __shared__ double xs [PF_NB * TR_ROWS] ;
+    __shared__ __attribute__((aligned(16))) double Wi [(PF_NB / TR_CW) * TR_CW * TR_CW] ; // inverse diagonal blocks
+    __builtin_amdgcn_s_setprio (3) ;
     int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
     TrGroup G = g [gi] ;
     int nb = G.nb, lda = G.lda ;
@@ -251,43 +354,106 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
         if (nvalid < 0) nvalid = 0 ;
         if (nvalid > nb) nvalid = nb ;
     }
+    int t = threadIdx.x ;
     // stage L11', identity-padded to a multiple of TR_CW and beyond a failed
-    // pivot (so the unrolled solve never divides by a zeroed diagonal)
-    for (int e = threadIdx.x ; e < nbp * nbp ; e += TR_ROWS)
+    // pivot; lane j owns row j of L11, 8 independent column loads in flight
     {
-        int j = e % nbp, k = e / nbp ;      // L11(j,k), j >= k
-        double v = (j == k) ? 1.0 : 0.0 ;
-        if (j < nvalid && k <= j) v = L11 [j + (i64) k * lda] ;
-        Lt [k * PF_NB + j] = v ;
+        int j = t ;
+        int jc = j < nb ? j : nb - 1 ;
+        for (int k0 = 0 ; k0 < nbp ; k0 += 8)
+        {
+            double tmp [8] ;
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                int k = k0 + c < nb ? k0 + c : nb - 1 ;
+                tmp [c] = L11 [jc + (i64) k * lda] ;
+            }
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                int k = k0 + c ;
+                double v = (j == k) ? 1.0 : 0.0 ;
+                if (j < nvalid && k <= j) v = tmp [c] ;
+                if (j < nbp) Lt [k * PF_NB + j] = v ;
+            }
+        }
+    }
+    int row = ((int) blockIdx.x - G.blk_start) * TR_ROWS + t ;
+    bool active = row < G.m ;
+    double *B = Lx + G.b_off + (active ? row : 0) ;
+    // prefetch the whole row of B into LDS (nb independent loads in flight)
+    for (int j0 = 0 ; j0 < nbp ; j0 += 8)
+    {
+        double tmp [8] ;
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++)
+        {
+            int j = j0 + c < nb ? j0 + c : nb - 1 ;
+            tmp [c] = B [(i64) j * lda] ;
+        }
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++) xs [(j0 + c) * TR_ROWS + t] = (j0 + c < nb) ? tmp [c] : 0.0 ;
     }
     __syncthreads () ;
-    int row = ((int) blockIdx.x - G.blk_start) * TR_ROWS + threadIdx.x ;
-    if (row >= G.m) return ;
-    double *B = Lx + G.b_off + row ;
+    // inverse of every TR_CW x TR_CW diagonal block: lane (b,q) computes column
+    // q of inv(L_bb) by forward substitution in registers
+    {
+        int b = t >> 3, q = t & 7 ;
+        if (b * TR_CW < nbp)
+        {
+            double y [TR_CW] ;
+#pragma unroll
+            for (int r = 0 ; r < TR_CW ; r++)
+            {
+                double acc = (r == q) ? 1.0 : 0.0 ;
+#pragma unroll
+                for (int e = 0 ; e < r ; e++)
+                    acc -= Lt [(b * TR_CW + e) * PF_NB + b * TR_CW + r] * y [e] ;
+                double v = acc / Lt [(b * TR_CW + r) * PF_NB + b * TR_CW + r] ;
+                y [r] = (r >= q) ? v : 0.0 ;
+            }
+#pragma unroll
+            for (int r = 0 ; r < TR_CW ; r++) Wi [(b * TR_CW + r) * TR_CW + q] = y [r] ;
+        }
+    }
+    __syncthreads () ;
+    if (!active) return ;
     for (int jb = 0 ; jb < nbp ; jb += TR_CW)
     {
         double xb [TR_CW] ;
 #pragma unroll
-        for (int c = 0 ; c < TR_CW ; c++)
-            xb [c] = (jb + c < nb) ? B [(i64) (jb + c) * lda] : 0.0 ;
-        for (int k = 0 ; k < jb ; k++)
+        for (int c = 0 ; c < TR_CW ; c++) xb [c] = xs [(jb + c) * TR_ROWS + t] ;
+        for (int kg = 0 ; kg < jb ; kg += TR_CW)
         {
-            double xk = B [(i64) k * lda] ;         // solved in an earlier group
-            const double *lt = Lt + k * PF_NB + jb ;
+            double xk [TR_CW] ;
 #pragma unroll
-            for (int c = 0 ; c < TR_CW ; c++) xb [c] -= xk * lt [c] ;
+            for (int d = 0 ; d < TR_CW ; d++) xk [d] = xs [(kg + d) * TR_ROWS + t] ;
+#pragma unroll
+            for (int d = 0 ; d < TR_CW ; d++)
+            {
+                const double *lt = Lt + (kg + d) * PF_NB + jb ;
+#pragma unroll
+                for (int c = 0 ; c < TR_CW ; c++) xb [c] -= xk [d] * lt [c] ;
+            }
+        }
+        // x_c = sum_{e<=c} v_e * inv(L_JJ)(c,e)
+        const double *w = Wi + jb * TR_CW ;
+        double xo [TR_CW] ;
+#pragma unroll
+        for (int c = 0 ; c < TR_CW ; c++)
+        {
+            double v = 0.0 ;
+#pragma unroll
+            for (int e = 0 ; e <= c ; e++) v += xb [e] * w [c * TR_CW + e] ;
+            xo [c] = (jb + c < nvalid) ? v : 0.0 ;
         }
 #pragma unroll
         for (int c = 0 ; c < TR_CW ; c++)
         {
-            double v = xb [c] ;
-#pragma unroll
-            for (int d = 0 ; d < c ; d++) v -= xb [d] * Lt [(jb + d) * PF_NB + jb + c] ;
-            xb [c] = v / Lt [(jb + c) * PF_NB + jb + c] ;
+            xs [(jb + c) * TR_ROWS + t] = xo [c] ;
+            if (jb + c < nb) B [(i64) (jb + c) * lda] = xo [c] ;
         }
-#pragma unroll
-        for (int c = 0 ; c < TR_CW ; c++)
-            if (jb + c < nb) B [(i64) (jb + c) * lda] = (jb + c < nvalid) ? xb [c] : 0.0 ;
     }
 }
 
@@ -473,6 +639,209 @@ __global__ void __launch_bounds__(256) k_update (const GemmGroup *g, int ng,
     }
 }
 
+// issue-bound v_fma_f64 loop (register only): the fp64 VALU ceiling
+template <int NACC>
+__global__ void __launch_bounds__(256) k_valu_peak (double *out, int iters)
+{
+    double acc [NACC] ;
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-9 * threadIdx.x ;
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) acc [q] = q ;
+    for (int it = 0 ; it < iters ; it++)
+    {
+#pragma unroll
+        for (int q = 0 ; q < NACC ; q++) acc [q] = __builtin_fma (acc [q], a, b) ;
+    }
+    double sum = 0 ;
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) sum += acc [q] ;
+    out [blockIdx.x * 256 + threadIdx.x] = sum ;
+}
+
+// mixed issue test: waves 0,1 of a block run the MFMA loop, waves 2,3 the VALU
+// loop -- do the fp64 matrix and vector pipes overlap on gfx950?
+__global__ void __launch_bounds__(256) k_mixed_peak (double *out, int it_mfma, int it_valu)
+{
+    int wave = threadIdx.x >> 6 ;
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1e-9 * threadIdx.x ;
+    double sum = 0 ;
+    if (wave < 2)
+    {
+        d4 acc [8] ;
+#pragma unroll
+        for (int q = 0 ; q < 8 ; q++) acc [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+        for (int it = 0 ; it < it_mfma ; it++)
+        {
+#pragma unroll
+            for (int q = 0 ; q < 8 ; q++)
+                acc [q] = __builtin_amdgcn_mfma_f64_16x16x4f64 (a, b, acc [q], 0, 0, 0) ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < 8 ; q++) sum += acc [q][0] + acc [q][1] + acc [q][2] + acc [q][3] ;
+    }
+    else
+    {
+        double acc [16] ;
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++) acc [q] = q ;
+        for (int it = 0 ; it < it_valu ; it++)
+        {
+#pragma unroll
+            for (int q = 0 ; q < 16 ; q++) acc [q] = __builtin_fma (acc [q], a, b) ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++) sum += acc [q] ;
+    }
+    out [blockIdx.x * 256 + threadIdx.x] = sum ;
+}
+
+// ---- dense update, second generation ------------------------------------------
+// Same contract as k_update.  Differences, all measured on MI355X:
+//  * the global loads of a full k-slab are unconditional (row indices clamped
+//    once, rows/cols past the tile edge are computed but never stored), so
+//    hipcc keeps 2*N loads in flight instead of branching and waiting on each;
+//    only the last, partial slab takes a masked path;
+//  * __launch_bounds__(256, MINW): with MINW = 2 two workgroups share a CU and
+//    one's barrier/LDS-store bubble is covered by the other's MFMA stream (one
+//    wave per SIMD tops out at ~35 TFLOP/s, two at ~47 on this part);
+//  * DB = true double-buffers the LDS slabs (one barrier per slab).
+template <int BM, int BN, int BK, int MINW, bool DB>
+__global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int ng,
+    double *Lx, double *CB)
+{
+    constexpr int LDT = BM + 16 ;
+    constexpr int LDU = BN + 16 ;
+    constexpr int WM = BM / 2, WN = BN / 2 ;
+    constexpr int TI = WM / 16, TJ = WN / 16 ;
+    constexpr int NA = BM * BK / 256, NB_ = BN * BK / 256 ;
+    constexpr int ASZ = BK * LDT, BSZ = BK * LDU ;
+    __shared__ double sm [(DB ? 2 : 1) * (ASZ + BSZ)] ;
+
+    int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
+    GemmGroup G = g [gi] ;
+    int I, J ;
+    decode_tile (G, (int) blockIdx.x - G.tile_start, I, J) ;
+    int row0 = I * BM, col0 = J * BN ;
+    int mrem = G.m - row0, nrem = G.n - col0 ;
+    i64 lda = G.lda ;
+    int K = G.k ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    int wm = wave & 1, wn = wave >> 1 ;
+
+    // element (idx % BM, idx / BM) of a slab, idx = tid + 256 q: the row is the
+    // same for every q when BM divides 256, the k offset advances by 256/BM
+    const double *pa, *pb ;
+    {
+        int i = tid % BM ; if (i > mrem - 1) i = mrem - 1 ;
+        int j = tid % BN ; if (j > nrem - 1) j = nrem - 1 ;
+        pa = Lx + G.a_off + row0 + i + (i64) (tid / BM) * lda ;
+        pb = Lx + G.b_off + col0 + j + (i64) (tid / BN) * lda ;
+    }
+    constexpr int KSA = 256 / BM, KSB = 256 / BN ;     // k stride between q's
+    static_assert (256 % BM == 0 && 256 % BN == 0, "tile must divide the block") ;
+    double ra [NA], rb [NB_] ;
+    auto gload_full = [&] (int k0)
+    {
+#pragma unroll
+        for (int q = 0 ; q < NA ; q++) ra [q] = pa [(i64) (k0 + q * KSA) * lda] ;
+#pragma unroll
+        for (int q = 0 ; q < NB_ ; q++) rb [q] = pb [(i64) (k0 + q * KSB) * lda] ;
+    } ;
+    auto gload_tail = [&] (int k0)
+    {
+#pragma unroll
+        for (int q = 0 ; q < NA ; q++)
+        {
+            int k = k0 + tid / BM + q * KSA ;
+            ra [q] = (k < K) ? pa [(i64) (k0 + q * KSA) * lda] : 0.0 ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < NB_ ; q++)
+        {
+            int k = k0 + tid / BN + q * KSB ;
+            rb [q] = (k < K) ? pb [(i64) (k0 + q * KSB) * lda] : 0.0 ;
+        }
+    } ;
+    auto gload = [&] (int k0) { if (k0 + BK <= K) gload_full (k0) ; else gload_tail (k0) ; } ;
+    auto lstore = [&] (int buf)
+    {
+        double *As = sm + buf * (ASZ + BSZ), *Bs = As + ASZ ;
+#pragma unroll
+        for (int q = 0 ; q < NA ; q++) As [(tid / BM + q * KSA) * LDT + (tid % BM)] = ra [q] ;
+#pragma unroll
+        for (int q = 0 ; q < NB_ ; q++) Bs [(tid / BN + q * KSB) * LDU + (tid % BN)] = rb [q] ;
+    } ;
+
+    d4 acc [TI][TJ] ;
+#pragma unroll
+    for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+        for (int b = 0 ; b < TJ ; b++) acc [a][b] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+
+    auto compute = [&] (int buf)
+    {
+        const double *As = sm + buf * (ASZ + BSZ), *Bs = As + ASZ ;
+        const double *ap = As + (lane >> 4) * LDT + wm * WM + (lane & 15) ;
+        const double *bp = Bs + (lane >> 4) * LDU + wn * WN + (lane & 15) ;
+#pragma unroll
+        for (int kk = 0 ; kk < BK ; kk += 4)
+        {
+            double af [TI], bf [TJ] ;
+#pragma unroll
+            for (int a = 0 ; a < TI ; a++) af [a] = ap [kk * LDT + a * 16] ;
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++) bf [b] = bp [kk * LDU + b * 16] ;
+#pragma unroll
+            for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+                for (int b = 0 ; b < TJ ; b++)
+                    acc [a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64 (
+                        bf [b], af [a], acc [a][b], 0, 0, 0) ;
+        }
+    } ;
+
+    gload (0) ;
+    if constexpr (DB)
+    {
+        lstore (0) ;
+        __syncthreads () ;
+        int buf = 0 ;
+        for (int k0 = 0 ; k0 < K ; k0 += BK)
+        {
+            bool more = k0 + BK < K ;
+            if (more) gload (k0 + BK) ;
+            compute (buf) ;
+            if (more) lstore (buf ^ 1) ;
+            __syncthreads () ;
+            buf ^= 1 ;
+        }
+    }
+    else
+    {
+        for (int k0 = 0 ; k0 < K ; k0 += BK)
+        {
+            __syncthreads () ;
+            lstore (0) ;
+            __syncthreads () ;
+            if (k0 + BK < K) gload (k0 + BK) ;
+            compute (0) ;
+        }
+    }
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+#pragma unroll
+    for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+        for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int i = wm * WM + a * 16 + (lane & 15) ;
+                int j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
+                if (i < mrem && j < nrem && (!G.tri || row0 + i >= col0 + j))
+                    C [i + (i64) j * G.ldc] -= acc [a][b][r] ;
+            }
+}
+
 // ---- triangular solves with the device-resident factor (nrhs columns) -------
 // Level-scheduled restatement of cholmod_l_super_lsolve / _ltsolve
 // (t_cholmod_super_solve.c:14-220, :222-411).  One workgroup per supernode of
@@ -591,6 +960,26 @@ __global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
     if (inverse) dst [perm [k]] = src [k] ; else dst [k] = src [perm [k]] ;
 }
 
-// plain dense C -= A*B' wrapper data for the micro-benchmark uses k_update too.
+// ---- micro-benchmark: issue-bound v_mfma_f64_16x16x4_f64 loop (no memory) ----
+// Measures the fp64 matrix-core ceiling that the roofline is priced against
+// (spec 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.4 GHz).
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
+{
+    d4 acc [NACC] ;
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x ;
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) acc [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    for (int it = 0 ; it < iters ; it++)
+    {
+#pragma unroll
+        for (int q = 0 ; q < NACC ; q++)
+            acc [q] = __builtin_amdgcn_mfma_f64_16x16x4f64 (a, b, acc [q], 0, 0, 0) ;
+    }
+    double sum = 0 ;
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) sum += acc [q][0] + acc [q][1] + acc [q][2] + acc [q][3] ;
+    out [blockIdx.x * 256 + threadIdx.x] = sum ;
+}
 
 } // namespace sship

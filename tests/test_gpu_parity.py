@@ -31,8 +31,8 @@ def rel_err_lower(x, xref, mask):
 # ---- dense kernels in isolation -------------------------------------------------
 
 @pytest.mark.parametrize("nsrow,nscol", [(7, 7), (40, 13), (64, 64), (65, 64), (200, 100),
-                                         (333, 129), (700, 530), (900, 64), (1500, 1100)])
-@pytest.mark.parametrize("flags", [0, ch.HIP_GEMM_VALU])
+                                         (333, 129), (700, 530), (900, 64), (1500, 1100), (2500, 1700)])
+@pytest.mark.parametrize("flags", [0, ch.HIP_GEMM_VALU, 4])
 def test_dense_partial_factorization(L, nsrow, nscol, flags):
     rng = np.random.default_rng(nsrow * 1000 + nscol)
     M = rng.standard_normal((nsrow, nsrow))
@@ -258,3 +258,4 @@ def test_update_kernel_microbench_runs(L):
     for flags in (0, 4, ch.HIP_GEMM_VALU):
         rate = L.cholmod_hip_bench_update_kernel(1024, 1024, 256, 2, flags)
         assert rate > 1e10
+    assert L.cholmod_hip_bench_mfma_peak(2, 2000) > 1e13
