@@ -162,6 +162,11 @@ typedef struct cholmod_common_struct
     int hip_factor_on_device ;
     int hip_flags ;                 /* CHOLMOD_HIP_* plan flags */
     int hip_profile ;               /* collect per-kernel-class device times */
+    /* multi-GPU, one process per GPU (see cholmod_hip.h): rank / world size of
+     * this process and the host-provided sum all-reduce on device memory */
+    int hip_rank, hip_world ;
+    int (*hip_allreduce) (void *dev_ptr, int64_t count_doubles, void *user) ;
+    void *hip_allreduce_user ;
 } cholmod_common ;
 
 typedef struct cholmod_sparse_struct
@@ -302,6 +307,9 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common) ;
 /* Device time and per-class statistics of the last factorization
  * (CHOLMOD_HIP_NSTATS doubles, see cholmod_hip.h). */
 int cholmod_l_hip_stats (cholmod_factor *L, double *stats, cholmod_common *Common) ;
+/* Multi-GPU: complete the factor on every rank after a distributed
+ * factorization (needed before cholmod_l_solve / cholmod_l_factor_to_host). */
+int cholmod_l_gather_factor (cholmod_factor *L, cholmod_common *Common) ;
 /* Re-run the numeric factorization on the matrix already resident in HBM. */
 int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L,
     cholmod_common *Common) ;

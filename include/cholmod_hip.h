@@ -35,7 +35,9 @@ extern "C" {
 #define CHOLMOD_HIP_TILE128         4    /* tuning: 128x128 update tiles on big regions
                                            (default: 64x64 everywhere, which fills the
                                            256 CUs on mid-size fronts)               */
-#define CHOLMOD_HIP_NO_LOOKAHEAD    8    /* tuning: single stream, no panel look-ahead */
+#define CHOLMOD_HIP_LOOKAHEAD       8    /* tuning: panel look-ahead on a second stream
+                                           (off by default: fp64 VALU panel code
+                                           starves next to fp64 MFMA waves)          */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 
@@ -67,6 +69,30 @@ cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
     const int64_t *s, int flags, int *status) ;
 
 void cholmod_hip_plan_destroy (cholmod_hip_plan *plan) ;
+
+/* ---- multi-GPU (one process per GPU; no counterpart in the reference, which is
+ * single-GPU: CHOLMOD/GPU/cholmod_gpu.c:160-164) -------------------------------
+ * Every rank builds the same plan from the same symbolic factor and passes its
+ * rank / world size.  The top of the supernodal etree is *shared*: every rank
+ * keeps the shared fronts as partial sums, factors their panels redundantly and
+ * takes every world-th tile of their trailing updates; the subtrees below are
+ * dealt to the ranks (largest first).  The only exchange is an in-place sum
+ * all-reduce of a block column of a shared front right before it is factored;
+ * the engine asks the host for it through this callback (bench.py / the tests
+ * implement it with torch.distributed: RCCL over xGMI, or gloo in CPU tests).
+ * The callback is entered with the engine stream idle and must return only when
+ * the result is visible to later device work.  Returns 0 on success. */
+typedef int (*cholmod_hip_allreduce_fn) (void *dev_ptr, int64_t count_doubles,
+    void *user) ;
+cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px,
+    const int64_t *s, int flags, int rank, int world, int *status) ;
+int cholmod_hip_set_allreduce (cholmod_hip_plan *plan,
+    cholmod_hip_allreduce_fn fn, void *user) ;
+/* owner[s] = rank that factors supernode s, -1 for the shared fronts */
+int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
+/* complete the factor on every rank (sums the ranks' private subtrees) */
+int cholmod_hip_gather_factor (cholmod_hip_plan *plan) ;
 
 /* Numeric factorization  L L' = S + beta*I  of the already permuted,
  * lower-stored matrix S = tril(P A P') (packed or unpacked CSC on the host:

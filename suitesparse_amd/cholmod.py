@@ -35,6 +35,7 @@ class Method(C.Structure):
 
 
 ERRFUNC = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_int, C.c_char_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class Common(C.Structure):
@@ -68,6 +69,8 @@ class Common(C.Structure):
         ("cholmod_gpu_gemm_calls", C.c_size_t), ("cholmod_gpu_syrk_calls", C.c_size_t),
         ("cholmod_gpu_trsm_calls", C.c_size_t), ("cholmod_gpu_potrf_calls", C.c_size_t),
         ("hip_factor_on_device", C.c_int), ("hip_flags", C.c_int), ("hip_profile", C.c_int),
+        ("hip_rank", C.c_int), ("hip_world", C.c_int),
+        ("hip_allreduce", C.c_void_p), ("hip_allreduce_user", C.c_void_p),
     ]
 
 
@@ -118,10 +121,13 @@ API_SYMBOLS = [
     "cholmod_l_gpu_memorysize", "cholmod_l_gpu_probe", "cholmod_l_gpu_deallocate",
     "cholmod_l_gpu_end", "cholmod_l_gpu_allocate",
     "cholmod_l_factor_to_host", "cholmod_l_hip_stats", "cholmod_l_refactorize_resident",
+    "cholmod_l_gather_factor",
 ]
 HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
+    "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
+    "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
@@ -208,6 +214,12 @@ def lib():
     sig("cholmod_hip_memorysize", C.c_int, [C.POINTER(sz), C.POINTER(sz)])
     sig("cholmod_hip_plan_create", vp, [i64, i64, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_int)])
     sig("cholmod_hip_plan_destroy", None, [vp])
+    sig("cholmod_hip_plan_create_dist", vp, [i64, i64, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int)])
+    sig("cholmod_hip_set_allreduce", C.c_int, [vp, ALLREDUCE_FN, vp])
+    sig("cholmod_hip_get_partition", C.c_int, [vp, vp])
+    sig("cholmod_hip_gather_factor", C.c_int, [vp])
+    sig("cholmod_l_gather_factor", C.c_int, [fc, cm])
     sig("cholmod_hip_factorize", C.c_int, [vp, vp, vp, vp, vp, dbl, C.c_int, vp, C.POINTER(i64)])
     sig("cholmod_hip_upload_matrix", C.c_int, [vp, vp, vp, vp, vp])
     sig("cholmod_hip_factorize_resident", C.c_int, [vp, dbl, C.c_int, C.POINTER(i64)])
@@ -236,7 +248,7 @@ class Session:
     """One cholmod_common plus convenience wrappers (tests / bench harness)."""
 
     def __init__(self, supernodal=SUPERNODAL, use_gpu=1, print_level=0, postorder=True,
-                 factor_on_device=False, hip_flags=0):
+                 factor_on_device=False, hip_flags=0, rank=0, world=1, allreduce=None):
         self.L = lib()
         self.cm = Common()
         self.L.cholmod_l_start(C.byref(self.cm))
@@ -247,6 +259,11 @@ class Session:
         self.cm.hip_factor_on_device = int(factor_on_device)
         self.cm.hip_flags = hip_flags
         self._keep = []
+        if world > 1:
+            # allreduce: a ctypes ALLREDUCE_FN (see suitesparse_amd/dist.py)
+            self.cm.hip_rank, self.cm.hip_world = rank, world
+            self._keep.append(allreduce)
+            self.cm.hip_allreduce = C.cast(allreduce, C.c_void_p)
 
     @property
     def status(self):

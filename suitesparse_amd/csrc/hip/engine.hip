@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <vector>
 
 using namespace sship ;
@@ -22,7 +23,7 @@ constexpr int NB = PF_NB ;      // inner panel width (potrf / trsm block)
 constexpr int OB = 512 ;        // outer block: trailing updates contract over <= OB columns
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -34,6 +35,7 @@ struct Launch {
     int stream = 0 ;    // 0 = main, 1 = look-ahead (panel) stream
     int wait_ev = -1 ;  // event this launch's stream waits for first
     int rec_ev = -1 ;   // event recorded on its stream right after it
+    i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: range of Lx summed over the ranks
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -140,6 +142,14 @@ struct cholmod_hip_plan {
     std::vector<i32> lvl_ptr, lvl_list ;        // fronts by level
     i64 relsize = 0, arena = 0 ;
     int nlevels = 0 ;
+    // multi-GPU: one process per GPU; owner[s] = rank that factors front s, or
+    // -1 for the shared top fronts every rank holds as partial sums
+    int rank = 0, world = 1 ;
+    std::vector<i32> owner ;
+    std::vector<i32> my_lvl_ptr, my_lvl_list ;  // this rank's fronts by level
+    cholmod_hip_allreduce_fn ar_fn = nullptr ;
+    void *ar_user = nullptr ;
+    double *d_xchg = nullptr ;
     Schedule sch ;
     double exec_flops = 0 ;
     // device
@@ -172,7 +182,7 @@ namespace {
 // of fronts (all of one etree level): two-level blocked right-looking Cholesky
 // of the first nscol columns of every front [panel | CB].
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
-    Schedule &S, int flags, double &exec_flops)
+    Schedule &S, int flags, const i32 *owner, int rank, int world)
 {
     bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
@@ -193,20 +203,27 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 G.tile_start = (i32) tiles ;
                 i64 cnt = G.tri ? (i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt
                                 : (i64) G.mt * G.nt ;
-                tiles += cnt ;
+                // this rank's share of the tiles: tile_add, tile_add + tile_mul, ...
+                i64 mine = (cnt > G.tile_add) ? (cnt - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
+                if (mine == 0) continue ;
+                tiles += mine ;
                 double elems = G.tri ? (double) G.n * (G.n + 1) / 2 + (double) (G.m - G.n) * G.n
                                      : (double) G.m * G.n ;
-                L.flops += 2.0 * elems * G.k ;
-                L.bytes += 16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k ;
+                double share = (double) mine / (double) cnt ;
+                L.flops += 2.0 * elems * G.k * share ;
+                L.bytes += (16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
                 S.gg.push_back (G) ;
             }
+            L.ng = (int) (S.gg.size () - L.goff) ;
             L.grid = (int) tiles ;
-            S.launches.push_back (L) ;
+            if (L.ng) S.launches.push_back (L) ;
             v.clear () ;
         }
     } ;
+    auto is_shared = [&] (int fid) { return owner && world > 1 && owner [fid] < 0 ; } ;
     auto add_update = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small,
-        const FrontD &f, int fid, int r0, int kc, int kk, int m, int ncols, bool to_cb)
+        const FrontD &f, int fid, int r0, int kc, int kk, int m, int ncols, bool to_cb,
+        bool split = false)
     {
         // target region: rows r0.., cols r0.. of the front (starts on the diagonal)
         if (m <= 0 || ncols <= 0 || kk <= 0) return ;
@@ -218,6 +235,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
         else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
+        G.tile_mul = 1 ; G.tile_add = 0 ;
+        if (split && is_shared (fid)) { G.tile_mul = world ; G.tile_add = rank ; }
         bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
@@ -230,7 +249,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     //   U_rest(ob): target = everything right of it, incl. CB   (main stream)
     // Emission order P(0) U_next(0) U_rest(0) P(1) ... is also a valid serial
     // order, which is what the profiling mode uses.
-    bool lookahead = !(flags & CHOLMOD_HIP_NO_LOOKAHEAD) && maxnscol > OB ;
+    bool lookahead = (flags & CHOLMOD_HIP_LOOKAHEAD) && world == 1 && maxnscol > OB ;
     int cur_stream = 0, pend_wait = -1 ;
     size_t mark = S.launches.size () ;
     auto tag_new = [&] ()
@@ -259,6 +278,21 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     }
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
+        // ---- multi-GPU: the block columns of the shared fronts hold per-rank
+        // partial sums (extend-adds of the rank's own subtrees + its share of
+        // the earlier trailing-update tiles); sum them before they are factored
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
+            int o1 = std::min (o0 + OB, f.nscol) ;
+            Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
+            La.ar_off = f.psx + (i64) o0 * f.nsrow ;
+            La.ar_cnt = (i64) (o1 - o0) * f.nsrow ;
+            La.bytes = 8.0 * La.ar_cnt ;
+            S.launches.push_back (La) ;
+        }
+        tag_new () ;
         // ---- P(ob): panel factorization of the outer block column ----------
         cur_stream = lookahead ? 1 : 0 ;
         if (lookahead && o0 == 0) pend_wait = ev_fork ;
@@ -319,8 +353,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 if (f.nscol <= o0) continue ;
                 int o1 = std::min (o0 + OB, f.nscol) ;
                 int kk = o1 - o0 ;
-                add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false) ;
-                add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true) ;
+                add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false, true) ;
+                add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true, true) ;
             }
             flush_updates (big, small) ;
             tag_new () ;
@@ -375,12 +409,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         }
         (void) ev_side_last ;
     }
-    for (int q = 0 ; q < nf ; q++)
-    {
-        const FrontD &f = fr [ids [q]] ;
-        double c = f.nscol, r = f.ncb ;
-        exec_flops += c * c * c / 3.0 + r * c * c + r * r * c ;
-    }
 }
 
 static int build_host (cholmod_hip_plan *P)
@@ -418,16 +446,16 @@ static int build_host (cholmod_hip_plan *P)
             P->level [f.parent] = std::max (P->level [f.parent], P->level [s] + 1) ;
         }
     }
-    i32 acc = 0 ;
-    for (i64 s = 0 ; s < nsuper ; s++)
+    // full child lists (tree order), used for the arena lifetimes
+    std::vector<i32> cptr (nsuper + 1, 0), call (std::max<i64> (nsuper, 1), 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++) cptr [s+1] = cptr [s] + nchild [s] ;
     {
-        P->fr [s].child_begin = acc ; acc += nchild [s] ; P->fr [s].child_end = P->fr [s].child_begin ;
-    }
-    P->child.assign (std::max<i32> (acc, 1), 0) ;
-    for (i64 s = 0 ; s < nsuper ; s++)
-    {
-        i32 p = P->fr [s].parent ;
-        if (p >= 0) P->child [P->fr [p].child_end++] = (i32) s ;
+        std::vector<i32> pos (cptr.begin (), cptr.end () - 1) ;
+        for (i64 s = 0 ; s < nsuper ; s++)
+        {
+            i32 p = P->fr [s].parent ;
+            if (p >= 0) call [pos [p]++] = (i32) s ;
+        }
     }
     int nlev = 0 ;
     for (i64 s = 0 ; s < nsuper ; s++) nlev = std::max (nlev, P->level [s] + 1) ;
@@ -440,7 +468,83 @@ static int build_host (cholmod_hip_plan *P)
         std::vector<i32> pos (P->lvl_ptr.begin (), P->lvl_ptr.end () - 1) ;
         for (i64 s = 0 ; s < nsuper ; s++) P->lvl_list [pos [P->level [s]]++] = (i32) s ;
     }
+    // executed flops: sum_s nscol^3/3 + ncb nscol^2 + ncb^2 nscol
+    std::vector<double> wsub (nsuper, 0.0) ;
+    P->exec_flops = 0 ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        double c = P->fr [s].nscol, r = P->fr [s].ncb ;
+        double own = c * c * c / 3.0 + r * c * c + r * r * c ;
+        P->exec_flops += own ;
+        wsub [s] += own ;
+        if (P->fr [s].parent >= 0) wsub [P->fr [s].parent] += wsub [s] ;
+    }
+    // ---- ownership: the top of the tree is shared by all ranks,
+    // the subtrees hanging off it are dealt to the ranks by decreasing weight
+    // (LPT).  A front becomes shared while its subtree outweighs 1/(4 world) of
+    // the whole factorization, so no solo subtree can unbalance the ranks.
+    P->owner.assign (std::max<i64> (nsuper, 1), 0) ;
+    if (P->world > 1 && nsuper > 0)
+    {
+        std::vector<i32> first (nsuper) ;
+        for (i64 s = 0 ; s < nsuper ; s++) first [s] = (i32) s ;
+        for (i64 s = 0 ; s < nsuper ; s++)
+            if (P->fr [s].parent >= 0) first [P->fr [s].parent] = std::min (first [P->fr [s].parent], first [s]) ;
+        typedef std::pair<double, i32> WS ;
+        std::priority_queue<WS> pq ;
+        double total = 0 ;
+        for (i64 s = 0 ; s < nsuper ; s++)
+            if (P->fr [s].parent < 0) { pq.push (WS (wsub [s], (i32) -s)) ; total += wsub [s] ; }
+        double thr = total / (4.0 * P->world) ;
+        std::vector<char> shared (nsuper, 0) ;
+        while (!pq.empty () && pq.top ().first > thr)
+        {
+            i32 t = -pq.top ().second ;
+            pq.pop () ;
+            shared [t] = 1 ;
+            for (i32 c = cptr [t] ; c < cptr [t+1] ; c++) pq.push (WS (wsub [call [c]], -call [c])) ;
+        }
+        std::vector<WS> solo ;
+        while (!pq.empty ()) { solo.push_back (pq.top ()) ; pq.pop () ; }   // weight desc, index asc
+        std::vector<double> load (P->world, 0.0) ;
+        for (const WS &e : solo)
+        {
+            int best = 0 ;
+            for (int r = 1 ; r < P->world ; r++) if (load [r] < load [best]) best = r ;
+            load [best] += e.first ;
+            i32 root = -e.second ;
+            for (i32 q = first [root] ; q <= root ; q++) P->owner [q] = best ;
+        }
+        for (i64 s = 0 ; s < nsuper ; s++) if (shared [s]) P->owner [s] = -1 ;
+    }
+    auto mine = [&] (i64 s) { return P->owner [s] < 0 || P->owner [s] == P->rank ; } ;
+    // this rank's view of the child lists: a shared parent pulls only the
+    // contribution blocks this rank computed (its own subtrees and its partial
+    // copies of shared children); the other ranks add theirs on their side and
+    // the sums meet in the all-reduce of the parent's block columns
+    i32 acc = 0 ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        P->fr [s].child_begin = acc ;
+        if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++) if (mine (call [c])) acc++ ;
+        P->fr [s].child_end = P->fr [s].child_begin ;
+        P->fr [s].assemble = (P->owner [s] == P->rank || (P->owner [s] < 0 && P->rank == 0)) ? 1 : 0 ;
+    }
+    P->child.assign (std::max<i32> (acc, 1), 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+        if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++)
+            if (mine (call [c])) P->child [P->fr [s].child_end++] = call [c] ;
+    P->my_lvl_ptr.assign (nlev + 1, 0) ;
+    P->my_lvl_list.clear () ;
+    for (int l = 0 ; l < nlev ; l++)
+    {
+        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
+            if (mine (P->lvl_list [q])) P->my_lvl_list.push_back (P->lvl_list [q]) ;
+        P->my_lvl_ptr [l+1] = (i32) P->my_lvl_list.size () ;
+    }
+    if (P->my_lvl_list.empty ()) P->my_lvl_list.push_back (0) ;
     // arena: a CB lives from its own level until its parent's level is assembled
+    // (same offsets on every rank)
     Arena A ;
     for (int l = 0 ; l < nlev ; l++)
     {
@@ -451,21 +555,22 @@ static int build_host (cholmod_hip_plan *P)
         }
         for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
         {
-            FrontD &f = P->fr [P->lvl_list [q]] ;
-            for (int c = f.child_begin ; c < f.child_end ; c++)
+            i32 sf = P->lvl_list [q] ;
+            for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
             {
-                FrontD &g = P->fr [P->child [c]] ;
+                FrontD &g = P->fr [call [c]] ;
                 A.release (g.cb, (i64) g.ncb * g.ncb) ;
             }
         }
     }
     P->arena = A.top ;
-    // launch schedule
+    // launch schedule of this rank
     Schedule &S = P->sch ;
     for (int l = 0 ; l < nlev ; l++)
     {
-        const i32 *ids = P->lvl_list.data () + P->lvl_ptr [l] ;
-        int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
+        const i32 *ids = P->my_lvl_list.data () + P->my_lvl_ptr [l] ;
+        int nf = P->my_lvl_ptr [l+1] - P->my_lvl_ptr [l] ;
+        if (nf == 0) continue ;
         Launch Lz {K_ZERO, 0, 0, S.zg.size (), 0, 0} ;
         int blocks = 0 ;
         for (int q = 0 ; q < nf ; q++)
@@ -495,7 +600,7 @@ static int build_host (cholmod_hip_plan *P)
         }
         Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
         if (Le.ng) S.launches.push_back (Le) ;
-        schedule_dense (P->fr, ids, nf, S, P->flags, P->exec_flops) ;
+        schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->rank, P->world) ;
     }
     return CHOLMOD_HIP_OK ;
 }
@@ -504,7 +609,7 @@ static void free_device (cholmod_hip_plan *P)
 {
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm} ;
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -551,6 +656,7 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_xchg, 2 * (size_t) P->world * sizeof (double))) ;
     if (P->nsuper > 0)
     {
         int grid = (int) ((P->nsuper * 64 + 255) / 256) ;
@@ -569,6 +675,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
     switch (L.kind)
     {
         case K_JOIN: break ;
+        case K_ALLREDUCE:
+            if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
+            HIPCHK (hipStreamSynchronize (st)) ;
+            if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            break ;
         case K_ZERO:
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
@@ -676,12 +787,30 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     }
     i64 sbad = -1 ;
     for (i64 s = 0 ; s < P->nsuper ; s++) if (info [s] != 0) { sbad = s ; break ; }
+    i64 binfo = sbad >= 0 ? info [sbad] : 0 ;
+    if (P->world > 1)
+    {
+        // agree on the first failing supernode: every rank publishes its own
+        // candidate in its slot of a small device array, the sum-all-reduce
+        // makes all slots visible everywhere
+        if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
+        std::vector<double> x (2 * (size_t) P->world, 0.0) ;
+        x [P->rank] = (double) (sbad >= 0 ? sbad : P->nsuper) ;
+        x [P->world + P->rank] = (double) binfo ;
+        HIPCHK (hipMemcpy (P->d_xchg, x.data (), x.size () * sizeof (double), hipMemcpyHostToDevice)) ;
+        if (P->ar_fn (P->d_xchg, (i64) x.size (), P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        HIPCHK (hipMemcpy (x.data (), P->d_xchg, x.size () * sizeof (double), hipMemcpyDeviceToHost)) ;
+        i64 best = P->nsuper ;
+        for (int r = 0 ; r < P->world ; r++)
+            if ((i64) x [r] < best) { best = (i64) x [r] ; binfo = (i64) x [P->world + r] ; }
+        sbad = best < P->nsuper ? best : -1 ;
+    }
     *minor = P->n ;
     if (sbad < 0) return CHOLMOD_HIP_OK ;
     const FrontD &f = P->fr [sbad] ;
-    *minor = f.k1 + info [sbad] - 1 ;
+    *minor = f.k1 + binfo - 1 ;
     i64 zero_from = P->px [sbad + 1] ;
-    if (info [sbad] == 1 || quick) zero_from = P->px [sbad] ;
+    if (binfo == 1 || quick) zero_from = P->px [sbad] ;
     if (zero_from < P->xsize)
         HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->xsize - zero_from) * sizeof (double), st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
@@ -722,19 +851,21 @@ int cholmod_hip_set_device (int device)
     return hipSetDevice (device) == hipSuccess ? CHOLMOD_HIP_OK : CHOLMOD_HIP_NO_DEVICE ;
 }
 
-cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
+cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
-    int flags, int *status)
+    int flags, int rank, int world, int *status)
 {
     int st_local ;
     if (!status) status = &st_local ;
     *status = CHOLMOD_HIP_OK ;
-    if (n < 0 || nsuper < 0 || !super || !pi || !px || !s) { *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
+    if (n < 0 || nsuper < 0 || !super || !pi || !px || !s || world < 1 || rank < 0 || rank >= world)
+    { *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
     bool host_only = (flags & CHOLMOD_HIP_PLAN_HOST_ONLY) != 0 ;
     if (!host_only && !cholmod_hip_probe ()) { *status = CHOLMOD_HIP_NO_DEVICE ; return nullptr ; }
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
     if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
     P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
+    P->rank = rank ; P->world = world ;
     P->super.assign (super, super + nsuper + 1) ;
     P->pi.assign (pi, pi + nsuper + 1) ;
     P->px.assign (px, px + nsuper + 1) ;
@@ -747,6 +878,52 @@ cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
         free_device (P) ; delete P ; return nullptr ;
     }
     return P ;
+}
+
+cholmod_hip_plan *cholmod_hip_plan_create (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
+    int flags, int *status)
+{
+    return cholmod_hip_plan_create_dist (n, nsuper, super, pi, px, s, flags, 0, 1, status) ;
+}
+
+int cholmod_hip_set_allreduce (cholmod_hip_plan *P, cholmod_hip_allreduce_fn fn, void *user)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    P->ar_fn = fn ; P->ar_user = user ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_get_partition (cholmod_hip_plan *P, int64_t *owner)
+{
+    if (!P || !owner) return CHOLMOD_HIP_INVALID ;
+    for (i64 q = 0 ; q < P->nsuper ; q++) owner [q] = P->owner [q] ;
+    return CHOLMOD_HIP_OK ;
+}
+
+/* After a distributed factorization every rank holds the shared fronts and its
+ * own subtrees; the other ranks' subtrees are still zero in its Lx.  Summing
+ * the solo ranges over the ranks completes the factor everywhere. */
+int cholmod_hip_gather_factor (cholmod_hip_plan *P)
+{
+    if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
+    if (P->world == 1) return CHOLMOD_HIP_OK ;
+    if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    const i64 chunk = (i64) 1 << 27 ;
+    for (i64 q = 0 ; q < P->nsuper ; )
+    {
+        if (P->owner [q] < 0) { q++ ; continue ; }
+        i64 e = q ;
+        while (e < P->nsuper && P->owner [e] >= 0) e++ ;
+        for (i64 off = P->px [q] ; off < P->px [e] ; off += chunk)
+        {
+            i64 cnt = std::min (chunk, P->px [e] - off) ;
+            if (P->ar_fn (P->d_Lx + off, cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        }
+        q = e ;
+    }
+    return CHOLMOD_HIP_OK ;
 }
 
 void cholmod_hip_plan_destroy (cholmod_hip_plan *P)
@@ -911,7 +1088,8 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     Schedule S ;
     i32 id = 0 ;
     double fl = 0 ;
-    schedule_dense (fr, &id, 1, S, flags, fl) ;
+    schedule_dense (fr, &id, 1, S, flags, nullptr, 0, 1) ;
+    (void) fl ;
     cholmod_hip_plan P ;
     P.flags = flags ;
     hipError_t e ;
@@ -977,7 +1155,7 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     GemmGroup G ;
     memset (&G, 0, sizeof (G)) ;
     G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
-    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ;
+    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
     G.mt = (i32) ((m + T - 1) / T) ; G.nt = (i32) ((n + T - 1) / T) ;
     GemmGroup *dg = nullptr ;
     (void) hipMalloc ((void **) &dg, sizeof (G)) ;

@@ -30,8 +30,8 @@ struct FrontD {
     i32 k1;         // first column                         (L->super[s])
     i32 nscol, nsrow, ncb;
     i32 parent;     // supernodal etree parent or -1
-    i32 child_begin, child_end;   // range in the child index array
-    i32 pad;
+    i32 child_begin, child_end;   // range in the child index array (this rank's view)
+    i32 assemble;   // 1: this rank scatters A into this front (exactly one rank does)
 };
 
 struct EaGroup { i32 front; i32 blk_start; };           // extend-add
@@ -46,9 +46,12 @@ struct GemmGroup {
     i32 tri;                    // 1: region starts on the diagonal (row0==col0):
                                 //    only tiles with I>=J, and i>=j inside
     i32 c_in_cb;                // 1: C lives in the CB arena
-    i32 tile_start;             // first tile of this group in the launch
+    i32 tile_start;             // first block of this group in the launch
     i32 mt, nt;                 // tile grid
     i32 front;
+    i32 tile_mul, tile_add;     // block b of the group owns tile b*tile_mul + tile_add
+                                // (multi-GPU: the tiles of a shared front's outer
+                                // update are dealt round-robin to the ranks)
     i32 pad;
 };
 
@@ -108,6 +111,7 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
     const FrontD &f = fr [supermap [k]] ;
+    if (!f.assemble) return ;
     i64 psx = f.psx, psi = f.psi ;
     int nsrow = f.nsrow, k1 = f.k1 ;
     const i64 *rows = Ls + psi ;
@@ -504,7 +508,7 @@ __global__ void __launch_bounds__(256) k_update (const GemmGroup *g, int ng,
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
-    decode_tile (G, (int) blockIdx.x - G.tile_start, I, J) ;
+    decode_tile (G, ((int) blockIdx.x - G.tile_start) * G.tile_mul + G.tile_add, I, J) ;
     int row0 = I * BM, col0 = J * BN ;
     int mrem = G.m - row0, nrem = G.n - col0 ;      // valid rows / cols in tile
     const double *A = Lx + G.a_off + row0 ;
@@ -720,7 +724,7 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
-    decode_tile (G, (int) blockIdx.x - G.tile_start, I, J) ;
+    decode_tile (G, ((int) blockIdx.x - G.tile_start) * G.tile_mul + G.tile_add, I, J) ;
     int row0 = I * BM, col0 = J * BN ;
     int mrem = G.m - row0, nrem = G.n - col0 ;
     i64 lda = G.lda ;

@@ -71,9 +71,20 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
 {
     if (L->hip_plan) return TRUE ;
     int st = 0 ;
-    cholmod_hip_plan *P = cholmod_hip_plan_create ((int64_t) L->n, (int64_t) L->nsuper,
-        L->super, L->pi, L->px, L->s, Common->hip_flags, &st) ;
+    int world = Common->hip_world > 1 ? Common->hip_world : 1 ;
+    cholmod_hip_plan *P = cholmod_hip_plan_create_dist ((int64_t) L->n, (int64_t) L->nsuper,
+        L->super, L->pi, L->px, L->s, Common->hip_flags, world > 1 ? Common->hip_rank : 0, world, &st) ;
     if (!P) return map_hip_status (st ? st : CHOLMOD_HIP_GPU_PROBLEM, Common, "HIP plan creation failed") ;
+    if (world > 1)
+    {
+        if (!Common->hip_allreduce)
+        {
+            cholmod_hip_plan_destroy (P) ;
+            ERROR (CHOLMOD_INVALID, "Common->hip_world > 1 needs Common->hip_allreduce") ;
+            return FALSE ;
+        }
+        cholmod_hip_set_allreduce (P, Common->hip_allreduce, Common->hip_allreduce_user) ;
+    }
     L->hip_plan = P ;
     return TRUE ;
 }
@@ -113,6 +124,11 @@ static int finish_numeric (int rc, int64_t minor, cholmod_factor *L, cholmod_com
     L->hip_host_valid = FALSE ;
     if (!Common->hip_factor_on_device)
     {
+        if (Common->hip_world > 1)
+        {
+            int rg = cholmod_hip_gather_factor ((cholmod_hip_plan *) L->hip_plan) ;
+            if (rg != CHOLMOD_HIP_OK) return map_hip_status (rg, Common, "factor gather failed") ;
+        }
         if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
         if (!L->x) return FALSE ;
         int r2 = cholmod_hip_download_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
@@ -226,6 +242,16 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common)
     int rc = cholmod_hip_download_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
     if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "factor download failed") ;
     L->hip_host_valid = TRUE ;
+    return TRUE ;
+}
+
+int cholmod_l_gather_factor (cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    if (!L->hip_plan || !L->hip_on_device) { ERROR (CHOLMOD_INVALID, "no numeric factor") ; return FALSE ; }
+    int rc = cholmod_hip_gather_factor ((cholmod_hip_plan *) L->hip_plan) ;
+    if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "factor gather failed") ;
     return TRUE ;
 }
 

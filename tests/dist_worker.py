@@ -1,0 +1,83 @@
+"""Worker for the multi-rank tests: one process per rank (gloo rendezvous on
+127.0.0.1).  mode "gpu": every rank drives the engine (ranks may share GPU 0),
+factorizes a partitioned problem and checks its gathered factor against the
+oracle.  mode "cpu": exercises the all-reduce callback on host memory."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode, case, out = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from suitesparse_amd import cholmod as ch
+    from suitesparse_amd import generators as G
+    from suitesparse_amd.dist import make_allreduce
+    res = {"rank": rank}
+    if mode == "cpu":
+        cb = make_allreduce(device_memory=False)
+        buf = np.arange(10, dtype=np.float64) * (rank + 1)
+        assert cb(buf.ctypes.data, buf.size, None) == 0
+        res["ok"] = bool(np.allclose(buf, np.arange(10) * sum(range(1, world + 1))))
+        res["calls"] = cb.stats["n"]
+    else:
+        from oracle.oracle import OracleFactor
+        if case == "p3d_20":
+            n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)
+        elif case == "p3d_32":
+            n, Ap, Ai, Ax = G.poisson3d(32); perm = G.geometric_nd(32, 32, 32, 4)
+        elif case == "p2d_90":
+            n, Ap, Ai, Ax = G.poisson2d(90); perm = G.geometric_nd(90, 90, 1, 4)
+        elif case == "box10":
+            n, Ap, Ai, Ax = G.box_stencil3d(10, 2); perm = G.geometric_nd(10, 10, 10, 3)
+        elif case == "p3d_16_notposdef":
+            n, Ap, Ai, Ax = G.poisson3d(16); perm = G.geometric_nd(16, 16, 16, 4)
+        else:
+            raise KeyError(case)
+        O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+        if case.endswith("notposdef"):
+            sup = O.super
+            cand = [s for s in range(O.nsuper // 3, O.nsuper) if sup[s + 1] - sup[s] >= 6]
+            kbad = int(sup[cand[0]] + 2)
+            Ax = Ax.copy()
+            Ax[Ap[int(O.Perm[kbad])]] = -3.0
+        st_o = O.factorize(Ax)
+        cb = make_allreduce()
+        S = ch.Session(rank=rank, world=world, allreduce=cb)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.analyze(A, perm)
+        ok = S.factorize(A, Lf)
+        fv = ch.FactorView(Lf)
+        owner = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_get_partition(fv.hip_plan, owner.ctypes.data)
+        m = O.lower_mask()
+        err = float(np.linalg.norm((fv.x - O.x)[m]) / np.linalg.norm(O.x[m]))
+        res.update(ok=int(ok), status=int(S.cm.status), oracle_status=int(st_o), err=err,
+                   minor=int(fv.minor), oracle_minor=int(O.minor),
+                   zero_pattern_equal=bool(np.array_equal(fv.x[m] != 0, O.x[m] != 0)),
+                   nshared=int((owner < 0).sum()), nsuper=int(fv.nsuper),
+                   owned=[int((owner == r).sum()) for r in range(world)],
+                   allreduce_calls=cb.stats["n"], allreduce_MB=cb.stats["bytes"] / 1e6)
+        if st_o == 0:
+            b = G.demo_rhs(n)
+            x = S.solve(Lf, b)
+            r = G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b
+            res["resid"] = float(np.linalg.norm(r) / np.linalg.norm(b))
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+    with open(f"{out}.{rank}", "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

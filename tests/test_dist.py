@@ -1,0 +1,128 @@
+"""Multi-rank path: ownership partition, the all-reduce callback
+over gloo (CPU, world_size 2/3), and -- on the GPU box -- full distributed
+factorizations with several ranks sharing GPU 0 through the gloo-staged
+exchange, each rank checking its gathered factor against the oracle."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from suitesparse_amd import cholmod as ch
+from suitesparse_amd import generators as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, mode, case, timeout=600):
+    port = _free_port()
+    out = os.path.join(tempfile.mkdtemp(), "res")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"),
+                                       mode, case, out], env=env, cwd=ROOT))
+    rcs = [p.wait(timeout=timeout) for p in procs]
+    assert rcs == [0] * world, rcs
+    return [json.load(open(f"{out}.{r}")) for r in range(world)]
+
+
+def _host_plans(world, n, Ap, Ai, Ax, perm):
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    fv = ch.FactorView(Lf)
+    f = Lf.contents
+    owners, stats, levels = [], [], None
+    for r in range(world):
+        st = C.c_int(0)
+        plan = S.L.cholmod_hip_plan_create_dist(fv.n, fv.nsuper, f.super, f.pi, f.px, f.s,
+                                                ch.HIP_PLAN_HOST_ONLY, r, world, C.byref(st))
+        assert plan and st.value == 0
+        o = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_get_partition(plan, o.ctypes.data)
+        sp = np.empty(fv.nsuper, dtype=np.int64)
+        lv = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_get_maps(plan, sp.ctypes.data, lv.ctypes.data, None)
+        s16 = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+        S.L.cholmod_hip_get_stats(plan, s16.ctypes.data)
+        owners.append(o); stats.append(s16); levels = (sp, lv)
+        S.L.cholmod_hip_plan_destroy(plan)
+    nscol = np.diff(fv.super).astype(float)
+    nsrow = np.diff(fv.pi).astype(float)
+    S.free_factor(Lf); S.free_sparse(A); S.finish()
+    return owners, stats, levels, nscol, nsrow
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_partition_is_consistent_and_balanced(world):
+    n, Ap, Ai, Ax = G.poisson3d(24)
+    owners, stats, (sparent, level), nscol, nsrow = _host_plans(world, n, Ap, Ai, Ax,
+                                                               G.geometric_nd(24, 24, 24, 4))
+    o = owners[0]
+    for other in owners[1:]:
+        assert np.array_equal(o, other)              # every rank derives the same map
+    assert o.min() == -1 and o.max() == world - 1
+    shared = o < 0
+    has_parent = sparent >= 0
+    # shared fronts are closed towards the root; a solo front's parent is solo
+    # on the same rank or shared
+    assert np.all(shared[sparent[shared & has_parent]])
+    solo = ~shared & has_parent
+    par = sparent[solo]
+    assert np.all((o[par] == o[solo]) | (o[par] < 0))
+    # load balance of the private subtrees (flop weights as the engine uses)
+    ncb = nsrow - nscol
+    w = nscol ** 3 / 3 + ncb * nscol ** 2 + ncb ** 2 * nscol
+    loads = np.array([w[o == r].sum() for r in range(world)])
+    assert loads.max() <= 1.5 * loads.mean() + 0.02 * w.sum()
+    # the executed-flop statistic is global, identical on every rank
+    assert all(abs(s[1] - w.sum()) < 1e-9 * w.sum() for s in stats)
+
+
+def test_world_one_has_no_shared_fronts():
+    n, Ap, Ai, Ax = G.poisson3d(10)
+    owners, _, _, _, _ = _host_plans(1, n, Ap, Ai, Ax, G.geometric_nd(10, 10, 10, 3))
+    assert np.all(owners[0] == 0)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_allreduce_callback_over_gloo_cpu(world):
+    res = _run_ranks(world, "cpu", "-")
+    assert all(r["ok"] and r["calls"] == 1 for r in res)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,case", [(2, "p3d_20"), (3, "p3d_32"), (2, "p2d_90"), (4, "box10")])
+def test_distributed_factorization_matches_oracle(world, case):
+    res = _run_ranks(world, "gpu", case)
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0, r
+        assert r["err"] < 1e-12, r
+        assert r["resid"] < 1e-11, r
+        assert r["nshared"] > 0 and r["nshared"] + sum(r["owned"]) == r["nsuper"], r
+        assert r["allreduce_calls"] > 0
+    assert len({json.dumps(r["owned"]) for r in res}) == 1
+
+
+@pytest.mark.gpu
+def test_distributed_not_posdef_protocol():
+    res = _run_ranks(2, "gpu", "p3d_16_notposdef")
+    for r in res:
+        assert r["oracle_status"] == 1 and r["ok"] == 1 and r["status"] == ch.NOT_POSDEF, r
+        assert r["minor"] == r["oracle_minor"], r
+        assert r["zero_pattern_equal"] and r["err"] < 1e-12, r
