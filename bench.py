@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="poisson3d")
-    ap.add_argument("--m", type=int, default=100)
+    ap.add_argument("--grid", "--m", dest="m", type=int, default=100, help="grid points per side")
     ap.add_argument("--cpu-sample-m", type=int, default=56)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
