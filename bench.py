@@ -38,10 +38,12 @@ def build_workload(name, m):
         return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, m, 4), f"poisson3d_{m}^3_geometricND_leaf4"
     if name == "poisson2d":
         n, Ap, Ai, Ax = G.poisson2d(m)
-        return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, 1, 4), f"poisson2d_{m}^2_geometricND_leaf4"
+        return (n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, 1, 4),
+                f"poisson2d_{m}^2_geometricND_leaf4 (G3_circuit stand-in, SURVEY 8d)")
     if name == "box3d":
         n, Ap, Ai, Ax = G.box_stencil3d(m, 3)
-        return n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, m, 4), f"box_stencil_r3_{m}^3_geometricND_leaf4"
+        return (n, Ap, Ai, Ax, -1, G.geometric_nd(m, m, m, 6, 3),
+                f"box_stencil_r3_{m}^3_geometricND_leaf6_width3 (nd24k stand-in, SURVEY 8d)")
     raise ValueError(name)
 
 

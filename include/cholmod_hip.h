@@ -163,6 +163,9 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
  * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */
 double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
 
+/* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
+int cholmod_hip_debug_potrf_cycles (long long *out8) ;
+
 /* Tuning probe: waves 0,1 of every block run the MFMA loop, waves 2,3 a
  * v_fma_f64 loop; returns the seconds the launch took. */
 double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu) ;

@@ -36,6 +36,7 @@ struct Launch {
     int wait_ev = -1 ;  // event this launch's stream waits for first
     int rec_ev = -1 ;   // event recorded on its stream right after it
     i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: range of Lx summed over the ranks
+    int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -327,6 +328,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 blocks += (m + TR_ROWS - 1) / TR_ROWS ;
                 S.tg.push_back (G) ;
                 Lt.flops += (double) m * nb * nb ;
+                Lt.aux = std::max (Lt.aux, (nb + TR_CW - 1) / TR_CW * TR_CW) ;
             }
             Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
             if (Lt.ng) S.launches.push_back (Lt) ;
@@ -668,6 +670,16 @@ static int upload_plan (cholmod_hip_plan *P)
     return CHOLMOD_HIP_OK ;
 }
 
+// k_trsm's dynamic LDS exceeds the 64 KB default limit for 64-wide panels
+static int raise_lds_limits ()
+{
+    static bool done = false ;
+    if (done) return CHOLMOD_HIP_OK ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    done = true ;
+    return CHOLMOD_HIP_OK ;
+}
+
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
@@ -687,11 +699,13 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb) ; break ;
         case K_POTRF:
-            hipLaunchKernelGGL (k_potrf, dim3 (L.grid), dim3 (64), 0, st,
-                P->d_pg + L.goff, P->d_Lx, P->d_info) ; break ;
+            hipLaunchKernelGGL (k_potrf<false>, dim3 (L.grid), dim3 (64), 0, st,
+                P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ; break ;
         case K_TRSM:
-            hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS), 0, st,
-                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info) ; break ;
+            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+            hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS),
+                (size_t) (L.aux * L.aux + L.aux * TR_ROWS + L.aux * TR_CW) * sizeof (double), st,
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ; break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
@@ -1207,6 +1221,34 @@ double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu)
     (void) hipFree (d) ;
     (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
     return ms * 1e-3 ;
+}
+
+/* tuning probe: per-phase shader-clock cycles of one 64x64 k_potrf (lane 0):
+ * out[0] stage, [1] panel update, [2] publish+barrier, [3] 8x8 factor,
+ * [4] row solve+store, [5] barrier, [6] write-back */
+int cholmod_hip_debug_potrf_cycles (long long *out8)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    const int n = 64 ;
+    std::vector<double> A (n * n) ;
+    for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < n ; i++) A [i + j * n] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j)) ;
+    double *d = nullptr ; i32 *dinfo = nullptr ; long long *dt = nullptr ; PfGroup *dg = nullptr ;
+    HIPCHK (hipMalloc ((void **) &d, n * n * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &dinfo, sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &dt, 8 * sizeof (long long))) ;
+    HIPCHK (hipMalloc ((void **) &dg, sizeof (PfGroup))) ;
+    PfGroup G {0, n, n, 0, 0} ;
+    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+    HIPCHK (hipMemset (dinfo, 0, sizeof (i32))) ;
+    for (int rep = 0 ; rep < 3 ; rep++)
+    {
+        HIPCHK (hipMemcpy (d, A.data (), n * n * sizeof (double), hipMemcpyHostToDevice)) ;
+        hipLaunchKernelGGL (k_potrf<true>, dim3 (1), dim3 (64), 0, 0, dg, d, dinfo, dt) ;
+        HIPCHK (hipDeviceSynchronize ()) ;
+    }
+    HIPCHK (hipMemcpy (out8, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
+    (void) hipFree (d) ; (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ;
+    return CHOLMOD_HIP_OK ;
 }
 
 double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)

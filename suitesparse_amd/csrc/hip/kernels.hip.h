@@ -187,6 +187,29 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
 // factorization and is reported 1-based, relative to the front, in info[front];
 // NaN pivots do not stop it (:907-908).  After a failure every remaining
 // column of this front is written as zero (:889-895, :926-931).
+// sqrt(d) and 1/sqrt(d) from one v_rsq_f64 seed and a coupled Goldschmidt
+// iteration (two quadratic steps + one correction): ~15 dependent FMAs instead
+// of the ~70 instructions of sqrt() followed by a full-precision division.
+// Both results are within 1 ulp for normal d; subnormal / huge / non-finite d
+// take the library path.
+__device__ __forceinline__ void sqrt_rsqrt (double d, double &r, double &ri)
+{
+    if (!(d > 1e-290 && d < 1e290)) { r = sqrt (d) ; ri = 1.0 / r ; return ; }
+    double y = __builtin_amdgcn_rsq (d) ;       // ~2^-26 relative accuracy
+    double g = d * y, h = 0.5 * y ;
+    double e = __builtin_fma (-h, g, 0.5) ;
+    g = __builtin_fma (g, e, g) ; h = __builtin_fma (h, e, h) ;
+    e = __builtin_fma (-h, g, 0.5) ;
+    g = __builtin_fma (g, e, g) ; h = __builtin_fma (h, e, h) ;
+    double t = __builtin_fma (-g, g, d) ;       // residual d - g^2
+    g = __builtin_fma (t, h, g) ;
+    // refine 1/g: ri = 2h, one Newton step on g * ri = 1
+    ri = h + h ;
+    double u = __builtin_fma (-g, ri, 1.0) ;
+    ri = __builtin_fma (u, ri, ri) ;
+    r = g ;
+}
+
 #define PF_NB 64
 #define PF_LD 66            /* even (16-B aligned pairs) and conflict-free for b128 */
 #define PF_CW 8             /* columns eliminated per group */
@@ -200,8 +223,12 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
 //      against it.  Two barriers per group instead of one per column.
 // The block is identity-padded to a multiple of PF_CW, so nb < 64 needs no
 // special cases.
-__global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32 *info)
+template <bool TIMED>
+__global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32 *info, long long *tim)
 {
+    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     __shared__ __attribute__((aligned(16))) double T [PF_NB * PF_LD] ;   // T[i][k] = L(i,k)
     __shared__ __attribute__((aligned(16))) double Tt [PF_NB * PF_NB] ;  // Tt[k][i] = L(i,k)
     // latency-critical single wave: outrank the MFMA update waves it may share
@@ -239,6 +266,7 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
         }
     }
     __syncthreads () ;
+    tick (0) ;
     int fail = -1 ;
     for (int jb = 0 ; jb < nbp ; jb += PF_CW)
     {
@@ -258,9 +286,11 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
                 for (int c = 0 ; c < PF_CW ; c++) a [c] -= x [u] * lt [c] ;
             }
         }
+        tick (1) ;
 #pragma unroll
         for (int c = 0 ; c < PF_CW ; c++) T [lane * PF_LD + jb + c] = a [c] ;
         __syncthreads () ;
+        tick (2) ;
         // diagonal block, lower part, same values in every lane
         double D [PF_CW][PF_CW], rinv [PF_CW] ;
 #pragma unroll
@@ -276,8 +306,8 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
                 if (d <= 0.0) fail = jb + c ;
                 else
                 {
-                    double r = sqrt (d) ;
-                    double ri = 1.0 / r ;
+                    double r, ri ;
+                    sqrt_rsqrt (d, r, ri) ;
                     D [c][c] = r ; rinv [c] = ri ;
 #pragma unroll
                     for (int r2 = c + 1 ; r2 < PF_CW ; r2++) D [r2][c] *= ri ;
@@ -289,6 +319,7 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
             }
             if (fail >= 0) { rinv [c] = 0.0 ; }
         }
+        tick (3) ;
         // own row against the factored diagonal block
         double x [PF_CW] ;
 #pragma unroll
@@ -307,7 +338,9 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
             T [lane * PF_LD + jb + c] = x [c] ;
             Tt [(jb + c) * PF_NB + lane] = x [c] ;
         }
+        tick (4) ;
         __syncthreads () ;
+        tick (5) ;
         if (fail >= 0) break ;
     }
     if (fail >= 0)
@@ -325,6 +358,8 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
             if (j < nb && lane >= j && lane < nb) A [lane + (i64) j * lda] = T [lane * PF_LD + j] ;
         }
     }
+    tick (6) ;
+    if constexpr (TIMED) { if (lane == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
 // ---- panel triangular solve: B := B * inv(L11)' , one thread per row --------
@@ -339,11 +374,15 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
 #define TR_ROWS 64
 #define TR_CW 8
 __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
-    double *Lx, const i32 *info)
+    double *Lx, const i32 *info, int ldl)
 {
-    __shared__ __attribute__((aligned(16))) double Lt [PF_NB * PF_NB] ;  // Lt[k][j] = L11(j,k)
-    __shared__ double xs [PF_NB * TR_ROWS] ;
-    __shared__ __attribute__((aligned(16))) double Wi [(PF_NB / TR_CW) * TR_CW * TR_CW] ; // inverse diagonal blocks
+    // dynamic LDS, sized by the widest block of the launch (ldl = its width
+    // rounded up to TR_CW): levels with thousands of narrow panels then fit many
+    // workgroups per CU instead of two
+    extern __shared__ __attribute__((aligned(16))) double trsm_lds [] ;
+    double *Lt = trsm_lds ;                         // Lt[k][j] = L11(j,k), ld = ldl
+    double *xs = Lt + ldl * ldl ;                   // xs[k][t], ld = TR_ROWS
+    double *Wi = xs + ldl * TR_ROWS ;               // inverse diagonal blocks
     __builtin_amdgcn_s_setprio (3) ;
     int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
     TrGroup G = g [gi] ;
@@ -379,7 +418,7 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
                 int k = k0 + c ;
                 double v = (j == k) ? 1.0 : 0.0 ;
                 if (j < nvalid && k <= j) v = tmp [c] ;
-                if (j < nbp) Lt [k * PF_NB + j] = v ;
+                if (j < nbp) Lt [k * ldl + j] = v ;
             }
         }
     }
@@ -413,8 +452,8 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
                 double acc = (r == q) ? 1.0 : 0.0 ;
 #pragma unroll
                 for (int e = 0 ; e < r ; e++)
-                    acc -= Lt [(b * TR_CW + e) * PF_NB + b * TR_CW + r] * y [e] ;
-                double v = acc / Lt [(b * TR_CW + r) * PF_NB + b * TR_CW + r] ;
+                    acc -= Lt [(b * TR_CW + e) * ldl + b * TR_CW + r] * y [e] ;
+                double v = acc / Lt [(b * TR_CW + r) * ldl + b * TR_CW + r] ;
                 y [r] = (r >= q) ? v : 0.0 ;
             }
 #pragma unroll
@@ -436,7 +475,7 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
 #pragma unroll
             for (int d = 0 ; d < TR_CW ; d++)
             {
-                const double *lt = Lt + (kg + d) * PF_NB + jb ;
+                const double *lt = Lt + (kg + d) * ldl + jb ;
 #pragma unroll
                 for (int c = 0 ; c < TR_CW ; c++) xb [c] -= xk [d] * lt [c] ;
             }

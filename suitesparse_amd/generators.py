@@ -103,12 +103,14 @@ def box_stencil3d(m: int, r: int):
     return (n,) + _csc_from_lower_coo(n, np.concatenate(rows), np.concatenate(cols), vals)
 
 
-def geometric_nd(mx: int, my: int = 1, mz: int = 1, leaf: int = 4) -> np.ndarray:
+def geometric_nd(mx: int, my: int = 1, mz: int = 1, leaf: int = 4, width: int = 1) -> np.ndarray:
     """Nested-dissection permutation of an mx*my*mz grid.
 
     nd(box): if all extents <= leaf emit the points lexicographically (x
     fastest); else cut the longest extent (ties x, y, z) at c = lo + extent//2,
-    recurse on [lo,c), then [c+1,hi), then emit plane c last.
+    recurse on [lo,c), then [c+width,hi), then emit the slab [c,c+width) last.
+    width = 1 is the survey's definition (7-point / 5-point stencils); a radius-r
+    box stencil needs width = r for the slab to be a separator.
     Returns Perm with Perm[k] = original index of the k-th pivot.
     """
     out = np.empty(mx * my * mz, dtype=np.int64)
@@ -127,18 +129,19 @@ def geometric_nd(mx: int, my: int = 1, mz: int = 1, leaf: int = 4) -> np.ndarray
             out[pos:pos + idx.size] = idx
             pos += idx.size
             continue
+        w = width
         if ex >= ey and ex >= ez:
             c = x0 + ex // 2
-            parts = [(0, (x0, c, y0, y1, z0, z1)), (0, (c + 1, x1, y0, y1, z0, z1)),
-                     (1, (c, c + 1, y0, y1, z0, z1))]
+            parts = [(0, (x0, c, y0, y1, z0, z1)), (0, (c + w, x1, y0, y1, z0, z1)),
+                     (1, (c, min(c + w, x1), y0, y1, z0, z1))]
         elif ey >= ez:
             c = y0 + ey // 2
-            parts = [(0, (x0, x1, y0, c, z0, z1)), (0, (x0, x1, c + 1, y1, z0, z1)),
-                     (1, (x0, x1, c, c + 1, z0, z1))]
+            parts = [(0, (x0, x1, y0, c, z0, z1)), (0, (x0, x1, c + w, y1, z0, z1)),
+                     (1, (x0, x1, c, min(c + w, y1), z0, z1))]
         else:
             c = z0 + ez // 2
-            parts = [(0, (x0, x1, y0, y1, z0, c)), (0, (x0, x1, y0, y1, c + 1, z1)),
-                     (1, (x0, x1, y0, y1, c, c + 1))]
+            parts = [(0, (x0, x1, y0, y1, z0, c)), (0, (x0, x1, y0, y1, c + w, z1)),
+                     (1, (x0, x1, y0, y1, c, min(c + w, z1)))]
         stack.extend(reversed(parts))
     assert pos == out.size
     return out
