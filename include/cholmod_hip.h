@@ -144,12 +144,15 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *  [8] its algorithmic flops (2*k per updated lower-trapezoid entry)
  *  [14] seconds in the 128x128 dense-update kernel (CHOLMOD_HIP_TILE128 only)
  *  [15] its algorithmic flops
+ *  [16] algorithmic bytes of the 64x64 update launches: 16 B read-modify-write
+ *       per updated entry + 8 B per operand entry (each panel entry once per
+ *       update region)     [17] all-reduce calls   [18] all-reduce bytes
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
-#define CHOLMOD_HIP_NSTATS 16
+#define CHOLMOD_HIP_NSTATS 24
 int cholmod_hip_get_stats (cholmod_hip_plan *plan, double *stats) ;
 int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 

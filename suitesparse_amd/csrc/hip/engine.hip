@@ -775,7 +775,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; }
+        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
+        if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
