@@ -170,10 +170,14 @@ def main():
                     "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": ps[16] / max(ps[7], 1),
                     "algorithmic_flops_per_launch": ps[8] / max(ps[7], 1),
+                    "small_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
+                                           "achieved_GBps": (ps[20] / ps[19] / 1e9) if ps[19] > 0 else None,
+                                           "hbm_peak_GBps": 8000.0},
                     "kernel": "k_update2<64,64,16,2,false>", "launches": int(ps[7]),
                     "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
                     "seconds_by_class": {"update64": ps[6], "update128": ps[14], "extend_add+zero": ps[9],
                                          "potrf": ps[11], "trsm": ps[12], "assemble": ps[13],
+                                         "small_fronts_fused": ps[19],
                                          "total_profiled": ps[0]}}
 
     resid = None

@@ -38,6 +38,8 @@ extern "C" {
 #define CHOLMOD_HIP_LOOKAHEAD       8    /* tuning: panel look-ahead on a second stream
                                            (off by default: fp64 VALU panel code
                                            starves next to fp64 MFMA waves)          */
+#define CHOLMOD_HIP_NO_SMALL_FRONTS 16   /* tuning: no fused LDS-resident kernel for
+                                           thin fronts (generic kernels everywhere)  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 
@@ -147,6 +149,8 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *  [16] algorithmic bytes of the 64x64 update launches: 16 B read-modify-write
  *       per updated entry + 8 B per operand entry (each panel entry once per
  *       update region)     [17] all-reduce calls   [18] all-reduce bytes
+ *  [19] seconds in the fused small-front kernel  [20] its algorithmic HBM bytes
+ *       (A entries aside: children CBs in, panel + CB out)   [21] fronts it handled
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)

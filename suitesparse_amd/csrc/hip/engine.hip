@@ -23,7 +23,7 @@ constexpr int NB = PF_NB ;      // inner panel width (potrf / trsm block)
 constexpr int OB = 512 ;        // outer block: trailing updates contract over <= OB columns
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -117,6 +117,7 @@ struct Schedule {
     std::vector<PfGroup> pg ;
     std::vector<TrGroup> tg ;
     std::vector<GemmGroup> gg ;
+    std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
     int nevents = 0 ;
 } ;
@@ -163,7 +164,8 @@ struct cholmod_hip_plan {
     i32 *d_lvl_list = nullptr ;
     double *d_Lx = nullptr, *d_cb = nullptr ;
     ZeroGroup *d_zg = nullptr ; EaGroup *d_eg = nullptr ; PfGroup *d_pg = nullptr ;
-    TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ;
+    TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ; i32 *d_sm = nullptr ;
+    double cur_beta = 0 ;
     // resident input matrix
     i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
     i64 s_nz = 0 ; bool s_unpacked = false ;
@@ -570,8 +572,51 @@ static int build_host (cholmod_hip_plan *P)
     Schedule &S = P->sch ;
     for (int l = 0 ; l < nlev ; l++)
     {
-        const i32 *ids = P->my_lvl_list.data () + P->my_lvl_ptr [l] ;
-        int nf = P->my_lvl_ptr [l+1] - P->my_lvl_ptr [l] ;
+        const i32 *all_ids = P->my_lvl_list.data () + P->my_lvl_ptr [l] ;
+        int all_nf = P->my_lvl_ptr [l+1] - P->my_lvl_ptr [l] ;
+        if (all_nf == 0) continue ;
+        // thin fronts go to the fused LDS-resident kernel, in three size classes
+        // so that the dynamic LDS of a launch fits its widest member
+        std::vector<i32> gen ;
+        {
+            static const int cls [3] = {48, 88, SM_MAX} ;
+            std::vector<i32> bucket [3] ;
+            for (int q = 0 ; q < all_nf ; q++)
+            {
+                i32 sid = all_ids [q] ;
+                const FrontD &f = P->fr [sid] ;
+                bool small_ok = !(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX
+                    && !(P->world > 1 && P->owner [sid] < 0) ;
+                if (!small_ok) { gen.push_back (sid) ; continue ; }
+                int c = f.nsrow <= cls [0] ? 0 : f.nsrow <= cls [1] ? 1 : 2 ;
+                bucket [c].push_back (sid) ;
+            }
+            for (int c = 0 ; c < 3 ; c++)
+            {
+                if (bucket [c].empty ()) continue ;
+                Launch Ls_ {K_SMALL, (int) bucket [c].size (), (int) bucket [c].size (), S.sm.size (), 0, 0} ;
+                int mx = 0 ;
+                for (i32 sid : bucket [c])
+                {
+                    FrontD &f = P->fr [sid] ;
+                    if (f.assemble == 1) f.assemble = 2 ;
+                    mx = std::max (mx, f.nsrow) ;
+                    double cc = f.nscol, r = f.ncb ;
+                    Ls_.flops += cc * cc * cc / 3.0 + r * cc * cc + r * r * cc ;
+                    Ls_.bytes += 8.0 * (f.nsrow * cc + r * (r + 1) / 2) ;
+                    for (int ch = f.child_begin ; ch < f.child_end ; ch++)
+                    {
+                        double rc = P->fr [P->child [ch]].ncb ;
+                        Ls_.bytes += 8.0 * rc * (rc + 1) / 2 + 4.0 * rc ;
+                    }
+                    S.sm.push_back (sid) ;
+                }
+                Ls_.aux = (mx | 1) * mx * (int) sizeof (double) ;
+                S.launches.push_back (Ls_) ;
+            }
+        }
+        const i32 *ids = gen.data () ;
+        int nf = (int) gen.size () ;
         if (nf == 0) continue ;
         Launch Lz {K_ZERO, 0, 0, S.zg.size (), 0, 0} ;
         int blocks = 0 ;
@@ -610,7 +655,7 @@ static int build_host (cholmod_hip_plan *P)
 static void free_device (cholmod_hip_plan *P)
 {
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
-        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg,
+        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -654,6 +699,7 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_pg = dupload (P->sch.pg, e) ; HIPCHK (e) ;
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
+    P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
@@ -676,6 +722,7 @@ static int raise_lds_limits ()
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -687,6 +734,13 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
     switch (L.kind)
     {
         case K_JOIN: break ;
+        case K_SMALL:
+            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+            hipLaunchKernelGGL (k_small_front, dim3 (L.grid), dim3 (256), (size_t) L.aux, st,
+                P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
+                P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                P->d_Lx, P->d_cb, P->d_info) ;
+            break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
             HIPCHK (hipStreamSynchronize (st)) ;
@@ -729,6 +783,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     hipStream_t st = P->stream ;
     if (!P->d_Sp) return CHOLMOD_HIP_INVALID ;
     bool prof = P->profiling ;
+    P->cur_beta = beta ;
     size_t nl = P->sch.launches.size () ;
     if (prof)
     {
@@ -777,6 +832,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         const Launch &L = P->sch.launches [q] ;
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
+        if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
@@ -796,6 +852,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;
+                case K_SMALL: S [19] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
             }
         }

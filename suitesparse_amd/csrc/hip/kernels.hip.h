@@ -31,7 +31,8 @@ struct FrontD {
     i32 nscol, nsrow, ncb;
     i32 parent;     // supernodal etree parent or -1
     i32 child_begin, child_end;   // range in the child index array (this rank's view)
-    i32 assemble;   // 1: this rank scatters A into this front (exactly one rank does)
+    i32 assemble;   // 1: k_assemble scatters A into this front on this rank, 2: the
+                    // fused small-front kernel does, 0: another rank does
 };
 
 struct EaGroup { i32 front; i32 blk_start; };           // extend-add
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
     const FrontD &f = fr [supermap [k]] ;
-    if (!f.assemble) return ;
+    if (f.assemble != 1) return ;      // 0: another rank's, 2: k_small_front does it
     i64 psx = f.psx, psi = f.psi ;
     int nsrow = f.nsrow, k1 = f.k1 ;
     const i64 *rows = Ls + psi ;
@@ -498,6 +499,94 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
             if (jb + c < nb) B [(i64) (jb + c) * lda] = xo [c] ;
         }
     }
+}
+
+// ---- fused small front: one workgroup, the whole front in LDS -----------------
+// For thin supernodes (nsrow <= SM_MAX) the level-batched generic kernels cost a
+// dozen launches and several HBM round trips per front.  Here one workgroup
+// builds the front in LDS (zero, scatter A, pull the children's contribution
+// blocks through the relative maps), eliminates its nscol columns (right-looking,
+// all 256 threads on the trailing update) and writes the panel and the
+// contribution block exactly once: HBM traffic = A entries + children CBs in,
+// panel + CB out.  Reference steps: t_cholmod_super_numeric.c:305-431 (assemble),
+// :743-772 (relative map scatter), :864-867 / :997-1002 (dpotrf / dtrsm), and the
+// dsyrk/dgemm its ancestors would have pulled (:682-717) as the CB.
+#define SM_MAX 136
+__global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
+    const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
+    i64 n, const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
+    double *Lx, double *CB, i32 *info)
+{
+    extern __shared__ __attribute__((aligned(16))) double F [] ;   // F(i,j) = F[i + j*ld]
+    const FrontD &f = fr [fronts [blockIdx.x]] ;
+    int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
+    int ld = ns | 1 ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    i64 psx = f.psx, psi = f.psi, cbo = f.cb ;
+    for (int e = tid ; e < ld * ns ; e += 256) F [e] = 0.0 ;
+    __syncthreads () ;
+    if (f.assemble)
+    {
+        const i64 *rows = Ls + psi ;
+        for (int k = tid ; k < nc ; k += 256)
+        {
+            i64 col = (i64) k1 + k ;
+            i64 p = Sp [col], pend = Snz ? p + Snz [col] : Sp [col + 1] ;
+            for ( ; p < pend ; p++)
+            {
+                i64 i = Si [p] ;
+                if (i < col) continue ;
+                int lo = 0, hi = ns ;
+                while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows [mid] < i) lo = mid + 1 ; else hi = mid ; }
+                if (lo < ns && rows [lo] == i) F [lo + k * ld] = Sx [p] ;
+            }
+            if (beta != 0.0) F [k + k * ld] += beta ;
+        }
+    }
+    __syncthreads () ;
+    for (int ci = f.child_begin ; ci < f.child_end ; ci++)
+    {
+        const FrontD &c = fr [child [ci]] ;
+        const i32 *rm = relmap + c.rel ;
+        int m = c.ncb ;
+        const double *src = CB + c.cb ;
+        for (int j = wave ; j < m ; j += 4)
+        {
+            int tj = rm [j] ;
+            const double *sc = src + (i64) j * m ;
+            for (int i = j + lane ; i < m ; i += 64) F [rm [i] + tj * ld] += sc [i] ;
+        }
+        __syncthreads () ;
+    }
+    int fail = -1 ;
+    int ti = tid & 31, tk = tid >> 5 ;
+    for (int j = 0 ; j < nc ; j++)
+    {
+        double d = F [j + j * ld] ;
+        if (d <= 0.0) { fail = j ; break ; }
+        double r, ri ;
+        sqrt_rsqrt (d, r, ri) ;
+        __syncthreads () ;                  // everyone has read the pivot
+        for (int i = j + tid ; i < ns ; i += 256) F [i + j * ld] = (i == j) ? r : F [i + j * ld] * ri ;
+        __syncthreads () ;
+        const double *lj = F + j * ld ;
+        for (int k = j + 1 + tk ; k < ns ; k += 8)
+        {
+            double lk = lj [k] ;
+            double *fk = F + k * ld ;
+            for (int i = k + ti ; i < ns ; i += 32) fk [i] -= lj [i] * lk ;
+        }
+        __syncthreads () ;
+    }
+    if (fail >= 0 && tid == 0) info [fronts [blockIdx.x]] = fail + 1 ;
+    int ngood = fail >= 0 ? fail : nc ;
+    // panel [L11; L21], columns before a failed pivot only (the rest stays zero)
+    for (int j = wave ; j < ngood ; j += 4)
+        for (int i = j + lane ; i < ns ; i += 64) Lx [psx + i + (i64) j * ns] = F [i + j * ld] ;
+    // contribution block (lower part)
+    for (int j = wave ; j < ncb ; j += 4)
+        for (int i = j + lane ; i < ncb ; i += 64)
+            CB [cbo + i + (i64) j * ncb] = F [(nc + i) + (nc + j) * ld] ;
 }
 
 // ---- dense update  C -= A * B'  (fp64 MFMA 16x16x4 tiles) -------------------
