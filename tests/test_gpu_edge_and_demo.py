@@ -1,0 +1,146 @@
+"""Edge cases of the path (as the reference's Tcov torture matrices probe them:
+empty, 1x1, diagonal, dense, unpacked / unsorted / upper-stored inputs) and the
+C demo driver that mirrors CHOLMOD/Demo/cholmod_l_demo.c on bcsstk01."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleFactor
+from suitesparse_amd import cholmod as ch
+from suitesparse_amd import generators as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(n, Ap, Ai, Ax, stype, perm=None, tol=1e-12):
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+    assert O.factorize(Ax) == 0
+    for k in ("Perm", "super", "pi", "px", "s"):
+        assert np.array_equal(getattr(fv, k), getattr(O, k)), k
+    if n:
+        m = O.lower_mask()
+        assert np.linalg.norm((fv.x - O.x)[m]) <= tol * np.linalg.norm(O.x[m])
+        b = G.demo_rhs(n)
+        x = S.solve(Lf, b)
+        r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
+        assert np.linalg.norm(r) <= 1e-11 * np.linalg.norm(b)
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
+
+
+def test_empty_matrix():
+    _check(0, np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int64), np.zeros(0), -1)
+
+
+def test_one_by_one():
+    _check(1, np.array([0, 1]), np.array([0]), np.array([4.0]), -1)
+
+
+def test_diagonal_matrix():
+    n = 37
+    _check(n, np.arange(n + 1), np.arange(n), np.linspace(1.0, 9.0, n), -1)
+
+
+@pytest.mark.parametrize("n", [50, 200, 700])
+def test_dense_spd_single_supernode(n):
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n))
+    Ad = M @ M.T + n * np.eye(n)
+    ii, jj = np.tril_indices(n)
+    order = np.lexsort((ii, jj))
+    Ai, cols, Ax = ii[order], jj[order], Ad[ii[order], jj[order]]
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=n), out=Ap[1:])
+    _check(n, Ap, Ai.astype(np.int64), Ax, -1)
+
+
+def test_arrow_matrix_with_given_perm():
+    n = 300
+    rows = np.concatenate([np.arange(n), np.full(n - 1, n - 1)])
+    cols = np.concatenate([np.arange(n), np.arange(n - 1)])
+    vals = np.concatenate([np.full(n, float(n)), np.full(n - 1, -1.0)])
+    order = np.lexsort((rows, cols))
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=n), out=Ap[1:])
+    _check(n, Ap, rows[order].astype(np.int64), vals[order], -1, perm=np.arange(n)[::-1].copy())
+
+
+def test_upper_stored_and_unpacked_unsorted_input():
+    """stype > 0 goes through one ptranspose, an unpacked matrix with unsorted
+    columns (nz[] used, gaps in i/x) through the unpacked code paths."""
+    n, Ap, Ai, Ax = G.poisson3d(9)
+    perm = G.geometric_nd(9, 9, 9, 3)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    assert O.factorize(Ax) == 0
+    m = O.lower_mask()
+    S = ch.Session()
+    # upper: transpose of the lower CSC = CSR of lower = CSC of upper
+    A_lo = S.sparse(n, Ap, Ai, Ax, -1)
+    A_up = S.L.cholmod_l_ptranspose(A_lo, 2, None, None, 0, C.byref(S.cm))
+    assert A_up.contents.stype == 1
+    # unpacked + unsorted copy of the lower matrix
+    cap = int(Ap[-1]) + 3 * n
+    A_un = S.L.cholmod_l_allocate_sparse(n, n, cap, 0, 0, -1, ch.REAL, C.byref(S.cm))
+    a = A_un.contents
+    p = ch._view(a.p, n + 1, C.c_int64, np.int64)
+    nz = ch._view(a.nz, n, C.c_int64, np.int64)
+    ai = ch._view(a.i, cap, C.c_int64, np.int64)
+    ax = ch._view(a.x, cap, C.c_double, np.float64)
+    ai[:] = 0
+    ax[:] = np.nan
+    rng = np.random.default_rng(1)
+    pos = 0
+    for j in range(n):
+        cnt = int(Ap[j + 1] - Ap[j])
+        o = rng.permutation(cnt)
+        p[j] = pos
+        nz[j] = cnt
+        ai[pos:pos + cnt] = Ai[Ap[j]:Ap[j + 1]][o]
+        ax[pos:pos + cnt] = Ax[Ap[j]:Ap[j + 1]][o]
+        pos += cnt + 3
+    p[n] = pos
+    for A in (A_up, A_un):
+        Lf = S.analyze(A, perm)
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        fv = ch.FactorView(Lf)
+        assert np.array_equal(fv.s, O.s) and np.array_equal(fv.px, O.px)
+        assert np.linalg.norm((fv.x - O.x)[m]) <= 1e-12 * np.linalg.norm(O.x[m])
+        S.free_factor(Lf)
+    for A in (A_lo, A_up, A_un):
+        S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
+
+
+def test_c_demo_driver_on_bcsstk01(golden_dir, tmp_path):
+    """BASELINE.json config #1: the demo flow in C against include/cholmod.h."""
+    rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))["bcsstk01"]
+    exe = str(tmp_path / "cholmod_l_demo")
+    lib = os.path.join(ROOT, "suitesparse_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "cholmod_l_demo.c"), "-L", lib, "-lcholmod_amd",
+                           f"-Wl,-rpath,{lib}", "-lm", "-o", exe])
+    permfile = tmp_path / "perm.txt"
+    permfile.write_text(" ".join(str(v) for v in rec["Perm"]))
+    with open(os.path.join(golden_dir, "bcsstk01.tri")) as f:
+        out = subprocess.run([exe, str(permfile)], stdin=f, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "nsuper 7 ssize 101 xsize 1064 maxcsize 169 maxesize 13" in txt, txt
+    assert "fl 6009 lnz 489" in txt, txt
+    assert "status 0 minor 48" in txt, txt
+    res = float(txt.split("residual")[1].split()[0])
+    assert res < 1e-12
+    assert "malloc_count 0 memory_inuse 0" in txt
