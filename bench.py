@@ -157,14 +157,14 @@ def main():
         if ps[6] > 0:
             ach = ps[8] / ps[6] / 1e12
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01b_pmc_summary.json")
+            pmc = os.path.join(ROOT, "profiles", "r01c_pmc_summary.json")
             if os.path.exists(pmc):
                 # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc
                 # passes of this same command (offline; see profiles/README.md)
                 pj = json.load(open(pmc))
                 if pj.get("workload") == wname and world == 1:
                     traffic = pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch"]
-                    traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01b_pmc_summary.json"
+                    traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01c_pmc_summary.json"
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note,

@@ -40,6 +40,7 @@ extern "C" {
                                            starves next to fp64 MFMA waves)          */
 #define CHOLMOD_HIP_NO_SMALL_FRONTS 16   /* tuning: no fused LDS-resident kernel for
                                            thin fronts (generic kernels everywhere)  */
+#define CHOLMOD_HIP_NO_XCD_SWIZZLE 32    /* tuning: plain block -> tile order          */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 

@@ -203,16 +203,29 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             for (auto &G : v)
             {
                 G.mt = (G.m + T - 1) / T ; G.nt = (G.n + T - 1) / T ;
-                G.tile_start = (i32) tiles ;
                 i64 cnt = G.tri ? (i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt
                                 : (i64) G.mt * G.nt ;
-                // this rank's share of the tiles: tile_add, tile_add + tile_mul, ...
-                i64 mine = (cnt > G.tile_add) ? (cnt - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
+                G.ntiles = (i32) cnt ;
+                // blocks this rank spends on the group (see decode_tile)
+                i64 mine ;
+                G.swz = 0 ;
+                if (G.tile_mul == 1 && cnt < 1024) mine = cnt ;
+                else
+                {
+                    i64 nch = (cnt + 63) / 64 ;
+                    i64 mych = nch > G.tile_add ? (nch - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
+                    mine = mych * 64 ;
+                    G.swz = !(flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) && mine >= 1024 ;
+                    if (G.swz) tiles = (tiles + 7) / 8 * 8 ;     // keep block % 8 == XCD aligned
+                    else if (G.tile_mul == 1) mine = cnt ;
+                }
                 if (mine == 0) continue ;
+                G.nblk = (i32) mine ;
+                G.tile_start = (i32) tiles ;
                 tiles += mine ;
                 double elems = G.tri ? (double) G.n * (G.n + 1) / 2 + (double) (G.m - G.n) * G.n
                                      : (double) G.m * G.n ;
-                double share = (double) mine / (double) cnt ;
+                double share = G.tile_mul == 1 ? 1.0 : std::min (1.0, (double) mine / (double) cnt) ;
                 L.flops += 2.0 * elems * G.k * share ;
                 L.bytes += (16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
                 S.gg.push_back (G) ;
@@ -1228,11 +1241,13 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     memset (&G, 0, sizeof (G)) ;
     G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
     G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
+    G.ntiles = (i32) (((m + T - 1) / T) * ((n + T - 1) / T)) ; G.nblk = (G.ntiles + 63) / 64 * 64 ;
+    G.swz = (flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) ? 0 : 1 ;
     G.mt = (i32) ((m + T - 1) / T) ; G.nt = (i32) ((n + T - 1) / T) ;
     GemmGroup *dg = nullptr ;
     (void) hipMalloc ((void **) &dg, sizeof (G)) ;
     (void) hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice) ;
-    int grid = G.mt * G.nt ;
+    int grid = G.nblk ;
     hipEvent_t e0, e1 ;
     (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
     auto launch = [&] ()

@@ -50,9 +50,11 @@ struct GemmGroup {
     i32 tile_start;             // first block of this group in the launch
     i32 mt, nt;                 // tile grid
     i32 front;
-    i32 tile_mul, tile_add;     // block b of the group owns tile b*tile_mul + tile_add
-                                // (multi-GPU: the tiles of a shared front's outer
-                                // update are dealt round-robin to the ranks)
+    i32 tile_mul, tile_add;     // multi-GPU: 64-tile chunk c of a shared front's outer
+                                // update belongs to the rank with c % tile_mul == tile_add
+    i32 ntiles;                 // tiles of the region (all ranks)
+    i32 nblk;                   // blocks this launch spends on the group (this rank)
+    i32 swz;                    // 1: XCD-aware super-tile walk (big groups)
     i32 pad;
 };
 
@@ -602,23 +604,51 @@ __global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
 // the column-major target and the read-modify-write is coalesced.
 typedef double d4 __attribute__((ext_vector_type(4))) ;
 
-__device__ __forceinline__ void decode_tile (const GemmGroup &G, int t, int &I, int &J)
+// Block -> tile map of an update region.
+//  * Tiles are enumerated in strips of 8 tile columns, row by row inside a strip,
+//    so 64 consecutive tiles form an 8x8 super-tile (16 operand panels for 64
+//    tiles instead of ~34 with a row-major order).
+//  * XCD awareness: the dispatcher hands block b to XCD b % 8 (observed, used for
+//    speed only); with G.swz the blocks of one XCD walk whole super-tiles, so the
+//    panels a super-tile shares meet in ONE L2 instead of in all eight.
+//  * Multi-GPU: the 64-tile chunks are dealt round-robin to the ranks
+//    (chunk c belongs to rank c % tile_mul == tile_add).
+// Returns false for a padding block (past the end of the rank's last chunk).
+__device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, int &J)
 {
-    if (!G.tri) { I = t % G.mt ; J = t / G.mt ; return ; }
-    // rows I < nt hold I+1 tiles (triangle), rows I >= nt hold nt tiles
-    i64 ntri = (i64) G.nt * (G.nt + 1) / 2 ;
-    if (t < ntri)
+    int t ;
+    if (G.tile_mul == 1 && !G.swz) t = u ;
+    else
     {
-        int r = (int) ((sqrt (8.0 * (double) t + 1.0) - 1.0) * 0.5) ;
-        while ((i64) (r + 1) * (r + 2) / 2 <= t) r++ ;
-        while ((i64) r * (r + 1) / 2 > t) r-- ;
-        I = r ; J = t - (int) ((i64) r * (r + 1) / 2) ;
+        int cl, within ;
+        if (G.swz && u < (G.nblk / 512) * 512) { int q = u >> 3 ; cl = (q >> 6) * 8 + (u & 7) ; within = q & 63 ; }
+        else { cl = u >> 6 ; within = u & 63 ; }
+        t = ((cl * G.tile_mul + G.tile_add) << 6) + within ;
+    }
+    if (t >= G.ntiles) return false ;
+    int S = 0, w, mt = G.mt, nt = G.nt ;
+    for ( ; ; S++)
+    {
+        w = nt - 8 * S ; if (w > 8) w = 8 ;
+        int rows = G.tri ? mt - 8 * S : mt ;
+        int c = G.tri ? w * (w + 1) / 2 + (rows - w) * w : rows * w ;
+        if (t < c) break ;
+        t -= c ;
+    }
+    if (!G.tri) { I = t / w ; J = 8 * S + t % w ; return true ; }
+    int tri = w * (w + 1) / 2 ;
+    if (t < tri)
+    {
+        int r = 0 ;
+        while ((r + 1) * (r + 2) / 2 <= t) r++ ;
+        I = 8 * S + r ; J = 8 * S + t - r * (r + 1) / 2 ;
     }
     else
     {
-        int u = t - (int) ntri ;
-        I = G.nt + u / G.nt ; J = u % G.nt ;
+        int t2 = t - tri ;
+        I = 8 * S + w + t2 / w ; J = 8 * S + t2 % w ;
     }
+    return true ;
 }
 
 template <int BM, int BN, int BK, bool USE_MFMA>
@@ -636,7 +666,8 @@ __global__ void __launch_bounds__(256) k_update (const GemmGroup *g, int ng,
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
-    decode_tile (G, ((int) blockIdx.x - G.tile_start) * G.tile_mul + G.tile_add, I, J) ;
+    if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
+    if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
     int row0 = I * BM, col0 = J * BN ;
     int mrem = G.m - row0, nrem = G.n - col0 ;      // valid rows / cols in tile
     const double *A = Lx + G.a_off + row0 ;
@@ -852,7 +883,8 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
-    decode_tile (G, ((int) blockIdx.x - G.tile_start) * G.tile_mul + G.tile_add, I, J) ;
+    if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
+    if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
     int row0 = I * BM, col0 = J * BN ;
     int mrem = G.m - row0, nrem = G.n - col0 ;
     i64 lda = G.lda ;
