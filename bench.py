@@ -170,6 +170,7 @@ def main():
                     "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": ps[16] / max(ps[7], 1),
                     "algorithmic_flops_per_launch": ps[8] / max(ps[7], 1),
+                    "extend_add": {"algorithmic_GB": ps[10] / 1e9, "seconds_incl_zero": ps[9]},
                     "small_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
                                            "achieved_GBps": (ps[20] / ps[19] / 1e9) if ps[19] > 0 else None,
                                            "hbm_peak_GBps": 8000.0},

@@ -636,11 +636,10 @@ static int build_host (cholmod_hip_plan *P)
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = P->fr [ids [q]] ;
-            i64 len = (i64) f.ncb * f.ncb ;
-            if (len == 0) continue ;
-            S.zg.push_back (ZeroGroup {f.cb, len, blocks, 0}) ;
-            blocks += (int) ((len + ZERO_CHUNK - 1) / ZERO_CHUNK) ;
-            Lz.bytes += 8.0 * len ;
+            if (f.ncb == 0) continue ;
+            S.zg.push_back (ZeroGroup {f.cb, (i64) f.ncb, blocks, 0}) ;
+            blocks += (f.ncb + ZERO_COLS - 1) / ZERO_COLS ;
+            Lz.bytes += 4.0 * (double) f.ncb * f.ncb ;
         }
         Lz.ng = (int) (S.zg.size () - Lz.goff) ; Lz.grid = blocks ;
         if (Lz.ng) S.launches.push_back (Lz) ;

@@ -132,15 +132,23 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
 }
 
 // ---- zero the contribution blocks of a level --------------------------------
+// Only the lower triangle is ever read (extend-add, k_small_front) or kept, so
+// only it is cleared: a block owns ZERO_COLS columns and clears rows j0..ncb-1.
 #define ZERO_CHUNK 8192
+#define ZERO_COLS 8
 __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, double *CB)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &ZeroGroup::blk_start) ;
     ZeroGroup G = g [gi] ;
-    i64 base = (i64) (blockIdx.x - G.blk_start) * ZERO_CHUNK ;
-    i64 end = base + ZERO_CHUNK ; if (end > G.len) end = G.len ;
+    int ncb = (int) G.len ;                 // len holds ncb (square side)
+    int j0 = ((int) blockIdx.x - G.blk_start) * ZERO_COLS ;
+    int j1 = j0 + ZERO_COLS < ncb ? j0 + ZERO_COLS : ncb ;
     double *dst = CB + G.off ;
-    for (i64 e = base + threadIdx.x ; e < end ; e += 256) dst [e] = 0.0 ;
+    for (int j = j0 ; j < j1 ; j++)
+    {
+        double *col = dst + (i64) j * ncb ;
+        for (int i = j0 + threadIdx.x ; i < ncb ; i += 256) col [i] = 0.0 ;
+    }
 }
 
 // ---- extend-add: pull the children's contribution blocks into a front -------
@@ -178,7 +186,16 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
             if (tc < Pnscol) { dst = Lx + Ppsx + (i64) tc * Pnsrow ; roff = 0 ; }
             else { dst = CB + Pcb + (i64) (tc - Pnscol) * Pncb ; roff = Pnscol ; }
             const double *sc = src + (i64) j * nc ;
-            for (int i = j + lane ; i < nc ; i += 64)
+            // four independent gather / read-modify-write chains in flight per wave
+            int i = j + lane ;
+            for ( ; i + 192 < nc ; i += 256)
+            {
+                int r0 = rm [i] - roff, r1 = rm [i + 64] - roff, r2 = rm [i + 128] - roff, r3 = rm [i + 192] - roff ;
+                double v0 = sc [i], v1 = sc [i + 64], v2 = sc [i + 128], v3 = sc [i + 192] ;
+                double d0 = dst [r0], d1 = dst [r1], d2 = dst [r2], d3 = dst [r3] ;
+                dst [r0] = d0 + v0 ; dst [r1] = d1 + v1 ; dst [r2] = d2 + v2 ; dst [r3] = d3 + v3 ;
+            }
+            for ( ; i < nc ; i += 64)
                 dst [rm [i] - roff] += sc [i] ;
         }
     }
