@@ -35,7 +35,8 @@ struct Launch {
     int stream = 0 ;    // 0 = main, 1 = look-ahead (panel) stream
     int wait_ev = -1 ;  // event this launch's stream waits for first
     int rec_ev = -1 ;   // event recorded on its stream right after it
-    i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: range of Lx summed over the ranks
+    i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: slab of Lx summed over the ranks: starts at
+    int ar_ld = 0, ar_r0 = 0, ar_nc = 0 ;   // ar_off (column o0), ld ar_ld, rows >= ar_r0 of ar_nc columns
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
 } ;
 
@@ -152,6 +153,7 @@ struct cholmod_hip_plan {
     cholmod_hip_allreduce_fn ar_fn = nullptr ;
     void *ar_user = nullptr ;
     double *d_xchg = nullptr ;
+    double *d_stage = nullptr ;             // packed block-column slab for the all-reduce
     Schedule sch ;
     double exec_flops = 0 ;
     // device
@@ -303,8 +305,12 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
             int o1 = std::min (o0 + OB, f.nscol) ;
             Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
+            // only rows >= o0 of the block column carry data (above lies the dead
+            // upper triangle): they are packed into a staging buffer, halving the
+            // volume for the fronts without rows below (the root)
             La.ar_off = f.psx + (i64) o0 * f.nsrow ;
-            La.ar_cnt = (i64) (o1 - o0) * f.nsrow ;
+            La.ar_ld = f.nsrow ; La.ar_r0 = o0 ; La.ar_nc = o1 - o0 ;
+            La.ar_cnt = (i64) (o1 - o0) * (f.nsrow - o0) ;
             La.bytes = 8.0 * La.ar_cnt ;
             S.launches.push_back (La) ;
         }
@@ -668,7 +674,7 @@ static void free_device (cholmod_hip_plan *P)
 {
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg} ;
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -717,6 +723,11 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 2 * (size_t) P->world * sizeof (double))) ;
+    {
+        i64 mx = 1 ;
+        for (const Launch &L : P->sch.launches) if (L.kind == K_ALLREDUCE && L.ar_r0 > 0) mx = std::max (mx, L.ar_cnt) ;
+        HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
+    }
     if (P->nsuper > 0)
     {
         int grid = (int) ((P->nsuper * 64 + 255) / 256) ;
@@ -755,8 +766,22 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
-            HIPCHK (hipStreamSynchronize (st)) ;
-            if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            if (L.ar_r0 == 0)
+            {
+                HIPCHK (hipStreamSynchronize (st)) ;
+                if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            }
+            else
+            {
+                size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
+                double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
+                HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
+                    (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
+                HIPCHK (hipStreamSynchronize (st)) ;
+                if (P->ar_fn (P->d_stage, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
+                    (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
+            }
             break ;
         case K_ZERO:
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
