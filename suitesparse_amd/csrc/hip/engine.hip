@@ -154,6 +154,13 @@ struct cholmod_hip_plan {
     void *ar_user = nullptr ;
     double *d_xchg = nullptr ;
     double *d_stage = nullptr ;             // packed block-column slab for the all-reduce
+    // triangular solves: per level, the supernodes one workgroup handles whole
+    // and the big ones walked in SOLVE_SB-column blocks by many workgroups
+    std::vector<SolveTask> sv_tasks ;       // [whole-supernode tasks by level | block tasks]
+    std::vector<i32> sv_ptr ;               // level -> range of whole-supernode tasks
+    std::vector<std::vector<i32>> sv_big ;  // level -> big supernodes
+    std::vector<i64> sv_blk ;               // (front, jb) -> index of its diagonal block task
+    SolveTask *d_sv = nullptr ;
     Schedule sch ;
     double exec_flops = 0 ;
     // device
@@ -587,6 +594,30 @@ static int build_host (cholmod_hip_plan *P)
         }
     }
     P->arena = A.top ;
+    // solve tasks (all supernodes: after cholmod_hip_gather_factor every rank holds L)
+    P->sv_tasks.clear () ; P->sv_ptr.assign (nlev + 1, 0) ; P->sv_big.assign (nlev, {}) ;
+    for (int l = 0 ; l < nlev ; l++)
+    {
+        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
+        {
+            i32 sid = P->lvl_list [q] ;
+            const FrontD &f = P->fr [sid] ;
+            // one workgroup streams ~50-100 GB/s: anything above ~16 MB of L gets the
+            // multi-workgroup block walk
+            if (f.nscol > 2 * SOLVE_SB || (i64) f.nsrow * f.nscol > ((i64) 2 << 20)) P->sv_big [l].push_back (sid) ;
+            else P->sv_tasks.push_back (SolveTask {sid, 0, f.nscol, 1}) ;
+        }
+        P->sv_ptr [l+1] = (i32) P->sv_tasks.size () ;
+    }
+    P->sv_blk.assign (std::max<i64> (nsuper, 1), -1) ;
+    for (int l = 0 ; l < nlev ; l++)
+        for (i32 sid : P->sv_big [l])
+        {
+            const FrontD &f = P->fr [sid] ;
+            P->sv_blk [sid] = (i64) P->sv_tasks.size () ;
+            for (int jb = 0 ; jb < f.nscol ; jb += SOLVE_SB)
+                P->sv_tasks.push_back (SolveTask {sid, jb, std::min (jb + SOLVE_SB, f.nscol), 0}) ;
+        }
     // launch schedule of this rank
     Schedule &S = P->sch ;
     for (int l = 0 ; l < nlev ; l++)
@@ -674,7 +705,7 @@ static void free_device (cholmod_hip_plan *P)
 {
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage} ;
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -718,6 +749,7 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
+    P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
     HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
@@ -1127,18 +1159,46 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
     {
         for (int l = 0 ; l < P->nlevels ; l++)
         {
-            int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
-            hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
-                P->d_lvl_list + P->lvl_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+            int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
+            if (nf) hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
+                P->d_sv + P->sv_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+            for (i32 sid : P->sv_big [l])
+            {
+                const FrontD &f = P->fr [sid] ;
+                int nblk = (f.nscol + SOLVE_SB - 1) / SOLVE_SB ;
+                for (int b = 0 ; b < nblk ; b++)
+                {
+                    int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
+                    hipLaunchKernelGGL (k_lsolve, dim3 (1), dim3 (256), 0, st,
+                        P->d_sv + P->sv_blk [sid] + b, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                    int rest = f.nsrow - (jb + w) ;
+                    if (rest > 0) hipLaunchKernelGGL (k_solve_fwd_update, dim3 ((rest + 255) / 256), dim3 (256), 0, st,
+                        (int) sid, jb, w, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                }
+            }
         }
     }
     if (which == 0 || which == 2)
     {
         for (int l = P->nlevels - 1 ; l >= 0 ; l--)
         {
-            int nf = P->lvl_ptr [l+1] - P->lvl_ptr [l] ;
-            hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
-                P->d_lvl_list + P->lvl_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+            for (i32 sid : P->sv_big [l])
+            {
+                const FrontD &f = P->fr [sid] ;
+                int nblk = (f.nscol + SOLVE_SB - 1) / SOLVE_SB ;
+                for (int b = nblk - 1 ; b >= 0 ; b--)
+                {
+                    int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
+                    int rest = f.nsrow - (jb + w) ;
+                    if (rest > 0) hipLaunchKernelGGL (k_solve_bwd_update, dim3 ((rest + 255) / 256), dim3 (256), 0, st,
+                        (int) sid, jb, w, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                    hipLaunchKernelGGL (k_ltsolve, dim3 (1), dim3 (256), 0, st,
+                        P->d_sv + P->sv_blk [sid] + b, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                }
+            }
+            int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
+            if (nf) hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
+                P->d_sv + P->sv_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
         }
     }
     HIPCHK (hipGetLastError ()) ;

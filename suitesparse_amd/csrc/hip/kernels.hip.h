@@ -1029,88 +1029,189 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 // the level.  Forward: x1 = L1 \ x1 ; X[Ls2] -= L2 * x1 (children of one parent
 // may hit the same rows, hence the atomic add).  Backward: x1 = L1' \ (x1 -
 // L2' * X[Ls2]) needs no atomics.
-__global__ void __launch_bounds__(256) k_lsolve (const i32 *fronts,
+struct SolveTask { i32 front ; i32 c0, c1 ; i32 below ; } ;   // columns [c0,c1) of a supernode
+
+__global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
 {
     __shared__ double xb [64] ;
-    const FrontD &f = fr [fronts [blockIdx.x]] ;
+    __shared__ double Dl [64 * 65] ;
+    SolveTask T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
     int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
     int lane = tid & 63, wave = tid >> 6 ;
+    int c0 = T.c0, c1 = T.c1 ;
     const double *L = Lx + f.psx ;
     const i64 *rows = Ls + f.psi ;
     for (int r = 0 ; r < nrhs ; r++)
     {
         double *x = X + (i64) r * ldx ;
-        for (int jb = 0 ; jb < nscol ; jb += 64)
+        for (int jb = c0 ; jb < c1 ; jb += 64)
         {
-            int nb = nscol - jb < 64 ? nscol - jb : 64 ;
+            int nb = c1 - jb < 64 ? c1 - jb : 64 ;
+            // stage the diagonal block in LDS (coalesced), so the sequential
+            // substitution below never waits on HBM
+            for (int e = tid ; e < 64 * 64 ; e += 256)
+            {
+                int i = e & 63, j = e >> 6 ;
+                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? L [(jb + i) + (i64) (jb + j) * nsrow] : (i == j ? 1.0 : 0.0) ;
+            }
+            __syncthreads () ;
             if (wave == 0)
             {
                 // dtrsv("L","N","N") on the 64-wide diagonal block, one wave
                 double xv = (lane < nb) ? x [k1 + jb + lane] : 0.0 ;
                 for (int j = 0 ; j < nb ; j++)
                 {
-                    double xj = __shfl (xv, j) / L [(jb + j) + (i64) (jb + j) * nsrow] ;
+                    double xj = __shfl (xv, j) / Dl [j * 65 + j] ;
                     if (lane == j) xv = xj ;
-                    else if (lane > j && lane < nb)
-                        xv -= L [(jb + lane) + (i64) (jb + j) * nsrow] * xj ;
+                    else if (lane > j) xv -= Dl [lane * 65 + j] * xj ;
                 }
                 xb [lane] = xv ;
                 if (lane < nb) x [k1 + jb + lane] = xv ;
             }
             __syncthreads () ;
-            for (int i = jb + nb + tid ; i < nscol ; i += 256)
+            for (int i = jb + nb + tid ; i < c1 ; i += 256)
             {
-                double acc = 0.0 ;
-                for (int j = 0 ; j < nb ; j++) acc += L [i + (i64) (jb + j) * nsrow] * xb [j] ;
-                x [k1 + i] -= acc ;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
+                const double *Li = L + i + (i64) jb * nsrow ;
+                int j = 0 ;
+                for ( ; j + 4 <= nb ; j += 4)
+                {
+                    double l0 = Li [(i64) j * nsrow], l1 = Li [(i64) (j + 1) * nsrow] ;
+                    double l2 = Li [(i64) (j + 2) * nsrow], l3 = Li [(i64) (j + 3) * nsrow] ;
+                    a0 += l0 * xb [j] ; a1 += l1 * xb [j + 1] ; a2 += l2 * xb [j + 2] ; a3 += l3 * xb [j + 3] ;
+                }
+                for ( ; j < nb ; j++) a0 += Li [(i64) j * nsrow] * xb [j] ;
+                x [k1 + i] -= (a0 + a1) + (a2 + a3) ;
             }
             __syncthreads () ;
         }
-        // dgemv: X[rows2] -= L2 * x1 ; siblings share ancestor rows -> atomic
-        for (int i = nscol + tid ; i < nsrow ; i += 256)
+        if (T.below)
         {
-            double acc = 0.0 ;
-            for (int j = 0 ; j < nscol ; j++) acc += L [i + (i64) j * nsrow] * x [k1 + j] ;
-            atomicAdd (&x [rows [i]], -acc) ;
+            // dgemv: X[rows2] -= L2 * x1 ; siblings share ancestor rows -> atomic
+            for (int i = nscol + tid ; i < nsrow ; i += 256)
+            {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
+                const double *Li = L + i ;
+                int j = 0 ;
+                for ( ; j + 4 <= nscol ; j += 4)
+                {
+                    double l0 = Li [(i64) j * nsrow], l1 = Li [(i64) (j + 1) * nsrow] ;
+                    double l2 = Li [(i64) (j + 2) * nsrow], l3 = Li [(i64) (j + 3) * nsrow] ;
+                    a0 += l0 * x [k1 + j] ; a1 += l1 * x [k1 + j + 1] ;
+                    a2 += l2 * x [k1 + j + 2] ; a3 += l3 * x [k1 + j + 3] ;
+                }
+                for ( ; j < nscol ; j++) a0 += Li [(i64) j * nsrow] * x [k1 + j] ;
+                atomicAdd (&x [rows [i]], -((a0 + a1) + (a2 + a3))) ;
+            }
         }
         __syncthreads () ;
     }
 }
 
-__global__ void __launch_bounds__(256) k_ltsolve (const i32 *fronts,
+// big supernodes, forward: rows below a solved column block [jb,jb+w) get
+// y(i) -= L(i, jb:jb+w) * x1(jb:jb+w); one thread per row, many workgroups
+#define SOLVE_SB 512
+__global__ void __launch_bounds__(256) k_solve_fwd_update (int fid, int jb, int w,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
+{
+    __shared__ double xs [SOLVE_SB] ;
+    const FrontD &f = fr [fid] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    int i = jb + w + (int) blockIdx.x * 256 + tid ;
+    for (int r = 0 ; r < nrhs ; r++)
+    {
+        double *x = X + (i64) r * ldx ;
+        for (int c = tid ; c < w ; c += 256) xs [c] = x [k1 + jb + c] ;
+        __syncthreads () ;
+        if (i < nsrow)
+        {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
+            const double *Li = L + i + (i64) jb * nsrow ;
+            int c = 0 ;
+            for ( ; c + 4 <= w ; c += 4)
+            {
+                double l0 = Li [(i64) c * nsrow], l1 = Li [(i64) (c + 1) * nsrow] ;
+                double l2 = Li [(i64) (c + 2) * nsrow], l3 = Li [(i64) (c + 3) * nsrow] ;
+                a0 += l0 * xs [c] ; a1 += l1 * xs [c + 1] ; a2 += l2 * xs [c + 2] ; a3 += l3 * xs [c + 3] ;
+            }
+            for ( ; c < w ; c++) a0 += Li [(i64) c * nsrow] * xs [c] ;
+            double acc = (a0 + a1) + (a2 + a3) ;
+            if (i < nscol) x [k1 + i] -= acc ;
+            else atomicAdd (&x [rows [i]], -acc) ;
+        }
+        __syncthreads () ;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
 {
     __shared__ double xb [64] ;
-    const FrontD &f = fr [fronts [blockIdx.x]] ;
+    __shared__ double ych [512] ;
+    __shared__ double Dl [64 * 65] ;
+    SolveTask T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
     int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
     int lane = tid & 63, wave = tid >> 6 ;
+    int c0 = T.c0, c1 = T.c1 ;
     const double *L = Lx + f.psx ;
     const i64 *rows = Ls + f.psi ;
     for (int r = 0 ; r < nrhs ; r++)
     {
         double *x = X + (i64) r * ldx ;
-        // dgemv("C"): x1 -= L2' * X[rows2]; one wave per column
-        for (int j = wave ; j < nscol ; j += 4)
+        if (T.below)
         {
-            double acc = 0.0 ;
-            for (int i = nscol + lane ; i < nsrow ; i += 64)
-                acc += L [i + (i64) j * nsrow] * x [rows [i]] ;
-            for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
-            if (lane == 0) x [k1 + j] -= acc ;
+            // dgemv("C"): x1 -= L2' * X[rows2].  The gathered X[rows2] is staged in
+            // LDS in chunks of 512 rows (one gather per row instead of one per row
+            // and column); a wave walks the columns, 8 independent loads per lane
+            for (int i0 = nscol ; i0 < nsrow ; i0 += 512)
+            {
+                int nr = nsrow - i0 < 512 ? nsrow - i0 : 512 ;
+                for (int q = tid ; q < 512 ; q += 256) ych [q] = (q < nr) ? x [rows [i0 + q]] : 0.0 ;
+                __syncthreads () ;
+                for (int j = wave ; j < nscol ; j += 4)
+                {
+                    const double *Lc = L + i0 + (i64) j * nsrow ;
+                    double v [8] ;
+#pragma unroll
+                    for (int u = 0 ; u < 8 ; u++) { int q = lane + 64 * u ; v [u] = (q < nr) ? Lc [q] : 0.0 ; }
+                    double acc = 0.0 ;
+#pragma unroll
+                    for (int u = 0 ; u < 8 ; u++) acc += v [u] * ych [lane + 64 * u] ;
+                    for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
+                    if (lane == 0) x [k1 + j] -= acc ;
+                }
+                __syncthreads () ;
+            }
         }
-        __syncthreads () ;
-        // dtrsv("L","C","N") by 64-wide blocks from the bottom
-        int last = ((nscol - 1) / 64) * 64 ;
-        for (int jb = last ; jb >= 0 ; jb -= 64)
+        // dtrsv("L","C","N") by 64-wide blocks from the bottom of [c0,c1)
+        int last = c0 + ((c1 - c0 - 1) / 64) * 64 ;
+        for (int jb = last ; jb >= c0 ; jb -= 64)
         {
-            int nb = nscol - jb < 64 ? nscol - jb : 64 ;
+            int nb = c1 - jb < 64 ? c1 - jb : 64 ;
+            for (int e = tid ; e < 64 * 64 ; e += 256)
+            {
+                int i = e & 63, j = e >> 6 ;
+                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? L [(jb + i) + (i64) (jb + j) * nsrow] : (i == j ? 1.0 : 0.0) ;
+            }
             for (int jj = wave ; jj < nb ; jj += 4)
             {
                 int j = jb + jj ;
-                double acc = 0.0 ;
-                for (int i = jb + nb + lane ; i < nscol ; i += 64)
-                    acc += L [i + (i64) j * nsrow] * x [k1 + i] ;
+                const double *Lc = L + (i64) j * nsrow ;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
+                int i = jb + nb + lane ;
+                for ( ; i + 192 < c1 ; i += 256)
+                {
+                    double l0 = Lc [i], l1 = Lc [i + 64], l2 = Lc [i + 128], l3 = Lc [i + 192] ;
+                    a0 += l0 * x [k1 + i] ; a1 += l1 * x [k1 + i + 64] ;
+                    a2 += l2 * x [k1 + i + 128] ; a3 += l3 * x [k1 + i + 192] ;
+                }
+                for ( ; i < c1 ; i += 64) a0 += Lc [i] * x [k1 + i] ;
+                double acc = (a0 + a1) + (a2 + a3) ;
                 for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
                 if (lane == 0) xb [jj] = x [k1 + j] - acc ;
             }
@@ -1120,15 +1221,59 @@ __global__ void __launch_bounds__(256) k_ltsolve (const i32 *fronts,
                 double xv = (lane < nb) ? xb [lane] : 0.0 ;
                 for (int j = nb - 1 ; j >= 0 ; j--)
                 {
-                    double xj = __shfl (xv, j) / L [(jb + j) + (i64) (jb + j) * nsrow] ;
+                    double xj = __shfl (xv, j) / Dl [j * 65 + j] ;
                     if (lane == j) xv = xj ;
-                    else if (lane < j)
-                        xv -= L [(jb + j) + (i64) (jb + lane) * nsrow] * xj ;
+                    else if (lane < j) xv -= Dl [j * 65 + lane] * xj ;
                 }
                 if (lane < nb) x [k1 + jb + lane] = xv ;
             }
             __syncthreads () ;
         }
+    }
+}
+
+// big supernodes, backward: x1(jb:jb+w) -= L(i, jb:jb+w)' * y(i) over the rows
+// i >= jb+w; a workgroup owns 256 rows, a wave walks the columns (rows
+// contiguous -> coalesced), partial sums meet in x1 by atomic add
+__global__ void __launch_bounds__(256) k_solve_bwd_update (int fid, int jb, int w,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
+{
+    __shared__ double yv [256] ;
+    const FrontD &f = fr [fid] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    int lane = tid & 63, wave = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    int r0 = jb + w + (int) blockIdx.x * 256 ;
+    int nr = nsrow - r0 < 256 ? nsrow - r0 : 256 ;
+    for (int r = 0 ; r < nrhs ; r++)
+    {
+        double *x = X + (i64) r * ldx ;
+        int i = r0 + tid ;
+        yv [tid] = (tid < nr) ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
+        __syncthreads () ;
+        for (int c = wave * 4 ; c < w ; c += 16)
+        {
+            // four columns per wave at once: 16 independent loads per lane
+            double v [4][4] ;
+#pragma unroll
+            for (int cc = 0 ; cc < 4 ; cc++)
+            {
+                const double *Lc = L + r0 + (i64) (jb + (c + cc < w ? c + cc : w - 1)) * nsrow ;
+#pragma unroll
+                for (int u = 0 ; u < 4 ; u++) { int q = lane + 64 * u ; v [cc][u] = (q < nr) ? Lc [q] : 0.0 ; }
+            }
+#pragma unroll
+            for (int cc = 0 ; cc < 4 ; cc++)
+            {
+                double acc = 0.0 ;
+#pragma unroll
+                for (int u = 0 ; u < 4 ; u++) acc += v [cc][u] * yv [lane + 64 * u] ;
+                for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
+                if (lane == 0 && c + cc < w) atomicAdd (&x [k1 + jb + c + cc], -acc) ;
+            }
+        }
+        __syncthreads () ;
     }
 }
 

@@ -53,7 +53,7 @@ def test_diagonal_matrix():
     _check(n, np.arange(n + 1), np.arange(n), np.linspace(1.0, 9.0, n), -1)
 
 
-@pytest.mark.parametrize("n", [50, 200, 700])
+@pytest.mark.parametrize("n", [50, 200, 700, 2600])
 def test_dense_spd_single_supernode(n):
     rng = np.random.default_rng(n)
     M = rng.standard_normal((n, n))
