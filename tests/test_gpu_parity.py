@@ -259,3 +259,40 @@ def test_update_kernel_microbench_runs(L):
         rate = L.cholmod_hip_bench_update_kernel(1024, 1024, 256, 2, flags)
         assert rate > 1e10
     assert L.cholmod_hip_bench_mfma_peak(2, 2000) > 1e13
+
+
+def test_shim_level_factorize_with_host_copy(L, golden_dir):
+    """The plain-pointer ABI exactly as INTEGRATION.md binds it: plan from the index
+    maps, cholmod_hip_factorize with an Lx_host buffer, solve on the device."""
+    n, Ap, Ai, Ax, stype, perm = _case("p3d_12_nd", golden_dir)
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    Lf = S.analyze(A, perm)
+    fv = ch.FactorView(Lf)
+    f = Lf.contents
+    # S = tril(P A P') by the library's own permuted transposes
+    A1 = S.L.cholmod_l_ptranspose(A, 2, None, None, 0, C.byref(S.cm))
+    Sm = S.L.cholmod_l_ptranspose(A1, 2, fv.Perm.ctypes.data, None, 0, C.byref(S.cm))
+    st = C.c_int(0)
+    plan = L.cholmod_hip_plan_create(fv.n, fv.nsuper, f.super, f.pi, f.px, f.s, 0, C.byref(st))
+    assert plan and st.value == 0
+    Lx = np.full(fv.xsize, np.nan)
+    minor = C.c_int64(-1)
+    sm = Sm.contents
+    rc = L.cholmod_hip_factorize(plan, sm.p, sm.i, None, sm.x, 0.0, 0, Lx.ctypes.data, C.byref(minor))
+    assert rc == 0 and minor.value == n
+    O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+    O.factorize(Ax)
+    assert rel_err_lower(Lx, O.x, O.lower_mask()) < TOL_L
+    y = np.ascontiguousarray(G.demo_rhs(n)[O.Perm])
+    assert L.cholmod_hip_solve(plan, 0, y.ctypes.data, 1, n) == 0
+    x = np.empty(n); x[O.Perm] = y
+    r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - G.demo_rhs(n)
+    assert np.linalg.norm(r) / np.linalg.norm(G.demo_rhs(n)) < TOL_RES
+    stats = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+    assert L.cholmod_hip_get_stats(plan, stats.ctypes.data) == 0 and stats[0] > 0
+    L.cholmod_hip_plan_destroy(plan)
+    S.free_sparse(Sm); S.free_sparse(A1)
+    S.free_factor(Lf); S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
