@@ -777,7 +777,7 @@ static int raise_lds_limits ()
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -791,10 +791,18 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
         case K_JOIN: break ;
         case K_SMALL:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            hipLaunchKernelGGL (k_small_front, dim3 (L.grid), dim3 (256), (size_t) L.aux, st,
-                P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
-                P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                P->d_Lx, P->d_cb, P->d_info) ;
+            // the narrowest class runs one wave per front: barriers are free and
+            // eight times more fronts are resident per CU
+            if (L.aux <= 49 * 48 * (int) sizeof (double))
+                hipLaunchKernelGGL (k_small_front<64>, dim3 (L.grid), dim3 (64), (size_t) L.aux, st,
+                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
+                    P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                    P->d_Lx, P->d_cb, P->d_info) ;
+            else
+                hipLaunchKernelGGL (k_small_front<256>, dim3 (L.grid), dim3 (256), (size_t) L.aux, st,
+                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
+                    P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                    P->d_Lx, P->d_cb, P->d_info) ;
             break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;

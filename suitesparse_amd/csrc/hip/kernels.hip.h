@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
 // :743-772 (relative map scatter), :864-867 / :997-1002 (dpotrf / dtrsm), and the
 // dsyrk/dgemm its ancestors would have pulled (:682-717) as the CB.
 #define SM_MAX 136
-__global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
+template <int NT>
+__global__ void __launch_bounds__(NT) k_small_front (const i32 *fronts,
     const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
     i64 n, const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
     double *Lx, double *CB, i32 *info)
@@ -542,12 +543,12 @@ __global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
     int ld = ns | 1 ;
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     i64 psx = f.psx, psi = f.psi, cbo = f.cb ;
-    for (int e = tid ; e < ld * ns ; e += 256) F [e] = 0.0 ;
+    for (int e = tid ; e < ld * ns ; e += NT) F [e] = 0.0 ;
     __syncthreads () ;
     if (f.assemble)
     {
         const i64 *rows = Ls + psi ;
-        for (int k = tid ; k < nc ; k += 256)
+        for (int k = tid ; k < nc ; k += NT)
         {
             i64 col = (i64) k1 + k ;
             i64 p = Sp [col], pend = Snz ? p + Snz [col] : Sp [col + 1] ;
@@ -569,7 +570,7 @@ __global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
         const i32 *rm = relmap + c.rel ;
         int m = c.ncb ;
         const double *src = CB + c.cb ;
-        for (int j = wave ; j < m ; j += 4)
+        for (int j = wave ; j < m ; j += NT / 64)
         {
             int tj = rm [j] ;
             const double *sc = src + (i64) j * m ;
@@ -586,10 +587,10 @@ __global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
         double r, ri ;
         sqrt_rsqrt (d, r, ri) ;
         __syncthreads () ;                  // everyone has read the pivot
-        for (int i = j + tid ; i < ns ; i += 256) F [i + j * ld] = (i == j) ? r : F [i + j * ld] * ri ;
+        for (int i = j + tid ; i < ns ; i += NT) F [i + j * ld] = (i == j) ? r : F [i + j * ld] * ri ;
         __syncthreads () ;
         const double *lj = F + j * ld ;
-        for (int k = j + 1 + tk ; k < ns ; k += 8)
+        for (int k = j + 1 + tk ; k < ns ; k += NT / 32)
         {
             double lk = lj [k] ;
             double *fk = F + k * ld ;
@@ -600,10 +601,10 @@ __global__ void __launch_bounds__(256) k_small_front (const i32 *fronts,
     if (fail >= 0 && tid == 0) info [fronts [blockIdx.x]] = fail + 1 ;
     int ngood = fail >= 0 ? fail : nc ;
     // panel [L11; L21], columns before a failed pivot only (the rest stays zero)
-    for (int j = wave ; j < ngood ; j += 4)
+    for (int j = wave ; j < ngood ; j += NT / 64)
         for (int i = j + lane ; i < ns ; i += 64) Lx [psx + i + (i64) j * ns] = F [i + j * ld] ;
     // contribution block (lower part)
-    for (int j = wave ; j < ncb ; j += 4)
+    for (int j = wave ; j < ncb ; j += NT / 64)
         for (int i = j + lane ; i < ncb ; i += 64)
             CB [cbo + i + (i64) j * ncb] = F [(nc + i) + (nc + j) * ld] ;
 }
