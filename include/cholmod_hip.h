@@ -152,6 +152,8 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *       update region)     [17] all-reduce calls   [18] all-reduce bytes
  *  [19] seconds in the fused small-front kernel  [20] its algorithmic HBM bytes
  *       (A entries aside: children CBs in, panel + CB out)   [21] fronts it handled
+ *  [22] subtrees the schedule sweeps one after the other to fit the CB arena
+ *       next to L (1 = plain level order)
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)

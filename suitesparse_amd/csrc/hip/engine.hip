@@ -144,6 +144,8 @@ struct cholmod_hip_plan {
     std::vector<i32> level, child, supermap ;
     std::vector<i32> lvl_ptr, lvl_list ;        // fronts by level
     i64 relsize = 0, arena = 0 ;
+    i64 arena_budget = 0 ;                  // bytes the CB arena may take (0 = no limit)
+    int nsplit = 1 ;                        // subtrees swept one after the other (memory)
     int nlevels = 0 ;
     // multi-GPU: one process per GPU; owner[s] = rank that factors front s, or
     // -1 for the shared top fronts every rank holds as partial sums
@@ -573,27 +575,96 @@ static int build_host (cholmod_hip_plan *P)
         P->my_lvl_ptr [l+1] = (i32) P->my_lvl_list.size () ;
     }
     if (P->my_lvl_list.empty ()) P->my_lvl_list.push_back (0) ;
-    // arena: a CB lives from its own level until its parent's level is assembled
-    // (same offsets on every rank)
-    Arena A ;
-    for (int l = 0 ; l < nlev ; l++)
+    // ---- execution order and contribution-block arena ---------------------------
+    // A *batch* = fronts factored together (one set of launches); a CB lives from
+    // its batch until the batch of its parent.  The plain order is one batch per
+    // etree level (all fronts of equal height at once): best batching, but every CB
+    // of two adjacent levels is alive at the same time (Poisson 200^3: 178 GB).
+    // When that does not fit next to L, the tree is cut into `nsplit` subtrees that
+    // are swept one after the other (level by level inside each), followed by the
+    // top part: the live set shrinks to one subtree's working set + the finished
+    // subtree roots + the top levels, at the price of more, smaller launches low in
+    // the tree.  nsplit doubles until the arena fits the budget.
+    std::vector<std::vector<i32>> batches, best_batches ;
+    std::vector<i64> best_cb (std::max<i64> (nsuper, 1), 0) ;
+    i64 best_arena = 0 ; int best_nsplit = 1 ;
+    i64 budget = P->arena_budget ;
+    for (int nsplit = 1 ; ; nsplit *= 2)
     {
-        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
+        batches.clear () ;
+        std::vector<i32> group (std::max<i64> (nsuper, 1), -1) ;     // -1 = top part
+        int ngroups = 0 ;
+        if (nsplit > 1 && nsuper > 0)
         {
-            FrontD &f = P->fr [P->lvl_list [q]] ;
-            f.cb = A.alloc ((i64) f.ncb * f.ncb) ;
-        }
-        for (int q = P->lvl_ptr [l] ; q < P->lvl_ptr [l+1] ; q++)
-        {
-            i32 sf = P->lvl_list [q] ;
-            for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
+            std::vector<i32> first (nsuper) ;
+            for (i64 s = 0 ; s < nsuper ; s++) first [s] = (i32) s ;
+            for (i64 s = 0 ; s < nsuper ; s++)
+                if (P->fr [s].parent >= 0) first [P->fr [s].parent] = std::min (first [P->fr [s].parent], first [s]) ;
+            typedef std::pair<double, i32> WS ;
+            std::priority_queue<WS> pq ;
+            for (i64 s = 0 ; s < nsuper ; s++) if (P->fr [s].parent < 0) pq.push (WS (wsub [s], (i32) -s)) ;
+            while (!pq.empty () && (int) pq.size () < nsplit)
             {
-                FrontD &g = P->fr [call [c]] ;
-                A.release (g.cb, (i64) g.ncb * g.ncb) ;
+                i32 t = -pq.top ().second ;
+                if (cptr [t+1] == cptr [t]) break ;                 // heaviest subtree is a leaf
+                pq.pop () ;
+                for (i32 c = cptr [t] ; c < cptr [t+1] ; c++) pq.push (WS (wsub [call [c]], -call [c])) ;
+            }
+            std::vector<i32> roots ;
+            while (!pq.empty ()) { roots.push_back (-pq.top ().second) ; pq.pop () ; }
+            std::sort (roots.begin (), roots.end ()) ;
+            for (i32 r : roots) { for (i32 q = first [r] ; q <= r ; q++) group [q] = ngroups ; ngroups++ ; }
+        }
+        // batches in postorder: a subtree group contributes its levels in increasing
+        // height when its root is reached, a front of the top part is a batch of its
+        // own right after its last descendant (supernodes are numbered in postorder,
+        // so "increasing index of the unit's last member" is a valid order and frees
+        // every contribution block as early as possible)
+        {
+            std::vector<std::vector<std::vector<i32>>> by (ngroups, std::vector<std::vector<i32>> (nlev)) ;
+            std::vector<i32> group_last (ngroups, -1) ;
+            for (i64 s = 0 ; s < nsuper ; s++)
+                if (group [s] >= 0) { by [group [s]][P->level [s]].push_back ((i32) s) ; group_last [group [s]] = (i32) s ; }
+            if (ngroups == 0)
+            {
+                std::vector<std::vector<i32>> lv (nlev) ;
+                for (i64 s = 0 ; s < nsuper ; s++) lv [P->level [s]].push_back ((i32) s) ;
+                for (auto &l : lv) if (!l.empty ()) batches.push_back (std::move (l)) ;
+            }
+            else
+            {
+                for (i64 s = 0 ; s < nsuper ; s++)
+                {
+                    if (group [s] < 0) batches.push_back (std::vector<i32> (1, (i32) s)) ;
+                    else if (group_last [group [s]] == (i32) s)
+                        for (auto &l : by [group [s]]) if (!l.empty ()) batches.push_back (std::move (l)) ;
+                }
             }
         }
+        Arena A ;
+        for (const auto &bt : batches)
+        {
+            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc ((i64) f.ncb * f.ncb) ; }
+            for (i32 sf : bt)
+                for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
+                {
+                    FrontD &g = P->fr [call [c]] ;
+                    A.release (g.cb, (i64) g.ncb * g.ncb) ;
+                }
+        }
+        // keep the first split that fits; if none does, the one with the smallest
+        // arena (upload_plan then reports the shortage)
+        if (nsplit == 1 || A.top < best_arena)
+        {
+            best_arena = A.top ; best_nsplit = nsplit ; best_batches = batches ;
+            for (i64 s = 0 ; s < nsuper ; s++) best_cb [s] = P->fr [s].cb ;
+        }
+        if (budget <= 0 || 8 * A.top <= budget || nsplit >= 256 || (nsplit > 1 && ngroups < nsplit / 2)) break ;
     }
-    P->arena = A.top ;
+    batches.swap (best_batches) ;
+    for (i64 s = 0 ; s < nsuper ; s++) P->fr [s].cb = best_cb [s] ;
+    P->arena = best_arena ;
+    P->nsplit = best_nsplit ;
     // solve tasks (all supernodes: after cholmod_hip_gather_factor every rank holds L)
     P->sv_tasks.clear () ; P->sv_ptr.assign (nlev + 1, 0) ; P->sv_big.assign (nlev, {}) ;
     for (int l = 0 ; l < nlev ; l++)
@@ -620,10 +691,13 @@ static int build_host (cholmod_hip_plan *P)
         }
     // launch schedule of this rank
     Schedule &S = P->sch ;
-    for (int l = 0 ; l < nlev ; l++)
+    std::vector<i32> mine_ids ;
+    for (const auto &bt : batches)
     {
-        const i32 *all_ids = P->my_lvl_list.data () + P->my_lvl_ptr [l] ;
-        int all_nf = P->my_lvl_ptr [l+1] - P->my_lvl_ptr [l] ;
+        mine_ids.clear () ;
+        for (i32 sf : bt) if (mine (sf)) mine_ids.push_back (sf) ;
+        const i32 *all_ids = mine_ids.data () ;
+        int all_nf = (int) mine_ids.size () ;
         if (all_nf == 0) continue ;
         // thin fronts go to the fused LDS-resident kernel, in three size classes
         // so that the dynamic LDS of a launch fits its widest member
@@ -910,6 +984,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
+        S [22] = P->nsplit ;
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
@@ -1020,6 +1095,22 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     P->px.assign (px, px + nsuper + 1) ;
     P->ssize = pi [nsuper] ; P->xsize = px [nsuper] ;
     P->Ls.assign (s, s + std::max<i64> (P->ssize, 1)) ;
+    // memory budget of the contribution-block arena (see build_host): what is left
+    // of the HBM next to L and the index maps.  Several ranks must derive the same
+    // schedule, so they use a nominal capacity instead of their momentary free
+    // memory.  CHOLMOD_HIP_ARENA_BUDGET_MB overrides (tests, tuning).
+    {
+        const char *e = getenv ("CHOLMOD_HIP_ARENA_BUDGET_MB") ;
+        double fixed = 8.0 * P->xsize + 8.0 * P->ssize + 4.0 * (P->ssize - n) + 3e9 ;
+        if (e && atof (e) > 0) P->arena_budget = (i64) (atof (e) * 1048576.0) ;
+        else if (world > 1) P->arena_budget = (i64) std::max (1e9, 270e9 - fixed) ;
+        else if (!host_only)
+        {
+            size_t freeb = 0, totalb = 0 ;
+            if (hipMemGetInfo (&freeb, &totalb) == hipSuccess)
+                P->arena_budget = (i64) std::max (1e9, (double) freeb - fixed) ;
+        }
+    }
     *status = build_host (P) ;
     if (*status == CHOLMOD_HIP_OK && !host_only) *status = upload_plan (P) ;
     if (*status != CHOLMOD_HIP_OK)
@@ -1242,6 +1333,7 @@ int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
     P->stats [3] = P->nlevels ;
     P->stats [4] = 8.0 * P->arena ;
     P->stats [5] = 8.0 * P->xsize ;
+    P->stats [22] = P->nsplit ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
     return CHOLMOD_HIP_OK ;
 }

@@ -296,3 +296,24 @@ def test_shim_level_factorize_with_host_copy(L, golden_dir):
     S.free_factor(Lf); S.free_sparse(A)
     assert S.cm.malloc_count == 0
     S.finish()
+
+
+def test_subtree_sweep_schedule_matches_oracle(L, golden_dir, monkeypatch):
+    """Force the memory-aware schedule (subtrees swept one after the other) and
+    check the factor is unchanged."""
+    n, Ap, Ai, Ax, stype, perm = _case("p3d_24_nd", golden_dir)
+    O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+    O.factorize(Ax)
+    monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", "8")
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    assert S.hip_stats(Lf)[22] > 1
+    assert rel_err_lower(ch.FactorView(Lf).x, O.x, O.lower_mask()) < TOL_L
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b) / np.linalg.norm(b) < TOL_RES
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()

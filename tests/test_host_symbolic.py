@@ -177,3 +177,34 @@ def test_invalid_arguments():
     S.free_sparse(A)
     S.free_sparse(A0)
     S.finish()
+
+
+def test_memory_budget_splits_the_sweep(monkeypatch):
+    """With a tight arena budget the schedule sweeps subtrees one after the other:
+    smaller arena, same executed flops, more launches."""
+    n, Ap, Ai, Ax = G.poisson3d(24)
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, G.geometric_nd(24, 24, 24, 4))
+    fv = ch.FactorView(Lf)
+    f = Lf.contents
+
+    def plan_stats():
+        st = C.c_int(0)
+        plan = S.L.cholmod_hip_plan_create(fv.n, fv.nsuper, f.super, f.pi, f.px, f.s,
+                                           ch.HIP_PLAN_HOST_ONLY, C.byref(st))
+        assert plan and st.value == 0
+        s24 = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+        S.L.cholmod_hip_get_stats(plan, s24.ctypes.data)
+        S.L.cholmod_hip_plan_destroy(plan)
+        return s24
+
+    base = plan_stats()
+    assert base[22] == 1
+    monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", str(0.55 * base[4] / 1048576.0))
+    tight = plan_stats()
+    assert tight[22] > 1 and tight[4] < 0.75 * base[4]
+    assert tight[1] == base[1] and tight[2] > base[2]
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
