@@ -8,8 +8,11 @@ the permuted input matrix already resident in HBM.  Metric = Common->fl / t,
 fl = sum_j ColCount[j]^2 (reference CHOLMOD/Cholesky/cholmod_rowcolcounts.c:
 517-528, demo convention CHOLMOD/Demo/cholmod_l_demo.c:691-692).
 
-N=1 workload: BASELINE.json configs[1], 3D 7-point Poisson 100^3 under geometric
-nested dissection.  N>1: the SAME factorization partitioned over
+Workload: the configuration BASELINE.json's metric is quoted on, 3D 7-point
+Poisson 200^3 (8M dof, fl = 4.25e14) under geometric nested dissection (SURVEY.md
+8d) -- it fits one MI355X (L 181.6 GB + contribution blocks).  If the
+device cannot hold it the bench falls back to 160^3, then 100^3 (configs[1]), and
+names the workload it actually ran.  N>1: the SAME factorization partitioned over
 the ranks (one process per GPU): private etree subtrees per rank, the shared top
 fronts kept as partial sums and summed block column by block column with a
 sum all-reduce over RCCL (torch.distributed "nccl"); strong scaling.
@@ -79,10 +82,11 @@ def cpu_baseline(sample_m):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="poisson3d")
-    ap.add_argument("--grid", "--m", dest="m", type=int, default=100, help="grid points per side")
+    ap.add_argument("--grid", "--m", dest="m", type=int, default=0,
+                    help="grid points per side (default: 200, falling back to 160 / 100 if HBM is short)")
     ap.add_argument("--cpu-sample-m", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
@@ -111,26 +115,47 @@ def main():
         raise RuntimeError("bench.py needs a HIP device; there is no CPU path to measure")
     lib.cholmod_hip_set_device(local_rank)
 
-    t0 = time.perf_counter()
-    n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, args.m)
-    t_gen = time.perf_counter() - t0
     allreduce = None
     if world > 1:
         from suitesparse_amd.dist import make_allreduce
         allreduce = make_allreduce()
-    S = ch.Session(factor_on_device=True, hip_flags=args.hip_flags, rank=rank, world=world,
-                   allreduce=allreduce)
-    A = S.sparse(n, Ap, Ai, Ax, stype)
-    t0 = time.perf_counter()
-    Lf = S.analyze(A, perm)
-    t_analyze = time.perf_counter() - t0
-    fl = S.cm.fl
-    fv = ch.FactorView(Lf)
-    # first factorization: builds the plan, uploads S (H2D, outside the timed region)
-    t0 = time.perf_counter()
-    ok = S.factorize(A, Lf)
-    t_first = time.perf_counter() - t0
-    assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+    grids = [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
+    S = None
+    for gi, m in enumerate(grids):
+        t0 = time.perf_counter()
+        n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, m)
+        t_gen = time.perf_counter() - t0
+        S = ch.Session(factor_on_device=True, hip_flags=args.hip_flags, rank=rank, world=world,
+                       allreduce=allreduce)
+        A = S.sparse(n, Ap, Ai, Ax, stype)
+        t0 = time.perf_counter()
+        Lf = S.analyze(A, perm)
+        t_analyze = time.perf_counter() - t0
+        fl = S.cm.fl
+        fv = ch.FactorView(Lf)
+        # reserve HBM for L and the contribution blocks (no collective in here)
+        t0 = time.perf_counter()
+        ok = S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm))
+        short = (ok != 1 and S.cm.status == ch.OUT_OF_MEMORY)
+        if world > 1:
+            # every rank must take the same decision
+            import torch
+            flag = torch.tensor([1.0 if short else 0.0], device="cuda")
+            dist.all_reduce(flag)
+            short = flag.item() > 0
+        if short and gi + 1 < len(grids):
+            if rank == 0:
+                print(f"[bench] {wname}: not enough HBM, falling back to grid {grids[gi + 1]}", file=sys.stderr)
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            continue
+        assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+        # first factorization: uploads S (H2D, outside the timed region)
+        ok = S.factorize(A, Lf)
+        t_first = time.perf_counter() - t0
+        assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+        break
 
     def barrier():
         if dist is not None:

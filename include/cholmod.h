@@ -307,6 +307,10 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common) ;
 /* Device time and per-class statistics of the last factorization
  * (CHOLMOD_HIP_NSTATS doubles, see cholmod_hip.h). */
 int cholmod_l_hip_stats (cholmod_factor *L, double *stats, cholmod_common *Common) ;
+/* Create the device plan of a symbolic factor now (HBM reservation for L and the
+ * contribution blocks) instead of at the first numeric factorization; FALSE with
+ * CHOLMOD_OUT_OF_MEMORY if the device cannot hold it. */
+int cholmod_l_hip_prepare (cholmod_factor *L, cholmod_common *Common) ;
 /* Multi-GPU: complete the factor on every rank after a distributed
  * factorization (needed before cholmod_l_solve / cholmod_l_factor_to_host). */
 int cholmod_l_gather_factor (cholmod_factor *L, cholmod_common *Common) ;

@@ -121,7 +121,7 @@ API_SYMBOLS = [
     "cholmod_l_gpu_memorysize", "cholmod_l_gpu_probe", "cholmod_l_gpu_deallocate",
     "cholmod_l_gpu_end", "cholmod_l_gpu_allocate",
     "cholmod_l_factor_to_host", "cholmod_l_hip_stats", "cholmod_l_refactorize_resident",
-    "cholmod_l_gather_factor",
+    "cholmod_l_gather_factor", "cholmod_l_hip_prepare",
 ]
 HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device",
@@ -220,6 +220,7 @@ def lib():
     sig("cholmod_hip_get_partition", C.c_int, [vp, vp])
     sig("cholmod_hip_gather_factor", C.c_int, [vp])
     sig("cholmod_l_gather_factor", C.c_int, [fc, cm])
+    sig("cholmod_l_hip_prepare", C.c_int, [fc, cm])
     sig("cholmod_hip_factorize", C.c_int, [vp, vp, vp, vp, vp, dbl, C.c_int, vp, C.POINTER(i64)])
     sig("cholmod_hip_upload_matrix", C.c_int, [vp, vp, vp, vp, vp])
     sig("cholmod_hip_factorize_resident", C.c_int, [vp, dbl, C.c_int, C.POINTER(i64)])

@@ -245,6 +245,15 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common)
     return TRUE ;
 }
 
+int cholmod_l_hip_prepare (cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    return ssamd_ensure_plan (L, Common) ;
+}
+
 int cholmod_l_gather_factor (cholmod_factor *L, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (FALSE) ;
