@@ -200,6 +200,11 @@ def main():
                 if pj.get("workload") == wname and world == 1:
                     traffic = pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch"]
                     traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01c_pmc_summary.json"
+                else:
+                    traffic_note = ("no PMC pass at this size (serialised counter collection over 9392 launches of a "
+                                    "181 GB factor exceeds the GPU-time budget); on the 100^3 workload the same kernel "
+                                    "moves 317 MB fetch + 215 MB write per launch against 399 MB algorithmic "
+                                    "(profiles/r01c_pmc_summary.json)")
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note,
