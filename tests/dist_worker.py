@@ -64,7 +64,8 @@ def main():
                    zero_pattern_equal=bool(np.array_equal(fv.x[m] != 0, O.x[m] != 0)),
                    nshared=int((owner < 0).sum()), nsuper=int(fv.nsuper),
                    owned=[int((owner == r).sum()) for r in range(world)],
-                   allreduce_calls=cb.stats["n"], allreduce_MB=cb.stats["bytes"] / 1e6)
+                   allreduce_calls=cb.stats["n"], allreduce_MB=cb.stats["bytes"] / 1e6,
+                   nsplit=int(S.hip_stats(Lf)[22]))
         if st_o == 0:
             b = G.demo_rhs(n)
             x = S.solve(Lf, b)

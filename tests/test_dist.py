@@ -27,13 +27,14 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, mode, case, timeout=600):
+def _run_ranks(world, mode, case, timeout=600, extra_env=None):
     port = _free_port()
     out = os.path.join(tempfile.mkdtemp(), "res")
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"),
                                        mode, case, out], env=env, cwd=ROOT))
     rcs = [p.wait(timeout=timeout) for p in procs]
@@ -126,3 +127,12 @@ def test_distributed_not_posdef_protocol():
         assert r["oracle_status"] == 1 and r["ok"] == 1 and r["status"] == ch.NOT_POSDEF, r
         assert r["minor"] == r["oracle_minor"], r
         assert r["zero_pattern_equal"] and r["err"] < 1e-12, r
+
+
+@pytest.mark.gpu
+def test_distributed_with_memory_split_schedule():
+    """Ranks + the memory-aware subtree sweep together (the 200^3 multi-GPU shape)."""
+    res = _run_ranks(3, "gpu", "p3d_32", extra_env={"CHOLMOD_HIP_ARENA_BUDGET_MB": "20"})
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+        assert r["nsplit"] > 1, r
