@@ -41,6 +41,8 @@ extern "C" {
 #define CHOLMOD_HIP_NO_SMALL_FRONTS 16   /* tuning: no fused LDS-resident kernel for
                                            thin fronts (generic kernels everywhere)  */
 #define CHOLMOD_HIP_NO_XCD_SWIZZLE 32    /* tuning: plain block -> tile order          */
+#define CHOLMOD_HIP_FIXED_OB       64    /* tuning: 512-column outer blocks everywhere  */
+#define CHOLMOD_HIP_WIDE_OB       128    /* tests: 2048-column outer blocks everywhere  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 

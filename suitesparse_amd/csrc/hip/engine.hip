@@ -20,7 +20,23 @@ using namespace sship ;
 namespace {
 
 constexpr int NB = PF_NB ;      // inner panel width (potrf / trsm block)
-constexpr int OB = 512 ;        // outer block: trailing updates contract over <= OB columns
+constexpr int MB = 512 ;        // mid block: inner (K = 64) updates stay inside MB columns
+// outer block (contraction length of the big trailing updates): MB for small
+// fronts, up to 2048 for the largest ones -- the update kernel reaches 52.8 /
+// 61.4 TFLOP/s at K = 512 / 2048 on a 16k x 16k region (the 16 B read-modify-
+// write of C is amortised over 4x more flops), at the price of OB/nsrow of the
+// flops moving to K = MB mid-level updates
+static inline int outer_block (int maxrows)
+{
+    static int t1 = -1, t2 = -1 ;
+    if (t1 < 0)
+    {
+        const char *e1 = getenv ("CHOLMOD_HIP_OB1024_ROWS"), *e2 = getenv ("CHOLMOD_HIP_OB2048_ROWS") ;
+        t1 = e1 ? atoi (e1) : 4000 ;
+        t2 = e2 ? atoi (e2) : 8000 ;
+    }
+    return maxrows >= t2 ? 2048 : maxrows >= t1 ? 1024 : MB ;
+}
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
 enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_NKIND } ;
@@ -200,8 +216,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
 {
     bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
-    int maxnscol = 0 ;
-    for (int q = 0 ; q < nf ; q++) maxnscol = std::max (maxnscol, fr [ids [q]].nscol) ;
+    int maxnscol = 0, maxrows = 0 ;
+    for (int q = 0 ; q < nf ; q++)
+    {
+        maxnscol = std::max (maxnscol, fr [ids [q]].nscol) ;
+        maxrows = std::max (maxrows, fr [ids [q]].nsrow) ;
+    }
+    const int OB = (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (maxrows) ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
         for (int pass = 0 ; pass < 2 ; pass++)
@@ -362,7 +383,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
             Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
             if (Lt.ng) S.launches.push_back (Lt) ;
-            // inner trailing update, restricted to the outer block column
+            // inner trailing update (K = nb), restricted to the mid block column
+            int m0 = o0 + ((i0 - o0) / MB) * MB ;
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
@@ -370,9 +392,25 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 int nb = std::min (NB, f.nscol - i0) ;
                 int i1 = i0 + nb ;
                 int o1 = std::min (o0 + OB, f.nscol) ;
-                add_update (big, small, f, ids [q], i1, i0, nb, f.nsrow - i1, o1 - i1, false) ;
+                int m1 = std::min (m0 + MB, o1) ;
+                add_update (big, small, f, ids [q], i1, i0, nb, f.nsrow - i1, m1 - i1, false) ;
             }
             flush_updates (big, small) ;
+            // mid-level update (K = MB) of the rest of the outer block column once
+            // a mid block is complete
+            bool mid_done = ((i0 + NB - o0) % MB == 0) || (i0 + NB >= std::min (o0 + OB, maxnscol)) ;
+            if (OB > MB && mid_done)
+            {
+                for (int q = 0 ; q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= m0) continue ;
+                    int o1 = std::min (o0 + OB, f.nscol) ;
+                    int m1 = std::min (m0 + MB, o1) ;
+                    if (o1 > m1) add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, o1 - m1, false) ;
+                }
+                flush_updates (big, small) ;
+            }
         }
         tag_new () ;
         int ev_panel = lookahead ? record_last () : -1 ;
@@ -1513,6 +1551,8 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
     if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
     bool valu = waves_per_simd < 0 ;            // negative: fp64 VALU FMA loop instead
     if (valu) waves_per_simd = -waves_per_simd ;
+    bool acc16 = waves_per_simd >= 100 ;        // 100 + w: sixteen accumulators per wave
+    if (acc16) waves_per_simd -= 100 ;
     if (waves_per_simd < 1) waves_per_simd = 1 ;
     if (iters < 1) iters = 1 ;
     int blocks = 256 * waves_per_simd ;         // 256 CUs x (4 waves per block = 1 per SIMD)
@@ -1521,10 +1561,12 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
     hipEvent_t e0, e1 ;
     (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
     if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
+    else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
     else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
     (void) hipDeviceSynchronize () ;
     (void) hipEventRecord (e0, 0) ;
     if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
+    else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
     else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
     (void) hipEventRecord (e1, 0) ;
     (void) hipEventSynchronize (e1) ;
@@ -1535,7 +1577,7 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
     (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
     if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
     if (valu) return (double) blocks * 256.0 * iters * 16.0 * 2.0 / (ms * 1e-3) ;
-    return (double) blocks * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) ;
+    return (double) blocks * 4.0 * iters * (acc16 ? 16.0 : 8.0) * 2048.0 / (ms * 1e-3) ;
 }
 
 } // extern "C"

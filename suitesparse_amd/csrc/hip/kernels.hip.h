@@ -1294,14 +1294,16 @@ template <int NACC>
 __global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
 {
     d4 acc [NACC] ;
-    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x ;
+    double a [4], b [4] ;
+#pragma unroll
+    for (int q = 0 ; q < 4 ; q++) { a [q] = 1.0 + 1e-9 * (threadIdx.x + q) ; b [q] = 1.0 - 1e-9 * (threadIdx.x + 3 * q) ; }
 #pragma unroll
     for (int q = 0 ; q < NACC ; q++) acc [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
     for (int it = 0 ; it < iters ; it++)
     {
 #pragma unroll
         for (int q = 0 ; q < NACC ; q++)
-            acc [q] = __builtin_amdgcn_mfma_f64_16x16x4f64 (a, b, acc [q], 0, 0, 0) ;
+            acc [q] = __builtin_amdgcn_mfma_f64_16x16x4f64 (a [q & 3], b [(q >> 2) & 3], acc [q], 0, 0, 0) ;
     }
     double sum = 0 ;
 #pragma unroll
