@@ -28,14 +28,16 @@ constexpr int MB = 512 ;        // mid block: inner (K = 64) updates stay inside
 // flops moving to K = MB mid-level updates
 static inline int outer_block (int maxrows)
 {
-    static int t1 = -1, t2 = -1 ;
+    static int t1 = -1, t2 = -1, t3 = -1 ;
     if (t1 < 0)
     {
         const char *e1 = getenv ("CHOLMOD_HIP_OB1024_ROWS"), *e2 = getenv ("CHOLMOD_HIP_OB2048_ROWS") ;
+        const char *e3 = getenv ("CHOLMOD_HIP_OB4096_ROWS") ;
         t1 = e1 ? atoi (e1) : 4000 ;
         t2 = e2 ? atoi (e2) : 8000 ;
+        t3 = e3 ? atoi (e3) : 24000 ;
     }
-    return maxrows >= t2 ? 2048 : maxrows >= t1 ? 1024 : MB ;
+    return maxrows >= t3 ? 4096 : maxrows >= t2 ? 2048 : maxrows >= t1 ? 1024 : MB ;
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
@@ -1476,6 +1478,12 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     {
         if (flags & CHOLMOD_HIP_GEMM_VALU)
             hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (small && (flags & 256))
+            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 32, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (small && (flags & 512))
+            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 3, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (small && (flags & 1024))
+            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 2, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (small)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else
