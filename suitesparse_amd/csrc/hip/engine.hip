@@ -328,30 +328,32 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     }
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
-        // ---- multi-GPU: the block columns of the shared fronts hold per-rank
-        // partial sums (extend-adds of the rank's own subtrees + its share of
-        // the earlier trailing-update tiles); sum them before they are factored
-        for (int q = 0 ; q < nf ; q++)
-        {
-            const FrontD &f = fr [ids [q]] ;
-            if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
-            int o1 = std::min (o0 + OB, f.nscol) ;
-            Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
-            // only rows >= o0 of the block column carry data (above lies the dead
-            // upper triangle): they are packed into a staging buffer, halving the
-            // volume for the fronts without rows below (the root)
-            La.ar_off = f.psx + (i64) o0 * f.nsrow ;
-            La.ar_ld = f.nsrow ; La.ar_r0 = o0 ; La.ar_nc = o1 - o0 ;
-            La.ar_cnt = (i64) (o1 - o0) * (f.nsrow - o0) ;
-            La.bytes = 8.0 * La.ar_cnt ;
-            S.launches.push_back (La) ;
-        }
-        tag_new () ;
         // ---- P(ob): panel factorization of the outer block column ----------
         cur_stream = lookahead ? 1 : 0 ;
         if (lookahead && o0 == 0) pend_wait = ev_fork ;
         for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
         {
+            // ---- multi-GPU: a mid block column of a shared front holds per-rank
+            // partial sums (extend-adds of the rank's own subtrees + its share of
+            // the earlier outer / mid update tiles); sum them before it is factored.
+            // Only rows >= i0 carry data (above lies the dead upper triangle): they
+            // are packed into a staging buffer, halving the volume for the root.
+            if ((i0 - o0) % MB == 0)
+            {
+                for (int q = 0 ; q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
+                    int o1 = std::min (o0 + OB, f.nscol) ;
+                    int m1 = std::min (i0 + MB, o1) ;
+                    Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
+                    La.ar_off = f.psx + (i64) i0 * f.nsrow ;
+                    La.ar_ld = f.nsrow ; La.ar_r0 = i0 ; La.ar_nc = m1 - i0 ;
+                    La.ar_cnt = (i64) (m1 - i0) * (f.nsrow - i0) ;
+                    La.bytes = 8.0 * La.ar_cnt ;
+                    S.launches.push_back (La) ;
+                }
+            }
             // potrf of the diagonal blocks
             Launch Lp {K_POTRF, 0, 0, S.pg.size (), 0, 0} ;
             for (int q = 0 ; q < nf ; q++)
@@ -409,7 +411,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     if (f.nscol <= m0) continue ;
                     int o1 = std::min (o0 + OB, f.nscol) ;
                     int m1 = std::min (m0 + MB, o1) ;
-                    if (o1 > m1) add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, o1 - m1, false) ;
+                    if (o1 > m1) add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, o1 - m1, false, true) ;
                 }
                 flush_updates (big, small) ;
             }

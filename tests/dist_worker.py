@@ -50,7 +50,8 @@ def main():
             Ax[Ap[int(O.Perm[kbad])]] = -3.0
         st_o = O.factorize(Ax)
         cb = make_allreduce()
-        S = ch.Session(rank=rank, world=world, allreduce=cb)
+        S = ch.Session(rank=rank, world=world, allreduce=cb,
+                       hip_flags=int(os.environ.get("CHOLMOD_TEST_HIP_FLAGS", "0")))
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)
         ok = S.factorize(A, Lf)

@@ -136,3 +136,13 @@ def test_distributed_with_memory_split_schedule():
     for r in res:
         assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
         assert r["nsplit"] > 1, r
+
+
+@pytest.mark.gpu
+def test_distributed_with_wide_outer_blocks():
+    """Mid-level (K = 512) updates of a wide outer block are dealt to the ranks
+    and every 512-column block is summed before it is factored."""
+    res = _run_ranks(3, "gpu", "p3d_32", extra_env={"CHOLMOD_TEST_HIP_FLAGS": "128"})
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+        assert r["allreduce_calls"] >= 3, r
