@@ -893,7 +893,7 @@ static int raise_lds_limits ()
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }

@@ -543,11 +543,13 @@ __global__ void __launch_bounds__(NT) k_small_front (const i32 *fronts,
     int ld = ns | 1 ;
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     i64 psx = f.psx, psi = f.psi, cbo = f.cb ;
+    __shared__ i64 rows_l [SM_MAX] ;        // the front's row list: binary searches hit LDS
     for (int e = tid ; e < ld * ns ; e += NT) F [e] = 0.0 ;
+    for (int e = tid ; e < ns ; e += NT) rows_l [e] = Ls [psi + e] ;
     __syncthreads () ;
     if (f.assemble)
     {
-        const i64 *rows = Ls + psi ;
+        const i64 *rows = rows_l ;
         for (int k = tid ; k < nc ; k += NT)
         {
             i64 col = (i64) k1 + k ;
