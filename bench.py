@@ -99,7 +99,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # CHOLMOD_HIP_SHARE_AS_WORLD=k with one rank: the engine's self test of the
+    # exchange path (fronts a k-rank run would share go through pack / RCCL
+    # all-reduce / unpack); measures that path's overhead on a 1-GPU box
+    selftest = world == 1 and int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) > 1
+    if selftest:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or selftest:
         import torch
         import torch.distributed as dist
         if args.dist_backend == "gloo":
@@ -116,7 +125,7 @@ def main():
     lib.cholmod_hip_set_device(local_rank)
 
     allreduce = None
-    if world > 1:
+    if dist is not None:
         from suitesparse_amd.dist import make_allreduce
         allreduce = make_allreduce()
     grids = [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
@@ -137,7 +146,7 @@ def main():
         t0 = time.perf_counter()
         ok = S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm))
         short = (ok != 1 and S.cm.status == ch.OUT_OF_MEMORY)
-        if world > 1:
+        if dist is not None:
             # every rank must take the same decision
             import torch
             flag = torch.tensor([1.0 if short else 0.0], device="cuda")
@@ -262,6 +271,12 @@ def main():
         }
         if resid is not None:
             line["residual_2norm"] = resid
+        if allreduce is not None:
+            nfac = max(args.steps + args.warmup + (0 if args.no_profile_pass else 1), 1)
+            line["exchange"] = {"backend": args.dist_backend, "allreduce_calls_per_factorization": allreduce.stats["n"] // nfac,
+                                "allreduce_GB_per_factorization": 1e-9 * allreduce.stats["bytes"] / nfac,
+                                "allreduce_GB_by_group_size": {str(k): 1e-9 * v / nfac for k, v in sorted(allreduce.stats["by_size"].items())},
+                                "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
         print(json.dumps(line))
     S.free_factor(Lf)
     S.free_sparse(A)

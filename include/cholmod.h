@@ -165,7 +165,8 @@ typedef struct cholmod_common_struct
     /* multi-GPU, one process per GPU (see cholmod_hip.h): rank / world size of
      * this process and the host-provided sum all-reduce on device memory */
     int hip_rank, hip_world ;
-    int (*hip_allreduce) (void *dev_ptr, int64_t count_doubles, void *user) ;
+    int (*hip_allreduce) (void *dev_ptr, int64_t count_doubles, int group_first,
+        int group_size, void *user) ;
     void *hip_allreduce_user ;
 } cholmod_common ;
 

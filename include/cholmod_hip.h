@@ -78,17 +78,23 @@ void cholmod_hip_plan_destroy (cholmod_hip_plan *plan) ;
 /* ---- multi-GPU (one process per GPU; no counterpart in the reference, which is
  * single-GPU: CHOLMOD/GPU/cholmod_gpu.c:160-164) -------------------------------
  * Every rank builds the same plan from the same symbolic factor and passes its
- * rank / world size.  The top of the supernodal etree is *shared*: every rank
- * keeps the shared fronts as partial sums, factors their panels redundantly and
- * takes every world-th tile of their trailing updates; the subtrees below are
- * dealt to the ranks (largest first).  The only exchange is an in-place sum
- * all-reduce of a block column of a shared front right before it is factored;
- * the engine asks the host for it through this callback (bench.py / the tests
- * implement it with torch.distributed: RCCL over xGMI, or gloo in CPU tests).
- * The callback is entered with the engine stream idle and must return only when
- * the result is visible to later device work.  Returns 0 on success. */
+ * rank / world size.  The supernodal etree is mapped proportionally: the root's
+ * front is *shared* by all ranks, the heavy children of a shared front split
+ * its rank group [first, first+size) between them where their weights allow,
+ * and the light subtrees below are dealt to the ranks of the group they hang
+ * off (largest first).  A shared front lives on every rank of its group as a
+ * partial sum; the group factors its panels redundantly and deals the tiles of
+ * its trailing updates round-robin.  The only exchange is an in-place sum
+ * all-reduce, over the front's group, of a 512-column block column right
+ * before it is factored; the engine asks the host for it through this callback
+ * (bench.py / the tests implement it with torch.distributed: RCCL over xGMI,
+ * or gloo in CPU tests).  group_first/group_size name the contiguous rank range
+ * that takes part (every rank of the range makes the same call, in the same
+ * order; ranks outside do not call).  The callback is entered with the data
+ * ready and must return only when the result is visible to later device work.
+ * Returns 0 on success. */
 typedef int (*cholmod_hip_allreduce_fn) (void *dev_ptr, int64_t count_doubles,
-    void *user) ;
+    int group_first, int group_size, void *user) ;
 cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     const int64_t *super, const int64_t *pi, const int64_t *px,
     const int64_t *s, int flags, int rank, int world, int *status) ;
@@ -96,6 +102,9 @@ int cholmod_hip_set_allreduce (cholmod_hip_plan *plan,
     cholmod_hip_allreduce_fn fn, void *user) ;
 /* owner[s] = rank that factors supernode s, -1 for the shared fronts */
 int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
+/* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it
+ * (size 1 = private to owner[s]) */
+int cholmod_hip_get_groups (cholmod_hip_plan *plan, int64_t *first, int64_t *size) ;
 /* complete the factor on every rank (sums the ranks' private subtrees) */
 int cholmod_hip_gather_factor (cholmod_hip_plan *plan) ;
 

@@ -35,7 +35,7 @@ class Method(C.Structure):
 
 
 ERRFUNC = C.CFUNCTYPE(None, C.c_int, C.c_char_p, C.c_int, C.c_char_p)
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p)
 
 
 class Common(C.Structure):
@@ -127,6 +127,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
+    "cholmod_hip_get_groups",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
@@ -218,6 +219,7 @@ def lib():
                                              C.POINTER(C.c_int)])
     sig("cholmod_hip_set_allreduce", C.c_int, [vp, ALLREDUCE_FN, vp])
     sig("cholmod_hip_get_partition", C.c_int, [vp, vp])
+    sig("cholmod_hip_get_groups", C.c_int, [vp, vp, vp])
     sig("cholmod_hip_gather_factor", C.c_int, [vp])
     sig("cholmod_l_gather_factor", C.c_int, [fc, cm])
     sig("cholmod_l_hip_prepare", C.c_int, [fc, cm])
@@ -261,8 +263,9 @@ class Session:
         self.cm.hip_factor_on_device = int(factor_on_device)
         self.cm.hip_flags = hip_flags
         self._keep = []
-        if world > 1:
-            # allreduce: a ctypes ALLREDUCE_FN (see suitesparse_amd/dist.py)
+        if world > 1 or allreduce is not None:
+            # allreduce: a ctypes ALLREDUCE_FN (see suitesparse_amd/dist.py); with
+            # world == 1 it is only used by the CHOLMOD_HIP_SHARE_AS_WORLD self test
             self.cm.hip_rank, self.cm.hip_world = rank, world
             self._keep.append(allreduce)
             self.cm.hip_allreduce = C.cast(allreduce, C.c_void_p)

@@ -55,6 +55,7 @@ struct Launch {
     int rec_ev = -1 ;   // event recorded on its stream right after it
     i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: slab of Lx summed over the ranks: starts at
     int ar_ld = 0, ar_r0 = 0, ar_nc = 0 ;   // ar_off (column o0), ld ar_ld, rows >= ar_r0 of ar_nc columns
+    int ar_g0 = 0, ar_gn = 1 ;              // ... over the ranks [ar_g0, ar_g0+ar_gn)
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
 } ;
 
@@ -168,7 +169,9 @@ struct cholmod_hip_plan {
     // multi-GPU: one process per GPU; owner[s] = rank that factors front s, or
     // -1 for the shared top fronts every rank holds as partial sums
     int rank = 0, world = 1 ;
+    bool force_shared = false ;     // single-rank self test of the exchange path
     std::vector<i32> owner ;
+    std::vector<i32> grp0, grpn ;   // ranks [grp0, grp0+grpn) hold front s (grpn == 1: solo)
     std::vector<i32> my_lvl_ptr, my_lvl_list ;  // this rank's fronts by level
     cholmod_hip_allreduce_fn ar_fn = nullptr ;
     void *ar_user = nullptr ;
@@ -214,7 +217,7 @@ namespace {
 // of fronts (all of one etree level): two-level blocked right-looking Cholesky
 // of the first nscol columns of every front [panel | CB].
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
-    Schedule &S, int flags, const i32 *owner, int rank, int world)
+    Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world)
 {
     bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
@@ -270,7 +273,9 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             v.clear () ;
         }
     } ;
-    auto is_shared = [&] (int fid) { return owner && world > 1 && owner [fid] < 0 ; } ;
+    // (owner [] < 0 only occurs with world > 1, or in the single-rank self test
+    // CHOLMOD_HIP_SHARE_AS_WORLD that drives the exchange path with one rank)
+    auto is_shared = [&] (int fid) { return owner && owner [fid] < 0 ; } ;
     auto add_update = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small,
         const FrontD &f, int fid, int r0, int kc, int kk, int m, int ncols, bool to_cb,
         bool split = false)
@@ -286,7 +291,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
         G.tile_mul = 1 ; G.tile_add = 0 ;
-        if (split && is_shared (fid)) { G.tile_mul = world ; G.tile_add = rank ; }
+        if (split && is_shared (fid)) { G.tile_mul = grpn [fid] ; G.tile_add = rank - grp0 [fid] ; }
         bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
@@ -351,6 +356,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     La.ar_ld = f.nsrow ; La.ar_r0 = i0 ; La.ar_nc = m1 - i0 ;
                     La.ar_cnt = (i64) (m1 - i0) * (f.nsrow - i0) ;
                     La.bytes = 8.0 * La.ar_cnt ;
+                    La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
                     S.launches.push_back (La) ;
                 }
             }
@@ -553,45 +559,138 @@ static int build_host (cholmod_hip_plan *P)
         wsub [s] += own ;
         if (P->fr [s].parent >= 0) wsub [P->fr [s].parent] += wsub [s] ;
     }
-    // ---- ownership: the top of the tree is shared by all ranks,
-    // the subtrees hanging off it are dealt to the ranks by decreasing weight
-    // (LPT).  A front becomes shared while its subtree outweighs 1/(4 world) of
-    // the whole factorization, so no solo subtree can unbalance the ranks.
+    // ---- ownership: proportional mapping of the supernodal etree.
+    // A front is *shared* while its subtree outweighs 1/(4 world) of the whole
+    // factorization; a shared front belongs to a contiguous group of ranks
+    // [grp0, grp0+grpn) (the root's group is everybody).  Where the heavy
+    // children of a shared front can split its group in proportion to their
+    // weights without unbalancing it (<= 10 % above the mean) they get disjoint
+    // sub-groups -- a sub-group of one rank owns the child's whole subtree --
+    // otherwise they inherit the parent's group.  The light subtrees hanging
+    // off the shared region are dealt, largest first, to the least loaded rank
+    // of their parent's group (LPT).  Every rank derives the same map.
     P->owner.assign (std::max<i64> (nsuper, 1), 0) ;
-    if (P->world > 1 && nsuper > 0)
+    P->grp0.assign (std::max<i64> (nsuper, 1), 0) ;
+    P->grpn.assign (std::max<i64> (nsuper, 1), 1) ;
+    // Self test of the exchange path on one GPU: CHOLMOD_HIP_SHARE_AS_WORLD=k with
+    // world == 1 marks the fronts a k-rank run would share, so the pack /
+    // all-reduce callback / unpack launches run (summing over the single rank).
+    int share_world = P->world ;
+    if (P->world == 1)
+    {
+        const char *e = getenv ("CHOLMOD_HIP_SHARE_AS_WORLD") ;
+        if (e && atoi (e) > 1) share_world = atoi (e) ;
+    }
+    P->force_shared = (P->world == 1 && share_world > 1) ;
+    if (share_world > 1 && nsuper > 0)
     {
         std::vector<i32> first (nsuper) ;
         for (i64 s = 0 ; s < nsuper ; s++) first [s] = (i32) s ;
         for (i64 s = 0 ; s < nsuper ; s++)
             if (P->fr [s].parent >= 0) first [P->fr [s].parent] = std::min (first [P->fr [s].parent], first [s]) ;
-        typedef std::pair<double, i32> WS ;
-        std::priority_queue<WS> pq ;
         double total = 0 ;
-        for (i64 s = 0 ; s < nsuper ; s++)
-            if (P->fr [s].parent < 0) { pq.push (WS (wsub [s], (i32) -s)) ; total += wsub [s] ; }
-        double thr = total / (4.0 * P->world) ;
+        for (i64 s = 0 ; s < nsuper ; s++) if (P->fr [s].parent < 0) total += wsub [s] ;
+        const double thr = total / (4.0 * share_world) ;
+        const bool subgroups = !getenv ("CHOLMOD_HIP_NO_SUBGROUPS") ;
+        double split_tol = 1.10 ;
+        if (const char *e = getenv ("CHOLMOD_HIP_SPLIT_TOL")) if (atof (e) >= 1.0) split_tol = atof (e) ;
         std::vector<char> shared (nsuper, 0) ;
-        while (!pq.empty () && pq.top ().first > thr)
+        std::vector<double> load (share_world, 0.0) ;
+        struct Solo { double w ; i32 root, g0, gn ; } ;
+        std::vector<Solo> solo ;
+        // top-down over the shared region (explicit stack; roots get everybody)
+        struct Item { i32 t, g0, gn ; } ;
+        std::vector<Item> stack ;
+        for (i64 s = nsuper ; s-- > 0 ; )
+            if (P->fr [s].parent < 0) stack.push_back (Item {(i32) s, 0, (i32) share_world}) ;
+        while (!stack.empty ())
         {
-            i32 t = -pq.top ().second ;
-            pq.pop () ;
-            shared [t] = 1 ;
-            for (i32 c = cptr [t] ; c < cptr [t+1] ; c++) pq.push (WS (wsub [call [c]], -call [c])) ;
+            Item it = stack.back () ; stack.pop_back () ;
+            if (wsub [it.t] <= thr || it.gn == 1)
+            {
+                solo.push_back (Solo {wsub [it.t], it.t, it.g0, it.gn}) ;
+                continue ;
+            }
+            shared [it.t] = 1 ;
+            P->grp0 [it.t] = it.g0 ; P->grpn [it.t] = it.gn ;
+            {
+                double c = P->fr [it.t].nscol, r = P->fr [it.t].ncb ;
+                double own = c * c * c / 3.0 + r * c * c + r * r * c ;
+                for (int q = it.g0 ; q < it.g0 + it.gn ; q++) load [q] += own / it.gn ;
+            }
+            // heavy children, heaviest first (ties: lower index)
+            std::vector<i32> heavy ;
+            for (i32 c = cptr [it.t] ; c < cptr [it.t+1] ; c++)
+            {
+                if (wsub [call [c]] > thr) heavy.push_back (call [c]) ;
+                else solo.push_back (Solo {wsub [call [c]], call [c], it.g0, it.gn}) ;
+            }
+            std::sort (heavy.begin (), heavy.end (), [&] (i32 x, i32 y)
+                { return wsub [x] != wsub [y] ? wsub [x] > wsub [y] : x < y ; }) ;
+            int nh = (int) heavy.size () ;
+            std::vector<i32> cnt (nh, 0) ;
+            bool split = subgroups && nh >= 2 && nh <= it.gn ;
+            if (split)
+            {
+                // largest-remainder apportionment of the gn ranks, at least one each
+                double wh = 0 ;
+                for (i32 h : heavy) wh += wsub [h] ;
+                int left = it.gn ;
+                std::vector<double> rem (nh) ;
+                for (int q = 0 ; q < nh ; q++)
+                {
+                    double x = it.gn * wsub [heavy [q]] / wh ;
+                    cnt [q] = std::max (1, (int) x) ;
+                    rem [q] = x - cnt [q] ;
+                    left -= cnt [q] ;
+                }
+                while (left > 0)
+                {
+                    int best = 0 ;
+                    for (int q = 1 ; q < nh ; q++) if (rem [q] > rem [best]) best = q ;
+                    cnt [best]++ ; rem [best] -= 1.0 ; left-- ;
+                }
+                while (left < 0)
+                {
+                    int best = -1 ;
+                    for (int q = 0 ; q < nh ; q++)
+                        if (cnt [q] > 1 && (best < 0 || rem [q] < rem [best])) best = q ;
+                    if (best < 0) break ;
+                    cnt [best]-- ; rem [best] += 1.0 ; left++ ;
+                }
+                double worst = 0 ;
+                for (int q = 0 ; q < nh ; q++) worst = std::max (worst, wsub [heavy [q]] / cnt [q]) ;
+                split = (left == 0) && worst <= split_tol * wh / it.gn ;
+            }
+            // children are pushed so that they pop in the apportionment order
+            int g = it.g0 + it.gn ;
+            for (int q = nh ; q-- > 0 ; )
+            {
+                if (split) { g -= cnt [q] ; stack.push_back (Item {heavy [q], (i32) g, cnt [q]}) ; }
+                else stack.push_back (Item {heavy [q], it.g0, it.gn}) ;
+            }
         }
-        std::vector<WS> solo ;
-        while (!pq.empty ()) { solo.push_back (pq.top ()) ; pq.pop () ; }   // weight desc, index asc
-        std::vector<double> load (P->world, 0.0) ;
-        for (const WS &e : solo)
+        std::stable_sort (solo.begin (), solo.end (), [] (const Solo &x, const Solo &y)
+            { return x.w != y.w ? x.w > y.w : x.root < y.root ; }) ;
+        for (const Solo &e : solo)
         {
-            int best = 0 ;
-            for (int r = 1 ; r < P->world ; r++) if (load [r] < load [best]) best = r ;
-            load [best] += e.first ;
-            i32 root = -e.second ;
-            for (i32 q = first [root] ; q <= root ; q++) P->owner [q] = best ;
+            int best = e.g0 ;
+            for (int r = e.g0 + 1 ; r < e.g0 + e.gn ; r++) if (load [r] < load [best]) best = r ;
+            load [best] += e.w ;
+            for (i32 q = first [e.root] ; q <= e.root ; q++)
+            {
+                P->owner [q] = P->world == 1 ? 0 : best ;
+                P->grp0 [q] = P->owner [q] ; P->grpn [q] = 1 ;
+            }
         }
-        for (i64 s = 0 ; s < nsuper ; s++) if (shared [s]) P->owner [s] = -1 ;
+        for (i64 s = 0 ; s < nsuper ; s++)
+        {
+            if (!shared [s]) continue ;
+            P->owner [s] = -1 ;
+            if (P->world == 1) { P->grp0 [s] = 0 ; P->grpn [s] = 1 ; }
+        }
     }
-    auto mine = [&] (i64 s) { return P->owner [s] < 0 || P->owner [s] == P->rank ; } ;
+    auto mine = [&] (i64 s) { return P->rank >= P->grp0 [s] && P->rank < P->grp0 [s] + P->grpn [s] ; } ;
     // this rank's view of the child lists: a shared parent pulls only the
     // contribution blocks this rank computed (its own subtrees and its partial
     // copies of shared children); the other ranks add theirs on their side and
@@ -602,7 +701,7 @@ static int build_host (cholmod_hip_plan *P)
         P->fr [s].child_begin = acc ;
         if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++) if (mine (call [c])) acc++ ;
         P->fr [s].child_end = P->fr [s].child_begin ;
-        P->fr [s].assemble = (P->owner [s] == P->rank || (P->owner [s] < 0 && P->rank == 0)) ? 1 : 0 ;
+        P->fr [s].assemble = (P->rank == P->grp0 [s]) ? 1 : 0 ;      // one rank of the group adds A
     }
     P->child.assign (std::max<i32> (acc, 1), 0) ;
     for (i64 s = 0 ; s < nsuper ; s++)
@@ -752,7 +851,7 @@ static int build_host (cholmod_hip_plan *P)
                 i32 sid = all_ids [q] ;
                 const FrontD &f = P->fr [sid] ;
                 bool small_ok = !(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX
-                    && !(P->world > 1 && P->owner [sid] < 0) ;
+                    && !(P->owner [sid] < 0) ;
                 if (!small_ok) { gen.push_back (sid) ; continue ; }
                 int c = f.nsrow <= cls [0] ? 0 : f.nsrow <= cls [1] ? 1 : 2 ;
                 bucket [c].push_back (sid) ;
@@ -812,7 +911,7 @@ static int build_host (cholmod_hip_plan *P)
         }
         Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
         if (Le.ng) S.launches.push_back (Le) ;
-        schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->rank, P->world) ;
+        schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->grp0.data (), P->grpn.data (), P->rank, P->world) ;
     }
     return CHOLMOD_HIP_OK ;
 }
@@ -925,7 +1024,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             if (L.ar_r0 == 0)
             {
                 HIPCHK (hipStreamSynchronize (st)) ;
-                if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
             }
             else
             {
@@ -934,7 +1033,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
                     (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
                 HIPCHK (hipStreamSynchronize (st)) ;
-                if (P->ar_fn (P->d_stage, L.ar_cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                if (P->ar_fn (P->d_stage, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
                 HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
                     (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
             }
@@ -1054,7 +1153,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     i64 sbad = -1 ;
     for (i64 s = 0 ; s < P->nsuper ; s++) if (info [s] != 0) { sbad = s ; break ; }
     i64 binfo = sbad >= 0 ? info [sbad] : 0 ;
-    if (P->world > 1)
+    if (P->world > 1 || P->force_shared)
     {
         // agree on the first failing supernode: every rank publishes its own
         // candidate in its slot of a small device array, the sum-all-reduce
@@ -1064,7 +1163,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         x [P->rank] = (double) (sbad >= 0 ? sbad : P->nsuper) ;
         x [P->world + P->rank] = (double) binfo ;
         HIPCHK (hipMemcpy (P->d_xchg, x.data (), x.size () * sizeof (double), hipMemcpyHostToDevice)) ;
-        if (P->ar_fn (P->d_xchg, (i64) x.size (), P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        if (P->ar_fn (P->d_xchg, (i64) x.size (), 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
         HIPCHK (hipMemcpy (x.data (), P->d_xchg, x.size () * sizeof (double), hipMemcpyDeviceToHost)) ;
         i64 best = P->nsuper ;
         for (int r = 0 ; r < P->world ; r++)
@@ -1176,6 +1275,13 @@ int cholmod_hip_set_allreduce (cholmod_hip_plan *P, cholmod_hip_allreduce_fn fn,
     return CHOLMOD_HIP_OK ;
 }
 
+int cholmod_hip_get_groups (cholmod_hip_plan *P, int64_t *first, int64_t *size)
+{
+    if (!P || !first || !size) return CHOLMOD_HIP_INVALID ;
+    for (i64 q = 0 ; q < P->nsuper ; q++) { first [q] = P->grp0 [q] ; size [q] = P->grpn [q] ; }
+    return CHOLMOD_HIP_OK ;
+}
+
 int cholmod_hip_get_partition (cholmod_hip_plan *P, int64_t *owner)
 {
     if (!P || !owner) return CHOLMOD_HIP_INVALID ;
@@ -1192,16 +1298,27 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     if (P->world == 1) return CHOLMOD_HIP_OK ;
     if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
+    // Fronts shared by everybody are already complete everywhere.  Of every other
+    // front exactly one rank (the first of its group) keeps its copy, the rest
+    // zero theirs; the sum over all ranks then completes the factor everywhere.
     const i64 chunk = (i64) 1 << 27 ;
+    auto everywhere = [&] (i64 q) { return P->grpn [q] == P->world ; } ;
     for (i64 q = 0 ; q < P->nsuper ; )
     {
-        if (P->owner [q] < 0) { q++ ; continue ; }
+        if (everywhere (q)) { q++ ; continue ; }
         i64 e = q ;
-        while (e < P->nsuper && P->owner [e] >= 0) e++ ;
+        while (e < P->nsuper && !everywhere (e)) e++ ;
+        for (i64 t = q ; t < e ; t++)
+        {
+            bool held = P->rank >= P->grp0 [t] && P->rank < P->grp0 [t] + P->grpn [t] ;
+            if (held && P->rank != P->grp0 [t])
+                HIPCHK (hipMemsetAsync (P->d_Lx + P->px [t], 0, (size_t) (P->px [t+1] - P->px [t]) * sizeof (double), P->stream)) ;
+        }
+        HIPCHK (hipStreamSynchronize (P->stream)) ;
         for (i64 off = P->px [q] ; off < P->px [e] ; off += chunk)
         {
             i64 cnt = std::min (chunk, P->px [e] - off) ;
-            if (P->ar_fn (P->d_Lx + off, cnt, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            if (P->ar_fn (P->d_Lx + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
         }
         q = e ;
     }
@@ -1399,7 +1516,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     Schedule S ;
     i32 id = 0 ;
     double fl = 0 ;
-    schedule_dense (fr, &id, 1, S, flags, nullptr, 0, 1) ;
+    schedule_dense (fr, &id, 1, S, flags, nullptr, nullptr, nullptr, 0, 1) ;
     (void) fl ;
     cholmod_hip_plan P ;
     P.flags = flags ;

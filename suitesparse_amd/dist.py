@@ -29,31 +29,56 @@ class _DevView:
             "version": 2, "strides": None}
 
 
+MAX_SUBGROUP_WORLD = 16
+
+
 def make_allreduce(group=None, device_memory=True):
     """Return a ctypes callback (keep a reference!) implementing the engine's sum
-    all-reduce with torch.distributed on `group` (default group if None).
+    all-reduce with torch.distributed.  The engine names the contiguous rank
+    range [first, first+size) that takes part: the whole world uses `group`
+    (default group if None); every proper sub-range of size >= 2 gets its own
+    process group, all of them created here, collectively and in the same order
+    on every rank (RCCL communicators are only instantiated on first use).
     device_memory=False treats the pointer as host memory (CPU-only tests)."""
     import torch
     import torch.distributed as dist
 
     backend = dist.get_backend(group)
-    calls = {"n": 0, "bytes": 0}
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    calls = {"n": 0, "bytes": 0, "by_size": {}}
+    groups = {(0, world): group}
+    if 2 < world <= MAX_SUBGROUP_WORLD:
+        base = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+        for size in range(world - 1, 1, -1):
+            for first in range(0, world - size + 1):
+                g = dist.new_group([base[r] for r in range(first, first + size)], backend=backend)
+                if first <= rank < first + size:
+                    groups[(first, size)] = g
 
-    def _fn(ptr, count, user):
+    def _fn(ptr, count, first, size, user):
         try:
             calls["n"] += 1
             calls["bytes"] += 8 * int(count)
+            calls["by_size"][int(size)] = calls["by_size"].get(int(size), 0) + 8 * int(count)
+            if size <= 1 and world > 1:
+                return 0
+            key = (int(first), int(size)) if world > 1 else (0, world)
+            if key not in groups:
+                raise RuntimeError(f"no process group for ranks [{first}, {first + size}) on rank {rank} "
+                                   f"(world {world}; set CHOLMOD_HIP_NO_SUBGROUPS=1 beyond {MAX_SUBGROUP_WORLD} ranks)")
+            g = groups[key]
             if not device_memory:
                 buf = (C.c_double * count).from_address(ptr)
                 t = torch.from_numpy(np.ctypeslib.as_array(buf))
-                dist.all_reduce(t, group=group)
+                dist.all_reduce(t, group=g)
                 return 0
             t = torch.as_tensor(_DevView(ptr, count), device="cuda")
             if backend == "nccl":
-                dist.all_reduce(t, group=group)
+                dist.all_reduce(t, group=g)
             else:
                 h = t.cpu()
-                dist.all_reduce(h, group=group)
+                dist.all_reduce(h, group=g)
                 t.copy_(h)
             torch.cuda.synchronize()
             return 0

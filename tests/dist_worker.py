@@ -16,7 +16,14 @@ def main():
     mode, case, out = sys.argv[1], sys.argv[2], sys.argv[3]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DIST_TEST_BACKEND", "gloo")
+    if backend == "nccl":       # RCCL: one rank per GPU (the 1-GPU box allows world 1 only)
+        import torch
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from suitesparse_amd import cholmod as ch
     from suitesparse_amd import generators as G
     from suitesparse_amd.dist import make_allreduce
@@ -24,7 +31,7 @@ def main():
     if mode == "cpu":
         cb = make_allreduce(device_memory=False)
         buf = np.arange(10, dtype=np.float64) * (rank + 1)
-        assert cb(buf.ctypes.data, buf.size, None) == 0
+        assert cb(buf.ctypes.data, buf.size, 0, world, None) == 0
         res["ok"] = bool(np.allclose(buf, np.arange(10) * sum(range(1, world + 1))))
         res["calls"] = cb.stats["n"]
     else:
@@ -66,6 +73,7 @@ def main():
                    nshared=int((owner < 0).sum()), nsuper=int(fv.nsuper),
                    owned=[int((owner == r).sum()) for r in range(world)],
                    allreduce_calls=cb.stats["n"], allreduce_MB=cb.stats["bytes"] / 1e6,
+                   allreduce_group_sizes=sorted(cb.stats["by_size"]),
                    nsplit=int(S.hip_stats(Lf)[22]))
         if st_o == 0:
             b = G.demo_rhs(n)
