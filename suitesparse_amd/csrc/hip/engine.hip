@@ -331,6 +331,25 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (S.launches.back ().rec_ev < 0) S.launches.back ().rec_ev = S.nevents++ ;
         ev_fork = S.launches.back ().rec_ev ;
     }
+    // Exchange look-ahead (multi-GPU): the update that completes the NEXT 512-column
+    // block column of a shared front is issued first (U_next), the rest of the
+    // trailing update (U_rest) right behind it, and the block column's all-reduce
+    // then runs -- host-driven, staged on the second stream -- while U_rest keeps
+    // the chip busy.  early [q] = block column of front q already summed this way.
+    const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
+    std::vector<int> early (nf, -1) ;
+    auto emit_ar = [&] (int q, int c0, int c1, int wait_ev)
+    {
+        const FrontD &f = fr [ids [q]] ;
+        Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
+        La.ar_off = f.psx + (i64) c0 * f.nsrow ;
+        La.ar_ld = f.nsrow ; La.ar_r0 = c0 ; La.ar_nc = c1 - c0 ;
+        La.ar_cnt = (i64) (c1 - c0) * (f.nsrow - c0) ;
+        La.bytes = 8.0 * La.ar_cnt ;
+        La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
+        La.wait_ev = wait_ev ;
+        S.launches.push_back (La) ;
+    } ;
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
         // ---- P(ob): panel factorization of the outer block column ----------
@@ -348,16 +367,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 for (int q = 0 ; q < nf ; q++)
                 {
                     const FrontD &f = fr [ids [q]] ;
-                    if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
-                    int o1 = std::min (o0 + OB, f.nscol) ;
-                    int m1 = std::min (i0 + MB, o1) ;
-                    Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
-                    La.ar_off = f.psx + (i64) i0 * f.nsrow ;
-                    La.ar_ld = f.nsrow ; La.ar_r0 = i0 ; La.ar_nc = m1 - i0 ;
-                    La.ar_cnt = (i64) (m1 - i0) * (f.nsrow - i0) ;
-                    La.bytes = 8.0 * La.ar_cnt ;
-                    La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
-                    S.launches.push_back (La) ;
+                    if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
+                    emit_ar (q, i0, std::min (i0 + MB, std::min (o0 + OB, f.nscol)), -1) ;
                 }
             }
             // potrf of the diagonal blocks
@@ -411,32 +422,82 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             bool mid_done = ((i0 + NB - o0) % MB == 0) || (i0 + NB >= std::min (o0 + OB, maxnscol)) ;
             if (OB > MB && mid_done)
             {
+                // U_next: the next mid block column of the shared fronts
+                bool any_next = false ;
+                for (int q = 0 ; xla && q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= m0 || !is_shared (ids [q])) continue ;
+                    int o1 = std::min (o0 + OB, f.nscol) ;
+                    int m1 = std::min (m0 + MB, o1) ;
+                    if (o1 <= m1) continue ;
+                    int mn = std::min (m1 + MB, o1) ;
+                    add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, mn - m1, false, true) ;
+                    any_next = true ;
+                }
+                int ev_next = -1 ;
+                if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
                 for (int q = 0 ; q < nf ; q++)
                 {
                     const FrontD &f = fr [ids [q]] ;
                     if (f.nscol <= m0) continue ;
                     int o1 = std::min (o0 + OB, f.nscol) ;
                     int m1 = std::min (m0 + MB, o1) ;
-                    if (o1 > m1) add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, o1 - m1, false, true) ;
+                    int c0 = (any_next && is_shared (ids [q])) ? std::min (m1 + MB, o1) : m1 ;
+                    if (o1 > c0) add_update (big, small, f, ids [q], c0, m0, m1 - m0, f.nsrow - c0, o1 - c0, false, true) ;
                 }
                 flush_updates (big, small) ;
+                for (int q = 0 ; any_next && q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= m0 || !is_shared (ids [q])) continue ;
+                    int o1 = std::min (o0 + OB, f.nscol) ;
+                    int m1 = std::min (m0 + MB, o1) ;
+                    if (o1 <= m1) continue ;
+                    emit_ar (q, m1, std::min (m1 + MB, o1), ev_next) ;
+                    early [q] = m1 ;
+                }
             }
         }
         tag_new () ;
         int ev_panel = lookahead ? record_last () : -1 ;
         if (!lookahead)
         {
-            // outer trailing update: everything right of the outer block column
+            // outer trailing update: everything right of the outer block column;
+            // for shared fronts the first 512 columns of it go first (U_next)
+            bool any_next = false ;
+            for (int q = 0 ; xla && q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                if (f.nscol <= o1) continue ;
+                int on = std::min (o1 + MB, f.nscol) ;
+                add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, on - o1, false, true) ;
+                any_next = true ;
+            }
+            int ev_next = -1 ;
+            if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
                 if (f.nscol <= o0) continue ;
                 int o1 = std::min (o0 + OB, f.nscol) ;
                 int kk = o1 - o0 ;
-                add_update (big, small, f, ids [q], o1, o0, kk, f.nsrow - o1, f.nscol - o1, false, true) ;
+                int c0 = (any_next && is_shared (ids [q])) ? std::min (o1 + MB, f.nscol) : o1 ;
+                add_update (big, small, f, ids [q], c0, o0, kk, f.nsrow - c0, f.nscol - c0, false, true) ;
                 add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true, true) ;
             }
             flush_updates (big, small) ;
+            for (int q = 0 ; any_next && q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                if (f.nscol <= o1) continue ;
+                emit_ar (q, o1, std::min (o1 + MB, f.nscol), ev_next) ;
+                early [q] = o1 ;
+            }
             tag_new () ;
             continue ;
         }
@@ -1000,7 +1061,7 @@ static int raise_lds_limits ()
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
-    if (!serial && L.wait_ev >= 0) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    if (!serial && L.wait_ev >= 0 && L.kind != K_ALLREDUCE) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     switch (L.kind)
     {
         case K_JOIN: break ;
@@ -1021,21 +1082,30 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
-            if (L.ar_r0 == 0)
             {
-                HIPCHK (hipStreamSynchronize (st)) ;
-                if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-            }
-            else
-            {
-                size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
-                double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
-                HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
-                    (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
-                HIPCHK (hipStreamSynchronize (st)) ;
-                if (P->ar_fn (P->d_stage, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-                HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
-                    (size_t) L.ar_nc, hipMemcpyDeviceToDevice, st)) ;
+                // ahead of time (wait_ev >= 0): the slab is complete once the event
+                // has fired; the main stream keeps running the rest of the trailing
+                // update, staging goes through the second stream
+                bool ahead = !serial && L.wait_ev >= 0 && P->stream2 ;
+                hipStream_t cs = ahead ? P->stream2 : st ;
+                if (ahead) HIPCHK (hipEventSynchronize (P->sync_ev [L.wait_ev])) ;
+                if (L.ar_r0 == 0)
+                {
+                    HIPCHK (hipStreamSynchronize (cs)) ;
+                    if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                }
+                else
+                {
+                    size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
+                    double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
+                    HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
+                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
+                    HIPCHK (hipStreamSynchronize (cs)) ;
+                    if (P->ar_fn (P->d_stage, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                    HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
+                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
+                    if (ahead) HIPCHK (hipStreamSynchronize (cs)) ;
+                }
             }
             break ;
         case K_ZERO:

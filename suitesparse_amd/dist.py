@@ -47,6 +47,7 @@ def make_allreduce(group=None, device_memory=True):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     calls = {"n": 0, "bytes": 0, "by_size": {}}
+    side = [None]
     groups = {(0, world): group}
     if 2 < world <= MAX_SUBGROUP_WORLD:
         base = list(range(world)) if group is None else dist.get_process_group_ranks(group)
@@ -73,14 +74,20 @@ def make_allreduce(group=None, device_memory=True):
                 t = torch.from_numpy(np.ctypeslib.as_array(buf))
                 dist.all_reduce(t, group=g)
                 return 0
-            t = torch.as_tensor(_DevView(ptr, count), device="cuda")
-            if backend == "nccl":
-                dist.all_reduce(t, group=g)
-            else:
-                h = t.cpu()
-                dist.all_reduce(h, group=g)
-                t.copy_(h)
-            torch.cuda.synchronize()
+            # a private non-blocking stream: the engine may still be running trailing
+            # updates on its own stream (exchange look-ahead), and anything issued on
+            # the legacy default stream would wait for them
+            if side[0] is None:
+                side[0] = torch.cuda.Stream()
+            with torch.cuda.stream(side[0]):
+                t = torch.as_tensor(_DevView(ptr, count), device="cuda")
+                if backend == "nccl":
+                    dist.all_reduce(t, group=g)
+                else:
+                    h = t.cpu()
+                    dist.all_reduce(h, group=g)
+                    t.copy_(h)
+            side[0].synchronize()
             return 0
         except Exception as e:          # never unwind through C
             print(f"[suitesparse_amd.dist] all-reduce failed: {e!r}", flush=True)

@@ -159,10 +159,13 @@ def test_distributed_with_memory_split_schedule():
 
 
 @pytest.mark.gpu
-def test_distributed_with_wide_outer_blocks():
+@pytest.mark.parametrize("flags", [128, 128 | 256, 256])
+def test_distributed_with_wide_outer_blocks(flags):
     """Mid-level (K = 512) updates of a wide outer block are dealt to the ranks
-    and every 512-column block is summed before it is factored."""
-    res = _run_ranks(3, "gpu", "p3d_32", extra_env={"CHOLMOD_TEST_HIP_FLAGS": "128"})
+    and every 512-column block is summed before it is factored -- ahead of time,
+    overlapped with the rest of the trailing update, unless flag 256
+    (CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) asks for the plain order."""
+    res = _run_ranks(3, "gpu", "p3d_32", extra_env={"CHOLMOD_TEST_HIP_FLAGS": str(flags)})
     for r in res:
         assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
         assert r["allreduce_calls"] >= 3, r
