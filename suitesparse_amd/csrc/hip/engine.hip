@@ -14,6 +14,7 @@
 #include <map>
 #include <queue>
 #include <vector>
+#include <chrono>
 
 using namespace sship ;
 
@@ -400,7 +401,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 blocks += (m + TR_ROWS - 1) / TR_ROWS ;
                 S.tg.push_back (G) ;
                 Lt.flops += (double) m * nb * nb ;
-                Lt.aux = std::max (Lt.aux, (nb + TR_CW - 1) / TR_CW * TR_CW) ;
+                Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
             }
             Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
             if (Lt.ng) S.launches.push_back (Lt) ;
@@ -1053,6 +1054,7 @@ static int raise_lds_limits ()
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
@@ -1115,13 +1117,23 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb) ; break ;
         case K_POTRF:
-            hipLaunchKernelGGL (k_potrf<false>, dim3 (L.grid), dim3 (64), 0, st,
-                P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ; break ;
+            if (P->flags & CHOLMOD_HIP_POTRF_VALU)
+                hipLaunchKernelGGL (k_potrf<false>, dim3 (L.grid), dim3 (64), 0, st,
+                    P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
+            else
+                hipLaunchKernelGGL (k_potrf_mfma, dim3 (L.grid), dim3 (256), 0, st,
+                    P->d_pg + L.goff, P->d_Lx, P->d_info) ;
+            break ;
         case K_TRSM:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS),
-                (size_t) (L.aux * L.aux + L.aux * TR_ROWS + L.aux * TR_CW) * sizeof (double), st,
-                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ; break ;
+            if (P->flags & CHOLMOD_HIP_TRSM_VALU)
+                hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS),
+                    (size_t) (L.aux * L.aux + L.aux * TR_ROWS + L.aux * TR_CW) * sizeof (double), st,
+                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ;
+            else
+                hipLaunchKernelGGL (k_trsm_mfma, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
+                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ;
+            break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
@@ -1145,6 +1157,9 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     hipStream_t st = P->stream ;
     if (!P->d_Sp) return CHOLMOD_HIP_INVALID ;
     bool prof = P->profiling ;
+    static const bool host_timing = getenv ("CHOLMOD_HIP_HOST_TIMING") != nullptr ;
+    auto now = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
+    double th0 = now () ;
     P->cur_beta = beta ;
     size_t nl = P->sch.launches.size () ;
     if (prof)
@@ -1174,13 +1189,18 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     }
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipEventRecord (P->ev1, st)) ;
+    double th1 = now () ;
     // not-positive-definite protocol (t_cholmod_super_numeric.c:905-968)
     std::vector<i32> info (std::max<i64> (P->nsuper, 1)) ;
     HIPCHK (hipMemcpyAsync (info.data (), P->d_info, info.size () * sizeof (i32),
         hipMemcpyDeviceToHost, st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
+    double th2 = now () ;
     float ms = 0 ;
     HIPCHK (hipEventElapsedTime (&ms, P->ev0, P->ev1)) ;
+    if (host_timing)
+        fprintf (stderr, "cholmod_hip: host enqueue %.3f ms, wait+info copy %.3f ms, device %.3f ms, %zu launches\n",
+            1e3 * (th1 - th0), 1e3 * (th2 - th1), (double) ms, nl) ;
     double *S = P->stats ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) S [q] = 0 ;
     S [0] = ms * 1e-3 ;

@@ -60,6 +60,8 @@ struct GemmGroup {
 
 // Contribution blocks are stored as full squares, ld = ncb (lower part used).
 
+typedef double d4 __attribute__((ext_vector_type(4))) ;
+
 __device__ __forceinline__ int lower_bound_i32 (const i32 *a, int n, int v)
 {
     int lo = 0, hi = n ;
@@ -382,6 +384,148 @@ __global__ void __launch_bounds__(64) k_potrf (const PfGroup *g, double *Lx, i32
     if constexpr (TIMED) { if (lane == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
+// ---- diagonal-block Cholesky, second generation --------------------------------
+// Same contract as k_potrf.  Four waves; the block is eliminated in 16-column
+// panels:
+//  (1) wave 0 factors the panel, lane = row of the panel (diagonal-block rows
+//      and the rows below ride through the same right-looking elimination), 16
+//      registers per lane.  The pivot and the multipliers travel by
+//      v_readlane, and the dependent chain per column is kept to
+//      readlane -> rcp + one Newton step -> mul -> fma: the square root and its
+//      reciprocal (sqrt_rsqrt) are taken off that chain -- the elimination
+//      itself runs on the unscaled columns (u = l * sqrt(d), an LDL' step),
+//      the scaled column l = u * rsqrt(d) is only what gets stored;
+//  (2) all four waves apply the panel to the trailing 16x16 tiles with
+//      v_mfma_f64_16x16x4 straight out of the k-major LDS copy.
+// 1/d from v_rcp_f64 plus one Newton step is within ~1.5 ulp, the result
+// differs from a division-based dpotrf by rounding only (parity tests: 1e-12).
+#define PF2_LD 64
+__device__ __forceinline__ double readlane_f64 (double v, int l)
+{
+    int lo = __double2loint (v), hi = __double2hiint (v) ;
+    lo = __builtin_amdgcn_readlane (lo, l) ;
+    hi = __builtin_amdgcn_readlane (hi, l) ;
+    return __hiloint2double (hi, lo) ;
+}
+__global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info)
+{
+    __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;   // T[k][i] = L(i,k)
+    __shared__ int s_fail ;
+    __builtin_amdgcn_s_setprio (3) ;
+    PfGroup G = g [blockIdx.x] ;
+    double *A = Lx + G.off ;
+    int nb = G.nb, lda = G.lda ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    if (info [G.front] != 0)
+    {
+        for (int k = wave ; k < nb ; k += 4)
+            if (lane >= k && lane < nb) A [lane + (i64) k * lda] = 0.0 ;
+        return ;
+    }
+    int nbp = (nb + 15) / 16 * 16 ;
+    int nblk = nbp / 16 ;
+    // stage: thread = (row i, columns wave + 4 q), all 16 loads in flight
+    {
+        int i = lane ;
+        int ic = i < nb ? i : nb - 1 ;
+        double tmp [16] ;
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = wave + 4 * q ;
+            tmp [q] = A [ic + (i64) (k < nb ? k : nb - 1) * lda] ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = wave + 4 * q ;
+            T [k * PF2_LD + i] = (i < nb && k < nb) ? tmp [q] : (i == k ? 1.0 : 0.0) ;
+        }
+    }
+    if (tid == 0) s_fail = -1 ;
+    __syncthreads () ;
+    int lr = lane & 15, lk = lane >> 4 ;
+    for (int jb = 0 ; jb < nblk ; jb++)
+    {
+        int c0 = 16 * jb ;
+        if (wave == 0)
+        {
+            // panel rows c0 .. 63: lane = row c0 + lane (lanes past the block idle)
+            int row = c0 + lane ;
+            int rr = row < PF_NB ? row : PF_NB - 1 ;
+            double a [16] ;
+#pragma unroll
+            for (int c = 0 ; c < 16 ; c++) a [c] = T [(c0 + c) * PF2_LD + rr] ;
+            int fail = -1 ;
+#pragma unroll
+            for (int c = 0 ; c < 16 ; c++)
+            {
+                double d = readlane_f64 (a [c], c) ;
+                if (fail < 0 && d <= 0.0) fail = c0 + c ;
+                double x = 0.0, r = 0.0, ri = 0.0 ;
+                if (fail < 0)
+                {
+                    // 1/d for the chain
+                    x = __builtin_amdgcn_rcp (d) ;
+                    double e = __builtin_fma (-d, x, 1.0) ;
+                    x = __builtin_fma (x, e, x) ;
+                    if (!(d > 1e-290 && d < 1e290)) x = 1.0 / d ;
+                }
+                double t = a [c] * x ;              // u(row,c) / d
+#pragma unroll
+                for (int c2 = c + 1 ; c2 < 16 ; c2++)
+                    a [c2] = __builtin_fma (-t, readlane_f64 (a [c], c2), a [c2]) ;
+                // off the chain: the stored, scaled column
+                if (fail < 0) sqrt_rsqrt (d, r, ri) ;
+                a [c] = (lane == c) ? r : a [c] * ri ;
+                if (fail >= 0) a [c] = 0.0 ;
+            }
+            if (row < PF_NB)
+            {
+#pragma unroll
+                for (int c = 0 ; c < 16 ; c++) if (row >= c0 + c) T [(c0 + c) * PF2_LD + row] = a [c] ;
+            }
+            if (fail >= 0 && lane == 0) s_fail = fail ;
+        }
+        __syncthreads () ;
+        if (s_fail >= 0) break ;
+        // trailing tiles (ti >= tj > jb), dealt round-robin to the waves
+        int nt = nblk - 1 - jb ;
+        int ntile = nt * (nt + 1) / 2 ;
+        for (int u = wave ; u < ntile ; u += 4)
+        {
+            // u -> (ti, tj) in the lower triangle of an nt x nt tile grid
+            int tj = 0, rem = u ;
+            while (rem >= nt - tj) { rem -= nt - tj ; tj++ ; }
+            int ti = tj + rem ;
+            int i0 = 16 * (jb + 1 + ti), j0 = 16 * (jb + 1 + tj) ;
+            d4 acc ;
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++) acc [r] = T [(j0 + lk + 4 * r) * PF2_LD + i0 + lr] ;
+#pragma unroll
+            for (int kk = 0 ; kk < 16 ; kk += 4)
+            {
+                double av = -T [(c0 + kk + lk) * PF2_LD + i0 + lr] ;
+                double bv = T [(c0 + kk + lk) * PF2_LD + j0 + lr] ;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, av, acc, 0, 0, 0) ;
+            }
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++) T [(j0 + lk + 4 * r) * PF2_LD + i0 + lr] = acc [r] ;
+        }
+        __syncthreads () ;
+    }
+    int fail = s_fail ;
+    if (fail >= 0 && tid == 0) info [G.front] = G.col0 + fail + 1 ;
+    // write-back of the lower triangle (columns at / beyond a failed pivot: zero)
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++)
+    {
+        int k = wave + 4 * q, i = lane ;
+        if (k < nb && i >= k && i < nb)
+            A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
+    }
+}
+
 // ---- panel triangular solve: B := B * inv(L11)' , one thread per row --------
 // dtrsm("R","L","C","N") of the reference (:997-1002).  L11' (nb <= 64) is
 // staged in LDS; a thread solves its row in groups of TR_CW columns held in
@@ -520,6 +664,154 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
     }
 }
 
+// ---- panel triangular solve on the matrix cores ------------------------------
+// Same contract as k_trsm (B := B * inv(L11)', dtrsm("R","L","C","N") of the
+// reference, t_cholmod_super_numeric.c:997-1002), organised as a blocked
+// substitution over 16-column blocks so that everything but the four 16x16
+// diagonal inverses runs on v_mfma_f64_16x16x4:
+//     X_j = (B_j - sum_{i<j} X_i * L_ji') * inv(L_jj)'
+// One workgroup = 4 waves = 64 rows; a wave owns 16 rows and needs no data of
+// the other waves after the staging phase.  LDS (k-major, so that the 16 lanes
+// of an MFMA operand read 16 consecutive doubles):
+//   Ls [k][c]  = -L11(c,k) below the diagonal, L11(k,k) on it (identity-padded
+//                to a multiple of 16 and beyond a failed pivot)
+//   Wd [b][k][c] = inv(L_bb)(c,k), computed per workgroup: lane q of wave b
+//                solves column q by forward substitution, reciprocals of the
+//                diagonal precomputed so the 16-step chain is mul + fma
+//   Xs [w][k][r] = solved X(r,k) of wave w's rows (the A operand of later blocks)
+//   Ts [w][k][r] = B_j - sum ... before the diagonal block is applied
+#define TRM_ROWS 64
+__host__ __device__ inline size_t trsm_mfma_lds_bytes (int ldl)
+{
+    return (size_t) (ldl * ldl + (ldl / 16) * 256 + 4 * ldl * 16 + 4 * 256 + ldl) * sizeof (double) ;
+}
+__global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
+    double *Lx, const i32 *info, int ldl)
+{
+    extern __shared__ __attribute__((aligned(16))) double trsm_lds [] ;
+    double *Ls = trsm_lds ;                         // [ldl][ldl]
+    double *Wd = Ls + ldl * ldl ;                   // [ldl/16][16][16]
+    double *Xs = Wd + (ldl / 16) * 256 ;            // [4][ldl][16]
+    double *Ts = Xs + 4 * ldl * 16 ;                // [4][16][16]
+    double *rd = Ts + 4 * 256 ;                     // [ldl]
+    __builtin_amdgcn_s_setprio (3) ;
+    int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
+    TrGroup G = g [gi] ;
+    int nb = G.nb, lda = G.lda ;
+    int nbp = (nb + 15) / 16 * 16 ;
+    int nblk = nbp / 16 ;
+    const double *L11 = Lx + G.l_off ;
+    int inf = info [G.front] ;
+    int nvalid = nb ;
+    if (inf != 0)
+    {
+        nvalid = inf - 1 - G.col0 ;
+        if (nvalid < 0) nvalid = 0 ;
+        if (nvalid > nb) nvalid = nb ;
+    }
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    int lr = lane & 15, lk = lane >> 4 ;
+    // this wave's 16 rows of B, straight into the accumulator layout:
+    // lane holds B(row lr, col 16 j + lk + 4 r)
+    int row0 = ((int) blockIdx.x - G.blk_start) * TRM_ROWS + wave * 16 ;
+    int row = row0 + lr ;
+    bool rok = row < G.m ;
+    double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;
+    d4 bj [4] ;
+#pragma unroll
+    for (int j = 0 ; j < 4 ; j++)
+#pragma unroll
+        for (int r = 0 ; r < 4 ; r++)
+        {
+            int c = 16 * j + lk + 4 * r ;
+            bj [j][r] = B [(i64) (c < nb ? c : nb - 1) * lda] ;
+        }
+    // stage L11: thread = (row j of L11, 4 columns apart)
+    {
+        int j = tid & 63 ;
+        int jc = j < nb ? j : nb - 1 ;
+        double tmp [16] ;
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = (tid >> 6) + 4 * q ;
+            tmp [q] = L11 [jc + (i64) (k < nb ? k : nb - 1) * lda] ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = (tid >> 6) + 4 * q ;
+            double v = (j == k) ? 1.0 : 0.0 ;
+            if (j < nvalid && k < j) v = -tmp [q] ;
+            if (j < nvalid && k == j) v = tmp [q] ;
+            if (j < nbp && k < nbp) Ls [k * ldl + j] = v ;
+        }
+    }
+    __syncthreads () ;
+    if (tid < nbp) rd [tid] = 1.0 / Ls [tid * ldl + tid] ;
+    __syncthreads () ;
+    // inverse of the 16x16 diagonal blocks: wave b, lane q < 16 -> column q
+    if (wave < nblk && lane < 16)
+    {
+        int b = wave, q = lane ;
+        const double *Lb = Ls + (16 * b) * ldl + 16 * b ;       // Lb [e * ldl + r] = -L_bb(r,e)
+        double acc [16], y [16] ;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; r++) acc [r] = (r == q) ? 1.0 : 0.0 ;
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++)
+        {
+            y [e] = acc [e] * rd [16 * b + e] ;
+#pragma unroll
+            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (Lb [e * ldl + r], y [e], acc [r]) ;
+        }
+#pragma unroll
+        for (int r = 0 ; r < 16 ; r++) Wd [b * 256 + q * 16 + r] = y [r] ;     // Wd[b][k=q][c=r]
+    }
+    __syncthreads () ;
+    double *Xw = Xs + wave * ldl * 16 ;
+    double *Tw = Ts + wave * 256 ;
+#pragma unroll
+    for (int j = 0 ; j < 4 ; j++)
+    {
+        if (j < nblk)
+        {
+            d4 acc = bj [j] ;
+            for (int i = 0 ; i < j ; i++)
+            {
+#pragma unroll
+                for (int kk = 0 ; kk < 16 ; kk += 4)
+                {
+                    int k = 16 * i + kk + lk ;
+                    double a = Xw [k * 16 + lr] ;
+                    double b = Ls [k * ldl + 16 * j + lr] ;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, a, acc, 0, 0, 0) ;
+                }
+            }
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++) Tw [(lk + 4 * r) * 16 + lr] = acc [r] ;
+            __syncthreads () ;
+            d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
+#pragma unroll
+            for (int kk = 0 ; kk < 16 ; kk += 4)
+            {
+                double a = Tw [(kk + lk) * 16 + lr] ;
+                double b = Wd [j * 256 + (kk + lk) * 16 + lr] ;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, a, x, 0, 0, 0) ;
+            }
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int c = 16 * j + lk + 4 * r ;
+                double v = (c < nvalid) ? x [r] : 0.0 ;
+                Xw [c * 16 + lr] = v ;
+                if (rok && c < nb) B [(i64) c * lda] = v ;
+            }
+            __syncthreads () ;
+        }
+    }
+}
+
 // ---- fused small front: one workgroup, the whole front in LDS -----------------
 // For thin supernodes (nsrow <= SM_MAX) the level-batched generic kernels cost a
 // dozen launches and several HBM round trips per front.  Here one workgroup
@@ -622,7 +914,6 @@ __global__ void __launch_bounds__(NT) k_small_front (const i32 *fronts,
 // The MFMA is issued as D' = Bfrag x Afrag so that a lane holds C(i0+(l&15),
 // j0+(l>>4)+4r): consecutive lanes then touch consecutive rows of a column of
 // the column-major target and the read-modify-write is coalesced.
-typedef double d4 __attribute__((ext_vector_type(4))) ;
 
 // Block -> tile map of an update region.
 //  * Tiles are enumerated in strips of 8 tile columns, row by row inside a strip,
