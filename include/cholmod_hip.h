@@ -35,9 +35,10 @@ extern "C" {
 #define CHOLMOD_HIP_TILE128         4    /* tuning: 128x128 update tiles on big regions
                                            (default: 64x64 everywhere, which fills the
                                            256 CUs on mid-size fronts)               */
-#define CHOLMOD_HIP_LOOKAHEAD       8    /* tuning: panel look-ahead on a second stream
-                                           (off by default: fp64 VALU panel code
-                                           starves next to fp64 MFMA waves)          */
+#define CHOLMOD_HIP_LOOKAHEAD       8    /* accepted and ignored (a panel look-ahead on a
+                                           second stream was measured and dropped:
+                                           fp64 VALU panel code starves next to fp64
+                                           MFMA waves)                                */
 #define CHOLMOD_HIP_NO_SMALL_FRONTS 16   /* tuning: no fused LDS-resident kernel for
                                            thin fronts (generic kernels everywhere)  */
 #define CHOLMOD_HIP_NO_XCD_SWIZZLE 32    /* tuning: plain block -> tile order          */
@@ -167,6 +168,7 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  *       update region)     [17] all-reduce calls   [18] all-reduce bytes
  *  [19] seconds in the fused small-front kernel  [20] its algorithmic HBM bytes
  *       (A entries aside: children CBs in, panel + CB out)   [21] fronts it handled
+ *  [23] the part of [6] spent in K < 512 (panel-level) update launches
  *  [22] subtrees the schedule sweeps one after the other to fit the CB arena
  *       next to L (1 = plain level order)
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add

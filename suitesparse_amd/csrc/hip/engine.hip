@@ -265,6 +265,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                                      : (double) G.m * G.n ;
                 double share = G.tile_mul == 1 ? 1.0 : std::min (1.0, (double) mine / (double) cnt) ;
                 L.flops += 2.0 * elems * G.k * share ;
+                L.aux = std::max (L.aux, (int) G.k) ;
                 L.bytes += (16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
                 S.gg.push_back (G) ;
             }
@@ -297,41 +298,12 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         (isbig ? big : small).push_back (G) ;
     } ;
     std::vector<GemmGroup> big, small ;
-    // Look-ahead (levels whose fronts span several outer blocks): the panel
-    // work of block ob+1 (potrf/trsm/inner updates, a handful of workgroups on
-    // the critical path) runs on a second stream while the big trailing update
-    // of block ob still occupies the chip.  The outer update is split in
-    //   U_next(ob): target = the next outer block column only   (panel stream)
-    //   U_rest(ob): target = everything right of it, incl. CB   (main stream)
-    // Emission order P(0) U_next(0) U_rest(0) P(1) ... is also a valid serial
-    // order, which is what the profiling mode uses.
-    bool lookahead = (flags & CHOLMOD_HIP_LOOKAHEAD) && world == 1 && maxnscol > OB ;
-    int cur_stream = 0, pend_wait = -1 ;
-    size_t mark = S.launches.size () ;
-    auto tag_new = [&] ()
-    {
-        // stamp the launches emitted since `mark` with the current stream; the
-        // first of them carries the pending wait
-        for (size_t q = mark ; q < S.launches.size () ; q++)
-        {
-            S.launches [q].stream = cur_stream ;
-            if (pend_wait >= 0) { S.launches [q].wait_ev = pend_wait ; pend_wait = -1 ; }
-        }
-        mark = S.launches.size () ;
-    } ;
     auto record_last = [&] () -> int
     {
         if (S.launches.size () == 0) return -1 ;
         if (S.launches.back ().rec_ev < 0) S.launches.back ().rec_ev = S.nevents++ ;
         return S.launches.back ().rec_ev ;
     } ;
-    int ev_fork = -1, ev_rest_prev = -1, ev_side_last = -1 ;
-    if (lookahead && !S.launches.empty ())
-    {
-        // everything before this level's dense phase is on the main stream
-        if (S.launches.back ().rec_ev < 0) S.launches.back ().rec_ev = S.nevents++ ;
-        ev_fork = S.launches.back ().rec_ev ;
-    }
     // Exchange look-ahead (multi-GPU): the update that completes the NEXT 512-column
     // block column of a shared front is issued first (U_next), the rest of the
     // trailing update (U_rest) right behind it, and the block column's all-reduce
@@ -351,18 +323,55 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         La.wait_ev = wait_ev ;
         S.launches.push_back (La) ;
     } ;
+    // One trailing-update step: for every listed front, columns [kc, kc+kk) update
+    // the in-front columns [t0, t1) (all rows from t0 down) and, if cb, the
+    // contribution block.  Steps with kk >= MB are `wide`: their tiles are dealt
+    // over the rank group of a shared front and they feed the exchange look-ahead.
+    struct Upd { int q, kc, kk, t0, t1 ; bool cb ; } ;
+    std::vector<Upd> step ;
+    auto emit_step = [&] (bool wide)
+    {
+        bool any_next = false ;
+        if (wide && xla)
+            for (const Upd &x : step)
+            {
+                if (!is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
+                const FrontD &f = fr [ids [x.q]] ;
+                int tn = std::min (x.t0 + MB, x.t1) ;
+                add_update (big, small, f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
+                any_next = true ;
+            }
+        int ev_next = -1 ;
+        if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
+        for (const Upd &x : step)
+        {
+            const FrontD &f = fr [ids [x.q]] ;
+            int c0 = x.t0 ;
+            if (any_next && is_shared (ids [x.q]) && x.t1 > x.t0) c0 = std::min (x.t0 + MB, x.t1) ;
+            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, wide) ;
+            if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, wide) ;
+        }
+        flush_updates (big, small) ;
+        if (any_next)
+            for (const Upd &x : step)
+            {
+                if (!is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
+                emit_ar (x.q, x.t0, std::min (x.t0 + MB, x.t1), ev_next) ;
+                early [x.q] = x.t0 ;
+            }
+        step.clear () ;
+    } ;
+    const int nblk_ob = OB / NB ;
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
-        // ---- P(ob): panel factorization of the outer block column ----------
-        cur_stream = lookahead ? 1 : 0 ;
-        if (lookahead && o0 == 0) pend_wait = ev_fork ;
         for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
         {
-            // ---- multi-GPU: a mid block column of a shared front holds per-rank
-            // partial sums (extend-adds of the rank's own subtrees + its share of
-            // the earlier outer / mid update tiles); sum them before it is factored.
-            // Only rows >= i0 carry data (above lies the dead upper triangle): they
-            // are packed into a staging buffer, halving the volume for the root.
+            // ---- multi-GPU: a 512-column block column of a shared front holds
+            // per-rank partial sums (extend-adds of the rank's own subtrees + its
+            // share of the earlier wide update tiles); sum them before it is
+            // factored.  Only rows >= i0 carry data (above lies the dead upper
+            // triangle): they are packed into a staging buffer, halving the volume
+            // for the root.
             if ((i0 - o0) % MB == 0)
             {
                 for (int q = 0 ; q < nf ; q++)
@@ -405,151 +414,37 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
             Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
             if (Lt.ng) S.launches.push_back (Lt) ;
-            // inner trailing update (K = nb), restricted to the mid block column
-            int m0 = o0 + ((i0 - o0) / MB) * MB ;
+            // ---- trailing updates inside the outer block column: recursive
+            // doubling.  With e 64-column blocks of it factored and p the largest
+            // power of two dividing e, the last p blocks (K = 64 p) update the
+            // next p blocks only.  Every column block is then read-modified-
+            // written log2 times instead of once per 64-column step (768 instead
+            // of 1792 column sweeps per 512 columns), with K up to OB/2 instead of
+            // 64 / 512 on the matrix cores.
+            int e = (i0 - o0) / NB + 1 ;
+            int p = e & -e ;
+            if (e >= nblk_ob) continue ;            // block column complete: outer update below
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= i0) continue ;
-                int nb = std::min (NB, f.nscol - i0) ;
-                int i1 = i0 + nb ;
                 int o1 = std::min (o0 + OB, f.nscol) ;
-                int m1 = std::min (m0 + MB, o1) ;
-                add_update (big, small, f, ids [q], i1, i0, nb, f.nsrow - i1, m1 - i1, false) ;
+                int t0 = o0 + e * NB ;
+                if (o1 <= t0) continue ;            // this front has no columns left in the block
+                int t1 = std::min (o0 + (e + p) * NB, o1) ;
+                int kc = o0 + (e - p) * NB ;
+                step.push_back (Upd {q, kc, t0 - kc, t0, t1, false}) ;
             }
-            flush_updates (big, small) ;
-            // mid-level update (K = MB) of the rest of the outer block column once
-            // a mid block is complete
-            bool mid_done = ((i0 + NB - o0) % MB == 0) || (i0 + NB >= std::min (o0 + OB, maxnscol)) ;
-            if (OB > MB && mid_done)
-            {
-                // U_next: the next mid block column of the shared fronts
-                bool any_next = false ;
-                for (int q = 0 ; xla && q < nf ; q++)
-                {
-                    const FrontD &f = fr [ids [q]] ;
-                    if (f.nscol <= m0 || !is_shared (ids [q])) continue ;
-                    int o1 = std::min (o0 + OB, f.nscol) ;
-                    int m1 = std::min (m0 + MB, o1) ;
-                    if (o1 <= m1) continue ;
-                    int mn = std::min (m1 + MB, o1) ;
-                    add_update (big, small, f, ids [q], m1, m0, m1 - m0, f.nsrow - m1, mn - m1, false, true) ;
-                    any_next = true ;
-                }
-                int ev_next = -1 ;
-                if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
-                for (int q = 0 ; q < nf ; q++)
-                {
-                    const FrontD &f = fr [ids [q]] ;
-                    if (f.nscol <= m0) continue ;
-                    int o1 = std::min (o0 + OB, f.nscol) ;
-                    int m1 = std::min (m0 + MB, o1) ;
-                    int c0 = (any_next && is_shared (ids [q])) ? std::min (m1 + MB, o1) : m1 ;
-                    if (o1 > c0) add_update (big, small, f, ids [q], c0, m0, m1 - m0, f.nsrow - c0, o1 - c0, false, true) ;
-                }
-                flush_updates (big, small) ;
-                for (int q = 0 ; any_next && q < nf ; q++)
-                {
-                    const FrontD &f = fr [ids [q]] ;
-                    if (f.nscol <= m0 || !is_shared (ids [q])) continue ;
-                    int o1 = std::min (o0 + OB, f.nscol) ;
-                    int m1 = std::min (m0 + MB, o1) ;
-                    if (o1 <= m1) continue ;
-                    emit_ar (q, m1, std::min (m1 + MB, o1), ev_next) ;
-                    early [q] = m1 ;
-                }
-            }
+            emit_step (p * NB >= MB) ;
         }
-        tag_new () ;
-        int ev_panel = lookahead ? record_last () : -1 ;
-        if (!lookahead)
-        {
-            // outer trailing update: everything right of the outer block column;
-            // for shared fronts the first 512 columns of it go first (U_next)
-            bool any_next = false ;
-            for (int q = 0 ; xla && q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                if (f.nscol <= o1) continue ;
-                int on = std::min (o1 + MB, f.nscol) ;
-                add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, on - o1, false, true) ;
-                any_next = true ;
-            }
-            int ev_next = -1 ;
-            if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
-            for (int q = 0 ; q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= o0) continue ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                int kk = o1 - o0 ;
-                int c0 = (any_next && is_shared (ids [q])) ? std::min (o1 + MB, f.nscol) : o1 ;
-                add_update (big, small, f, ids [q], c0, o0, kk, f.nsrow - c0, f.nscol - c0, false, true) ;
-                add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true, true) ;
-            }
-            flush_updates (big, small) ;
-            for (int q = 0 ; any_next && q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= o0 || !is_shared (ids [q])) continue ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                if (f.nscol <= o1) continue ;
-                emit_ar (q, o1, std::min (o1 + MB, f.nscol), ev_next) ;
-                early [q] = o1 ;
-            }
-            tag_new () ;
-            continue ;
-        }
-        // ---- U_next(ob) on the panel stream, after U_rest(ob-1) --------------
+        // outer trailing update: everything right of the outer block column
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= o0) continue ;
             int o1 = std::min (o0 + OB, f.nscol) ;
-            int o2 = std::min (o1 + OB, f.nscol) ;
-            add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, o2 - o1, false) ;
+            step.push_back (Upd {q, o0, o1 - o0, o1, f.nscol, true}) ;
         }
-        pend_wait = ev_rest_prev ;
-        flush_updates (big, small) ;
-        tag_new () ;
-        pend_wait = -1 ;
-        if (S.launches.size () > 0 && S.launches.back ().stream == 1) ev_side_last = -2 ;
-        // ---- U_rest(ob) on the main stream, after P(ob) ----------------------
-        cur_stream = 0 ;
-        for (int q = 0 ; q < nf ; q++)
-        {
-            const FrontD &f = fr [ids [q]] ;
-            if (f.nscol <= o0) continue ;
-            int o1 = std::min (o0 + OB, f.nscol) ;
-            int o2 = std::min (o1 + OB, f.nscol) ;
-            int kk = o1 - o0 ;
-            add_update (big, small, f, ids [q], o2, o0, kk, f.nsrow - o2, f.nscol - o2, false) ;
-            add_update (big, small, f, ids [q], f.nscol, o0, kk, f.ncb, f.ncb, true) ;
-        }
-        pend_wait = ev_panel ;
-        size_t before = S.launches.size () ;
-        flush_updates (big, small) ;
-        tag_new () ;
-        pend_wait = -1 ;
-        if (S.launches.size () > before) ev_rest_prev = record_last () ;
-    }
-    if (lookahead)
-    {
-        // join: the main stream must not run ahead of the panel stream's tail
-        int last_side = -1 ;
-        for (size_t q = S.launches.size () ; q-- > 0 ; )
-            if (S.launches [q].stream == 1) { last_side = (int) q ; break ; }
-        if (last_side >= 0)
-        {
-            int e = S.launches [last_side].rec_ev ;
-            if (e < 0) { e = S.nevents++ ; S.launches [last_side].rec_ev = e ; }
-            S.launches.push_back (Launch {K_JOIN, 0, 0, 0, 0, 0}) ;
-            S.launches.back ().stream = 0 ;
-            S.launches.back ().wait_ev = e ;
-        }
-        (void) ev_side_last ;
+        emit_step (true) ;
     }
 }
 
@@ -1231,7 +1126,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             double sec = t * 1e-3 ;
             switch (L.kind)
             {
-                case K_UPD_SMALL: S [6] += sec ; break ;
+                case K_UPD_SMALL: S [6] += sec ; if (L.aux < MB) { S [23] += sec ; } break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;
