@@ -192,6 +192,10 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
 
 /* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;
+/* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */
+int cholmod_hip_debug_panel_cycles (long long *out16) ;
+/* Tuning probe: cycles for n repetitions of basic fp64 instruction patterns (one wave). */
+int cholmod_hip_debug_latency (long long *out8, int n) ;
 
 /* Tuning probe: waves 0,1 of every block run the MFMA loop, waves 2,3 a
  * v_fma_f64 loop; returns the seconds the launch took. */

@@ -133,7 +133,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak",
-    "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles",
+    "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
     "cholmod_hip_dense_partial_factor",
     "cholmod_hip_version",
 ]
@@ -236,6 +236,8 @@ def lib():
     sig("cholmod_hip_bench_mfma_peak", dbl, [C.c_int, C.c_int])
     sig("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int])
     sig("cholmod_hip_debug_potrf_cycles", C.c_int, [vp])
+    sig("cholmod_hip_debug_panel_cycles", C.c_int, [vp])
+    sig("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
     sig("cholmod_hip_version", C.c_char_p, [])
     _lib = L

@@ -949,7 +949,8 @@ static int raise_lds_limits ()
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
@@ -1016,8 +1017,8 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 hipLaunchKernelGGL (k_potrf<false>, dim3 (L.grid), dim3 (64), 0, st,
                     P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
             else
-                hipLaunchKernelGGL (k_potrf_mfma, dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_pg + L.goff, P->d_Lx, P->d_info) ;
+                hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (L.grid), dim3 (256), 0, st,
+                    P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
             break ;
         case K_TRSM:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
@@ -1026,8 +1027,8 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     (size_t) (L.aux * L.aux + L.aux * TR_ROWS + L.aux * TR_CW) * sizeof (double), st,
                     P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ;
             else
-                hipLaunchKernelGGL (k_trsm_mfma, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
-                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ;
+                hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
+                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
             break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
@@ -1655,6 +1656,96 @@ int cholmod_hip_debug_potrf_cycles (long long *out8)
     }
     HIPCHK (hipMemcpy (out8, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
     (void) hipFree (d) ; (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+/* tuning probe: per-phase shader-clock cycles of the matrix-core panel kernels
+ * on one 64x64 diagonal block with 64 rows below it.  out16 [0..7]: k_potrf_mfma
+ * (stage, column chain, scale+store, barrier, trailing tiles, barrier,
+ * write-back); out16 [8..15]: k_trsm_mfma (stage, reciprocals, diagonal
+ * inverses, update MFMAs, barrier, diagonal MFMAs + store, barrier). */
+int cholmod_hip_debug_panel_cycles (long long *out16)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+    const int n = 64, m = 128 ;
+    std::vector<double> A ((size_t) m * n) ;
+    for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < m ; i++) A [i + (size_t) j * m] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j)) ;
+    double *d = nullptr ; i32 *dinfo = nullptr ; long long *dt = nullptr ; PfGroup *dg = nullptr ; TrGroup *dtg = nullptr ;
+    HIPCHK (hipMalloc ((void **) &d, A.size () * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &dinfo, sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &dt, 16 * sizeof (long long))) ;
+    HIPCHK (hipMalloc ((void **) &dg, sizeof (PfGroup))) ;
+    HIPCHK (hipMalloc ((void **) &dtg, sizeof (TrGroup))) ;
+    PfGroup G {0, m, n, 0, 0} ;
+    TrGroup T {0, n, m, m - n, n, 0, 0, 0} ;
+    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+    HIPCHK (hipMemcpy (dtg, &T, sizeof (T), hipMemcpyHostToDevice)) ;
+    HIPCHK (hipMemset (dinfo, 0, sizeof (i32))) ;
+    for (int rep = 0 ; rep < 3 ; rep++)
+    {
+        HIPCHK (hipMemcpy (d, A.data (), A.size () * sizeof (double), hipMemcpyHostToDevice)) ;
+        hipLaunchKernelGGL (k_potrf_mfma<true>, dim3 (1), dim3 (256), 0, 0, dg, d, dinfo, dt) ;
+        hipLaunchKernelGGL (k_trsm_mfma<true>, dim3 (1), dim3 (256), trsm_mfma_lds_bytes (64), 0,
+            dtg, 1, d, dinfo, 64, dt + 8) ;
+        HIPCHK (hipDeviceSynchronize ()) ;
+    }
+    HIPCHK (hipMemcpy (out16, dt, 16 * sizeof (long long), hipMemcpyDeviceToHost)) ;
+    (void) hipFree (d) ;
+    // wall time of whole launches (HIP events, ns): [7] one potrf workgroup,
+    // [15] a trsm over 16 000 rows (250 workgroups) as at the top of Poisson 100^3
+    {
+        const int mm = 16064 ;
+        double *big = nullptr ;
+        HIPCHK (hipMalloc ((void **) &big, (size_t) mm * n * sizeof (double))) ;
+        std::vector<double> Ab ((size_t) mm * n) ;
+        for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < mm ; i++) Ab [i + (size_t) j * mm] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j) % 97) ;
+        PfGroup G2 {0, mm, n, 0, 0} ;
+        TrGroup T2 {0, n, mm, mm - n, n, 0, 0, 0} ;
+        HIPCHK (hipMemcpy (dg, &G2, sizeof (G2), hipMemcpyHostToDevice)) ;
+        HIPCHK (hipMemcpy (dtg, &T2, sizeof (T2), hipMemcpyHostToDevice)) ;
+        hipEvent_t e0, e1, e2 ;
+        (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ; (void) hipEventCreate (&e2) ;
+        float best_p = 1e30f, best_t = 1e30f ;
+        for (int rep = 0 ; rep < 5 ; rep++)
+        {
+            HIPCHK (hipMemcpy (big, Ab.data (), Ab.size () * sizeof (double), hipMemcpyHostToDevice)) ;
+            HIPCHK (hipEventRecord (e0, 0)) ;
+            hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (1), dim3 (256), 0, 0, dg, big, dinfo, (long long *) nullptr) ;
+            HIPCHK (hipEventRecord (e1, 0)) ;
+            hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 ((mm - n + TRM_ROWS - 1) / TRM_ROWS), dim3 (256),
+                trsm_mfma_lds_bytes (64), 0, dtg, 1, big, dinfo, 64, (long long *) nullptr) ;
+            HIPCHK (hipEventRecord (e2, 0)) ;
+            HIPCHK (hipDeviceSynchronize ()) ;
+            float a = 0, b = 0 ;
+            HIPCHK (hipEventElapsedTime (&a, e0, e1)) ;
+            HIPCHK (hipEventElapsedTime (&b, e1, e2)) ;
+            best_p = std::min (best_p, a) ; best_t = std::min (best_t, b) ;
+        }
+        out16 [7] = (long long) (best_p * 1e6) ;
+        out16 [15] = (long long) (best_t * 1e6) ;
+        (void) hipFree (big) ;
+        (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ; (void) hipEventDestroy (e2) ;
+    }
+    (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ; (void) hipFree (dtg) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+/* tuning probe: cycles per repetition of the basic fp64 instruction patterns of
+ * the panel kernels, one wave (see k_latency_probe); out8 [v] = cycles for n reps */
+int cholmod_hip_debug_latency (long long *out8, int n)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    double *sink = nullptr ; long long *dt = nullptr ;
+    HIPCHK (hipMalloc ((void **) &sink, 64 * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &dt, 8 * sizeof (long long))) ;
+    for (int rep = 0 ; rep < 2 ; rep++)
+    {
+        hipLaunchKernelGGL (k_latency_probe, dim3 (1), dim3 (64), 0, 0, sink, dt, n) ;
+        HIPCHK (hipDeviceSynchronize ()) ;
+    }
+    HIPCHK (hipMemcpy (out8, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
+    (void) hipFree (sink) ; (void) hipFree (dt) ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -212,11 +212,15 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
 // sqrt(d) and 1/sqrt(d) from one v_rsq_f64 seed and a coupled Goldschmidt
 // iteration (two quadratic steps + one correction): ~15 dependent FMAs instead
 // of the ~70 instructions of sqrt() followed by a full-precision division.
-// Both results are within 1 ulp for normal d; subnormal / huge / non-finite d
-// take the library path.
+// Both results are within 1 ulp for normal d.
+// Branch-free: arguments outside [1e-290, 1e290] are rescaled by 2^(+-512)
+// around the iteration (v_ldexp_f64), so there is no slow path for hipcc to
+// if-convert onto the caller's dependency chain.  d <= 0 or non-finite gives
+// NaN / garbage, which every caller masks (a failed pivot).
 __device__ __forceinline__ void sqrt_rsqrt (double d, double &r, double &ri)
 {
-    if (!(d > 1e-290 && d < 1e290)) { r = sqrt (d) ; ri = 1.0 / r ; return ; }
+    int sh = d > 1e290 ? -512 : (d < 1e-290 ? 512 : 0) ;
+    d = __builtin_ldexp (d, sh) ;
     double y = __builtin_amdgcn_rsq (d) ;       // ~2^-26 relative accuracy
     double g = d * y, h = 0.5 * y ;
     double e = __builtin_fma (-h, g, 0.5) ;
@@ -229,7 +233,8 @@ __device__ __forceinline__ void sqrt_rsqrt (double d, double &r, double &ri)
     ri = h + h ;
     double u = __builtin_fma (-g, ri, 1.0) ;
     ri = __builtin_fma (u, ri, ri) ;
-    r = g ;
+    r = __builtin_ldexp (g, -(sh >> 1)) ;
+    ri = __builtin_ldexp (ri, sh >> 1) ;
 }
 
 #define PF_NB 64
@@ -407,8 +412,12 @@ __device__ __forceinline__ double readlane_f64 (double v, int l)
     hi = __builtin_amdgcn_readlane (hi, l) ;
     return __hiloint2double (hi, lo) ;
 }
-__global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info)
+template <bool TIMED>
+__global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info, long long *tim)
 {
+    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;   // T[k][i] = L(i,k)
     __shared__ int s_fail ;
     __builtin_amdgcn_s_setprio (3) ;
@@ -444,6 +453,7 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
     }
     if (tid == 0) s_fail = -1 ;
     __syncthreads () ;
+    tick (0) ;
     int lr = lane & 15, lk = lane >> 4 ;
     for (int jb = 0 ; jb < nblk ; jb++)
     {
@@ -457,37 +467,46 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
 #pragma unroll
             for (int c = 0 ; c < 16 ; c++) a [c] = T [(c0 + c) * PF2_LD + rr] ;
             int fail = -1 ;
+            double dv = 1.0 ;                   // lane c keeps the pivot of column c
 #pragma unroll
             for (int c = 0 ; c < 16 ; c++)
             {
                 double d = readlane_f64 (a [c], c) ;
                 if (fail < 0 && d <= 0.0) fail = c0 + c ;
-                double x = 0.0, r = 0.0, ri = 0.0 ;
-                if (fail < 0)
-                {
-                    // 1/d for the chain
-                    x = __builtin_amdgcn_rcp (d) ;
-                    double e = __builtin_fma (-d, x, 1.0) ;
-                    x = __builtin_fma (x, e, x) ;
-                    if (!(d > 1e-290 && d < 1e290)) x = 1.0 / d ;
-                }
+                // (past a failed pivot the columns carry garbage; they are
+                // zeroed below, and nothing flows back into earlier columns)
+                double x = __builtin_amdgcn_rcp (d) ;
+                double e = __builtin_fma (-d, x, 1.0) ;
+                x = __builtin_fma (x, e, x) ;
                 double t = a [c] * x ;              // u(row,c) / d
 #pragma unroll
                 for (int c2 = c + 1 ; c2 < 16 ; c2++)
                     a [c2] = __builtin_fma (-t, readlane_f64 (a [c], c2), a [c2]) ;
-                // off the chain: the stored, scaled column
-                if (fail < 0) sqrt_rsqrt (d, r, ri) ;
-                a [c] = (lane == c) ? r : a [c] * ri ;
-                if (fail >= 0) a [c] = 0.0 ;
+                if (lane == c) dv = d ;
             }
+            tick (1) ;
+            // off the chain: sqrt / rsqrt of the 16 pivots side by side in lanes
+            // 0..15, then the stored columns l = u * rsqrt(d)
+            double r, ri ;
+            sqrt_rsqrt (dv, r, ri) ;
+#pragma unroll
+            for (int c = 0 ; c < 16 ; c++)
+            {
+                double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
+                a [c] = (lane == c) ? rc : a [c] * ric ;
+                if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
+            }
+            // (entries above the diagonal of the 16x16 block are never read again)
             if (row < PF_NB)
             {
 #pragma unroll
-                for (int c = 0 ; c < 16 ; c++) if (row >= c0 + c) T [(c0 + c) * PF2_LD + row] = a [c] ;
+                for (int c = 0 ; c < 16 ; c++) T [(c0 + c) * PF2_LD + row] = a [c] ;
             }
             if (fail >= 0 && lane == 0) s_fail = fail ;
+            tick (2) ;
         }
         __syncthreads () ;
+        tick (3) ;
         if (s_fail >= 0) break ;
         // trailing tiles (ti >= tj > jb), dealt round-robin to the waves
         int nt = nblk - 1 - jb ;
@@ -512,7 +531,9 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++) T [(j0 + lk + 4 * r) * PF2_LD + i0 + lr] = acc [r] ;
         }
+        tick (4) ;
         __syncthreads () ;
+        tick (5) ;
     }
     int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + fail + 1 ;
@@ -524,6 +545,78 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
         if (k < nb && i >= k && i < nb)
             A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
     }
+    tick (6) ;
+    if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
+}
+
+// ---- tuning probe: issue / latency of the fp64 ops the panel kernels chain -----
+// one wave; out[v] = shader-clock cycles for n repetitions of variant v
+__global__ void __launch_bounds__(64) k_latency_probe (double *sink, long long *out, int n)
+{
+    double x = 1.0 + threadIdx.x * 1e-9, a = 0.999999, b = 1e-7 ;
+    long long t0, t1 ;
+    // 0: dependent v_fma_f64
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++) { x = __builtin_fma (x, a, b) ; asm volatile ("" : "+v" (x)) ; }
+    t1 = __builtin_readcyclecounter () ; out [0] = t1 - t0 ;
+    // 1: 8 independent v_fma_f64 chains (issue rate)
+    double y [8] ;
+    for (int q = 0 ; q < 8 ; q++) y [q] = x + q ;
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++)
+    {
+#pragma unroll
+        for (int q = 0 ; q < 8 ; q++) { y [q] = __builtin_fma (y [q], a, b) ; asm volatile ("" : "+v" (y [q])) ; }
+    }
+    t1 = __builtin_readcyclecounter () ; out [1] = t1 - t0 ;
+    for (int q = 0 ; q < 8 ; q++) x += y [q] ;
+    // 2: dependent v_rcp_f64
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++) { x = __builtin_amdgcn_rcp (x) ; asm volatile ("" : "+v" (x)) ; }
+    t1 = __builtin_readcyclecounter () ; out [2] = t1 - t0 ;
+    // 3: readlane pair -> fma with the scalar, 8 independent accumulators
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++)
+    {
+#pragma unroll
+        for (int q = 0 ; q < 8 ; q++)
+        {
+            double sv = readlane_f64 (x, q) ;
+            y [q] = __builtin_fma (sv, a, y [q]) ; asm volatile ("" : "+v" (y [q])) ;
+        }
+    }
+    t1 = __builtin_readcyclecounter () ; out [3] = t1 - t0 ;
+    for (int q = 0 ; q < 8 ; q++) x += y [q] ;
+    // 4: dependent chain through readlane: x -> readlane -> fma -> x
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++)
+    {
+        double sv = readlane_f64 (x, 3) ;
+        x = __builtin_fma (sv, a, b) ; asm volatile ("" : "+v" (x)) ;
+    }
+    t1 = __builtin_readcyclecounter () ; out [4] = t1 - t0 ;
+    // 5: dependent v_mul_f64
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++) { x = x * a ; asm volatile ("" : "+v" (x)) ; }
+    t1 = __builtin_readcyclecounter () ; out [5] = t1 - t0 ;
+    // 6: dependent MFMA accumulate chain
+    d4 acc = {x, x, x, x} ;
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++) { acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (a, b, acc, 0, 0, 0) ; }
+    t1 = __builtin_readcyclecounter () ; out [6] = t1 - t0 ;
+    x += acc [0] ;
+    // 7: LDS broadcast read -> fma dependent chain
+    __shared__ double lds [64] ;
+    lds [threadIdx.x] = a ;
+    __syncthreads () ;
+    t0 = __builtin_readcyclecounter () ;
+    for (int i = 0 ; i < n ; i++)
+    {
+        int idx = ((int) x) & 63 ;
+        x = __builtin_fma (lds [idx], x, b) ; asm volatile ("" : "+v" (x)) ;
+    }
+    t1 = __builtin_readcyclecounter () ; out [7] = t1 - t0 ;
+    sink [threadIdx.x] = x ;
 }
 
 // ---- panel triangular solve: B := B * inv(L11)' , one thread per row --------
@@ -685,9 +778,13 @@ __host__ __device__ inline size_t trsm_mfma_lds_bytes (int ldl)
 {
     return (size_t) (ldl * ldl + (ldl / 16) * 256 + 4 * ldl * 16 + 4 * 256 + ldl) * sizeof (double) ;
 }
+template <bool TIMED>
 __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
-    double *Lx, const i32 *info, int ldl)
+    double *Lx, const i32 *info, int ldl, long long *tim)
 {
+    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     extern __shared__ __attribute__((aligned(16))) double trsm_lds [] ;
     double *Ls = trsm_lds ;                         // [ldl][ldl]
     double *Wd = Ls + ldl * ldl ;                   // [ldl/16][16][16]
@@ -711,22 +808,14 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     }
     int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     int lr = lane & 15, lk = lane >> 4 ;
-    // this wave's 16 rows of B, straight into the accumulator layout:
-    // lane holds B(row lr, col 16 j + lk + 4 r)
     int row0 = ((int) blockIdx.x - G.blk_start) * TRM_ROWS + wave * 16 ;
     int row = row0 + lr ;
     bool rok = row < G.m ;
     double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;
+    // stage L11 (thread = row j of L11, columns 4 apart); the loads of this
+    // wave's 16 rows of B are issued right behind and only waited for when the
+    // first block needs them
     d4 bj [4] ;
-#pragma unroll
-    for (int j = 0 ; j < 4 ; j++)
-#pragma unroll
-        for (int r = 0 ; r < 4 ; r++)
-        {
-            int c = 16 * j + lk + 4 * r ;
-            bj [j][r] = B [(i64) (c < nb ? c : nb - 1) * lda] ;
-        }
-    // stage L11: thread = (row j of L11, 4 columns apart)
     {
         int j = tid & 63 ;
         int jc = j < nb ? j : nb - 1 ;
@@ -737,6 +826,15 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
             int k = (tid >> 6) + 4 * q ;
             tmp [q] = L11 [jc + (i64) (k < nb ? k : nb - 1) * lda] ;
         }
+        // B straight into the accumulator layout: lane holds B(row lr, col 16 j + lk + 4 r)
+#pragma unroll
+        for (int jj = 0 ; jj < 4 ; jj++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int c = 16 * jj + lk + 4 * r ;
+                bj [jj][r] = B [(i64) (c < nb ? c : nb - 1) * lda] ;
+            }
 #pragma unroll
         for (int q = 0 ; q < 16 ; q++)
         {
@@ -748,27 +846,46 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
         }
     }
     __syncthreads () ;
-    if (tid < nbp) rd [tid] = 1.0 / Ls [tid * ldl + tid] ;
-    __syncthreads () ;
-    // inverse of the 16x16 diagonal blocks: wave b, lane q < 16 -> column q
-    if (wave < nblk && lane < 16)
+    tick (0) ;
+    // inverse of the 16x16 diagonal blocks: wave b; lane r < 16 holds row r of
+    // the block in registers and solves column r of the inverse by forward
+    // substitution, the (lane-uniform) multipliers travelling by v_readlane
+    if (wave < nblk)
     {
-        int b = wave, q = lane ;
-        const double *Lb = Ls + (16 * b) * ldl + 16 * b ;       // Lb [e * ldl + r] = -L_bb(r,e)
-        double acc [16], y [16] ;
+        int b = wave ;
+        int rl = lane & 15 ;
+        double Lr [16], acc [16], y [16] ;
 #pragma unroll
-        for (int r = 0 ; r < 16 ; r++) acc [r] = (r == q) ? 1.0 : 0.0 ;
+        for (int e = 0 ; e < 16 ; e++) Lr [e] = Ls [(16 * b + e) * ldl + 16 * b + rl] ;   // -L_bb(rl,e), diag +
+        double rdv = 0.0 ;
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++) if (rl == e) rdv = Lr [e] ;
+        {
+            // 1 / diagonal: v_rcp_f64 + two Newton steps
+            double x = __builtin_amdgcn_rcp (rdv) ;
+            double t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
+            t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
+            rdv = x ;
+        }
+        tick (1) ;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; r++) acc [r] = (r == rl) ? 1.0 : 0.0 ;
 #pragma unroll
         for (int e = 0 ; e < 16 ; e++)
         {
-            y [e] = acc [e] * rd [16 * b + e] ;
+            y [e] = acc [e] * readlane_f64 (rdv, e) ;
 #pragma unroll
-            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (Lb [e * ldl + r], y [e], acc [r]) ;
+            for (int r = e + 1 ; r < 16 ; r++)
+                acc [r] = __builtin_fma (readlane_f64 (Lr [e], r), y [e], acc [r]) ;
         }
+        if (lane < 16)
+        {
 #pragma unroll
-        for (int r = 0 ; r < 16 ; r++) Wd [b * 256 + q * 16 + r] = y [r] ;     // Wd[b][k=q][c=r]
+            for (int r = 0 ; r < 16 ; r++) Wd [b * 256 + lane * 16 + r] = y [r] ;     // Wd[b][k=q][c=r]
+        }
     }
     __syncthreads () ;
+    tick (2) ;
     double *Xw = Xs + wave * ldl * 16 ;
     double *Tw = Ts + wave * 256 ;
 #pragma unroll
@@ -790,7 +907,9 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
             }
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++) Tw [(lk + 4 * r) * 16 + lr] = acc [r] ;
+            tick (3) ;
             __syncthreads () ;
+            tick (4) ;
             d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
 #pragma unroll
             for (int kk = 0 ; kk < 16 ; kk += 4)
@@ -807,9 +926,12 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
                 Xw [c * 16 + lr] = v ;
                 if (rok && c < nb) B [(i64) c * lda] = v ;
             }
+            tick (5) ;
             __syncthreads () ;
+            tick (6) ;
         }
     }
+    if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
 // ---- fused small front: one workgroup, the whole front in LDS -----------------
