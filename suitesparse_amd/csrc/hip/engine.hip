@@ -185,6 +185,16 @@ struct cholmod_hip_plan {
     std::vector<std::vector<i32>> sv_big ;  // level -> big supernodes
     std::vector<i64> sv_blk ;               // (front, jb) -> index of its diagonal block task
     SolveTask *d_sv = nullptr ;
+    // explicit inverses of the 64x64 diagonal blocks of the big supernodes (solve
+    // only; built lazily after each factorization, see k_diag_inv64)
+    std::vector<InvTask> inv_tasks ;        // all blocks, grouped by supernode
+    std::vector<i64> inv_first ;            // supernode -> index of its first block
+    InvTask *d_inv_tasks = nullptr ;
+    double *d_winv = nullptr ;
+    bool winv_valid = false ;
+    double *d_solved = nullptr ; i64 solved_cap = 0 ; int max_big_nscol = 0 ;
+    double *d_sv_acc = nullptr ; i64 sv_acc_cap = 0 ;
+    unsigned int *d_ticket = nullptr ;
     Schedule sch ;
     double exec_flops = 0 ;
     // device
@@ -773,19 +783,21 @@ static int build_host (cholmod_hip_plan *P)
             const FrontD &f = P->fr [sid] ;
             // one workgroup streams ~50-100 GB/s: anything above ~16 MB of L gets the
             // multi-workgroup block walk
-            if (f.nscol > 2 * SOLVE_SB || (i64) f.nsrow * f.nscol > ((i64) 2 << 20)) P->sv_big [l].push_back (sid) ;
+            if (f.nscol > SOLVE_BIG_COLS || (i64) f.nsrow * f.nscol > ((i64) 2 << 20)) P->sv_big [l].push_back (sid) ;
             else P->sv_tasks.push_back (SolveTask {sid, 0, f.nscol, 1}) ;
         }
         P->sv_ptr [l+1] = (i32) P->sv_tasks.size () ;
     }
     P->sv_blk.assign (std::max<i64> (nsuper, 1), -1) ;
+    P->inv_tasks.clear () ; P->inv_first.assign (std::max<i64> (nsuper, 1), -1) ; P->max_big_nscol = 0 ;
     for (int l = 0 ; l < nlev ; l++)
         for (i32 sid : P->sv_big [l])
         {
             const FrontD &f = P->fr [sid] ;
-            P->sv_blk [sid] = (i64) P->sv_tasks.size () ;
+            P->inv_first [sid] = (i64) P->inv_tasks.size () ;
+            P->max_big_nscol = std::max (P->max_big_nscol, f.nscol) ;
             for (int jb = 0 ; jb < f.nscol ; jb += SOLVE_SB)
-                P->sv_tasks.push_back (SolveTask {sid, jb, std::min (jb + SOLVE_SB, f.nscol), 0}) ;
+                P->inv_tasks.push_back (InvTask {sid, jb, (i64) P->inv_tasks.size () * 8192}) ;
         }
     // launch schedule of this rank
     Schedule &S = P->sch ;
@@ -877,7 +889,8 @@ static void free_device (cholmod_hip_plan *P)
 {
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv} ;
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1065,6 +1078,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             hipEvent_t e ; HIPCHK (hipEventCreate (&e)) ; P->evpool.push_back (e) ;
         }
     }
+    P->winv_valid = false ;                 // the diagonal-block inverses follow the factor
     HIPCHK (hipEventRecord (P->ev0, st)) ;
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
@@ -1283,6 +1297,7 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
     if (P->world == 1) return CHOLMOD_HIP_OK ;
     if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
+    P->winv_valid = false ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     // Fronts shared by everybody are already complete everywhere.  Of every other
     // front exactly one rank (the first of its group) keeps its copy, the rest
@@ -1366,6 +1381,7 @@ int cholmod_hip_upload_factor (cholmod_hip_plan *P, const double *Lx_host)
 {
     if (!P || P->host_only || !Lx_host) return CHOLMOD_HIP_INVALID ;
     HIPCHK (hipMemcpy (P->d_Lx, Lx_host, P->xsize * sizeof (double), hipMemcpyHostToDevice)) ;
+    P->winv_valid = false ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -1398,6 +1414,40 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         P->x_cap = need ;
     }
     hipStream_t st = P->stream ;
+    // workspace of the big-supernode walk
+    if (!P->inv_tasks.empty ())
+    {
+        if (!P->d_winv)
+        {
+            HIPCHK (hipMalloc ((void **) &P->d_winv, P->inv_tasks.size () * 8192 * sizeof (double))) ;
+            HIPCHK (hipMalloc ((void **) &P->d_inv_tasks, P->inv_tasks.size () * sizeof (InvTask))) ;
+            HIPCHK (hipMemcpy (P->d_inv_tasks, P->inv_tasks.data (), P->inv_tasks.size () * sizeof (InvTask), hipMemcpyHostToDevice)) ;
+            HIPCHK (hipMalloc ((void **) &P->d_ticket, sizeof (unsigned int))) ;
+            HIPCHK (hipMemset (P->d_ticket, 0, sizeof (unsigned int))) ;
+            P->winv_valid = false ;
+        }
+        if ((i64) P->max_big_nscol * nrhs > P->solved_cap)
+        {
+            if (P->d_solved) (void) hipFree (P->d_solved) ;
+            P->d_solved = nullptr ;
+            P->solved_cap = (i64) P->max_big_nscol * nrhs ;
+            HIPCHK (hipMalloc ((void **) &P->d_solved, P->solved_cap * sizeof (double))) ;
+        }
+        if (64 * nrhs > P->sv_acc_cap)
+        {
+            if (P->d_sv_acc) (void) hipFree (P->d_sv_acc) ;
+            P->d_sv_acc = nullptr ;
+            P->sv_acc_cap = 64 * nrhs ;
+            HIPCHK (hipMalloc ((void **) &P->d_sv_acc, P->sv_acc_cap * sizeof (double))) ;
+            HIPCHK (hipMemset (P->d_sv_acc, 0, P->sv_acc_cap * sizeof (double))) ;
+        }
+        if (!P->winv_valid)
+        {
+            hipLaunchKernelGGL (k_diag_inv64, dim3 ((unsigned) P->inv_tasks.size ()), dim3 (64), 0, st,
+                P->d_inv_tasks, P->d_fr, P->d_Lx, P->d_winv) ;
+            P->winv_valid = true ;
+        }
+    }
     HIPCHK (hipMemcpyAsync (P->d_X, X, need * sizeof (double), hipMemcpyHostToDevice, st)) ;
     if (which == 0 || which == 1)
     {
@@ -1413,12 +1463,14 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
                 for (int b = 0 ; b < nblk ; b++)
                 {
                     int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
-                    hipLaunchKernelGGL (k_lsolve, dim3 (1), dim3 (256), 0, st,
-                        P->d_sv + P->sv_blk [sid] + b, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
                     int rest = f.nsrow - (jb + w) ;
-                    if (rest > 0) hipLaunchKernelGGL (k_solve_fwd_update, dim3 ((rest + 255) / 256), dim3 (256), 0, st,
-                        (int) sid, jb, w, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                    hipLaunchKernelGGL (k_solve_fwd_blk, dim3 (std::max (1, (rest + 255) / 256)), dim3 (256), 0, st,
+                        (int) sid, jb, w, P->d_winv + (P->inv_first [sid] + b) * 8192,
+                        P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs,
+                        P->d_solved, (i64) P->max_big_nscol) ;
                 }
+                hipLaunchKernelGGL (k_solve_commit, dim3 ((f.nscol + 255) / 256), dim3 (256), 0, st,
+                    (int) sid, P->d_fr, P->d_X, (i64) ldx, (int) nrhs, P->d_solved, (i64) P->max_big_nscol) ;
             }
         }
     }
@@ -1434,10 +1486,9 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
                 {
                     int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
                     int rest = f.nsrow - (jb + w) ;
-                    if (rest > 0) hipLaunchKernelGGL (k_solve_bwd_update, dim3 ((rest + 255) / 256), dim3 (256), 0, st,
-                        (int) sid, jb, w, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
-                    hipLaunchKernelGGL (k_ltsolve, dim3 (1), dim3 (256), 0, st,
-                        P->d_sv + P->sv_blk [sid] + b, P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                    hipLaunchKernelGGL (k_solve_bwd_blk, dim3 (std::max (1, (rest + 255) / 256)), dim3 (256), 0, st,
+                        (int) sid, jb, w, P->d_winv + (P->inv_first [sid] + b) * 8192 + 4096,
+                        P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc, P->d_ticket) ;
                 }
             }
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;

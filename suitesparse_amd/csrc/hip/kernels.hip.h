@@ -1476,12 +1476,15 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
             if (wave == 0)
             {
                 // dtrsv("L","N","N") on the 64-wide diagonal block, one wave
+                // (reciprocal diagonal once per lane and v_readlane broadcasts: a
+                // division or a ds_bpermute on the 64-step chain costs 5x the rest)
                 double xv = (lane < nb) ? x [k1 + jb + lane] : 0.0 ;
+                double rdi = 1.0 / Dl [lane * 65 + lane] ;
                 for (int j = 0 ; j < nb ; j++)
                 {
-                    double xj = __shfl (xv, j) / Dl [j * 65 + j] ;
+                    double xj = readlane_f64 (xv, j) * readlane_f64 (rdi, j) ;
                     if (lane == j) xv = xj ;
-                    else if (lane > j) xv -= Dl [lane * 65 + j] * xj ;
+                    else if (lane > j) xv = __builtin_fma (-Dl [lane * 65 + j], xj, xv) ;
                 }
                 xb [lane] = xv ;
                 if (lane < nb) x [k1 + jb + lane] = xv ;
@@ -1528,7 +1531,8 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
 
 // big supernodes, forward: rows below a solved column block [jb,jb+w) get
 // y(i) -= L(i, jb:jb+w) * x1(jb:jb+w); one thread per row, many workgroups
-#define SOLVE_SB 512
+#define SOLVE_SB 64          /* column block of the big-front walk */
+#define SOLVE_BIG_COLS 1024  /* fronts wider than this (or > 16 MB) take the multi-workgroup walk */
 __global__ void __launch_bounds__(256) k_solve_fwd_update (int fid, int jb, int w,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
 {
@@ -1635,11 +1639,12 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
             if (wave == 0)
             {
                 double xv = (lane < nb) ? xb [lane] : 0.0 ;
+                double rdi = 1.0 / Dl [lane * 65 + lane] ;
                 for (int j = nb - 1 ; j >= 0 ; j--)
                 {
-                    double xj = __shfl (xv, j) / Dl [j * 65 + j] ;
+                    double xj = readlane_f64 (xv, j) * readlane_f64 (rdi, j) ;
                     if (lane == j) xv = xj ;
-                    else if (lane < j) xv -= Dl [j * 65 + lane] * xj ;
+                    else if (lane < j) xv = __builtin_fma (-Dl [j * 65 + lane], xj, xv) ;
                 }
                 if (lane < nb) x [k1 + jb + lane] = xv ;
             }
@@ -1691,6 +1696,216 @@ __global__ void __launch_bounds__(256) k_solve_bwd_update (int fid, int jb, int 
         }
         __syncthreads () ;
     }
+}
+
+// ---- big supernodes, third generation: one launch per 64-column block --------
+// The 64x64 diagonal blocks of the big supernodes are inverted once per
+// factorization (k_diag_inv64, every block independent); the solves then
+// contain no substitution chain at all:
+//   forward  (k_solve_fwd_blk): every workgroup forms x_b = inv(L_bb) x_b itself
+//            (a 64x64 matrix-vector product, 32 KB of inverse out of L2) and
+//            applies it to its 256 rows below, X[rows] -= L[rows, b] x_b;
+//            workgroup 0 stores x_b in a side buffer (the other workgroups of the
+//            launch may still be reading the unsolved x_b), copied back by
+//            k_solve_commit once the supernode is done;
+//   backward (k_solve_bwd_blk): every workgroup adds its rows' share of
+//            L[rows, b]' x[rows] into a 64-entry accumulator; the last one to
+//            arrive (ticket counter) forms x_b = inv(L_bb)' (x_b - acc).
+// Inverse layout (per block, 2 x 4096 doubles): Wm [k*64 + r] = W(r,k) and
+// WmT [k*64 + c] = W(k,c), both zero outside the lower triangle and
+// identity-padded past the supernode's last column.
+struct InvTask { i32 front ; i32 jb ; i64 w_off ; } ;
+
+__global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const FrontD *fr,
+    const double *Lx, double *Winv)
+{
+    __shared__ double Lm [64 * 64] ;        // Lm [e*64 + r] = L(r,e)
+    __shared__ double Wl [64 * 65] ;        // Wl [k*65 + q] = W(k,q)
+    __shared__ double rdl [64] ;
+    InvTask T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
+    int nsrow = f.nsrow, q = threadIdx.x ;
+    int nb = f.nscol - T.jb < 64 ? f.nscol - T.jb : 64 ;
+    const double *L = Lx + f.psx + T.jb + (i64) T.jb * nsrow ;
+    for (int e = 0 ; e < 64 ; e++)
+        Lm [e * 64 + q] = (q < nb && e < nb && e <= q) ? L [q + (i64) e * nsrow] : (q == e ? 1.0 : 0.0) ;
+    __syncthreads () ;
+    rdl [q] = 1.0 / Lm [q * 64 + q] ;
+    __syncthreads () ;
+    // lane q = column q of the inverse, rows in blocks of 16
+    for (int R = 0 ; R < 4 ; R++)
+    {
+        double acc [16] ;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; r++) acc [r] = (16 * R + r == q) ? 1.0 : 0.0 ;
+        for (int k = 0 ; k < 16 * R ; k++)
+        {
+            double wk = Wl [k * 65 + q] ;
+#pragma unroll
+            for (int r = 0 ; r < 16 ; r++) acc [r] = __builtin_fma (-Lm [k * 64 + 16 * R + r], wk, acc [r]) ;
+        }
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++)
+        {
+            double y = acc [e] * rdl [16 * R + e] ;
+            Wl [(16 * R + e) * 65 + q] = y ;
+#pragma unroll
+            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (-Lm [(16 * R + e) * 64 + 16 * R + r], y, acc [r]) ;
+        }
+    }
+    __syncthreads () ;
+    double *Wm = Winv + T.w_off, *WmT = Wm + 4096 ;
+    for (int k = 0 ; k < 64 ; k++)
+    {
+        Wm [k * 64 + q] = Wl [q * 65 + k] ;     // W(r = q, k)
+        WmT [k * 64 + q] = Wl [k * 65 + q] ;    // W(k, c = q)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_solve_fwd_blk (int fid, int jb, int w, const double *Wm,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs,
+    double *solved, i64 ld_solved)
+{
+    __shared__ double t [64], xs [64], part [4][64] ;
+    const FrontD &f = fr [fid] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    int r = tid & 63, p = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    int i = jb + w + (int) blockIdx.x * 256 + tid ;
+    // the 16 entries of the inverse this thread needs, and its row of L, do not
+    // depend on the right-hand side
+    double wv [16] ;
+#pragma unroll
+    for (int u = 0 ; u < 16 ; u++) wv [u] = Wm [(p + 4 * u) * 64 + r] ;
+    for (int rhs = 0 ; rhs < nrhs ; rhs++)
+    {
+        double *x = X + (i64) rhs * ldx ;
+        if (tid < 64) t [tid] = (tid < w) ? x [k1 + jb + tid] : 0.0 ;
+        __syncthreads () ;
+        double a = 0.0 ;
+#pragma unroll
+        for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (wv [u], t [p + 4 * u], a) ;
+        part [p][r] = a ;
+        __syncthreads () ;
+        if (tid < 64)
+        {
+            double v = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
+            xs [tid] = v ;
+            if (blockIdx.x == 0 && tid < w) solved [rhs * ld_solved + jb + tid] = v ;
+        }
+        __syncthreads () ;
+        if (i < nsrow)
+        {
+            const double *Li = L + i + (i64) jb * nsrow ;
+            double acc [4] = {0.0, 0.0, 0.0, 0.0} ;
+            int c = 0 ;
+            for ( ; c + 16 <= w ; c += 16)
+            {
+                double l [16] ;
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) l [u] = Li [(i64) (c + u) * nsrow] ;
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) acc [u & 3] = __builtin_fma (l [u], xs [c + u], acc [u & 3]) ;
+            }
+            for ( ; c < w ; c++) acc [0] = __builtin_fma (Li [(i64) c * nsrow], xs [c], acc [0]) ;
+            double s = (acc [0] + acc [1]) + (acc [2] + acc [3]) ;
+            if (i < nscol) x [k1 + i] -= s ;
+            else atomicAdd (&x [rows [i]], -s) ;
+        }
+        __syncthreads () ;
+    }
+}
+
+// solved values of columns [0, nscol) of a big supernode back into X
+__global__ void __launch_bounds__(256) k_solve_commit (int fid, const FrontD *fr, double *X, i64 ldx,
+    int nrhs, const double *solved, i64 ld_solved)
+{
+    const FrontD &f = fr [fid] ;
+    int j = (int) blockIdx.x * 256 + threadIdx.x ;
+    if (j >= f.nscol) return ;
+    for (int rhs = 0 ; rhs < nrhs ; rhs++) X [(i64) rhs * ldx + f.k1 + j] = solved [rhs * ld_solved + j] ;
+}
+
+__global__ void __launch_bounds__(256) k_solve_bwd_blk (int fid, int jb, int w, const double *WmT,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs,
+    double *accbuf, unsigned int *ticket)
+{
+    __shared__ double t [64], part [4][64] ;
+    __shared__ double Tw [4][64 * 17] ;      // per wave: 64 rows x 16 columns of products
+    __shared__ unsigned int s_last ;
+    const FrontD &f = fr [fid] ;
+    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    int lane = tid & 63, wave = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    const i64 *rows = Ls + f.psi ;
+    int r0 = jb + w + (int) blockIdx.x * 256 ;
+    int nr = nsrow - r0 < 256 ? nsrow - r0 : 256 ;
+    if (nr > 0)
+    {
+        // thread = row: its 64 entries of L (coalesced over the threads, all loads
+        // in flight) times its x; the column sums over a wave's 64 rows go through
+        // an LDS transpose (16 columns at a time) instead of cross-lane shuffles
+        int i = r0 + tid ;
+        bool ok = tid < nr ;
+        const double *Li = L + (ok ? i : r0) + (i64) jb * nsrow ;
+        double l [64] ;
+#pragma unroll
+        for (int c = 0 ; c < 64 ; c++) l [c] = Li [(i64) (c < w ? c : w - 1) * nsrow] ;
+        int c16 = lane & 15, seg = lane >> 4 ;
+        for (int rhs = 0 ; rhs < nrhs ; rhs++)
+        {
+            const double *x = X + (i64) rhs * ldx ;
+            double y = ok ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
+#pragma unroll
+            for (int q = 0 ; q < 4 ; q++)
+            {
+#pragma unroll
+                for (int c = 0 ; c < 16 ; c++) Tw [wave][lane * 17 + c] = l [16 * q + c] * y ;
+                __builtin_amdgcn_s_waitcnt (0xc07f) ;      // lgkmcnt(0): own wave's LDS writes landed
+                __builtin_amdgcn_wave_barrier () ;
+                double sum = 0.0 ;
+#pragma unroll
+                for (int rr = 0 ; rr < 16 ; rr++) sum += Tw [wave][(seg * 16 + rr) * 17 + c16] ;
+                sum += __shfl_xor (sum, 16) ;
+                sum += __shfl_xor (sum, 32) ;
+                if (seg == 0) part [wave][16 * q + c16] = sum ;
+                __builtin_amdgcn_wave_barrier () ;
+            }
+            __syncthreads () ;
+            if (tid < w) atomicAdd (&accbuf [rhs * 64 + tid], (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid])) ;
+            __syncthreads () ;
+        }
+    }
+    // the last workgroup to get here finishes the block
+    __threadfence () ;
+    if (tid == 0) s_last = (atomicAdd (ticket, 1u) == gridDim.x - 1) ? 1u : 0u ;
+    __syncthreads () ;
+    if (!s_last) return ;
+    __threadfence () ;
+    int c = tid & 63, p = tid >> 6 ;
+    double wv [16] ;
+#pragma unroll
+    for (int u = 0 ; u < 16 ; u++) wv [u] = WmT [(p + 4 * u) * 64 + c] ;
+    for (int rhs = 0 ; rhs < nrhs ; rhs++)
+    {
+        double *x = X + (i64) rhs * ldx ;
+        if (tid < 64)
+        {
+            double a = __hip_atomic_load (&accbuf [rhs * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+            t [tid] = (tid < w) ? x [k1 + jb + tid] - a : 0.0 ;
+            accbuf [rhs * 64 + tid] = 0.0 ;
+        }
+        __syncthreads () ;
+        double a = 0.0 ;
+#pragma unroll
+        for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (wv [u], t [p + 4 * u], a) ;
+        part [p][c] = a ;
+        __syncthreads () ;
+        if (tid < w) x [k1 + jb + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
+        __syncthreads () ;
+    }
+    if (tid == 0) *ticket = 0u ;
 }
 
 // gather / scatter by the fill-reducing permutation (cholmod_solve.c:105,:322)
