@@ -771,12 +771,11 @@ __global__ void __launch_bounds__(TR_ROWS) k_trsm (const TrGroup *g, int ng,
 //   Wd [b][k][c] = inv(L_bb)(c,k), computed per workgroup: lane q of wave b
 //                solves column q by forward substitution, reciprocals of the
 //                diagonal precomputed so the 16-step chain is mul + fma
-//   Xs [w][k][r] = solved X(r,k) of wave w's rows (the A operand of later blocks)
-//   Ts [w][k][r] = B_j - sum ... before the diagonal block is applied
+// Solved blocks and intermediates stay in registers (see the layout note below).
 #define TRM_ROWS 64
 __host__ __device__ inline size_t trsm_mfma_lds_bytes (int ldl)
 {
-    return (size_t) (ldl * ldl + (ldl / 16) * 256 + 4 * ldl * 16 + 4 * 256 + ldl) * sizeof (double) ;
+    return (size_t) (ldl * ldl + (ldl / 16) * 256) * sizeof (double) ;
 }
 template <bool TIMED>
 __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
@@ -788,9 +787,6 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     extern __shared__ __attribute__((aligned(16))) double trsm_lds [] ;
     double *Ls = trsm_lds ;                         // [ldl][ldl]
     double *Wd = Ls + ldl * ldl ;                   // [ldl/16][16][16]
-    double *Xs = Wd + (ldl / 16) * 256 ;            // [4][ldl][16]
-    double *Ts = Xs + 4 * ldl * 16 ;                // [4][16][16]
-    double *rd = Ts + 4 * 256 ;                     // [ldl]
     __builtin_amdgcn_s_setprio (3) ;
     int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
     TrGroup G = g [gi] ;
@@ -886,49 +882,48 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     }
     __syncthreads () ;
     tick (2) ;
-    double *Xw = Xs + wave * ldl * 16 ;
-    double *Tw = Ts + wave * 256 ;
+    // The accumulator layout of v_mfma_f64_16x16x4 (lane (lr,lk) holds columns
+    // lk + 4 r, r = 0..3) IS its A-operand layout for the k-steps s = r (k = 4 s +
+    // lk): a solved block X_i and the intermediate B_j - sum feed the next MFMAs
+    // straight from registers, no LDS round trip, no barrier.
+    d4 xr [4] ;
 #pragma unroll
     for (int j = 0 ; j < 4 ; j++)
     {
         if (j < nblk)
         {
             d4 acc = bj [j] ;
-            for (int i = 0 ; i < j ; i++)
-            {
 #pragma unroll
-                for (int kk = 0 ; kk < 16 ; kk += 4)
+            for (int i = 0 ; i < 4 ; i++)
+            {
+                if (i < j)
                 {
-                    int k = 16 * i + kk + lk ;
-                    double a = Xw [k * 16 + lr] ;
-                    double b = Ls [k * ldl + 16 * j + lr] ;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, a, acc, 0, 0, 0) ;
+#pragma unroll
+                    for (int s4 = 0 ; s4 < 4 ; s4++)
+                    {
+                        double b = Ls [(16 * i + 4 * s4 + lk) * ldl + 16 * j + lr] ;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, xr [i][s4], acc, 0, 0, 0) ;
+                    }
                 }
             }
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++) Tw [(lk + 4 * r) * 16 + lr] = acc [r] ;
             tick (3) ;
-            __syncthreads () ;
-            tick (4) ;
             d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
 #pragma unroll
-            for (int kk = 0 ; kk < 16 ; kk += 4)
+            for (int s4 = 0 ; s4 < 4 ; s4++)
             {
-                double a = Tw [(kk + lk) * 16 + lr] ;
-                double b = Wd [j * 256 + (kk + lk) * 16 + lr] ;
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, a, x, 0, 0, 0) ;
+                double b = Wd [j * 256 + (4 * s4 + lk) * 16 + lr] ;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, acc [s4], x, 0, 0, 0) ;
             }
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++)
             {
                 int c = 16 * j + lk + 4 * r ;
                 double v = (c < nvalid) ? x [r] : 0.0 ;
-                Xw [c * 16 + lr] = v ;
+                x [r] = v ;
                 if (rok && c < nb) B [(i64) c * lda] = v ;
             }
+            xr [j] = x ;
             tick (5) ;
-            __syncthreads () ;
-            tick (6) ;
         }
     }
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
