@@ -127,7 +127,7 @@ def main():
     allreduce = None
     if dist is not None:
         from suitesparse_amd.dist import make_allreduce
-        allreduce = make_allreduce()
+        allreduce = make_allreduce(subgroups=None)     # the plan's own rank groups are created below
     grids = [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
     S = None
     for gi, m in enumerate(grids):
@@ -160,6 +160,13 @@ def main():
             S.finish()
             continue
         assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+        if allreduce is not None and world > 1:
+            # process groups for the rank ranges this plan shares fronts over
+            # (same partition on every rank -> same collective new_group calls)
+            g0 = np.empty(fv.nsuper, dtype=np.int64)
+            gn = np.empty(fv.nsuper, dtype=np.int64)
+            assert S.L.cholmod_hip_get_groups(ch.FactorView(Lf).hip_plan, g0.ctypes.data, gn.ctypes.data) == 0
+            allreduce.create_groups(sorted(set(zip(g0[gn > 1].tolist(), gn[gn > 1].tolist()))))
         # first factorization: uploads S (H2D, outside the timed region)
         ok = S.factorize(A, Lf)
         t_first = time.perf_counter() - t0

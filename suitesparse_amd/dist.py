@@ -32,13 +32,16 @@ class _DevView:
 MAX_SUBGROUP_WORLD = 16
 
 
-def make_allreduce(group=None, device_memory=True):
+def make_allreduce(group=None, device_memory=True, subgroups="all"):
     """Return a ctypes callback (keep a reference!) implementing the engine's sum
     all-reduce with torch.distributed.  The engine names the contiguous rank
     range [first, first+size) that takes part: the whole world uses `group`
-    (default group if None); every proper sub-range of size >= 2 gets its own
-    process group, all of them created here, collectively and in the same order
-    on every rank (RCCL communicators are only instantiated on first use).
+    (default group if None); every proper sub-range of size >= 2 needs its own
+    process group, created collectively and in the same order on every rank:
+    subgroups="all" creates all of them here (fine for a handful of ranks);
+    subgroups=None creates none -- call cb.create_groups(ranges) with the ranges
+    the plan actually uses (cholmod_hip_get_groups; identical on every rank)
+    before the first factorization.
     device_memory=False treats the pointer as host memory (CPU-only tests)."""
     import torch
     import torch.distributed as dist
@@ -49,13 +52,20 @@ def make_allreduce(group=None, device_memory=True):
     calls = {"n": 0, "bytes": 0, "by_size": {}}
     side = [None]
     groups = {(0, world): group}
-    if 2 < world <= MAX_SUBGROUP_WORLD:
-        base = list(range(world)) if group is None else dist.get_process_group_ranks(group)
-        for size in range(world - 1, 1, -1):
-            for first in range(0, world - size + 1):
-                g = dist.new_group([base[r] for r in range(first, first + size)], backend=backend)
-                if first <= rank < first + size:
-                    groups[(first, size)] = g
+    base = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+
+    def create_groups(ranges):
+        """Collective: every rank passes the same list of (first, size)."""
+        for first, size in sorted({(int(a), int(b)) for a, b in ranges}):
+            if size < 2 or size >= world or (first, size) in groups:
+                continue
+            g = dist.new_group([base[r] for r in range(first, first + size)], backend=backend)
+            # (ranks outside the range keep the handle too; they never use it)
+            groups[(first, size)] = g
+
+    if subgroups == "all" and 2 < world <= MAX_SUBGROUP_WORLD:
+        create_groups([(first, size) for size in range(world - 1, 1, -1)
+                       for first in range(0, world - size + 1)])
 
     def _fn(ptr, count, first, size, user):
         try:
@@ -67,7 +77,8 @@ def make_allreduce(group=None, device_memory=True):
             key = (int(first), int(size)) if world > 1 else (0, world)
             if key not in groups:
                 raise RuntimeError(f"no process group for ranks [{first}, {first + size}) on rank {rank} "
-                                   f"(world {world}; set CHOLMOD_HIP_NO_SUBGROUPS=1 beyond {MAX_SUBGROUP_WORLD} ranks)")
+                                   f"(world {world}): create it with cb.create_groups(...) on every rank, or "
+                                   f"set CHOLMOD_HIP_NO_SUBGROUPS=1")
             g = groups[key]
             if not device_memory:
                 buf = (C.c_double * count).from_address(ptr)
@@ -95,4 +106,5 @@ def make_allreduce(group=None, device_memory=True):
 
     cb = ch.ALLREDUCE_FN(_fn)
     cb.stats = calls
+    cb.create_groups = create_groups
     return cb
