@@ -989,23 +989,111 @@ __global__ void __launch_bounds__(NT) k_small_front (const i32 *fronts,
         }
         __syncthreads () ;
     }
+    // Right-looking elimination in panels of 8 columns:
+    //  (1) every thread factors the 8x8 diagonal block redundantly in registers
+    //      (uniform values, LDS broadcast reads), as an LDL' recurrence whose
+    //      dependent chain per column is rcp + one Newton step -> mul -> fma; the
+    //      eight square roots are taken afterwards, eight independent chains;
+    //  (2) thread = row: the row rides through the same elimination with the
+    //      (uniform) multipliers, is scaled and stored;
+    //  (3) the trailing 16x16 tiles get the rank-8 update on the matrix cores
+    //      (two v_mfma_f64_16x16x4 per tile, operands straight out of the front).
+    // Two barriers per 8 columns instead of three per column.
     int fail = -1 ;
-    int ti = tid & 31, tk = tid >> 5 ;
-    for (int j = 0 ; j < nc ; j++)
+    int lr = lane & 15, lk = lane >> 4 ;
+    constexpr int NW = NT / 64 ;
+    for (int j0 = 0 ; j0 < nc && fail < 0 ; j0 += 8)
     {
-        double d = F [j + j * ld] ;
-        if (d <= 0.0) { fail = j ; break ; }
-        double r, ri ;
-        sqrt_rsqrt (d, r, ri) ;
-        __syncthreads () ;                  // everyone has read the pivot
-        for (int i = j + tid ; i < ns ; i += NT) F [i + j * ld] = (i == j) ? r : F [i + j * ld] * ri ;
-        __syncthreads () ;
-        const double *lj = F + j * ld ;
-        for (int k = j + 1 + tk ; k < ns ; k += NT / 32)
+        int pc = nc - j0 < 8 ? nc - j0 : 8 ;
+        double D [8][8], piv [8], xinv [8] ;
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++)
+#pragma unroll
+            for (int r = c ; r < 8 ; r++)
+            {
+                int rr = j0 + r < ns ? j0 + r : ns - 1, cc = j0 + c < ns ? j0 + c : ns - 1 ;
+                D [r][c] = (r < pc && c < pc) ? F [rr + cc * ld] : (r == c ? 1.0 : 0.0) ;
+            }
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++)
         {
-            double lk = lj [k] ;
-            double *fk = F + k * ld ;
-            for (int i = k + ti ; i < ns ; i += 32) fk [i] -= lj [i] * lk ;
+            double d = D [c][c] ;
+            if (fail < 0 && c < pc && d <= 0.0) fail = j0 + c ;
+            piv [c] = d ;
+            double x = __builtin_amdgcn_rcp (d) ;
+            double e = __builtin_fma (-d, x, 1.0) ;
+            x = __builtin_fma (x, e, x) ;
+            if (fail >= 0) x = 0.0 ;
+            xinv [c] = x ;
+#pragma unroll
+            for (int c2 = c + 1 ; c2 < 8 ; c2++)
+            {
+                double t = D [c2][c] * x ;
+#pragma unroll
+                for (int r = c2 ; r < 8 ; r++) D [r][c2] = __builtin_fma (-t, D [r][c], D [r][c2]) ;
+            }
+        }
+        double rt [8], ri [8] ;
+#pragma unroll
+        for (int c = 0 ; c < 8 ; c++) sqrt_rsqrt (piv [c], rt [c], ri [c]) ;
+        int nvalid = fail >= 0 ? fail - j0 : pc ;           // columns of this panel that exist
+        // own row (rows j0 .. ns-1, one per thread; NT >= ns by construction)
+        int row = j0 + tid ;
+        if (row < ns)
+        {
+            double a [8] ;
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++) a [c] = (c < pc) ? F [row + (j0 + c) * ld] : 0.0 ;
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                double t = a [c] * xinv [c] ;
+#pragma unroll
+                for (int c2 = c + 1 ; c2 < 8 ; c2++) a [c2] = __builtin_fma (-t, D [c2][c], a [c2]) ;
+            }
+#pragma unroll
+            for (int c = 0 ; c < 8 ; c++)
+            {
+                double v = (tid == c) ? rt [c] : a [c] * ri [c] ;
+                if (c >= nvalid) v = 0.0 ;
+                if (c < pc && row >= j0 + c) F [row + (j0 + c) * ld] = v ;
+            }
+        }
+        __syncthreads () ;
+        if (fail >= 0) break ;
+        // trailing tiles over rows / columns t0 .. ns-1
+        int t0 = j0 + pc ;
+        int nd = (ns - t0 + 15) / 16 ;
+        int ntile = nd * (nd + 1) / 2 ;
+        for (int u = wave ; u < ntile ; u += NW)
+        {
+            int tj = 0, rem = u ;
+            while (rem >= nd - tj) { rem -= nd - tj ; tj++ ; }
+            int tiw = tj + rem ;
+            int i0 = t0 + 16 * tiw, c0 = t0 + 16 * tj ;
+            int ir = i0 + lr < ns ? i0 + lr : ns - 1 ;
+            int jr = c0 + lr < ns ? c0 + lr : ns - 1 ;
+            d4 acc ;
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int jc = c0 + lk + 4 * r < ns ? c0 + lk + 4 * r : ns - 1 ;
+                acc [r] = F [ir + jc * ld] ;
+            }
+#pragma unroll
+            for (int kk = 0 ; kk < 8 ; kk += 4)
+            {
+                int k = kk + lk ;
+                double av = (k < pc) ? -F [ir + (j0 + k) * ld] : 0.0 ;
+                double bv = (k < pc) ? F [jr + (j0 + k) * ld] : 0.0 ;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, av, acc, 0, 0, 0) ;
+            }
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int i = i0 + lr, j = c0 + lk + 4 * r ;
+                if (i < ns && j < ns && i >= j) F [i + j * ld] = acc [r] ;
+            }
         }
         __syncthreads () ;
     }
