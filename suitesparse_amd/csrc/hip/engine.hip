@@ -173,6 +173,7 @@ struct cholmod_hip_plan {
     bool force_shared = false ;     // single-rank self test of the exchange path
     std::vector<i32> owner ;
     std::vector<i32> grp0, grpn ;   // ranks [grp0, grp0+grpn) hold front s (grpn == 1: solo)
+    std::vector<char> assign_cb ;   // front's CB is written (not updated) by its first trailing update
     std::vector<i32> my_lvl_ptr, my_lvl_list ;  // this rank's fronts by level
     cholmod_hip_allreduce_fn ar_fn = nullptr ;
     void *ar_user = nullptr ;
@@ -228,7 +229,8 @@ namespace {
 // of fronts (all of one etree level): two-level blocked right-looking Cholesky
 // of the first nscol columns of every front [panel | CB].
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
-    Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world)
+    Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
+    const char *assign_cb = nullptr)
 {
     bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
@@ -276,7 +278,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 double share = G.tile_mul == 1 ? 1.0 : std::min (1.0, (double) mine / (double) cnt) ;
                 L.flops += 2.0 * elems * G.k * share ;
                 L.aux = std::max (L.aux, (int) G.k) ;
-                L.bytes += (16.0 * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
+                L.bytes += ((G.assign ? 8.0 : 16.0) * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
                 S.gg.push_back (G) ;
             }
             L.ng = (int) (S.gg.size () - L.goff) ;
@@ -303,6 +305,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
         G.tile_mul = 1 ; G.tile_add = 0 ;
+        // first update of a contribution block nobody zeroed: C = -A*B'
+        G.assign = (to_cb && kc == 0 && assign_cb && assign_cb [fid]) ? 1 : 0 ;
         if (split && is_shared (fid)) { G.tile_mul = grpn [fid] ; G.tile_add = rank - grp0 [fid] ; }
         bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
@@ -537,6 +541,7 @@ static int build_host (cholmod_hip_plan *P)
     // off the shared region are dealt, largest first, to the least loaded rank
     // of their parent's group (LPT).  Every rank derives the same map.
     P->owner.assign (std::max<i64> (nsuper, 1), 0) ;
+    P->assign_cb.assign (std::max<i64> (nsuper, 1), 0) ;
     P->grp0.assign (std::max<i64> (nsuper, 1), 0) ;
     P->grpn.assign (std::max<i64> (nsuper, 1), 1) ;
     // Self test of the exchange path on one GPU: CHOLMOD_HIP_SHARE_AS_WORLD=k with
@@ -852,35 +857,61 @@ static int build_host (cholmod_hip_plan *P)
         const i32 *ids = gen.data () ;
         int nf = (int) gen.size () ;
         if (nf == 0) continue ;
+        // Contribution blocks of unshared fronts are never zero-filled: their first
+        // trailing update writes C = -L21*L21' (GemmGroup.assign) and the children's
+        // contributions to the CB part are extend-added after the dense phase.  Only
+        // the children's contributions to the PANEL must be in place before it.
+        // (Shared fronts keep the zero-fill: a rank writes only its share of the CB
+        // tiles, the rest must read as zero in its partial sum.)
+        bool can_assign = !(P->flags & (CHOLMOD_HIP_GEMM_VALU | CHOLMOD_HIP_NO_CB_ASSIGN)) ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = P->fr [ids [q]] ;
+            P->assign_cb [ids [q]] = (can_assign && f.ncb > 0 && P->owner [ids [q]] >= 0) ? 1 : 0 ;
+        }
         Launch Lz {K_ZERO, 0, 0, S.zg.size (), 0, 0} ;
         int blocks = 0 ;
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = P->fr [ids [q]] ;
-            if (f.ncb == 0) continue ;
+            if (f.ncb == 0 || P->assign_cb [ids [q]]) continue ;
             S.zg.push_back (ZeroGroup {f.cb, (i64) f.ncb, blocks, 0}) ;
             blocks += (f.ncb + ZERO_COLS - 1) / ZERO_COLS ;
             Lz.bytes += 4.0 * (double) f.ncb * f.ncb ;
         }
         Lz.ng = (int) (S.zg.size () - Lz.goff) ; Lz.grid = blocks ;
         if (Lz.ng) S.launches.push_back (Lz) ;
-        Launch Le {K_EA, 0, 0, S.eg.size (), 0, 0} ;
-        blocks = 0 ;
-        for (int q = 0 ; q < nf ; q++)
+        for (int phase = 0 ; phase < 2 ; phase++)
         {
-            const FrontD &f = P->fr [ids [q]] ;
-            if (f.child_end == f.child_begin) continue ;
-            S.eg.push_back (EaGroup {ids [q], blocks}) ;
-            blocks += (f.nsrow + EA_TW - 1) / EA_TW ;
-            for (int c = f.child_begin ; c < f.child_end ; c++)
+            // phase 0 (before the dense phase): everything into the panel columns, and
+            // into the CB columns of the zero-filled fronts; phase 1 (after it): the CB
+            // columns of the assign fronts
+            Launch Le {K_EA, 0, 0, S.eg.size (), 0, 0} ;
+            blocks = 0 ;
+            for (int q = 0 ; q < nf ; q++)
             {
-                double r = P->fr [P->child [c]].ncb ;
-                Le.bytes += (r * (r + 1) / 2) * 24.0 + 4.0 * r ;   // CB read + target RMW + map
+                const FrontD &f = P->fr [ids [q]] ;
+                if (f.child_end == f.child_begin) continue ;
+                bool asg = P->assign_cb [ids [q]] != 0 ;
+                int lo = phase == 0 ? 0 : f.nscol ;
+                int hi = phase == 0 ? (asg ? f.nscol : f.nsrow) : f.nsrow ;
+                if (phase == 1 && !asg) continue ;
+                if (hi <= lo) continue ;
+                S.eg.push_back (EaGroup {ids [q], blocks, lo, hi}) ;
+                blocks += (hi - lo + EA_TW - 1) / EA_TW ;
+                if (phase == 0)
+                    for (int c = f.child_begin ; c < f.child_end ; c++)
+                    {
+                        double r = P->fr [P->child [c]].ncb ;
+                        Le.bytes += (r * (r + 1) / 2) * 24.0 + 4.0 * r ;   // CB read + target RMW + map
+                    }
             }
+            Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
+            if (Le.ng) S.launches.push_back (Le) ;
+            if (phase == 0)
+                schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->grp0.data (), P->grpn.data (),
+                    P->rank, P->world, P->assign_cb.data ()) ;
         }
-        Le.ng = (int) (S.eg.size () - Le.goff) ; Le.grid = blocks ;
-        if (Le.ng) S.launches.push_back (Le) ;
-        schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->grp0.data (), P->grpn.data (), P->rank, P->world) ;
     }
     return CHOLMOD_HIP_OK ;
 }

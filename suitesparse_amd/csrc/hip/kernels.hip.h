@@ -35,7 +35,7 @@ struct FrontD {
                     // fused small-front kernel does, 0: another rank does
 };
 
-struct EaGroup { i32 front; i32 blk_start; };           // extend-add
+struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi; };   // extend-add into target columns [c_lo, c_hi)
 struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
 struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
 struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
@@ -55,7 +55,7 @@ struct GemmGroup {
     i32 ntiles;                 // tiles of the region (all ranks)
     i32 nblk;                   // blocks this launch spends on the group (this rank)
     i32 swz;                    // 1: XCD-aware super-tile walk (big groups)
-    i32 pad;
+    i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
 };
 
 // Contribution blocks are stored as full squares, ld = ncb (lower part used).
@@ -165,8 +165,8 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &EaGroup::blk_start) ;
     const FrontD &P = fr [g [gi].front] ;
-    int c0 = ((int) blockIdx.x - g [gi].blk_start) * EA_TW ;
-    int c1 = c0 + EA_TW ;
+    int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * EA_TW ;
+    int c1 = c0 + EA_TW < g [gi].c_hi ? c0 + EA_TW : g [gi].c_hi ;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
     i64 Ppsx = P.psx, Pcb = P.cb ;
     int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
@@ -1518,7 +1518,10 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
                 int i = wm * WM + a * 16 + (lane & 15) ;
                 int j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
                 if (i < mrem && j < nrem && (!G.tri || row0 + i >= col0 + j))
-                    C [i + (i64) j * G.ldc] -= acc [a][b][r] ;
+                {
+                    if (G.assign) C [i + (i64) j * G.ldc] = -acc [a][b][r] ;
+                    else C [i + (i64) j * G.ldc] -= acc [a][b][r] ;
+                }
             }
 }
 
