@@ -2006,9 +2006,15 @@ __global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
 // ---- micro-benchmark: issue-bound v_mfma_f64_16x16x4_f64 loop (no memory) ----
 // Measures the fp64 matrix-core ceiling that the roofline is priced against
 // (spec 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 2048 flop / 64 cycles x 2.4 GHz).
-template <int NACC>
+// FILL: what sits between two MFMAs -- 0 nothing, 1 s_nop 3, 2 one independent
+// v_fma_f32, 3 one LDS read (the pattern of a real kernel's operand fetch)
+template <int NACC, int FILL = 0>
 __global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
 {
+    __shared__ double lds_fill [256] ;
+    lds_fill [threadIdx.x] = 1.0 ;
+    float ff = threadIdx.x ;
+    double lacc = 0.0 ;
     d4 acc [NACC] ;
     double a [4], b [4] ;
 #pragma unroll
@@ -2019,9 +2025,14 @@ __global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
     {
 #pragma unroll
         for (int q = 0 ; q < NACC ; q++)
+        {
             acc [q] = __builtin_amdgcn_mfma_f64_16x16x4f64 (a [q & 3], b [(q >> 2) & 3], acc [q], 0, 0, 0) ;
+            if constexpr (FILL == 1) asm volatile ("s_nop 3") ;
+            if constexpr (FILL == 2) { ff = __builtin_fmaf (ff, 1.0001f, 0.5f) ; asm volatile ("" : "+v" (ff)) ; }
+            if constexpr (FILL == 3) { lacc += lds_fill [(threadIdx.x + q + it) & 255] ; }
+        }
     }
-    double sum = 0 ;
+    double sum = lacc + ff ;
 #pragma unroll
     for (int q = 0 ; q < NACC ; q++) sum += acc [q][0] + acc [q][1] + acc [q][2] + acc [q][3] ;
     out [blockIdx.x * 256 + threadIdx.x] = sum ;
