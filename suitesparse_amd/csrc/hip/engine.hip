@@ -778,6 +778,27 @@ static int build_host (cholmod_hip_plan *P)
     for (i64 s = 0 ; s < nsuper ; s++) P->fr [s].cb = best_cb [s] ;
     P->arena = best_arena ;
     P->nsplit = best_nsplit ;
+    if (P->world > 1)
+    {
+        // The batch order above is laid out over ALL fronts so that every rank takes
+        // the same split decision; the arena itself only has to hold the contribution
+        // blocks of this rank's fronts (its subtrees + its shared fronts): lay them
+        // out again over the chosen batches, a fraction of the global footprint.
+        Arena A ;
+        for (const auto &bt : batches)
+        {
+            for (i32 sf : bt) if (mine (sf)) { FrontD &f = P->fr [sf] ; f.cb = A.alloc ((i64) f.ncb * f.ncb) ; }
+            for (i32 sf : bt)
+                if (mine (sf))
+                    for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
+                        if (mine (call [c]))
+                        {
+                            FrontD &g = P->fr [call [c]] ;
+                            A.release (g.cb, (i64) g.ncb * g.ncb) ;
+                        }
+        }
+        P->arena = A.top ;
+    }
     // solve tasks (all supernodes: after cholmod_hip_gather_factor every rank holds L)
     P->sv_tasks.clear () ; P->sv_ptr.assign (nlev + 1, 0) ; P->sv_big.assign (nlev, {}) ;
     for (int l = 0 ; l < nlev ; l++)
@@ -1652,9 +1673,12 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     memset (&G, 0, sizeof (G)) ;
     G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
     G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
-    G.ntiles = (i32) (((m + T - 1) / T) * ((n + T - 1) / T)) ; G.nblk = (G.ntiles + 63) / 64 * 64 ;
+    int TM = T, TN = T ;
+    if (flags & 2048) { TM = 128 ; TN = 64 ; }      // experimental rectangular tiles (non-tri only)
+    if (flags & 4096) { TM = 64 ; TN = 128 ; }
+    G.ntiles = (i32) (((m + TM - 1) / TM) * ((n + TN - 1) / TN)) ; G.nblk = (G.ntiles + 63) / 64 * 64 ;
     G.swz = (flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) ? 0 : 1 ;
-    G.mt = (i32) ((m + T - 1) / T) ; G.nt = (i32) ((n + T - 1) / T) ;
+    G.mt = (i32) ((m + TM - 1) / TM) ; G.nt = (i32) ((n + TN - 1) / TN) ;
     GemmGroup *dg = nullptr ;
     (void) hipMalloc ((void **) &dg, sizeof (G)) ;
     (void) hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice) ;
@@ -1671,6 +1695,10 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 3, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (small && (flags & 1024))
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 2, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (flags & 2048)
+            hipLaunchKernelGGL ((k_update2<128, 64, 16, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (flags & 4096)
+            hipLaunchKernelGGL ((k_update2<64, 128, 16, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (small)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else
