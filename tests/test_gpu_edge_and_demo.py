@@ -144,3 +144,71 @@ def test_c_demo_driver_on_bcsstk01(golden_dir, tmp_path):
     res = float(txt.split("residual")[1].split()[0])
     assert res < 1e-12
     assert "malloc_count 0 memory_inuse 0" in txt
+
+
+def test_big_supernode_block_walk_solves_multi_rhs():
+    """A 1400-column supernode with 100 rows below it (> 1024 columns: the solve
+    walks it in 64-column blocks with the precomputed diagonal-block inverses,
+    k_solve_fwd_blk / k_solve_bwd_blk) followed by a dense 200-column root;
+    three right-hand sides, L / L' / A systems against the oracle."""
+    n1, n2 = 1400, 200
+    n = n1 + n2
+    rng = np.random.default_rng(7)
+    M = rng.standard_normal((n, n)) * 0.05
+    Ad = M @ M.T + np.eye(n) * 4.0
+    mask = np.zeros((n, n), dtype=bool)
+    mask[:n1, :n1] = True
+    mask[n1:, n1:] = True
+    mask[n1 + 100:, :n1] = True            # only the last 100 rows couple to the first block
+    mask[:n1, n1 + 100:] = True
+    Ad = np.where(mask, Ad, 0.0)
+    Ad += np.eye(n) * (np.abs(Ad).sum(axis=1).max())
+    ii, jj = np.nonzero(np.tril(mask))
+    order = np.lexsort((ii, jj))
+    Ai, cols = ii[order].astype(np.int64), jj[order]
+    Ax = Ad[Ai, cols]
+    Ap = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(cols, minlength=n), out=Ap[1:])
+    perm = np.arange(n, dtype=np.int64)
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    assert O.factorize(Ax) == 0
+    assert np.array_equal(fv.super, O.super) and fv.nsuper >= 2
+    assert np.diff(fv.super).max() >= 1400 - 64
+    m = O.lower_mask()
+    assert np.linalg.norm((fv.x - O.x)[m]) <= 1e-12 * np.linalg.norm(O.x[m])
+    b = rng.standard_normal((3, n))
+    y = S.solve(Lf, b, ch.SYS_L)
+    assert np.linalg.norm(y - O.lsolve(b)) / np.linalg.norm(y) < 1e-11
+    z = S.solve(Lf, b, ch.SYS_Lt)
+    assert np.linalg.norm(z - O.ltsolve(b)) / np.linalg.norm(z) < 1e-11
+    x = S.solve(Lf, b)
+    for k in range(3):
+        r = G.sym_matvec(n, Ap, Ai, Ax, -1, x[k]) - b[k]
+        assert np.linalg.norm(r) / np.linalg.norm(b[k]) < 1e-11
+    # a second factorization invalidates the inverses: solve again after refactorizing
+    assert S.factorize(A, Lf) == 1
+    x2 = S.solve(Lf, b[0])
+    assert np.linalg.norm(x2 - x[0]) / np.linalg.norm(x[0]) < 1e-12
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+@pytest.mark.parametrize("seed,n,density", [(1, 400, 0.02), (2, 900, 0.008), (3, 1500, 0.004)])
+def test_random_sparse_spd(seed, n, density):
+    """Unstructured patterns (no grid, no given ordering): natural order plus the
+    reference's postorder; maps bit-exact, factor and residual vs the oracle."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    R = sp.random(n, n, density=density, random_state=seed, format="csr")
+    Asym = (R + R.T).tocsr()
+    Asym.data[:] = -np.abs(Asym.data) - 0.1
+    Asym = Asym + sp.diags(np.asarray(-Asym.sum(axis=1)).ravel() + 1.0)
+    T = sp.tril(Asym).tocsc()
+    T.sort_indices()
+    _check(n, T.indptr.astype(np.int64), T.indices.astype(np.int64), T.data.astype(np.float64), -1, tol=1e-12)
