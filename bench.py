@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--check", action="store_true", help="also solve and print the residual")
     ap.add_argument("--hip-flags", type=int, default=0)
+    ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"],
+                    help="geometric = the nested dissection SURVEY 8d prescribes for the metric (default); "
+                         "builtin = cholmod_l_analyze's own ordering (host/order.c), for information")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) or gloo (ranks sharing a GPU, tests)")
     args = ap.parse_args()
 
@@ -135,7 +138,11 @@ def main():
         n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, m)
         t_gen = time.perf_counter() - t0
         S = ch.Session(factor_on_device=True, hip_flags=args.hip_flags, rank=rank, world=world,
-                       allreduce=allreduce)
+                       allreduce=allreduce, ordering="default")
+        if args.ordering == "builtin":
+            perm = None
+            wname = wname.split("_geometricND")[0] + "_builtinND"
+
         A = S.sparse(n, Ap, Ai, Ax, stype)
         t0 = time.perf_counter()
         Lf = S.analyze(A, perm)

@@ -254,10 +254,23 @@ class Session:
     """One cholmod_common plus convenience wrappers (tests / bench harness)."""
 
     def __init__(self, supernodal=SUPERNODAL, use_gpu=1, print_level=0, postorder=True,
-                 factor_on_device=False, hip_flags=0, rank=0, world=1, allreduce=None):
+                 factor_on_device=False, hip_flags=0, rank=0, world=1, allreduce=None,
+                 ordering="natural"):
+        """ordering (used by analyze() when no permutation is passed): "natural"
+        (the harness default: tests pin results to the oracle's natural order),
+        "default" (cholmod_l_start's strategy: the built-in nested dissection) or
+        "nesdis"."""
         self.L = lib()
         self.cm = Common()
         self.L.cholmod_l_start(C.byref(self.cm))
+        if ordering == "natural":
+            self.cm.nmethods = 1
+            self.cm.method[0].ordering = 0          # CHOLMOD_NATURAL
+        elif ordering == "nesdis":
+            self.cm.nmethods = 1
+            self.cm.method[0].ordering = 4          # CHOLMOD_NESDIS
+        elif ordering != "default":
+            raise ValueError(ordering)
         self.cm.supernodal = supernodal
         self.cm.useGPU = use_gpu
         self.cm.print = print_level

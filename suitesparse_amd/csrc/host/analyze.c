@@ -543,10 +543,11 @@ static int permuted_patterns (cholmod_sparse *A, Int *Perm, cholmod_sparse **U, 
 }
 
 /* reference: Cholesky/cholmod_analyze.c:401-935.  Orderings available in this
- * build: the user's permutation (CHOLMOD_GIVEN) and the natural ordering; the
- * ordering packages (AMD, COLAMD, METIS/NESDIS) are out of scope, so the
- * "try several methods, keep the sparsest" loop (:569-804) reduces to the one
- * candidate at hand.  Then etree, column counts, weighted postorder composed
+ * build: the user's permutation (CHOLMOD_GIVEN), the natural ordering, and a
+ * built-in nested dissection (order.c) that stands in for the ordering packages
+ * (AMD, COLAMD, METIS/NESDIS are not part of this build); the "try several
+ * methods, keep the sparsest" loop (:569-804) reduces to the one candidate at
+ * hand.  Then etree, column counts, weighted postorder composed
  * into L->Perm (:855-906) and the supernodal symbolic factorization (:913-931). */
 cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSparse_long *UserPerm,
     SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
@@ -608,7 +609,22 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
             else for (Int k = 0 ; k < n ; k++) Perm [k] = UserPerm [k] ;
             L->ordering = CHOLMOD_GIVEN ;
         }
-        else L->ordering = CHOLMOD_NATURAL ;
+        else
+        {
+            /* no UserPerm.  Default strategy (nmethods == 0; the reference would try
+             * AMD and METIS, cholmod_analyze.c:569-804) and any explicit request for
+             * an ordering package: the built-in nested dissection (order.c).
+             * method [0].ordering == CHOLMOD_NATURAL (or GIVEN without a
+             * permutation) keeps the natural order. */
+            int want = (Common->nmethods >= 1) ? Common->method [0].ordering : CHOLMOD_NESDIS ;
+            if (want == CHOLMOD_NATURAL || want == CHOLMOD_GIVEN) L->ordering = CHOLMOD_NATURAL ;
+            else
+            {
+                ok = ssamd_nested_dissection (n, A->p, A->i, Perm, Common) ;
+                L->ordering = CHOLMOD_NESDIS ;
+                if (!ok && Common->status == CHOLMOD_OK) ERROR (CHOLMOD_OUT_OF_MEMORY, "ordering failed") ;
+            }
+        }
     }
     ok = ok && permuted_patterns (A, L->Perm, &U, &Lw, Common) ;
     if (ok)

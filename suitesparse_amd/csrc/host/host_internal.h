@@ -34,6 +34,7 @@ void ssamd_colcounts (Int n, const Int *Lp, const Int *Li, const Int *Parent, co
     Int *ColCount, Int *work5n) ;
 
 /* numeric.c */
+int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cholmod_common *Common) ;
 int ssamd_resolve_use_gpu (cholmod_common *Common) ;
 int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common) ;
 
