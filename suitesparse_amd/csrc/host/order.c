@@ -22,6 +22,9 @@
  * O(nnz) per recursion depth. */
 
 #include "host_internal.h"
+#include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define ND_LEAF 96
 
@@ -29,31 +32,49 @@ typedef struct
 {
     Int n ;
     const Int *Gp, *Gi ;    /* symmetric adjacency, no diagonal */
-    Int *mark ;             /* mark [v] == tag: v belongs to the current subset */
-    Int *level ;            /* BFS level (valid for the current component) */
-    Int *queue ;            /* BFS order */
-    Int *out ;              /* permutation under construction */
-    Int nout ;
+    Int *mark ;             /* mark [v] == tag: v belongs to the subset with that tag; -1: ordered */
+    Int *level ;            /* BFS level */
+    Int *visit ;            /* BFS stamps (globally unique), scratch class store */
+    Int *queue ;            /* BFS orders: a subset uses queue [start, start+count) */
+    Int *list ;             /* a subset's vertices: list [start, start+count) */
+    Int *tmp ;              /* scratch, same slicing */
+    Int *Perm ;             /* a subset's slot: Perm [start, start+count) */
+    Int next_tag, next_stamp ;
+    int failed ;
 } ND ;
 
-/* BFS inside the vertices with mark == tag and visit != stamp; returns count,
- * queue [0..count) in BFS order, *height = last level */
-static Int nd_bfs (ND *g, Int root, Int tag, Int *visit, Int stamp, Int *height)
+static Int nd_new_stamp (ND *g) { return __atomic_add_fetch (&g->next_stamp, 1, __ATOMIC_RELAXED) ; }
+static Int nd_new_tag (ND *g) { return __atomic_add_fetch (&g->next_tag, 1, __ATOMIC_RELAXED) ; }
+
+static void nd_process (ND *g, Int start, Int count) ;
+
+/* hand a subset on: an OpenMP task (big subsets) or a plain call */
+static void nd_push (ND *g, Int start, Int count)
+{
+    if (count <= 0) return ;
+    #pragma omp task firstprivate (g, start, count) if (count > 4096)
+    nd_process (g, start, count) ;
+}
+
+/* BFS from root inside the vertices with mark == tag; queue [0..count) in BFS
+ * order, *height = last level; returns the number of vertices reached */
+static Int nd_bfs (ND *g, Int *queue, Int root, Int tag, Int stamp, Int *height)
 {
     Int head = 0, tail = 0 ;
-    g->queue [tail++] = root ; visit [root] = stamp ; g->level [root] = 0 ;
+    Int *visit = g->visit, *level = g->level ;
+    queue [tail++] = root ; visit [root] = stamp ; level [root] = 0 ;
     while (head < tail)
     {
-        Int v = g->queue [head++] ;
+        Int v = queue [head++] ;
         for (Int p = g->Gp [v] ; p < g->Gp [v+1] ; p++)
         {
             Int w = g->Gi [p] ;
             if (g->mark [w] != tag || visit [w] == stamp) continue ;
-            visit [w] = stamp ; g->level [w] = g->level [v] + 1 ;
-            g->queue [tail++] = w ;
+            visit [w] = stamp ; level [w] = level [v] + 1 ;
+            queue [tail++] = w ;
         }
     }
-    *height = g->level [g->queue [tail-1]] ;
+    *height = level [queue [tail-1]] ;
     return tail ;
 }
 
@@ -64,19 +85,155 @@ static Int nd_degree_in (const ND *g, Int v, Int tag)
     return d ;
 }
 
+/* Order one subset: either completely (leaf, small components) or by cutting it
+ * and pushing the parts.  Touches only its own vertices and its own slices of the
+ * position-indexed arrays, so disjoint subsets can be processed concurrently. */
+static void nd_process (ND *g, Int start, Int count)
+{
+    const Int *Gp = g->Gp, *Gi = g->Gi ;
+    Int *S = g->list + start, *queue = g->queue + start, *tmp = g->tmp + start, *Perm = g->Perm + start ;
+    Int *visit = g->visit ;
+    Int tag = nd_new_tag (g) ;
+    for (Int k = 0 ; k < count ; k++) g->mark [S [k]] = tag ;
+    /* connected components, all in one pass (a diagonal matrix has n of them):
+     * small ones are ordered at once (reverse BFS order), big ones are pushed */
+    Int height = 0 ;
+    Int nc = nd_bfs (g, queue, S [0], tag, nd_new_stamp (g), &height) ;
+    if (nc < count)
+    {
+        Int a = 0 ;
+        Int stamp = nd_new_stamp (g) ;
+        for (Int k = 0 ; k < count ; k++)
+        {
+            Int v = S [k] ;
+            if (visit [v] == stamp) continue ;
+            Int h = 0 ;
+            Int c = nd_bfs (g, tmp + a, v, tag, stamp, &h) ;
+            if (c <= ND_LEAF)
+                for (Int q = 0 ; q < c ; q++) { Perm [a + q] = tmp [a + c - 1 - q] ; g->mark [tmp [a + q]] = -1 ; }
+            a += c ;
+        }
+        /* list = components in discovery order; the big ones become subsets of their own */
+        for (Int k = 0 ; k < count ; k++) S [k] = tmp [k] ;
+        for (Int k = 0 ; k < count ; )
+        {
+            Int v = S [k] ;
+            if (g->mark [v] == -1) { k++ ; continue ; }
+            /* a big component occupies a contiguous run of not-yet-ordered vertices that
+             * ends where the next component (ordered or not) begins: recover its length
+             * from the BFS levels -- a component starts at level 0 */
+            Int e = k + 1 ;
+            while (e < count && g->mark [S [e]] != -1 && g->level [S [e]] != 0) e++ ;
+            nd_push (g, start + k, e - k) ;
+            k = e ;
+        }
+        return ;
+    }
+    /* connected subset: pseudo-peripheral root (George-Liu): restart from a
+     * minimum-degree vertex of the last level while the structure gets deeper */
+    if (count > ND_LEAF)
+        for (int sweep = 0 ; sweep < 4 ; sweep++)
+        {
+            Int cand = queue [nc-1], cd = nd_degree_in (g, cand, tag) ;
+            for (Int k = nc - 1 ; k >= 0 && g->level [queue [k]] == height ; k--)
+            {
+                Int d = nd_degree_in (g, queue [k], tag) ;
+                if (d < cd) { cd = d ; cand = queue [k] ; }
+            }
+            Int h2 = 0 ;
+            nd_bfs (g, queue, cand, tag, nd_new_stamp (g), &h2) ;
+            if (h2 <= height) { height = h2 ; break ; }
+            height = h2 ;
+        }
+    if (count <= ND_LEAF || height < 2)
+    {
+        /* leaf (or too "round" to cut, e.g. a clique): reverse Cuthill-McKee from a
+         * pseudo-peripheral vertex of the leaf */
+        Int root = queue [nc-1] ;
+        nd_bfs (g, queue, root, tag, nd_new_stamp (g), &height) ;
+        for (Int k = 0 ; k < count ; k++) Perm [k] = queue [count - 1 - k] ;
+        for (Int k = 0 ; k < count ; k++) g->mark [S [k]] = -1 ;
+        return ;
+    }
+    /* level sizes (queue is in level order) */
+    Int *lsize = tmp ;                  /* height+1 <= count entries */
+    for (Int l = 0 ; l <= height ; l++) lsize [l] = 0 ;
+    for (Int k = 0 ; k < count ; k++) lsize [g->level [queue [k]]]++ ;
+    Int best = -1, bsz = 0 ;
+    {
+        Int cum = 0 ;
+        for (Int l = 1 ; l < height ; l++)
+        {
+            cum += lsize [l-1] ;
+            double frac = (double) cum / (double) count ;
+            if (frac >= 0.3 && frac <= 0.7 && (best < 0 || lsize [l] < bsz)) { best = l ; bsz = lsize [l] ; }
+        }
+        if (best < 0)
+        {
+            /* no level in the balanced window: the level holding the median vertex */
+            cum = 0 ;
+            for (Int l = 1 ; l < height ; l++)
+            {
+                cum += lsize [l-1] ;
+                best = l ;
+                if (2 * (cum + lsize [l]) >= count) break ;
+            }
+        }
+    }
+    /* classify: 0 lower (levels < best, and separator vertices with no neighbour in
+     * level best+1), 1 upper, 2 separator */
+    Int nlow = 0, nup = 0, nsep = 0 ;
+    for (Int k = 0 ; k < count ; k++)
+    {
+        Int v = queue [k], l = g->level [v] ;
+        Int cls = l < best ? 0 : (l > best ? 1 : 2) ;
+        if (cls == 2)
+        {
+            int touches = 0 ;
+            for (Int p = Gp [v] ; p < Gp [v+1] && !touches ; p++)
+            {
+                Int w = Gi [p] ;
+                if (g->mark [w] == tag && g->level [w] == best + 1) touches = 1 ;
+            }
+            if (!touches) cls = 0 ;
+        }
+        visit [v] = -(cls + 1) ;        /* class store: -1, -2, -3 (never a stamp) */
+        if (cls == 0) nlow++ ; else if (cls == 1) nup++ ; else nsep++ ;
+    }
+    /* list = [lower | upper | separator]; the separator is ordered last in the slot */
+    {
+        Int a = 0, b = nlow, c = nlow + nup ;
+        for (Int k = 0 ; k < count ; k++)
+        {
+            Int v = queue [k] ;
+            Int cls = -visit [v] - 1 ;
+            if (cls == 0) tmp [a++] = v ; else if (cls == 1) tmp [b++] = v ; else tmp [c++] = v ;
+        }
+        for (Int k = 0 ; k < count ; k++) { S [k] = tmp [k] ; visit [S [k]] = 0 ; }
+    }
+    for (Int k = 0 ; k < nsep ; k++)
+    {
+        Perm [nlow + nup + k] = S [nlow + nup + k] ;
+        g->mark [S [nlow + nup + k]] = -1 ;
+    }
+    nd_push (g, start + nlow, nup) ;
+    nd_push (g, start, nlow) ;
+}
+
 int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cholmod_common *Common)
 {
     if (n == 0) return TRUE ;
+    double t_graph = omp_get_wtime () ;
     /* symmetric adjacency of the stored triangle */
     Int nz = Ap [n] ;
     Int *Gp = cholmod_l_calloc ((size_t) n + 2, sizeof (Int), Common) ;
     Int *Gi = cholmod_l_malloc ((size_t) (2 * nz + 1), sizeof (Int), Common) ;
-    Int *iw = cholmod_l_malloc ((size_t) (6 * n + 6), sizeof (Int), Common) ;
+    Int *iw = cholmod_l_malloc ((size_t) (8 * n + 8), sizeof (Int), Common) ;
     if (!Gp || !Gi || !iw)
     {
         if (Gp) cholmod_l_free ((size_t) n + 2, sizeof (Int), Gp, Common) ;
         if (Gi) cholmod_l_free ((size_t) (2 * nz + 1), sizeof (Int), Gi, Common) ;
-        if (iw) cholmod_l_free ((size_t) (6 * n + 6), sizeof (Int), iw, Common) ;
+        if (iw) cholmod_l_free ((size_t) (8 * n + 8), sizeof (Int), iw, Common) ;
         return FALSE ;
     }
     for (Int j = 0 ; j < n ; j++)
@@ -98,170 +255,29 @@ int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cho
     }
     ND g ;
     g.n = n ; g.Gp = Gp ; g.Gi = Gi ;
-    g.mark = iw ; g.level = iw + n ; g.queue = iw + 2 * n ; g.out = Perm ; g.nout = 0 ;
-    Int *visit = iw + 3 * n ;           /* BFS stamps */
-    Int *list = iw + 4 * n ;            /* vertex lists of the pending subsets, stack-allocated */
-    Int *tmp = iw + 5 * n ;
-    /* work stack of subsets: (start, count, tag) over `list`; tags are unique */
-    /* (every pop pushes at most two subsets and a leaf pushes none: never more than
-     * n + 1 pending) */
-    Int cap = n + 2, top = 0 ;
-    Int *stk = cholmod_l_malloc ((size_t) (3 * cap), sizeof (Int), Common) ;
-    int ok = stk != NULL ;
-    Int next_tag = 1, stamp = 0 ;
-    for (Int v = 0 ; v < n ; v++) { g.mark [v] = 0 ; visit [v] = 0 ; list [v] = v ; }
-    /* Every subset owns the slot [start, start+count) of both `list` and Perm: its
-     * separator is written to the END of the slot at once, the two parts keep the
-     * front of it and are pushed for later. */
-    if (ok)
+    g.mark = iw ; g.level = iw + n ; g.queue = iw + 2 * n ; g.visit = iw + 3 * n ;
+    g.list = iw + 4 * n ; g.tmp = iw + 5 * n ; g.Perm = Perm ;
+    g.next_tag = 0 ; g.next_stamp = 0 ; g.failed = 0 ;
+    for (Int v = 0 ; v < n ; v++) { g.mark [v] = 0 ; g.visit [v] = 0 ; g.list [v] = v ; }
+    /* Disjoint subsets are independent: every cut spawns its two parts as OpenMP
+     * tasks (small ones run inline).  The result does not depend on the schedule:
+     * a subset's order is a function of its own vertex list.  The team is kept
+     * small; the top of the recursion is serial anyway. */
+    double t_start = omp_get_wtime () ;
+    int nth = omp_get_max_threads () ;
+    if (nth > 16) nth = 16 ;
+    if (n < 20000) nth = 1 ;
+    #pragma omp parallel num_threads (nth)
     {
-        stk [0] = 0 ; stk [1] = n ; stk [2] = 0 ;      /* start in list, count, tag 0 (= everything) */
-        top = 1 ;
+        #pragma omp single
+        nd_process (&g, 0, n) ;
     }
-    /* slot base of a subset == its start in `list` (lists are permuted in place so
-     * that a subset's vertices always occupy list [start, start+count) and Perm
-     * [start, start+count) is its slot) */
-    while (ok && top > 0)
-    {
-        top-- ;
-        Int start = stk [3*top], count = stk [3*top+1], tag = stk [3*top+2] ;
-        Int *S = list + start ;
-        if (count <= 0) continue ;
-        /* (re)mark the subset with its tag */
-        for (Int k = 0 ; k < count ; k++) g.mark [S [k]] = tag ;
-        /* connected components, all in one pass (a diagonal matrix has n of them):
-         * small ones are ordered at once (reverse BFS order), big ones are pushed */
-        stamp++ ;
-        Int height = 0 ;
-        Int nc = nd_bfs (&g, S [0], tag, visit, stamp, &height) ;
-        if (nc < count)
-        {
-            Int *qsave = g.queue ;
-            Int a = 0 ;
-            stamp++ ;
-            for (Int k = 0 ; k < count ; k++)
-            {
-                Int v = S [k] ;
-                if (visit [v] == stamp) continue ;
-                g.queue = tmp + a ;
-                Int h = 0 ;
-                Int c = nd_bfs (&g, v, tag, visit, stamp, &h) ;
-                if (c <= ND_LEAF)
-                {
-                    for (Int q = 0 ; q < c ; q++) { Perm [start + a + q] = tmp [a + c - 1 - q] ; g.mark [tmp [a + q]] = -1 ; }
-                }
-                else
-                {
-                    if (top + 1 > cap) { ok = FALSE ; break ; }
-                    stk [3*top] = start + a ; stk [3*top+1] = c ; stk [3*top+2] = -1 ; top++ ;   /* tag assigned below */
-                }
-                a += c ;
-            }
-            g.queue = qsave ;
-            if (!ok) break ;
-            for (Int k = 0 ; k < count ; k++) S [k] = tmp [k] ;
-            /* fresh tags for the pushed components (top-down over the entries just pushed) */
-            for (Int q = top - 1 ; q >= 0 && stk [3*q+2] == -1 ; q--) stk [3*q+2] = next_tag++ ;
-            continue ;
-        }
-        /* connected subset: pseudo-peripheral root (George-Liu): restart from a
-         * minimum-degree vertex of the last level while the structure gets deeper */
-        if (count > ND_LEAF)
-            for (int sweep = 0 ; sweep < 4 ; sweep++)
-            {
-                Int cand = g.queue [nc-1], cd = nd_degree_in (&g, cand, tag) ;
-                for (Int k = nc - 1 ; k >= 0 && g.level [g.queue [k]] == height ; k--)
-                {
-                    Int d = nd_degree_in (&g, g.queue [k], tag) ;
-                    if (d < cd) { cd = d ; cand = g.queue [k] ; }
-                }
-                Int h2 = 0 ;
-                stamp++ ;
-                nd_bfs (&g, cand, tag, visit, stamp, &h2) ;
-                if (h2 <= height) { height = h2 ; break ; }
-                height = h2 ;
-            }
-        if (count <= ND_LEAF || height < 2)
-        {
-            /* leaf (or too "round" to cut, e.g. a clique): reverse Cuthill-McKee from a
-             * pseudo-peripheral vertex of the leaf */
-            Int root = g.queue [nc-1] ;
-            stamp++ ;
-            nd_bfs (&g, root, tag, visit, stamp, &height) ;
-            for (Int k = 0 ; k < count ; k++) Perm [start + k] = g.queue [count - 1 - k] ;
-            for (Int k = 0 ; k < count ; k++) g.mark [S [k]] = -1 ;    /* done */
-            continue ;
-        }
-        /* level sizes (queue is in level order) */
-        Int *lsize = tmp ;                  /* height+1 entries */
-        for (Int l = 0 ; l <= height ; l++) lsize [l] = 0 ;
-        for (Int k = 0 ; k < count ; k++) lsize [g.level [g.queue [k]]]++ ;
-        Int best = -1, below = 0, bsz = 0 ;
-        {
-            Int cum = 0 ;
-            for (Int l = 1 ; l < height ; l++)
-            {
-                cum += lsize [l-1] ;
-                double frac = (double) cum / (double) count ;
-                if (frac >= 0.3 && frac <= 0.7 && (best < 0 || lsize [l] < bsz)) { best = l ; bsz = lsize [l] ; below = cum ; }
-            }
-            if (best < 0)
-            {
-                /* no level in the balanced window: the level holding the median vertex */
-                cum = 0 ;
-                for (Int l = 1 ; l < height ; l++)
-                {
-                    cum += lsize [l-1] ;
-                    best = l ; below = cum ;
-                    if (2 * (cum + lsize [l]) >= count) break ;
-                }
-            }
-        }
-        (void) below ;
-        /* classify: 0 lower (levels < best, and separator vertices with no neighbour
-         * in level best+1), 1 upper, 2 separator */
-        Int nlow = 0, nup = 0, nsep = 0 ;
-        for (Int k = 0 ; k < count ; k++)
-        {
-            Int v = g.queue [k], l = g.level [v] ;
-            Int cls = l < best ? 0 : (l > best ? 1 : 2) ;
-            if (cls == 2)
-            {
-                int touches = 0 ;
-                for (Int p = Gp [v] ; p < Gp [v+1] && !touches ; p++)
-                {
-                    Int w = Gi [p] ;
-                    if (g.mark [w] == tag && g.level [w] == best + 1) touches = 1 ;
-                }
-                if (!touches) cls = 0 ;
-            }
-            visit [v] = -(cls + 1) ;        /* reuse visit as class store: -1, -2, -3 */
-            if (cls == 0) nlow++ ; else if (cls == 1) nup++ ; else nsep++ ;
-        }
-        /* list = [lower | upper | separator]; the separator goes to the end of the slot */
-        {
-            Int a = 0, b = nlow, c = nlow + nup ;
-            for (Int k = 0 ; k < count ; k++)
-            {
-                Int v = g.queue [k] ;
-                Int cls = -visit [v] - 1 ;
-                if (cls == 0) tmp [a++] = v ; else if (cls == 1) tmp [b++] = v ; else tmp [c++] = v ;
-            }
-            /* tmp also held lsize: it is no longer needed */
-            for (Int k = 0 ; k < count ; k++) { S [k] = tmp [k] ; visit [S [k]] = 0 ; }
-        }
-        for (Int k = 0 ; k < nsep ; k++)
-        {
-            Perm [start + nlow + nup + k] = S [nlow + nup + k] ;
-            g.mark [S [nlow + nup + k]] = -1 ;
-        }
-        if (top + 2 > cap) { ok = FALSE ; break ; }
-        stk [3*top] = start + nlow ; stk [3*top+1] = nup ; stk [3*top+2] = next_tag++ ; top++ ;
-        stk [3*top] = start ; stk [3*top+1] = nlow ; stk [3*top+2] = next_tag++ ; top++ ;
-    }
-    if (stk) cholmod_l_free ((size_t) (3 * cap), sizeof (Int), stk, Common) ;
+    if (getenv ("CHOLMOD_ORDER_TIMING"))
+        fprintf (stderr, "ssamd_nested_dissection: n %ld, %d threads, graph %.3f s, dissection %.3f s\n", (long) n, nth,
+            t_start - t_graph, omp_get_wtime () - t_start) ;
+    int ok = !g.failed ;
     cholmod_l_free ((size_t) n + 2, sizeof (Int), Gp, Common) ;
     cholmod_l_free ((size_t) (2 * nz + 1), sizeof (Int), Gi, Common) ;
-    cholmod_l_free ((size_t) (6 * n + 6), sizeof (Int), iw, Common) ;
+    cholmod_l_free ((size_t) (8 * n + 8), sizeof (Int), iw, Common) ;
     return ok ;
 }
