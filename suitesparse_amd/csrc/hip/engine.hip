@@ -311,6 +311,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
+    bool owner_has_shared = false ;
+    for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) owner_has_shared = true ;
     std::vector<GemmGroup> big, small ;
     auto record_last = [&] () -> int
     {
@@ -376,6 +378,9 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         step.clear () ;
     } ;
     const int nblk_ob = OB / NB ;
+    // panel look-ahead: one GPU only (the second stream stages the exchange otherwise)
+    const bool pla = (flags & CHOLMOD_HIP_PANEL_LOOKAHEAD) && world == 1 && !owner_has_shared && maxnscol > OB ;
+    int ev_rest_prev = -1 ;
     for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
     {
         for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
@@ -450,6 +455,47 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
             emit_step (p * NB >= MB) ;
         }
+        if (pla)
+        {
+            // ---- panel look-ahead (one GPU): the outer update is split in
+            //   U_next(ob): the next outer block column only           (main stream)
+            //   U_rest(ob): everything right of it + the CB            (second stream)
+            // so that the latency-bound panel work of block ob+1 (main stream) runs
+            // beside the big U_rest(ob).  Dependencies: U_rest(ob) after panel(ob)
+            // [event] and after U_rest(ob-1) [stream order]; U_next(ob) after
+            // U_rest(ob-1) [event], which last wrote its target.  The emission order
+            // panel, U_next, U_rest is also a valid serial order (profiling mode).
+            int ev_panel = record_last () ;
+            size_t first = S.launches.size () ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= o0) continue ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                int o2 = std::min (o1 + OB, f.nscol) ;
+                if (o2 > o1) add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, o2 - o1, false, false) ;
+            }
+            flush_updates (big, small) ;
+            if (S.launches.size () > first && ev_rest_prev >= 0) S.launches [first].wait_ev = ev_rest_prev ;
+            first = S.launches.size () ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= o0) continue ;
+                int o1 = std::min (o0 + OB, f.nscol) ;
+                int o2 = std::min (o1 + OB, f.nscol) ;
+                if (f.nscol > o2) add_update (big, small, f, ids [q], o2, o0, o1 - o0, f.nsrow - o2, f.nscol - o2, false, false) ;
+                add_update (big, small, f, ids [q], f.nscol, o0, o1 - o0, f.ncb, f.ncb, true, false) ;
+            }
+            flush_updates (big, small) ;
+            if (S.launches.size () > first)
+            {
+                for (size_t q = first ; q < S.launches.size () ; q++) S.launches [q].stream = 1 ;
+                S.launches [first].wait_ev = ev_panel ;
+                ev_rest_prev = record_last () ;
+            }
+            continue ;
+        }
         // outer trailing update: everything right of the outer block column
         for (int q = 0 ; q < nf ; q++)
         {
@@ -459,6 +505,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             step.push_back (Upd {q, o0, o1 - o0, o1, f.nscol, true}) ;
         }
         emit_step (true) ;
+    }
+    if (pla && ev_rest_prev >= 0)
+    {
+        // the main stream must not run ahead of the second stream's tail
+        Launch Lj {K_JOIN, 0, 0, 0, 0, 0} ;
+        Lj.wait_ev = ev_rest_prev ;
+        S.launches.push_back (Lj) ;
     }
 }
 

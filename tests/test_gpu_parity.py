@@ -32,7 +32,7 @@ def rel_err_lower(x, xref, mask):
 
 @pytest.mark.parametrize("nsrow,nscol", [(7, 7), (40, 13), (64, 64), (65, 64), (200, 100),
                                          (333, 129), (700, 530), (900, 64), (1500, 1100), (2500, 1700)])
-@pytest.mark.parametrize("flags", [0, ch.HIP_GEMM_VALU, 4, 128])
+@pytest.mark.parametrize("flags", [0, ch.HIP_GEMM_VALU, 4, 128, 4096, 64 | 4096])   # 4096: panel look-ahead (64: 512-wide outer blocks)
 def test_dense_partial_factorization(L, nsrow, nscol, flags):
     rng = np.random.default_rng(nsrow * 1000 + nscol)
     M = rng.standard_normal((nsrow, nsrow))
