@@ -13,7 +13,8 @@
  *
  * Algorithm, for a vertex subset S of the graph of A+A':
  *   - split S into connected components; each is ordered on its own;
- *   - |S| <= leaf: reverse Cuthill-McKee order inside the leaf;
+ *   - |S| <= leaf (96): exact minimum degree on the piece (bit-mask elimination
+ *     graph); a larger piece that cannot be cut (a clique): reverse Cuthill-McKee;
  *   - else: pseudo-peripheral root by repeated BFS (George-Liu), level
  *     structure L_0..L_h; the separator is the smallest level among those that
  *     leave 30..70 % of the vertices below it (or the median level); separator
@@ -45,6 +46,55 @@ typedef struct
 
 static Int nd_new_stamp (ND *g) { return __atomic_add_fetch (&g->next_stamp, 1, __ATOMIC_RELAXED) ; }
 static Int nd_new_tag (ND *g) { return __atomic_add_fetch (&g->next_tag, 1, __ATOMIC_RELAXED) ; }
+
+/* Minimum-degree order of a small connected piece (count <= ND_LEAF <= 128
+ * vertices) on its induced subgraph: the elimination graph is kept exactly, as
+ * one 128-bit adjacency mask per vertex (a pivot's neighbours become a clique).
+ * Ties go to the vertex met first.  verts [] is overwritten with the order. */
+static void nd_leaf_min_degree (ND *g, Int *verts, Int count, Int tag, Int *out)
+{
+    unsigned long long lo [ND_LEAF], hi [ND_LEAF] ;
+    for (Int k = 0 ; k < count ; k++) g->level [verts [k]] = k ;       /* local ids (we own these vertices) */
+    for (Int k = 0 ; k < count ; k++)
+    {
+        Int v = verts [k] ;
+        unsigned long long a = 0, b = 0 ;
+        for (Int p = g->Gp [v] ; p < g->Gp [v+1] ; p++)
+        {
+            Int w = g->Gi [p] ;
+            if (g->mark [w] != tag) continue ;
+            Int id = g->level [w] ;
+            if (id < 64) a |= 1ull << id ; else b |= 1ull << (id - 64) ;
+        }
+        lo [k] = a ; hi [k] = b ;
+    }
+    unsigned long long alive_lo = count >= 64 ? ~0ull : ((1ull << count) - 1) ;
+    unsigned long long alive_hi = count > 64 ? (count >= 128 ? ~0ull : ((1ull << (count - 64)) - 1)) : 0 ;
+    for (Int step = 0 ; step < count ; step++)
+    {
+        int best = -1, bd = 1 << 30 ;
+        for (int k = 0 ; k < (int) count ; k++)
+        {
+            int al = k < 64 ? (int) ((alive_lo >> k) & 1) : (int) ((alive_hi >> (k - 64)) & 1) ;
+            if (!al) continue ;
+            int d = __builtin_popcountll (lo [k] & alive_lo) + __builtin_popcountll (hi [k] & alive_hi) ;
+            if (d < bd) { bd = d ; best = k ; }
+        }
+        out [step] = verts [best] ;
+        if (best < 64) alive_lo &= ~(1ull << best) ; else alive_hi &= ~(1ull << (best - 64)) ;
+        unsigned long long nl = lo [best] & alive_lo, nh = hi [best] & alive_hi ;
+        for (unsigned long long m = nl ; m ; m &= m - 1)
+        {
+            int u = __builtin_ctzll (m) ;
+            lo [u] = (lo [u] | nl) & ~(1ull << u) ; hi [u] |= nh ;
+        }
+        for (unsigned long long m = nh ; m ; m &= m - 1)
+        {
+            int u = 64 + __builtin_ctzll (m) ;
+            lo [u] |= nl ; hi [u] = (hi [u] | nh) & ~(1ull << (u - 64)) ;
+        }
+    }
+}
 
 static void nd_process (ND *g, Int start, Int count) ;
 
@@ -110,7 +160,10 @@ static void nd_process (ND *g, Int start, Int count)
             Int h = 0 ;
             Int c = nd_bfs (g, tmp + a, v, tag, stamp, &h) ;
             if (c <= ND_LEAF)
-                for (Int q = 0 ; q < c ; q++) { Perm [a + q] = tmp [a + c - 1 - q] ; g->mark [tmp [a + q]] = -1 ; }
+            {
+                nd_leaf_min_degree (g, tmp + a, c, tag, Perm + a) ;
+                for (Int q = 0 ; q < c ; q++) g->mark [tmp [a + q]] = -1 ;
+            }
             a += c ;
         }
         /* list = components in discovery order; the big ones become subsets of their own */
@@ -147,8 +200,15 @@ static void nd_process (ND *g, Int start, Int count)
         }
     if (count <= ND_LEAF || height < 2)
     {
-        /* leaf (or too "round" to cut, e.g. a clique): reverse Cuthill-McKee from a
-         * pseudo-peripheral vertex of the leaf */
+        if (count <= ND_LEAF)
+        {
+            /* leaf: exact minimum degree on the piece */
+            nd_leaf_min_degree (g, queue, count, tag, Perm) ;
+            for (Int k = 0 ; k < count ; k++) g->mark [S [k]] = -1 ;
+            return ;
+        }
+        /* too "round" to cut (e.g. a clique): reverse Cuthill-McKee from a
+         * pseudo-peripheral vertex */
         Int root = queue [nc-1] ;
         nd_bfs (g, queue, root, tag, nd_new_stamp (g), &height) ;
         for (Int k = 0 ; k < count ; k++) Perm [k] = queue [count - 1 - k] ;
