@@ -215,19 +215,22 @@ def main():
         if ps[6] > 0:
             ach = ps[8] / ps[6] / 1e12
             traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01c_pmc_summary.json")
+            pmc = os.path.join(ROOT, "profiles", "r01j_pmc_summary.json")
             if os.path.exists(pmc):
                 # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc
                 # passes of this same command (offline; see profiles/README.md)
                 pj = json.load(open(pmc))
                 if pj.get("workload") == wname and world == 1:
                     traffic = pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch"]
-                    traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01c_pmc_summary.json"
+                    traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01j_pmc_summary.json"
                 else:
-                    traffic_note = ("no PMC pass at this size (serialised counter collection over 9392 launches of a "
-                                    "181 GB factor exceeds the GPU-time budget); on the 100^3 workload the same kernel "
-                                    "moves 317 MB fetch + 215 MB write per launch against 399 MB algorithmic "
-                                    "(profiles/r01c_pmc_summary.json)")
+                    traffic_note = ("no PMC pass at this size (serialised counter collection over the 9274 update "
+                                    "launches of a 181 GB factor did not finish in 17 minutes even when restricted "
+                                    "to this kernel); on the 100^3 workload the same kernel moves "
+                                    f"{pj['fetch_bytes_per_launch_raw'] / 1e6:.0f} MB fetch + "
+                                    f"{pj['write_bytes_per_launch'] / 1e6:.0f} MB write per launch "
+                                    "(profiles/r01j_pmc_summary.json; bench.py --grid 100 prints it beside the "
+                                    "algorithmic bytes)")
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note,
