@@ -44,8 +44,7 @@ extern "C" {
 #define CHOLMOD_HIP_NO_XCD_SWIZZLE 32    /* tuning: plain block -> tile order          */
 #define CHOLMOD_HIP_FIXED_OB       64    /* tuning: 512-column outer blocks everywhere  */
 #define CHOLMOD_HIP_WIDE_OB       128    /* tests: 2048-column outer blocks everywhere  */
-#define CHOLMOD_HIP_PANEL_LOOKAHEAD 4096  /* tuning (one GPU): panel of the next outer block
-                                           column beside the rest of the trailing update */
+#define CHOLMOD_HIP_PANEL_LOOKAHEAD 4096  /* accepted and ignored, like CHOLMOD_HIP_LOOKAHEAD */
 #define CHOLMOD_HIP_NO_CB_ASSIGN   2048   /* tuning: zero-fill every contribution block and
                                            extend-add before the dense phase           */
 #define CHOLMOD_HIP_POTRF_VALU    1024    /* debug: single-wave diagonal-block Cholesky  */

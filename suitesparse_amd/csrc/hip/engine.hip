@@ -240,7 +240,14 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         maxnscol = std::max (maxnscol, fr [ids [q]].nscol) ;
         maxrows = std::max (maxrows, fr [ids [q]].nsrow) ;
     }
-    const int OB = (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (maxrows) ;
+    // Outer block width: a property of the FRONT (its row count), not of the batch --
+    // the ranks of a multi-GPU group see different batches around the same shared
+    // front and must cut its updates into the same regions.
+    auto ob_of = [&] (const FrontD &f) -> int
+    {
+        return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow) ;
+    } ;
+    (void) maxrows ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
         for (int pass = 0 ; pass < 2 ; pass++)
@@ -311,8 +318,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
-    bool owner_has_shared = false ;
-    for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) owner_has_shared = true ;
     std::vector<GemmGroup> big, small ;
     auto record_last = [&] () -> int
     {
@@ -343,15 +348,15 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the in-front columns [t0, t1) (all rows from t0 down) and, if cb, the
     // contribution block.  Steps with kk >= MB are `wide`: their tiles are dealt
     // over the rank group of a shared front and they feed the exchange look-ahead.
-    struct Upd { int q, kc, kk, t0, t1 ; bool cb ; } ;
+    struct Upd { int q, kc, kk, t0, t1 ; bool cb, wide ; } ;
     std::vector<Upd> step ;
-    auto emit_step = [&] (bool wide)
+    auto emit_step = [&] ()
     {
         bool any_next = false ;
-        if (wide && xla)
+        if (xla)
             for (const Upd &x : step)
             {
-                if (!is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
+                if (!x.wide || !is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
                 const FrontD &f = fr [ids [x.q]] ;
                 int tn = std::min (x.t0 + MB, x.t1) ;
                 add_update (big, small, f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
@@ -363,155 +368,98 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         {
             const FrontD &f = fr [ids [x.q]] ;
             int c0 = x.t0 ;
-            if (any_next && is_shared (ids [x.q]) && x.t1 > x.t0) c0 = std::min (x.t0 + MB, x.t1) ;
-            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, wide) ;
-            if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, wide) ;
+            bool ahead = any_next && x.wide && is_shared (ids [x.q]) && x.t1 > x.t0 ;
+            if (ahead) c0 = std::min (x.t0 + MB, x.t1) ;
+            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide) ;
+            if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
         }
         flush_updates (big, small) ;
         if (any_next)
             for (const Upd &x : step)
             {
-                if (!is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
+                if (!x.wide || !is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
                 emit_ar (x.q, x.t0, std::min (x.t0 + MB, x.t1), ev_next) ;
                 early [x.q] = x.t0 ;
             }
         step.clear () ;
     } ;
-    const int nblk_ob = OB / NB ;
-    // panel look-ahead: one GPU only (the second stream stages the exchange otherwise)
-    const bool pla = (flags & CHOLMOD_HIP_PANEL_LOOKAHEAD) && world == 1 && !owner_has_shared && maxnscol > OB ;
-    int ev_rest_prev = -1 ;
-    for (int o0 = 0 ; o0 < maxnscol ; o0 += OB)
+    for (int i0 = 0 ; i0 < maxnscol ; i0 += NB)
     {
-        for (int i0 = o0 ; i0 < std::min (o0 + OB, maxnscol) ; i0 += NB)
+        // ---- multi-GPU: a 512-column block column of a shared front holds per-rank
+        // partial sums (extend-adds of the rank's own subtrees + its share of the
+        // earlier wide update tiles); sum them before it is factored.  Only rows
+        // >= i0 carry data (above lies the dead upper triangle): they are packed
+        // into a staging buffer, halving the volume for the root.
+        if (i0 % MB == 0)
         {
-            // ---- multi-GPU: a 512-column block column of a shared front holds
-            // per-rank partial sums (extend-adds of the rank's own subtrees + its
-            // share of the earlier wide update tiles); sum them before it is
-            // factored.  Only rows >= i0 carry data (above lies the dead upper
-            // triangle): they are packed into a staging buffer, halving the volume
-            // for the root.
-            if ((i0 - o0) % MB == 0)
-            {
-                for (int q = 0 ; q < nf ; q++)
-                {
-                    const FrontD &f = fr [ids [q]] ;
-                    if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
-                    emit_ar (q, i0, std::min (i0 + MB, std::min (o0 + OB, f.nscol)), -1) ;
-                }
-            }
-            // potrf of the diagonal blocks
-            Launch Lp {K_POTRF, 0, 0, S.pg.size (), 0, 0} ;
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= i0) continue ;
-                int nb = std::min (NB, f.nscol - i0) ;
-                PfGroup G {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, nb, ids [q], i0} ;
-                S.pg.push_back (G) ;
-                Lp.flops += (double) nb * nb * nb / 3.0 ;
+                if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
+                emit_ar (q, i0, std::min (i0 + MB, f.nscol), -1) ;
             }
-            Lp.ng = Lp.grid = (int) (S.pg.size () - Lp.goff) ;
-            if (Lp.ng) S.launches.push_back (Lp) ;
-            // trsm of the rows below
-            Launch Lt {K_TRSM, 0, 0, S.tg.size (), 0, 0} ;
-            int blocks = 0 ;
-            for (int q = 0 ; q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= i0) continue ;
-                int nb = std::min (NB, f.nscol - i0) ;
-                int m = f.nsrow - (i0 + nb) ;
-                if (m <= 0) continue ;
-                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
-                           f.psx + (i0 + nb) + (i64) i0 * f.nsrow, f.nsrow, m, nb,
-                           ids [q], i0, blocks} ;
-                blocks += (m + TR_ROWS - 1) / TR_ROWS ;
-                S.tg.push_back (G) ;
-                Lt.flops += (double) m * nb * nb ;
-                Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
-            }
-            Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
-            if (Lt.ng) S.launches.push_back (Lt) ;
-            // ---- trailing updates inside the outer block column: recursive
-            // doubling.  With e 64-column blocks of it factored and p the largest
-            // power of two dividing e, the last p blocks (K = 64 p) update the
-            // next p blocks only.  Every column block is then read-modified-
-            // written log2 times instead of once per 64-column step (768 instead
-            // of 1792 column sweeps per 512 columns), with K up to OB/2 instead of
-            // 64 / 512 on the matrix cores.
-            int e = (i0 - o0) / NB + 1 ;
-            int p = e & -e ;
-            if (e >= nblk_ob) continue ;            // block column complete: outer update below
-            for (int q = 0 ; q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                int t0 = o0 + e * NB ;
-                if (o1 <= t0) continue ;            // this front has no columns left in the block
-                int t1 = std::min (o0 + (e + p) * NB, o1) ;
-                int kc = o0 + (e - p) * NB ;
-                step.push_back (Upd {q, kc, t0 - kc, t0, t1, false}) ;
-            }
-            emit_step (p * NB >= MB) ;
         }
-        if (pla)
-        {
-            // ---- panel look-ahead (one GPU): the outer update is split in
-            //   U_next(ob): the next outer block column only           (main stream)
-            //   U_rest(ob): everything right of it + the CB            (second stream)
-            // so that the latency-bound panel work of block ob+1 (main stream) runs
-            // beside the big U_rest(ob).  Dependencies: U_rest(ob) after panel(ob)
-            // [event] and after U_rest(ob-1) [stream order]; U_next(ob) after
-            // U_rest(ob-1) [event], which last wrote its target.  The emission order
-            // panel, U_next, U_rest is also a valid serial order (profiling mode).
-            int ev_panel = record_last () ;
-            size_t first = S.launches.size () ;
-            for (int q = 0 ; q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= o0) continue ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                int o2 = std::min (o1 + OB, f.nscol) ;
-                if (o2 > o1) add_update (big, small, f, ids [q], o1, o0, o1 - o0, f.nsrow - o1, o2 - o1, false, false) ;
-            }
-            flush_updates (big, small) ;
-            if (S.launches.size () > first && ev_rest_prev >= 0) S.launches [first].wait_ev = ev_rest_prev ;
-            first = S.launches.size () ;
-            for (int q = 0 ; q < nf ; q++)
-            {
-                const FrontD &f = fr [ids [q]] ;
-                if (f.nscol <= o0) continue ;
-                int o1 = std::min (o0 + OB, f.nscol) ;
-                int o2 = std::min (o1 + OB, f.nscol) ;
-                if (f.nscol > o2) add_update (big, small, f, ids [q], o2, o0, o1 - o0, f.nsrow - o2, f.nscol - o2, false, false) ;
-                add_update (big, small, f, ids [q], f.nscol, o0, o1 - o0, f.ncb, f.ncb, true, false) ;
-            }
-            flush_updates (big, small) ;
-            if (S.launches.size () > first)
-            {
-                for (size_t q = first ; q < S.launches.size () ; q++) S.launches [q].stream = 1 ;
-                S.launches [first].wait_ev = ev_panel ;
-                ev_rest_prev = record_last () ;
-            }
-            continue ;
-        }
-        // outer trailing update: everything right of the outer block column
+        // potrf of the diagonal blocks
+        Launch Lp {K_POTRF, 0, 0, S.pg.size (), 0, 0} ;
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
-            if (f.nscol <= o0) continue ;
-            int o1 = std::min (o0 + OB, f.nscol) ;
-            step.push_back (Upd {q, o0, o1 - o0, o1, f.nscol, true}) ;
+            if (f.nscol <= i0) continue ;
+            int nb = std::min (NB, f.nscol - i0) ;
+            PfGroup G {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, nb, ids [q], i0} ;
+            S.pg.push_back (G) ;
+            Lp.flops += (double) nb * nb * nb / 3.0 ;
         }
-        emit_step (true) ;
-    }
-    if (pla && ev_rest_prev >= 0)
-    {
-        // the main stream must not run ahead of the second stream's tail
-        Launch Lj {K_JOIN, 0, 0, 0, 0, 0} ;
-        Lj.wait_ev = ev_rest_prev ;
-        S.launches.push_back (Lj) ;
+        Lp.ng = Lp.grid = (int) (S.pg.size () - Lp.goff) ;
+        if (Lp.ng) S.launches.push_back (Lp) ;
+        // trsm of the rows below
+        Launch Lt {K_TRSM, 0, 0, S.tg.size (), 0, 0} ;
+        int blocks = 0 ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= i0) continue ;
+            int nb = std::min (NB, f.nscol - i0) ;
+            int m = f.nsrow - (i0 + nb) ;
+            if (m <= 0) continue ;
+            TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
+                       f.psx + (i0 + nb) + (i64) i0 * f.nsrow, f.nsrow, m, nb,
+                       ids [q], i0, blocks} ;
+            blocks += (m + TR_ROWS - 1) / TR_ROWS ;
+            S.tg.push_back (G) ;
+            Lt.flops += (double) m * nb * nb ;
+            Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
+        }
+        Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
+        if (Lt.ng) S.launches.push_back (Lt) ;
+        // ---- trailing updates.  Inside an outer block column of the front (OB
+        // columns, ob_of): recursive doubling -- with e 64-column blocks of it
+        // factored and p the largest power of two dividing e, the last p blocks
+        // (K = 64 p) update the next p blocks only; every column block is then
+        // read-modified-written log2 times instead of once per 64-column step (768
+        // instead of 1792 column sweeps per 512 columns), with K up to OB/2 on the
+        // matrix cores.  When the outer block column (or the front) is complete:
+        // one K = OB update of everything to its right, contribution block included.
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= i0) continue ;
+            int OBq = ob_of (f) ;
+            int o0 = (i0 / OBq) * OBq ;
+            int o1 = std::min (o0 + OBq, f.nscol) ;
+            if (i0 + NB >= o1)
+            {
+                step.push_back (Upd {q, o0, o1 - o0, o1, f.nscol, true, true}) ;
+                continue ;
+            }
+            int e = (i0 - o0) / NB + 1 ;
+            int p = e & -e ;
+            int t0 = o0 + e * NB ;
+            int t1 = std::min (o0 + (e + p) * NB, o1) ;
+            int kc = o0 + (e - p) * NB ;
+            step.push_back (Upd {q, kc, t0 - kc, t0, t1, false, p * NB >= MB}) ;
+        }
+        emit_step () ;
     }
 }
 
