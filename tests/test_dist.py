@@ -201,3 +201,14 @@ def test_distributed_rank_subgroups():
     for r in res:
         sizes.update(r["allreduce_group_sizes"])
     assert 4 in sizes and (2 in sizes or 3 in sizes), sizes
+
+
+@pytest.mark.gpu
+def test_distributed_with_mixed_outer_block_widths():
+    """Outer block width is per front: with the row thresholds lowered, the root
+    (1609 rows) is cut in 2048-wide, its children in 1024-wide and the rest in
+    512-wide outer block columns inside the same batches, on every rank alike."""
+    res = _run_ranks(4, "gpu", "p3d_32", extra_env={"CHOLMOD_HIP_OB1024_ROWS": "500",
+                                                     "CHOLMOD_HIP_OB2048_ROWS": "1200"})
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
