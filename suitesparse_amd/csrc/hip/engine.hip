@@ -180,11 +180,10 @@ struct cholmod_hip_plan {
     double *d_xchg = nullptr ;
     double *d_stage = nullptr ;             // packed block-column slab for the all-reduce
     // triangular solves: per level, the supernodes one workgroup handles whole
-    // and the big ones walked in SOLVE_SB-column blocks by many workgroups
+    // and the big ones walked in SOLVE_SB-column blocks by many workgroups (k_solve_*_blk)
     std::vector<SolveTask> sv_tasks ;       // [whole-supernode tasks by level | block tasks]
     std::vector<i32> sv_ptr ;               // level -> range of whole-supernode tasks
     std::vector<std::vector<i32>> sv_big ;  // level -> big supernodes
-    std::vector<i64> sv_blk ;               // (front, jb) -> index of its diagonal block task
     SolveTask *d_sv = nullptr ;
     // explicit inverses of the 64x64 diagonal blocks of the big supernodes (solve
     // only; built lazily after each factorization, see k_diag_inv64)
@@ -815,7 +814,6 @@ static int build_host (cholmod_hip_plan *P)
         }
         P->sv_ptr [l+1] = (i32) P->sv_tasks.size () ;
     }
-    P->sv_blk.assign (std::max<i64> (nsuper, 1), -1) ;
     P->inv_tasks.clear () ; P->inv_first.assign (std::max<i64> (nsuper, 1), -1) ; P->max_big_nscol = 0 ;
     for (int l = 0 ; l < nlev ; l++)
         for (i32 sid : P->sv_big [l])

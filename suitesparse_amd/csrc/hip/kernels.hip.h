@@ -1615,43 +1615,9 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
     }
 }
 
-// big supernodes, forward: rows below a solved column block [jb,jb+w) get
-// y(i) -= L(i, jb:jb+w) * x1(jb:jb+w); one thread per row, many workgroups
+// column block of the big-supernode walk (k_solve_fwd_blk / k_solve_bwd_blk below)
 #define SOLVE_SB 64          /* column block of the big-front walk */
 #define SOLVE_BIG_COLS 1024  /* fronts wider than this (or > 16 MB) take the multi-workgroup walk */
-__global__ void __launch_bounds__(256) k_solve_fwd_update (int fid, int jb, int w,
-    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
-{
-    __shared__ double xs [SOLVE_SB] ;
-    const FrontD &f = fr [fid] ;
-    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
-    const double *L = Lx + f.psx ;
-    const i64 *rows = Ls + f.psi ;
-    int i = jb + w + (int) blockIdx.x * 256 + tid ;
-    for (int r = 0 ; r < nrhs ; r++)
-    {
-        double *x = X + (i64) r * ldx ;
-        for (int c = tid ; c < w ; c += 256) xs [c] = x [k1 + jb + c] ;
-        __syncthreads () ;
-        if (i < nsrow)
-        {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
-            const double *Li = L + i + (i64) jb * nsrow ;
-            int c = 0 ;
-            for ( ; c + 4 <= w ; c += 4)
-            {
-                double l0 = Li [(i64) c * nsrow], l1 = Li [(i64) (c + 1) * nsrow] ;
-                double l2 = Li [(i64) (c + 2) * nsrow], l3 = Li [(i64) (c + 3) * nsrow] ;
-                a0 += l0 * xs [c] ; a1 += l1 * xs [c + 1] ; a2 += l2 * xs [c + 2] ; a3 += l3 * xs [c + 3] ;
-            }
-            for ( ; c < w ; c++) a0 += Li [(i64) c * nsrow] * xs [c] ;
-            double acc = (a0 + a1) + (a2 + a3) ;
-            if (i < nscol) x [k1 + i] -= acc ;
-            else atomicAdd (&x [rows [i]], -acc) ;
-        }
-        __syncthreads () ;
-    }
-}
 
 __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
@@ -1739,50 +1705,6 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
     }
 }
 
-// big supernodes, backward: x1(jb:jb+w) -= L(i, jb:jb+w)' * y(i) over the rows
-// i >= jb+w; a workgroup owns 256 rows, a wave walks the columns (rows
-// contiguous -> coalesced), partial sums meet in x1 by atomic add
-__global__ void __launch_bounds__(256) k_solve_bwd_update (int fid, int jb, int w,
-    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
-{
-    __shared__ double yv [256] ;
-    const FrontD &f = fr [fid] ;
-    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
-    int lane = tid & 63, wave = tid >> 6 ;
-    const double *L = Lx + f.psx ;
-    const i64 *rows = Ls + f.psi ;
-    int r0 = jb + w + (int) blockIdx.x * 256 ;
-    int nr = nsrow - r0 < 256 ? nsrow - r0 : 256 ;
-    for (int r = 0 ; r < nrhs ; r++)
-    {
-        double *x = X + (i64) r * ldx ;
-        int i = r0 + tid ;
-        yv [tid] = (tid < nr) ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
-        __syncthreads () ;
-        for (int c = wave * 4 ; c < w ; c += 16)
-        {
-            // four columns per wave at once: 16 independent loads per lane
-            double v [4][4] ;
-#pragma unroll
-            for (int cc = 0 ; cc < 4 ; cc++)
-            {
-                const double *Lc = L + r0 + (i64) (jb + (c + cc < w ? c + cc : w - 1)) * nsrow ;
-#pragma unroll
-                for (int u = 0 ; u < 4 ; u++) { int q = lane + 64 * u ; v [cc][u] = (q < nr) ? Lc [q] : 0.0 ; }
-            }
-#pragma unroll
-            for (int cc = 0 ; cc < 4 ; cc++)
-            {
-                double acc = 0.0 ;
-#pragma unroll
-                for (int u = 0 ; u < 4 ; u++) acc += v [cc][u] * yv [lane + 64 * u] ;
-                for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
-                if (lane == 0 && c + cc < w) atomicAdd (&x [k1 + jb + c + cc], -acc) ;
-            }
-        }
-        __syncthreads () ;
-    }
-}
 
 // ---- big supernodes, third generation: one launch per 64-column block --------
 // The 64x64 diagonal blocks of the big supernodes are inverted once per
