@@ -1,4 +1,4 @@
-"""A short randomised parity run (tools/fuzz.py: random SPD patterns, orderings,
+"""A short randomised parity run (tests/fuzz_runner.py: random SPD patterns, orderings,
 not-positive-definite injections, plan flags, 1-3 right-hand sides) against the oracle."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [3, 11])
 def test_randomised_parity(seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz.py"), "40", str(seed)],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_runner.py"), "40", str(seed)],
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "40 cases, 0 failures" in out.stdout, out.stdout[-2000:]
