@@ -262,6 +262,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_m)
         mf = lib.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
+        mf_big = lib.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 0)
         mpeak = lib.cholmod_hip_bench_mfma_peak(2, 20000)
         value = fl * args.steps / elapsed / 1e9        # one job, all ranks together
         line = {
@@ -282,6 +283,7 @@ def main():
             "pct_fp64_mfma_peak_per_gpu": 100.0 * value / world / (1e3 * FP64_MFMA_PEAK_TFLOPS),
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "measured_update_kernel_TFLOPs_8192x8192x512": mf / 1e12 if mf > 0 else None,
+            "measured_update_kernel_TFLOPs_16384x16384x4096": mf_big / 1e12 if mf_big > 0 else None,
             "measured_mfma_f64_16x16x4_issue_peak_TFLOPs": mpeak / 1e12 if mpeak > 0 else None,
             "roofline": roof, "cpu_baseline": cpu,
             "host_seconds": {"generate": t_gen, "analyze": t_analyze, "first_factorize_incl_plan_h2d": t_first},
