@@ -10,6 +10,9 @@
  * cholmod_rowcolcounts.c, cholmod_analyze.c; CHOLMOD/Supernodal/
  * cholmod_super_symbolic.c. */
 #include "host_internal.h"
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 /* ---- elimination tree ------------------------------------------------------------ */
 
@@ -549,6 +552,13 @@ static int permuted_patterns (cholmod_sparse *A, Int *Perm, cholmod_sparse **U, 
  * methods, keep the sparsest" loop (:569-804) reduces to the one candidate at
  * hand.  Then etree, column counts, weighted postorder composed
  * into L->Perm (:855-906) and the supernodal symbolic factorization (:913-931). */
+static double ssamd_now (void)
+{
+    struct timespec ts ;
+    clock_gettime (CLOCK_MONOTONIC, &ts) ;
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec ;
+}
+
 cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSparse_long *UserPerm,
     SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
 {
@@ -556,6 +566,8 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
     RETURN_IF_NULL (A, NULL) ;
     (void) fset ; (void) fsize ;
     Common->status = CHOLMOD_OK ;
+    const int timing = getenv ("CHOLMOD_ANALYZE_TIMING") != NULL ;
+    double tt [8] ; tt [0] = ssamd_now () ;
     if (A->stype == 0)
     {
         ERROR (CHOLMOD_NOT_INSTALLED, "analysis of A*A' (stype 0) not built") ;
@@ -626,7 +638,9 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
             }
         }
     }
+    tt [1] = ssamd_now () ;
     ok = ok && permuted_patterns (A, L->Perm, &U, &Lw, Common) ;
+    tt [2] = ssamd_now () ;
     if (ok)
     {
         Int *Perm = L->Perm, *ColCount = L->ColCount ;
@@ -665,7 +679,12 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
             }
         }
     }
+    tt [3] = ssamd_now () ;
     if (ok) ok = cholmod_l_super_symbolic2 (for_whom, U, NULL, Parent, L, Common) ;
+    tt [4] = ssamd_now () ;
+    if (timing)
+        fprintf (stderr, "cholmod_l_analyze: ordering %.3f s, permute %.3f s, etree+colcounts+postorder(+re-permute) %.3f s, super_symbolic %.3f s\n",
+            tt [1] - tt [0], tt [2] - tt [1], tt [3] - tt [2], tt [4] - tt [3]) ;
     cholmod_l_free_sparse (&U, Common) ;
     cholmod_l_free_sparse (&Lw, Common) ;
     if (Parent) cholmod_l_free (n + 1, sizeof (Int), Parent, Common) ;
