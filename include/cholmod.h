@@ -301,6 +301,12 @@ int cholmod_l_gpu_probe (cholmod_common *Common) ;
 int cholmod_l_gpu_deallocate (cholmod_common *Common) ;
 void cholmod_l_gpu_end (cholmod_common *Common) ;
 int cholmod_l_gpu_allocate (cholmod_common *Common) ;
+/* int-flavour counterparts: inert, as in the reference (cholmod_gpu.c:84-86) */
+int cholmod_gpu_memorysize (size_t *total_mem, size_t *available_mem, cholmod_common *Common) ;
+int cholmod_gpu_probe (cholmod_common *Common) ;
+int cholmod_gpu_deallocate (cholmod_common *Common) ;
+void cholmod_gpu_end (cholmod_common *Common) ;
+int cholmod_gpu_allocate (cholmod_common *Common) ;
 
 /* ---- this library only --------------------------------------------------------- */
 /* Materialise L->x on the host from the device-resident factor. */

@@ -112,6 +112,7 @@ API_SYMBOLS = [
     "cholmod_l_allocate_dense", "cholmod_l_zeros", "cholmod_l_ones", "cholmod_l_copy_dense",
     "cholmod_l_free_dense", "cholmod_l_free_factor",
     "cholmod_l_read_sparse", "cholmod_l_check_factor", "cholmod_l_check_sparse",
+    "cholmod_gpu_memorysize", "cholmod_gpu_probe", "cholmod_gpu_deallocate", "cholmod_gpu_end", "cholmod_gpu_allocate",
     "cholmod_l_gpu_stats", "cholmod_l_sdmult", "cholmod_l_norm_dense", "cholmod_l_norm_sparse",
     "cholmod_l_analyze", "cholmod_l_analyze_p", "cholmod_l_analyze_p2",
     "cholmod_l_factorize", "cholmod_l_factorize_p", "cholmod_l_solve", "cholmod_l_solve2",

@@ -32,6 +32,21 @@ int cholmod_l_gpu_probe (cholmod_common *Common)
  * (cholmod_gpu.c:364-486).  The HIP engine keeps L itself resident and sizes
  * its HBM reservation per symbolic factor (cholmod_hip_plan_create), so these
  * two calls only validate that a device exists.  0 = ok, as in the reference. */
+/* int-flavour symbols: present and inert in the reference (#ifndef DLONG return 0,
+ * CHOLMOD/GPU/cholmod_gpu.c:84-86, :176, :216, :262, :372); kept so that code linking
+ * both flavours resolves. */
+int cholmod_gpu_memorysize (size_t *total_mem, size_t *available_mem, cholmod_common *Common)
+{
+    (void) Common ;
+    if (total_mem) *total_mem = 0 ;
+    if (available_mem) *available_mem = 0 ;
+    return 0 ;
+}
+int cholmod_gpu_probe (cholmod_common *Common) { (void) Common ; return 0 ; }
+int cholmod_gpu_deallocate (cholmod_common *Common) { (void) Common ; return 0 ; }
+void cholmod_gpu_end (cholmod_common *Common) { (void) Common ; }
+int cholmod_gpu_allocate (cholmod_common *Common) { (void) Common ; return 0 ; }
+
 int cholmod_l_gpu_allocate (cholmod_common *Common)
 {
     if (!Common) return 1 ;
