@@ -27,7 +27,7 @@ def test_headers_and_symbol_lists_agree():
     declared = set()
     for h in ("cholmod.h", "cholmod_hip.h"):
         txt = open(os.path.join(root, "include", h)).read()
-        declared |= set(re.findall(r"\b(cholmod_(?:l|hip)_[a-z0-9_]+)\s*\(", txt))
+        declared |= set(re.findall(r"\b(cholmod_(?:l|hip|gpu)_[a-z0-9_]+)\s*\(", txt))
     assert declared == set(ch.API_SYMBOLS + ch.HIP_SYMBOLS)
 
 
