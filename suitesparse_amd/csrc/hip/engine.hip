@@ -838,8 +838,11 @@ static int build_host (cholmod_hip_plan *P)
         // so that the dynamic LDS of a launch fits its widest member
         std::vector<i32> gen ;
         {
-            static const int cls [3] = {48, 88, SM_MAX} ;
-            std::vector<i32> bucket [3] ;
+            // size classes by rows (the LDS of a launch is sized by its widest member:
+            // 19 / 33 / 62 / 101 / 149 KB -> 8 / 4 / 2 / 1 / 1 fronts per CU)
+            static const int NCLS = 5 ;
+            static const int cls [NCLS] = {48, 64, 88, 112, SM_MAX} ;
+            std::vector<i32> bucket [NCLS] ;
             for (int q = 0 ; q < all_nf ; q++)
             {
                 i32 sid = all_ids [q] ;
@@ -847,10 +850,23 @@ static int build_host (cholmod_hip_plan *P)
                 bool small_ok = !(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX
                     && !(P->owner [sid] < 0) ;
                 if (!small_ok) { gen.push_back (sid) ; continue ; }
-                int c = f.nsrow <= cls [0] ? 0 : f.nsrow <= cls [1] ? 1 : 2 ;
+                int c = 0 ;
+                while (c < NCLS - 1 && f.nsrow > cls [c]) c++ ;
                 bucket [c].push_back (sid) ;
             }
-            for (int c = 0 ; c < 3 ; c++)
+            // a class too thin to fill the chip rides with the next larger one (a launch
+            // costs more than the occupancy it would win)
+            for (int c = 0 ; c < NCLS - 1 ; c++)
+            {
+                if (bucket [c].empty () || bucket [c].size () >= 256) continue ;
+                int up = c + 1 ;
+                while (up < NCLS - 1 && bucket [up].empty ()) up++ ;
+                if (bucket [up].empty ()) continue ;
+                bucket [up].insert (bucket [up].end (), bucket [c].begin (), bucket [c].end ()) ;
+                std::sort (bucket [up].begin (), bucket [up].end ()) ;
+                bucket [c].clear () ;
+            }
+            for (int c = 0 ; c < NCLS ; c++)
             {
                 if (bucket [c].empty ()) continue ;
                 Launch Ls_ {K_SMALL, (int) bucket [c].size (), (int) bucket [c].size (), S.sm.size (), 0, 0} ;
