@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--check", action="store_true", help="also solve and print the residual")
     ap.add_argument("--hip-flags", type=int, default=0)
+    ap.add_argument("--matrix", default=None,
+                    help="factor a symmetric positive definite Matrix Market / triplet file instead of a synthetic "
+                         "workload (e.g. $SSGET/ND/nd24k.mtx when present), ordered by the built-in nested dissection")
     ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"],
                     help="geometric = the nested dissection SURVEY 8d prescribes for the metric (default); "
                          "builtin = cholmod_l_analyze's own ordering (host/order.c), for information")
@@ -131,11 +134,18 @@ def main():
     if dist is not None:
         from suitesparse_amd.dist import make_allreduce
         allreduce = make_allreduce(subgroups=None)     # the plan's own rank groups are created below
-    grids = [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
+    grids = [0] if args.matrix else [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
     S = None
     for gi, m in enumerate(grids):
         t0 = time.perf_counter()
-        n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, m)
+        if args.matrix:
+            from suitesparse_amd import generators as G
+            n, Ap, Ai, Ax, stype = G.read_triplet(args.matrix)
+            if stype == 0:
+                raise SystemExit("bench.py --matrix needs a symmetric file (one triangle stored)")
+            perm, wname = None, os.path.basename(args.matrix) + "_builtinND"
+        else:
+            n, Ap, Ai, Ax, stype, perm, wname = build_workload(args.workload, m)
         t_gen = time.perf_counter() - t0
         S = ch.Session(factor_on_device=True, hip_flags=args.hip_flags, rank=rank, world=world,
                        allreduce=allreduce, ordering="default")
@@ -270,7 +280,7 @@ def main():
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "file" if args.matrix else "synthetic",
             "config": {"workload": wname, "n": int(n), "nnz_lower": int(Ap[-1]),
                        "fl": fl, "executed_flops": exec_flops, "nsuper": fv.nsuper,
                        "Lx_GB": 8e-9 * fv.xsize, "arena_GB": 1e-9 * stats[4],
