@@ -235,8 +235,8 @@ def main():
                     traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01j_pmc_summary.json"
                 else:
                     traffic_note = ("no PMC pass at this size (serialised counter collection over the 9274 update "
-                                    "launches of a 181 GB factor did not finish in 17 minutes even when restricted "
-                                    "to this kernel); on the 100^3 workload the same kernel moves "
+                                    "launches of a 181 GB factor did not finish in 25 minutes for a single factorization, "
+                                    "restricted to this kernel); on the 100^3 workload the same kernel moves "
                                     f"{pj['fetch_bytes_per_launch_raw'] / 1e6:.0f} MB fetch + "
                                     f"{pj['write_bytes_per_launch'] / 1e6:.0f} MB write per launch "
                                     "(profiles/r01j_pmc_summary.json; bench.py --grid 100 prints it beside the "
