@@ -234,13 +234,16 @@ def main():
                     traffic = pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch"]
                     traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01j_pmc_summary.json"
                 else:
-                    traffic_note = ("no PMC pass at this size (serialised counter collection over the 9274 update "
-                                    "launches of a 181 GB factor did not finish in 25 minutes for a single factorization, "
-                                    "restricted to this kernel); on the 100^3 workload the same kernel moves "
-                                    f"{pj['fetch_bytes_per_launch_raw'] / 1e6:.0f} MB fetch + "
-                                    f"{pj['write_bytes_per_launch'] / 1e6:.0f} MB write per launch "
-                                    "(profiles/r01j_pmc_summary.json; bench.py --grid 100 prints it beside the "
-                                    "algorithmic bytes)")
+                    big = os.path.join(ROOT, "profiles", "r01k_pmc_summary_poisson190.json")
+                    bj = json.load(open(big)) if os.path.exists(big) else None
+                    traffic_note = ("no PMC pass at this size: rocprofv3 --pmc did not finish a single 200^3 factorization "
+                                    "(9274 update launches of the subtree-sweep schedule) in 25 minutes, three attempts; "
+                                    "the same passes take seconds up to 190^3 (plain level order, 1774 launches)")
+                    if bj:
+                        traffic_note += (f": at 190^3 this kernel fetches {bj['fetch_bytes_per_launch_raw'] / 1e9:.2f} GB (raw) and "
+                                         f"writes {bj['write_bytes_per_launch'] / 1e9:.2f} GB per launch "
+                                         "(profiles/r01k_pmc_summary_poisson190.json; see DESIGN.md section 4 for why the "
+                                         "fetch side exceeds the algorithmic bytes)")
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_note": traffic_note,
