@@ -14,7 +14,7 @@ from suitesparse_amd import generators as G
 
 
 def rand_spd(rng, n, density, band):
-    R = sp.random(n, n, density=density, random_state=int(rng.integers(1 << 30)), format="coo")
+    R = sp.random(n, n, density=min(1.0, density), random_state=int(rng.integers(1 << 30)), format="coo")
     if band:
         keep = np.abs(R.row - R.col) < max(2, n // 8)
         R = sp.coo_matrix((R.data[keep], (R.row[keep], R.col[keep])), shape=(n, n))
