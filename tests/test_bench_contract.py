@@ -34,3 +34,26 @@ def test_bench_json_line_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
     assert d["residual_2norm"] < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_gloo():
+    """The N > 1 launch line of the driver (torch.distributed.run, one rank per GPU);
+    on the 1-GPU box the two ranks share GPU 0 and exchange through gloo."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "32", "--steps", "2", "--warmup", "1",
+                          "--dist-backend", "gloo", "--check"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
+    assert d["exchange"]["allreduce_calls_per_factorization"] > 0
+    assert d["residual_2norm"] < 1e-11
