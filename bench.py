@@ -90,7 +90,9 @@ def main():
     ap.add_argument("--cpu-sample-m", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
-    ap.add_argument("--check", action="store_true", help="also solve and print the residual")
+    ap.add_argument("--check", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the solve / residual / factor invariants after the timed region")
     ap.add_argument("--hip-flags", type=int, default=0)
     ap.add_argument("--matrix", default=None,
                     help="factor a symmetric positive definite Matrix Market / triplet file instead of a synthetic "
@@ -260,15 +262,26 @@ def main():
                                          "small_fronts_fused": ps[19],
                                          "total_profiled": ps[0]}}
 
-    resid = None
-    if args.check:
+    # correctness of what was just timed (outside the timed region): device solve ->
+    # residual, and one pass over the resident factor for its invariants; for the
+    # Poisson grids log det(A) is known in closed form (a checksum of the whole factor)
+    resid, checks = None, None
+    if not args.no_check:
         from suitesparse_amd import generators as G
         if world > 1:
             assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
+        t0 = time.perf_counter()
         b = G.demo_rhs(n)
         x = S.solve(Lf, b)
+        t_solve = time.perf_counter() - t0
         r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
         resid = float(np.linalg.norm(r) / np.linalg.norm(b))
+        checks = S.factor_checks(Lf)
+        checks["solve_seconds_incl_h2d_d2h"] = t_solve
+        if not args.matrix and args.workload in ("poisson3d", "poisson2d"):
+            ld = G.poisson_logdet(*([m] * (3 if args.workload == "poisson3d" else 2)))
+            checks["logdet_closed_form"] = ld
+            checks["logdet_rel_err"] = abs(2.0 * checks["half_logdet"] - ld) / abs(ld)
 
     if rank == 0:
         cpu = None
@@ -303,6 +316,7 @@ def main():
         }
         if resid is not None:
             line["residual_2norm"] = resid
+            line["factor_checks"] = checks
         if allreduce is not None:
             nfac = max(args.steps + args.warmup + (0 if args.no_profile_pass else 1), 1)
             line["exchange"] = {"backend": args.dist_backend, "allreduce_calls_per_factorization": allreduce.stats["n"] // nfac,

@@ -26,6 +26,7 @@ extern "C" {
 #define CHOLMOD_HIP_NOT_POSDEF    1     /* success, but minor < n            */
 #define CHOLMOD_HIP_NO_DEVICE   (-1)    /* no usable gfx950 device / runtime */
 #define CHOLMOD_HIP_OUT_OF_MEMORY (-2)
+#define CHOLMOD_HIP_TOO_LARGE   (-3)    /* n or nsuper beyond the engine's 32-bit maps */
 #define CHOLMOD_HIP_INVALID     (-4)
 #define CHOLMOD_HIP_GPU_PROBLEM (-5)    /* a HIP call or kernel failed       */
 
@@ -157,6 +158,15 @@ int cholmod_hip_solve (cholmod_hip_plan *plan, int which, double *X,
  *                        row in the parent of row i below d's diagonal block */
 int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
     int64_t *level, int64_t *relmap) ;
+
+/* Size-independent invariants of the device-resident factor, one pass over Lx
+ * (the checks CHOLMOD/Check/cholmod_check.c:1823-2000 cannot do on values, at
+ * sizes no CPU oracle reaches):  out5[0] = sum_j log L(j,j)  (= logdet(A)/2,
+ * known in closed form for the Poisson grids);  out5[1] = entries != 0 in the
+ * dead strictly-upper triangles of the diagonal blocks;  out5[2] = non-finite
+ * entries of the lower trapezoids;  out5[3] = ||L||_F^2 over the lower
+ * trapezoids;  out5[4] = diagonal entries <= 0. */
+int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
 
 /* Statistics of the last factorization / of the plan (doubles):
  *  [0] device seconds, whole factorization (HIP events on the engine stream)

@@ -135,7 +135,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
-    "cholmod_hip_dense_partial_factor",
+    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks",
     "cholmod_hip_version",
 ]
 
@@ -240,6 +240,7 @@ def lib():
     sig("cholmod_hip_debug_panel_cycles", C.c_int, [vp])
     sig("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
+    sig("cholmod_hip_factor_checks", C.c_int, [vp, vp])
     sig("cholmod_hip_version", C.c_char_p, [])
     _lib = L
     return L
@@ -362,6 +363,16 @@ class Session:
         s = (C.c_double * CHOLMOD_HIP_NSTATS)()
         self.L.cholmod_l_hip_stats(Lf, C.byref(s), C.byref(self.cm))
         return np.array(list(s))
+
+    def factor_checks(self, Lf):
+        """Invariants of the device-resident factor (cholmod_hip_factor_checks):
+        dict(half_logdet, upper_nonzeros, nonfinite, fro2, nonpositive_diag)."""
+        out = np.zeros(5)
+        rc = self.L.cholmod_hip_factor_checks(Lf.contents.hip_plan, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"cholmod_hip_factor_checks failed: {rc}")
+        return dict(half_logdet=out[0], upper_nonzeros=int(out[1]), nonfinite=int(out[2]),
+                    fro2=out[3], nonpositive_diag=int(out[4]))
 
     def set_profiling(self, Lf, on=True):
         if Lf.contents.hip_plan:

@@ -27,18 +27,17 @@ constexpr int MB = 512 ;        // mid block: inner (K = 64) updates stay inside
 // 61.4 TFLOP/s at K = 512 / 2048 on a 16k x 16k region (the 16 B read-modify-
 // write of C is amortised over 4x more flops), at the price of OB/nsrow of the
 // flops moving to K = MB mid-level updates
-static inline int outer_block (int maxrows)
+struct ObThresholds { int t1, t2, t3 ; } ;
+// read at every plan build (tests change the thresholds between plans)
+static inline ObThresholds outer_block_thresholds ()
 {
-    static int t1 = -1, t2 = -1, t3 = -1 ;
-    if (t1 < 0)
-    {
-        const char *e1 = getenv ("CHOLMOD_HIP_OB1024_ROWS"), *e2 = getenv ("CHOLMOD_HIP_OB2048_ROWS") ;
-        const char *e3 = getenv ("CHOLMOD_HIP_OB4096_ROWS") ;
-        t1 = e1 ? atoi (e1) : 4000 ;
-        t2 = e2 ? atoi (e2) : 8000 ;
-        t3 = e3 ? atoi (e3) : 24000 ;
-    }
-    return maxrows >= t3 ? 4096 : maxrows >= t2 ? 2048 : maxrows >= t1 ? 1024 : MB ;
+    const char *e1 = getenv ("CHOLMOD_HIP_OB1024_ROWS"), *e2 = getenv ("CHOLMOD_HIP_OB2048_ROWS") ;
+    const char *e3 = getenv ("CHOLMOD_HIP_OB4096_ROWS") ;
+    return ObThresholds {e1 ? atoi (e1) : 4000, e2 ? atoi (e2) : 8000, e3 ? atoi (e3) : 24000} ;
+}
+static inline int outer_block (int maxrows, const ObThresholds &t)
+{
+    return maxrows >= t.t3 ? 4096 : maxrows >= t.t2 ? 2048 : maxrows >= t.t1 ? 1024 : MB ;
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
@@ -195,6 +194,8 @@ struct cholmod_hip_plan {
     double *d_solved = nullptr ; i64 solved_cap = 0 ; int max_big_nscol = 0 ;
     double *d_sv_acc = nullptr ; i64 sv_acc_cap = 0 ;
     unsigned int *d_ticket = nullptr ;
+    CheckTask *d_chk = nullptr ; i64 nchk = 0 ;     // cholmod_hip_factor_checks task list (lazy)
+    double *d_chk_out = nullptr ;
     Schedule sch ;
     double exec_flops = 0 ;
     // device
@@ -242,9 +243,10 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // Outer block width: a property of the FRONT (its row count), not of the batch --
     // the ranks of a multi-GPU group see different batches around the same shared
     // front and must cut its updates into the same regions.
+    const ObThresholds obt = outer_block_thresholds () ;
     auto ob_of = [&] (const FrontD &f) -> int
     {
-        return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow) ;
+        return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow, obt) ;
     } ;
     (void) maxrows ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
@@ -508,6 +510,22 @@ static int build_host (cholmod_hip_plan *P)
             if (p >= 0) call [pos [p]++] = (i32) s ;
         }
     }
+    // every member of the subtree rooted at `root`, through the real child lists:
+    // supernodes need not be numbered in etree postorder (Common->postorder = FALSE,
+    // arbitrary maps handed to cholmod_hip_plan_create), so a subtree is not an
+    // index range in general -- only parent > child is guaranteed
+    std::vector<i32> st_stack ;
+    auto for_subtree = [&] (i32 root, auto &&fn)
+    {
+        st_stack.clear () ;
+        st_stack.push_back (root) ;
+        while (!st_stack.empty ())
+        {
+            i32 t = st_stack.back () ; st_stack.pop_back () ;
+            fn (t) ;
+            for (i32 c = cptr [t] ; c < cptr [t+1] ; c++) st_stack.push_back (call [c]) ;
+        }
+    } ;
     int nlev = 0 ;
     for (i64 s = 0 ; s < nsuper ; s++) nlev = std::max (nlev, P->level [s] + 1) ;
     P->nlevels = nlev ;
@@ -556,10 +574,6 @@ static int build_host (cholmod_hip_plan *P)
     P->force_shared = (P->world == 1 && share_world > 1) ;
     if (share_world > 1 && nsuper > 0)
     {
-        std::vector<i32> first (nsuper) ;
-        for (i64 s = 0 ; s < nsuper ; s++) first [s] = (i32) s ;
-        for (i64 s = 0 ; s < nsuper ; s++)
-            if (P->fr [s].parent >= 0) first [P->fr [s].parent] = std::min (first [P->fr [s].parent], first [s]) ;
         double total = 0 ;
         for (i64 s = 0 ; s < nsuper ; s++) if (P->fr [s].parent < 0) total += wsub [s] ;
         const double thr = total / (4.0 * share_world) ;
@@ -649,11 +663,11 @@ static int build_host (cholmod_hip_plan *P)
             int best = e.g0 ;
             for (int r = e.g0 + 1 ; r < e.g0 + e.gn ; r++) if (load [r] < load [best]) best = r ;
             load [best] += e.w ;
-            for (i32 q = first [e.root] ; q <= e.root ; q++)
+            for_subtree (e.root, [&] (i32 q)
             {
                 P->owner [q] = P->world == 1 ? 0 : best ;
                 P->grp0 [q] = P->owner [q] ; P->grpn [q] = 1 ;
-            }
+            }) ;
         }
         for (i64 s = 0 ; s < nsuper ; s++)
         {
@@ -663,6 +677,17 @@ static int build_host (cholmod_hip_plan *P)
         }
     }
     auto mine = [&] (i64 s) { return P->rank >= P->grp0 [s] && P->rank < P->grp0 [s] + P->grpn [s] ; } ;
+    // thin fronts (fused LDS-resident kernel): their contribution blocks are packed
+    // lower triangles, the generic fronts' full squares
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        FrontD &f = P->fr [s] ;
+        f.cbp = (!(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX && !(P->owner [s] < 0)) ? 1 : 0 ;
+    }
+    auto cb_len = [&] (const FrontD &f) -> i64
+    {
+        return f.cbp ? (i64) f.ncb * (f.ncb + 1) / 2 : (i64) f.ncb * f.ncb ;
+    } ;
     // this rank's view of the child lists: a shared parent pulls only the
     // contribution blocks this rank computed (its own subtrees and its partial
     // copies of shared children); the other ranks add theirs on their side and
@@ -709,10 +734,6 @@ static int build_host (cholmod_hip_plan *P)
         int ngroups = 0 ;
         if (nsplit > 1 && nsuper > 0)
         {
-            std::vector<i32> first (nsuper) ;
-            for (i64 s = 0 ; s < nsuper ; s++) first [s] = (i32) s ;
-            for (i64 s = 0 ; s < nsuper ; s++)
-                if (P->fr [s].parent >= 0) first [P->fr [s].parent] = std::min (first [P->fr [s].parent], first [s]) ;
             typedef std::pair<double, i32> WS ;
             std::priority_queue<WS> pq ;
             for (i64 s = 0 ; s < nsuper ; s++) if (P->fr [s].parent < 0) pq.push (WS (wsub [s], (i32) -s)) ;
@@ -726,7 +747,7 @@ static int build_host (cholmod_hip_plan *P)
             std::vector<i32> roots ;
             while (!pq.empty ()) { roots.push_back (-pq.top ().second) ; pq.pop () ; }
             std::sort (roots.begin (), roots.end ()) ;
-            for (i32 r : roots) { for (i32 q = first [r] ; q <= r ; q++) group [q] = ngroups ; ngroups++ ; }
+            for (i32 r : roots) { for_subtree (r, [&] (i32 q) { group [q] = ngroups ; }) ; ngroups++ ; }
         }
         // batches in postorder: a subtree group contributes its levels in increasing
         // height when its root is reached, a front of the top part is a batch of its
@@ -757,12 +778,12 @@ static int build_host (cholmod_hip_plan *P)
         Arena A ;
         for (const auto &bt : batches)
         {
-            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc ((i64) f.ncb * f.ncb) ; }
+            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f)) ; }
             for (i32 sf : bt)
                 for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
                 {
                     FrontD &g = P->fr [call [c]] ;
-                    A.release (g.cb, (i64) g.ncb * g.ncb) ;
+                    A.release (g.cb, cb_len (g)) ;
                 }
         }
         // keep the first split that fits; if none does, the one with the smallest
@@ -787,14 +808,14 @@ static int build_host (cholmod_hip_plan *P)
         Arena A ;
         for (const auto &bt : batches)
         {
-            for (i32 sf : bt) if (mine (sf)) { FrontD &f = P->fr [sf] ; f.cb = A.alloc ((i64) f.ncb * f.ncb) ; }
+            for (i32 sf : bt) if (mine (sf)) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f)) ; }
             for (i32 sf : bt)
                 if (mine (sf))
                     for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
                         if (mine (call [c]))
                         {
                             FrontD &g = P->fr [call [c]] ;
-                            A.release (g.cb, (i64) g.ncb * g.ncb) ;
+                            A.release (g.cb, cb_len (g)) ;
                         }
         }
         P->arena = A.top ;
@@ -838,18 +859,17 @@ static int build_host (cholmod_hip_plan *P)
         // so that the dynamic LDS of a launch fits its widest member
         std::vector<i32> gen ;
         {
-            // size classes by rows (the LDS of a launch is sized by its widest member:
-            // 19 / 33 / 62 / 101 / 149 KB -> 8 / 4 / 2 / 1 / 1 fronts per CU)
+            // size classes by rows (the LDS of a launch is sized by its widest member;
+            // packed triangle: 4.4 / 9.6 / 16.9 KB, one wave per front -> the 32-wave cap
+            // or 16 / 9 fronts per CU; 37.7 / 75.7 KB, four waves per front -> 4 / 2 per CU)
             static const int NCLS = 5 ;
-            static const int cls [NCLS] = {48, 64, 88, 112, SM_MAX} ;
+            static const int cls [NCLS] = {32, 48, 64, 96, SM_MAX} ;
             std::vector<i32> bucket [NCLS] ;
             for (int q = 0 ; q < all_nf ; q++)
             {
                 i32 sid = all_ids [q] ;
                 const FrontD &f = P->fr [sid] ;
-                bool small_ok = !(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX
-                    && !(P->owner [sid] < 0) ;
-                if (!small_ok) { gen.push_back (sid) ; continue ; }
+                if (!f.cbp) { gen.push_back (sid) ; continue ; }
                 int c = 0 ;
                 while (c < NCLS - 1 && f.nsrow > cls [c]) c++ ;
                 bucket [c].push_back (sid) ;
@@ -886,7 +906,7 @@ static int build_host (cholmod_hip_plan *P)
                     }
                     S.sm.push_back (sid) ;
                 }
-                Ls_.aux = (mx | 1) * mx * (int) sizeof (double) ;
+                Ls_.aux = mx ;                              // widest member: LDS sizing, waves per front
                 S.launches.push_back (Ls_) ;
             }
         }
@@ -957,7 +977,7 @@ static void free_device (cholmod_hip_plan *P)
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket} ;
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1031,7 +1051,7 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_small_front<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -1045,18 +1065,18 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
         case K_JOIN: break ;
         case K_SMALL:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            // the narrowest class runs one wave per front: barriers are free and
-            // eight times more fronts are resident per CU
-            if (L.aux <= 49 * 48 * (int) sizeof (double))
-                hipLaunchKernelGGL (k_small_front<64>, dim3 (L.grid), dim3 (64), (size_t) L.aux, st,
-                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
+            // fronts of <= 64 rows run one wave per front (lane = row, no cross-wave
+            // hand-off), wider ones four
+            if (L.aux <= 64)
+                hipLaunchKernelGGL (k_thin_front<1>, dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
+                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux) ;
             else
-                hipLaunchKernelGGL (k_small_front<256>, dim3 (L.grid), dim3 (256), (size_t) L.aux, st,
-                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->n, P->d_Sp,
+                hipLaunchKernelGGL (k_thin_front<4>, dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
+                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux) ;
             break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
@@ -1292,6 +1312,8 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     *status = CHOLMOD_HIP_OK ;
     if (n < 0 || nsuper < 0 || !super || !pi || !px || !s || world < 1 || rank < 0 || rank >= world)
     { *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
+    // front descriptors, relative maps and the supernode map are 32-bit on the device
+    if (n > INT32_MAX || nsuper > INT32_MAX) { *status = CHOLMOD_HIP_TOO_LARGE ; return nullptr ; }
     bool host_only = (flags & CHOLMOD_HIP_PLAN_HOST_ONLY) != 0 ;
     if (!host_only && !cholmod_hip_probe ()) { *status = CHOLMOD_HIP_NO_DEVICE ; return nullptr ; }
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
@@ -1566,6 +1588,30 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipMemcpyAsync (X, P->d_X, need * sizeof (double), hipMemcpyDeviceToHost, st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
+{
+    if (!P || P->host_only || !out5) return CHOLMOD_HIP_INVALID ;
+    for (int q = 0 ; q < 5 ; q++) out5 [q] = 0 ;
+    if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
+    if (!P->d_chk)
+    {
+        std::vector<CheckTask> t ;
+        for (i64 s = 0 ; s < P->nsuper ; s++)
+            for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS) t.push_back (CheckTask {(i32) s, c0}) ;
+        hipError_t e ;
+        P->d_chk = dupload (t, e) ; HIPCHK (e) ;
+        P->nchk = (i64) t.size () ;
+        HIPCHK (hipMalloc ((void **) &P->d_chk_out, 5 * sizeof (double))) ;
+    }
+    HIPCHK (hipMemsetAsync (P->d_chk_out, 0, 5 * sizeof (double), P->stream)) ;
+    hipLaunchKernelGGL (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
+        P->d_chk, P->d_fr, P->d_Lx, P->d_chk_out) ;
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -32,7 +32,10 @@ struct FrontD {
     i32 parent;     // supernodal etree parent or -1
     i32 child_begin, child_end;   // range in the child index array (this rank's view)
     i32 assemble;   // 1: k_assemble scatters A into this front on this rank, 2: the
-                    // fused small-front kernel does, 0: another rank does
+                    // fused thin-front kernel does, 0: another rank does
+    i32 cbp;        // 1: the contribution block is stored as a packed lower triangle
+                    // (column j holds rows j..ncb-1; written by k_thin_front), 0: as a
+                    // full square with ld = ncb (written by the dense update kernel)
 };
 
 struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi; };   // extend-add into target columns [c_lo, c_hi)
@@ -58,7 +61,10 @@ struct GemmGroup {
     i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
 };
 
-// Contribution blocks are stored as full squares, ld = ncb (lower part used).
+// Contribution blocks of the generic fronts are stored as full squares, ld = ncb
+// (lower part used); those of the thin fronts as packed lower triangles:
+// element (i,j), i >= j, of a packed triangle of order m lives at tri_col(j,m) + i.
+__host__ __device__ __forceinline__ int tri_col (int j, int m) { return j * m - ((j * (j + 1)) >> 1) ; }
 
 typedef double d4 __attribute__((ext_vector_type(4))) ;
 
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
             int roff ;
             if (tc < Pnscol) { dst = Lx + Ppsx + (i64) tc * Pnsrow ; roff = 0 ; }
             else { dst = CB + Pcb + (i64) (tc - Pnscol) * Pncb ; roff = Pnscol ; }
-            const double *sc = src + (i64) j * nc ;
+            const double *sc = Cc.cbp ? src + tri_col (j, nc) : src + (i64) j * nc ;
             // four independent gather / read-modify-write chains in flight per wave
             int i = j + lane ;
             for ( ; i + 192 < nc ; i += 256)
@@ -929,183 +935,318 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
-// ---- fused small front: one workgroup, the whole front in LDS -----------------
-// For thin supernodes (nsrow <= SM_MAX) the level-batched generic kernels cost a
-// dozen launches and several HBM round trips per front.  Here one workgroup
-// builds the front in LDS (zero, scatter A, pull the children's contribution
-// blocks through the relative maps), eliminates its nscol columns (right-looking,
-// all 256 threads on the trailing update) and writes the panel and the
-// contribution block exactly once: HBM traffic = A entries + children CBs in,
-// panel + CB out.  Reference steps: t_cholmod_super_numeric.c:305-431 (assemble),
-// :743-772 (relative map scatter), :864-867 / :997-1002 (dpotrf / dtrsm), and the
-// dsyrk/dgemm its ancestors would have pulled (:682-717) as the CB.
+// ---- thin fronts: the whole front in LDS, one pass over HBM -------------------
+// For thin supernodes (nsrow <= SM_MAX; 98 % of the supernodes of a 2D / circuit
+// problem, the leaf levels of every problem) the level-batched generic kernels
+// cost a dozen launches and several HBM round trips per front.  Here one
+// workgroup (ONE WAVE when nsrow <= 64, four otherwise) builds the front in LDS
+// as a packed lower triangle, eliminates its nscol columns and streams the
+// result out: HBM traffic = A entries + children's contribution blocks in,
+// panel + contribution block out, every byte once and contiguous.
+// Reference steps: t_cholmod_super_numeric.c:305-431 (assemble), :743-772
+// (relative-map scatter), :864-867 / :997-1002 (dpotrf / dtrsm) and the
+// dsyrk/dgemm its ancestors would have pulled (:682-717) as the contribution block.
+//  (1) the row list, the column pointers of A and the first batch of the first
+//      child's contribution block are requested before anything is waited for;
+//  (2) children's contribution blocks are packed triangles: a flat, fully
+//      coalesced stream, eight loads per thread in flight, scatter-added into the
+//      LDS front through the relative map (one barrier per child: two children
+//      may hit the same entry, two entries of one child never do);
+//  (3) 16-column panels: wave 0 eliminates the panel with lane = row -- its 64
+//      rows ride through the same right-looking step, pivots and multipliers by
+//      v_readlane, the chain per column is rcp + Newton -> mul -> fma (LDL' on the
+//      unscaled columns; sqrt/rsqrt once per panel, 16 pivots side by side); the
+//      other waves solve their rows against the published 16x16 block;
+//      finished columns go to Lx straight from registers;
+//  (4) the trailing update runs on the matrix cores out of the packed front; the
+//      one after the last panel IS the contribution block and is written to HBM
+//      from the accumulators (packed), never back to LDS.
 #define SM_MAX 136
-template <int NT>
-__global__ void __launch_bounds__(NT) k_small_front (const i32 *fronts,
-    const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
-    i64 n, const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
-    double *Lx, double *CB, i32 *info)
+#define TF_PW 16
+__host__ __device__ inline size_t thin_front_lds_bytes (int ns_max)
 {
-    extern __shared__ __attribute__((aligned(16))) double F [] ;   // F(i,j) = F[i + j*ld]
-    const FrontD &f = fr [fronts [blockIdx.x]] ;
-    int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
-    int ld = ns | 1 ;
-    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
-    i64 psx = f.psx, psi = f.psi, cbo = f.cb ;
-    __shared__ i64 rows_l [SM_MAX] ;        // the front's row list: binary searches hit LDS
-    for (int e = tid ; e < ld * ns ; e += NT) F [e] = 0.0 ;
-    for (int e = tid ; e < ns ; e += NT) rows_l [e] = Ls [psi + e] ;
-    __syncthreads () ;
-    if (f.assemble)
+    int nsp = (ns_max + 1) & ~1 ;
+    return (size_t) (ns_max * (ns_max + 1) / 2 + TF_PW) * sizeof (double) + 2 * (size_t) nsp * sizeof (i32) ;
+}
+// (i,j) of the e-th entry of a packed lower triangle of order m
+__device__ __forceinline__ void tri_decode (int e, int m, int &i, int &j)
+{
+    float b = (float) (2 * m + 1) ;
+    int jj = (int) ((b - __builtin_sqrtf (b * b - 8.0f * (float) e)) * 0.5f) ;
+    jj = jj < 0 ? 0 : (jj > m - 1 ? m - 1 : jj) ;
+    int st = jj * m - ((jj * (jj - 1)) >> 1) ;             // first entry of column jj
+    while (st > e) { jj-- ; st -= m - jj ; }
+    while (st + (m - jj) <= e) { st += m - jj ; jj++ ; }
+    j = jj ; i = jj + (e - st) ;
+}
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
+    const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
+    const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
+    double *Lx, double *CB, i32 *info, int ns_max)
+{
+    constexpr int NT = 64 * NW ;
+    constexpr int NLD = 8 ;                                 // child entries in flight per thread
+    extern __shared__ __attribute__((aligned(16))) double tf_lds [] ;
+    double *F = tf_lds ;                                    // packed lower triangle of the front
+    double *pv = F + ns_max * (ns_max + 1) / 2 ;            // 1 / L(c,c) of the current panel
+    i32 *rows_l = (i32 *) (pv + TF_PW) ;                    // the front's row list
+    i32 *rm_l = rows_l + ((ns_max + 1) & ~1) ;              // relative map of the current child
+    __shared__ int s_fail ;
+    const i32 fid = fronts [blockIdx.x] ;
+    const FrontD &f = fr [fid] ;
+    const int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    const i64 psx = f.psx, cbo = f.cb ;
+    const int T = ns * (ns + 1) / 2 ;
+    // ---- (1) requests first
+    i64 rowv = (tid < ns) ? Ls [f.psi + tid] : 0 ;
+    i64 p0 = 0, p1 = 0 ;
+    const bool asm_col = f.assemble && tid < nc ;
+    if (asm_col)
     {
-        const i64 *rows = rows_l ;
-        for (int k = tid ; k < nc ; k += NT)
+        i64 col = (i64) k1 + tid ;
+        p0 = Sp [col] ; p1 = Snz ? p0 + Snz [col] : Sp [col + 1] ;
+    }
+    for (int e = tid ; e < T ; e += NT) F [e] = 0.0 ;
+    if (tid == 0) s_fail = -1 ;
+    if (tid < ns) rows_l [tid] = (i32) rowv ;
+    __syncthreads () ;
+    // ---- A into the panel columns (ASSIGN semantics, entries outside the pattern dropped)
+    if (asm_col)
+    {
+        const int k = tid ;
+        const i64 col = (i64) k1 + k ;
+        double *Fc = F + tri_col (k, ns) ;
+        for (i64 p = p0 ; p < p1 ; p += 4)
         {
-            i64 col = (i64) k1 + k ;
-            i64 p = Sp [col], pend = Snz ? p + Snz [col] : Sp [col + 1] ;
-            for ( ; p < pend ; p++)
+            i64 ii [4] ; double xx [4] ;
+#pragma unroll
+            for (int u = 0 ; u < 4 ; u++)
             {
-                i64 i = Si [p] ;
-                if (i < col) continue ;
-                int lo = 0, hi = ns ;
-                while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows [mid] < i) lo = mid + 1 ; else hi = mid ; }
-                if (lo < ns && rows [lo] == i) F [lo + k * ld] = Sx [p] ;
+                i64 q = p + u < p1 ? p + u : p1 - 1 ;
+                ii [u] = Si [q] ; xx [u] = Sx [q] ;
             }
-            if (beta != 0.0) F [k + k * ld] += beta ;
+#pragma unroll
+            for (int u = 0 ; u < 4 ; u++)
+            {
+                if (p + u >= p1 || ii [u] < col) continue ;
+                int lo = k, hi = ns ;
+                while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows_l [mid] < (i32) ii [u]) lo = mid + 1 ; else hi = mid ; }
+                if (lo < ns && rows_l [lo] == (i32) ii [u]) Fc [lo] = xx [u] ;
+            }
         }
+        if (beta != 0.0) Fc [k] += beta ;
     }
     __syncthreads () ;
+    // ---- (2) children
     for (int ci = f.child_begin ; ci < f.child_end ; ci++)
     {
         const FrontD &c = fr [child [ci]] ;
+        const int m = c.ncb ;
         const i32 *rm = relmap + c.rel ;
-        int m = c.ncb ;
         const double *src = CB + c.cb ;
-        for (int j = wave ; j < m ; j += NT / 64)
+        for (int e = tid ; e < m ; e += NT) rm_l [e] = rm [e] ;
+        if (c.cbp)
         {
-            int tj = rm [j] ;
-            const double *sc = src + (i64) j * m ;
-            for (int i = j + lane ; i < m ; i += 64) F [rm [i] + tj * ld] += sc [i] ;
+            const int tot = m * (m + 1) / 2 ;
+            for (int base = 0 ; base < tot ; base += NLD * NT)
+            {
+                double v [NLD] ;
+#pragma unroll
+                for (int q = 0 ; q < NLD ; q++)
+                {
+                    int e = base + tid + NT * q ;
+                    v [q] = src [e < tot ? e : tot - 1] ;
+                }
+                if (base == 0) __syncthreads () ;           // rm_l complete
+#pragma unroll
+                for (int q = 0 ; q < NLD ; q++)
+                {
+                    int e = base + tid + NT * q ;
+                    if (e < tot)
+                    {
+                        int i, j ;
+                        tri_decode (e, m, i, j) ;
+                        F [tri_col (rm_l [j], ns) + rm_l [i]] += v [q] ;
+                    }
+                }
+            }
+        }
+        else
+        {
+            // square child (a generic front under a thin parent): column by column
+            __syncthreads () ;
+            for (int j = wave ; j < m ; j += NW)
+            {
+                double *Ft = F + tri_col (rm_l [j], ns) ;
+                const double *sc = src + (i64) j * m ;
+                for (int i = j + lane ; i < m ; i += 64) Ft [rm_l [i]] += sc [i] ;
+            }
         }
         __syncthreads () ;
     }
-    // Right-looking elimination in panels of 8 columns:
-    //  (1) every thread factors the 8x8 diagonal block redundantly in registers
-    //      (uniform values, LDS broadcast reads), as an LDL' recurrence whose
-    //      dependent chain per column is rcp + one Newton step -> mul -> fma; the
-    //      eight square roots are taken afterwards, eight independent chains;
-    //  (2) thread = row: the row rides through the same elimination with the
-    //      (uniform) multipliers, is scaled and stored;
-    //  (3) the trailing 16x16 tiles get the rank-8 update on the matrix cores
-    //      (two v_mfma_f64_16x16x4 per tile, operands straight out of the front).
-    // Two barriers per 8 columns instead of three per column.
+    // ---- (3), (4): 16-column panels
+    const int lr = lane & 15, lk = lane >> 4 ;
     int fail = -1 ;
-    int lr = lane & 15, lk = lane >> 4 ;
-    constexpr int NW = NT / 64 ;
-    for (int j0 = 0 ; j0 < nc && fail < 0 ; j0 += 8)
+    for (int c0 = 0 ; c0 < nc ; c0 += TF_PW)
     {
-        int pc = nc - j0 < 8 ? nc - j0 : 8 ;
-        double D [8][8], piv [8], xinv [8] ;
+        const int pc = nc - c0 < TF_PW ? nc - c0 : TF_PW ;
+        const int row = c0 + tid ;
+        const bool rok = row < ns ;
+        double a [TF_PW] ;
 #pragma unroll
-        for (int c = 0 ; c < 8 ; c++)
-#pragma unroll
-            for (int r = c ; r < 8 ; r++)
-            {
-                int rr = j0 + r < ns ? j0 + r : ns - 1, cc = j0 + c < ns ? j0 + c : ns - 1 ;
-                D [r][c] = (r < pc && c < pc) ? F [rr + cc * ld] : (r == c ? 1.0 : 0.0) ;
-            }
-#pragma unroll
-        for (int c = 0 ; c < 8 ; c++)
+        for (int c = 0 ; c < TF_PW ; c++)
+            a [c] = (rok && c < pc && row >= c0 + c) ? F [tri_col (c0 + c, ns) + row] : 0.0 ;
+        if (wave == 0)
         {
-            double d = D [c][c] ;
-            if (fail < 0 && c < pc && d <= 0.0) fail = j0 + c ;
-            piv [c] = d ;
-            double x = __builtin_amdgcn_rcp (d) ;
-            double e = __builtin_fma (-d, x, 1.0) ;
-            x = __builtin_fma (x, e, x) ;
-            if (fail >= 0) x = 0.0 ;
-            xinv [c] = x ;
+            double dv = 1.0 ;                               // lane c keeps the pivot of column c
 #pragma unroll
-            for (int c2 = c + 1 ; c2 < 8 ; c2++)
+            for (int c = 0 ; c < TF_PW ; c++)
             {
-                double t = D [c2][c] * x ;
+                if (c < pc)
+                {
+                    double d = readlane_f64 (a [c], c) ;
+                    if (fail < 0 && d <= 0.0) fail = c0 + c ;
+                    double x = __builtin_amdgcn_rcp (d) ;
+                    double e = __builtin_fma (-d, x, 1.0) ;
+                    x = __builtin_fma (x, e, x) ;
+                    double t = a [c] * x ;                  // u(row,c) / d
 #pragma unroll
-                for (int r = c2 ; r < 8 ; r++) D [r][c2] = __builtin_fma (-t, D [r][c], D [r][c2]) ;
+                    for (int c2 = c + 1 ; c2 < TF_PW ; c2++)
+                        if (c2 < pc) a [c2] = __builtin_fma (-t, readlane_f64 (a [c], c2), a [c2]) ;
+                    if (lane == c) dv = d ;
+                }
+            }
+            double r, ri ;
+            sqrt_rsqrt (dv, r, ri) ;
+#pragma unroll
+            for (int c = 0 ; c < TF_PW ; c++)
+            {
+                double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
+                a [c] = (lane == c) ? rc : a [c] * ric ;
+                if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
+            }
+            if (lane < TF_PW) pv [lane] = ri ;
+            if (lane == 0) s_fail = fail ;
+        }
+        if (NW > 1)
+        {
+            // publish the factored 16 x 16 block, then the other waves solve their rows
+            if (wave == 0 && rok)
+            {
+#pragma unroll
+                for (int c = 0 ; c < TF_PW ; c++)
+                    if (c < pc && row >= c0 + c) F [tri_col (c0 + c, ns) + row] = a [c] ;
+            }
+            __syncthreads () ;
+            fail = s_fail ;
+            if (wave > 0)
+            {
+                const int nvalid = fail >= 0 ? fail - c0 : pc ;
+#pragma unroll
+                for (int c = 0 ; c < TF_PW ; c++)
+                {
+                    if (c < pc)
+                    {
+                        double xv = a [c] * pv [c] ;
+                        if (c >= nvalid) xv = 0.0 ;
+                        a [c] = xv ;
+                        const double *Lc = F + tri_col (c0 + c, ns) + c0 ;      // L11(c2, c) at Lc [c2]
+#pragma unroll
+                        for (int c2 = c + 1 ; c2 < TF_PW ; c2++)
+                            if (c2 < pc) a [c2] = __builtin_fma (-xv, Lc [c2], a [c2]) ;
+                    }
+                }
+                if (rok)
+                {
+#pragma unroll
+                    for (int c = 0 ; c < TF_PW ; c++)
+                        if (c < pc) F [tri_col (c0 + c, ns) + row] = a [c] ;
+                }
             }
         }
-        double rt [8], ri [8] ;
-#pragma unroll
-        for (int c = 0 ; c < 8 ; c++) sqrt_rsqrt (piv [c], rt [c], ri [c]) ;
-        int nvalid = fail >= 0 ? fail - j0 : pc ;           // columns of this panel that exist
-        // own row (rows j0 .. ns-1, one per thread; NT >= ns by construction)
-        int row = j0 + tid ;
-        if (row < ns)
+        else
         {
-            double a [8] ;
-#pragma unroll
-            for (int c = 0 ; c < 8 ; c++) a [c] = (c < pc) ? F [row + (j0 + c) * ld] : 0.0 ;
-#pragma unroll
-            for (int c = 0 ; c < 8 ; c++)
+            if (rok)
             {
-                double t = a [c] * xinv [c] ;
 #pragma unroll
-                for (int c2 = c + 1 ; c2 < 8 ; c2++) a [c2] = __builtin_fma (-t, D [c2][c], a [c2]) ;
+                for (int c = 0 ; c < TF_PW ; c++)
+                    if (c < pc && row >= c0 + c) F [tri_col (c0 + c, ns) + row] = a [c] ;
             }
+        }
+        // finished columns: registers -> Lx (columns at / beyond a failed pivot stay zero)
+        if (rok)
+        {
+            double *Lr = Lx + psx + row + (i64) c0 * ns ;
 #pragma unroll
-            for (int c = 0 ; c < 8 ; c++)
-            {
-                double v = (tid == c) ? rt [c] : a [c] * ri [c] ;
-                if (c >= nvalid) v = 0.0 ;
-                if (c < pc && row >= j0 + c) F [row + (j0 + c) * ld] = v ;
-            }
+            for (int c = 0 ; c < TF_PW ; c++)
+                if (c < pc && row >= c0 + c && (fail < 0 || c0 + c < fail)) Lr [(i64) c * ns] = a [c] ;
         }
         __syncthreads () ;
+        if (NW == 1) fail = s_fail ;
         if (fail >= 0) break ;
-        // trailing tiles over rows / columns t0 .. ns-1
-        int t0 = j0 + pc ;
-        int nd = (ns - t0 + 15) / 16 ;
-        int ntile = nd * (nd + 1) / 2 ;
+        // trailing update of rows / columns t0 .. ns-1 with the pc panel columns
+        const int t0 = c0 + pc ;
+        const bool last = t0 >= nc ;
+        const int nd = (ns - t0 + 15) >> 4 ;
+        const int ntile = nd * (nd + 1) / 2 ;
         for (int u = wave ; u < ntile ; u += NW)
         {
             int tj = 0, rem = u ;
             while (rem >= nd - tj) { rem -= nd - tj ; tj++ ; }
-            int tiw = tj + rem ;
-            int i0 = t0 + 16 * tiw, c0 = t0 + 16 * tj ;
-            int ir = i0 + lr < ns ? i0 + lr : ns - 1 ;
-            int jr = c0 + lr < ns ? c0 + lr : ns - 1 ;
+            const int i0 = t0 + 16 * (tj + rem), j0 = t0 + 16 * tj ;
+            const int i = i0 + lr ;
+            const int ir = i < ns ? i : ns - 1 ;
+            const int jr = j0 + lr < ns ? j0 + lr : ns - 1 ;
             d4 acc ;
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++)
             {
-                int jc = c0 + lk + 4 * r < ns ? c0 + lk + 4 * r : ns - 1 ;
-                acc [r] = F [ir + jc * ld] ;
+                int j = j0 + lk + 4 * r ;
+                acc [r] = (i < ns && j <= i) ? F [tri_col (j, ns) + i] : 0.0 ;
             }
 #pragma unroll
-            for (int kk = 0 ; kk < 8 ; kk += 4)
+            for (int kk = 0 ; kk < TF_PW ; kk += 4)
             {
-                int k = kk + lk ;
-                double av = (k < pc) ? -F [ir + (j0 + k) * ld] : 0.0 ;
-                double bv = (k < pc) ? F [jr + (j0 + k) * ld] : 0.0 ;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, av, acc, 0, 0, 0) ;
+                if (kk < pc)
+                {
+                    int k = kk + lk ;
+                    const double *Fk = F + tri_col (c0 + (k < pc ? k : pc - 1), ns) ;
+                    double av = (k < pc) ? -Fk [ir] : 0.0 ;
+                    double bv = (k < pc) ? Fk [jr] : 0.0 ;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, av, acc, 0, 0, 0) ;
+                }
             }
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
+            if (last)
             {
-                int i = i0 + lr, j = c0 + lk + 4 * r ;
-                if (i < ns && j < ns && i >= j) F [i + j * ld] = acc [r] ;
+                double *Co = CB + cbo ;
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int j = j0 + lk + 4 * r ;
+                    if (i < ns && j <= i) Co [tri_col (j - nc, ncb) + (i - nc)] = acc [r] ;
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int j = j0 + lk + 4 * r ;
+                    if (i < ns && j <= i) F [tri_col (j, ns) + i] = acc [r] ;
+                }
             }
         }
-        __syncthreads () ;
+        if (!last) __syncthreads () ;
     }
-    if (fail >= 0 && tid == 0) info [fronts [blockIdx.x]] = fail + 1 ;
-    int ngood = fail >= 0 ? fail : nc ;
-    // panel [L11; L21], columns before a failed pivot only (the rest stays zero)
-    for (int j = wave ; j < ngood ; j += NT / 64)
-        for (int i = j + lane ; i < ns ; i += 64) Lx [psx + i + (i64) j * ns] = F [i + j * ld] ;
-    // contribution block (lower part)
-    for (int j = wave ; j < ncb ; j += NT / 64)
-        for (int i = j + lane ; i < ncb ; i += 64)
-            CB [cbo + i + (i64) j * ncb] = F [(nc + i) + (nc + j) * ld] ;
+    if (fail >= 0)
+    {
+        if (tid == 0) info [fid] = fail + 1 ;
+        // the ancestors of a failed front compute values nobody keeps; give them zeros
+        const int tot = ncb * (ncb + 1) / 2 ;
+        for (int e = tid ; e < tot ; e += NT) CB [cbo + e] = 0.0 ;
+    }
 }
 
 // ---- dense update  C -= A * B'  (fp64 MFMA 16x16x4 tiles) -------------------
@@ -1923,6 +2064,60 @@ __global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
     if (inverse) dst [perm [k]] = src [k] ; else dst [k] = src [perm [k]] ;
+}
+
+// ---- size-independent invariants of a device-resident factor ----------------
+// One pass over Lx (parity checks at sizes the CPU oracle cannot reach):
+//   out[0] += sum_j log L(j,j)          (= logdet(A)/2, analytic for Poisson grids)
+//   out[1] += entries != 0 in the dead strictly-upper triangles of the diagonal
+//             blocks (the reference never writes them)
+//   out[2] += non-finite entries of the lower trapezoids
+//   out[3] += sum of squares of the lower trapezoids (||L||_F^2)
+//   out[4] += diagonal entries <= 0
+// A workgroup owns CHK_COLS columns of one supernode; wave w takes the columns
+// == w (mod 4), lanes stride the rows (coalesced).
+#define CHK_COLS 64
+struct CheckTask { i32 front ; i32 c0 ; } ;
+__global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, const FrontD *fr,
+    const double *Lx, double *out)
+{
+    CheckTask T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
+    int nsrow = f.nsrow, nscol = f.nscol ;
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6 ;
+    const double *L = Lx + f.psx ;
+    double slog = 0.0, sq = 0.0 ;
+    double nup = 0.0, nbad = 0.0, nneg = 0.0 ;
+    int c1 = T.c0 + CHK_COLS < nscol ? T.c0 + CHK_COLS : nscol ;
+    for (int j = T.c0 + wave ; j < c1 ; j += 4)
+    {
+        const double *col = L + (i64) j * nsrow ;
+        for (int i = lane ; i < nsrow ; i += 64)
+        {
+            double v = col [i] ;
+            if (i < j) { if (v != 0.0) nup += 1.0 ; }
+            else
+            {
+                if (!(v - v == 0.0)) nbad += 1.0 ; else sq = __builtin_fma (v, v, sq) ;
+                if (i == j) { if (v > 0.0) slog += log (v) ; else nneg += 1.0 ; }
+            }
+        }
+    }
+    double acc [5] = {slog, nup, nbad, sq, nneg} ;
+    __shared__ double red [4][5] ;
+#pragma unroll
+    for (int q = 0 ; q < 5 ; q++)
+    {
+        double v = acc [q] ;
+        for (int o = 32 ; o > 0 ; o >>= 1) v += __shfl_down (v, o) ;
+        if (lane == 0) red [wave][q] = v ;
+    }
+    __syncthreads () ;
+    if (threadIdx.x < 5)
+    {
+        double v = (red [0][threadIdx.x] + red [1][threadIdx.x]) + (red [2][threadIdx.x] + red [3][threadIdx.x]) ;
+        if (v != 0.0) atomicAdd (&out [threadIdx.x], v) ;
+    }
 }
 
 // ---- micro-benchmark: issue-bound v_mfma_f64_16x16x4_f64 loop (no memory) ----

@@ -74,6 +74,7 @@ static int map_hip_status (int rc, cholmod_common *Common, const char *what)
         case CHOLMOD_HIP_NOT_POSDEF: return TRUE ;
         case CHOLMOD_HIP_OUT_OF_MEMORY: ERROR (CHOLMOD_OUT_OF_MEMORY, what) ; return FALSE ;
         case CHOLMOD_HIP_INVALID: ERROR (CHOLMOD_INVALID, what) ; return FALSE ;
+        case CHOLMOD_HIP_TOO_LARGE: ERROR (CHOLMOD_TOO_LARGE, "problem too large for the HIP engine (32-bit maps)") ; return FALSE ;
         case CHOLMOD_HIP_NO_DEVICE:
             ERROR (CHOLMOD_GPU_PROBLEM, "no usable HIP device: the numeric factorization of this "
                 "library runs only on the GPU engine") ;

@@ -147,6 +147,22 @@ def geometric_nd(mx: int, my: int = 1, mz: int = 1, leaf: int = 4, width: int = 
     return out
 
 
+def poisson_logdet(*dims: int) -> float:
+    """log det of the Dirichlet 5-/7-point Poisson matrix on a grid with the given
+    extents (poisson2d / poisson3d above), in closed form: the eigenvalues are
+    2*len(dims) - 2*sum_d cos(i_d*pi/(m_d+1)), i_d = 1..m_d.  For a Cholesky factor
+    L of any symmetric permutation of A, sum_j 2*log L(j,j) equals this number --
+    a whole-factor checksum at sizes no CPU oracle reaches."""
+    import math
+    lam = np.zeros((1,) * len(dims))
+    for ax, m in enumerate(dims):
+        c = 2.0 - 2.0 * np.cos(np.arange(1, m + 1) * np.pi / (m + 1))
+        shape = [1] * len(dims)
+        shape[ax] = m
+        lam = lam + c.reshape(shape)
+    return math.fsum(np.log(lam).ravel().tolist()) if lam.size <= 2_000_000 else float(np.sum(np.log(lam), dtype=np.longdouble))
+
+
 def demo_rhs(n: int) -> np.ndarray:
     """b(i) = 1 + i/n, the demo's right-hand side."""
     return 1.0 + np.arange(n, dtype=np.float64) / n

@@ -42,8 +42,8 @@ def _run_ranks(world, mode, case, timeout=600, extra_env=None):
     return [json.load(open(f"{out}.{r}")) for r in range(world)]
 
 
-def _host_plans(world, n, Ap, Ai, Ax, perm):
-    S = ch.Session(use_gpu=0)
+def _host_plans(world, n, Ap, Ai, Ax, perm, postorder=True):
+    S = ch.Session(use_gpu=0, postorder=postorder)
     A = S.sparse(n, Ap, Ai, Ax, -1)
     Lf = S.analyze(A, perm)
     fv = ch.FactorView(Lf)
@@ -112,6 +112,28 @@ def test_partition_is_consistent_and_balanced(world):
     assert loads.max() <= 1.3 * loads.mean(), loads / loads.mean()
     # the executed-flop statistic is global, identical on every rank
     assert all(abs(s[1] - w.sum()) < 1e-9 * w.sum() for s in stats)
+
+
+@pytest.mark.parametrize("world", [2, 5, 8])
+def test_partition_without_etree_postorder(world):
+    """Common->postorder = FALSE with a random UserPerm: supernodes are
+    not numbered in etree postorder, a subtree is not an index range.  Groups must
+    still nest (a child's group inside its parent's) and solo subtrees stay whole."""
+    n, Ap, Ai, Ax = G.poisson2d(30)
+    perm = np.random.default_rng(30).permutation(n)
+    owners, _, (sparent, level), _, _ = _host_plans(world, n, Ap, Ai, Ax, perm, postorder=False)
+    o = owners[0]
+    for other in owners[1:]:
+        assert np.array_equal(o, other)
+    g0, gn = _host_plans.groups[0]
+    hp = np.where(sparent >= 0)[0]
+    pa = sparent[hp]
+    assert np.all((g0[hp] >= g0[pa]) & (g0[hp] + gn[hp] <= g0[pa] + gn[pa]))
+    shared = o < 0
+    assert np.all(shared[sparent[shared & (sparent >= 0)]])
+    solo = ~shared & (sparent >= 0)
+    assert np.all((o[sparent[solo]] == o[solo]) | (o[sparent[solo]] < 0))
+    assert np.all(gn[shared] >= 2) and np.all(gn[~shared] == 1)
 
 
 def test_world_one_has_no_shared_fronts():

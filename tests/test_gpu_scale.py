@@ -1,0 +1,284 @@
+"""GPU parity at the sizes BASELINE.json's configurations live at (run with -m gpu).
+
+* Against the oracle, at sizes it finishes in seconds: Poisson 64^3 (config 2's
+  family), SURVEY 8d's nd24k stand-in (box stencil r=3 on 42^3) and G3_circuit
+  stand-in (2D Poisson 1259^2), the same with the big-front code paths forced
+  (4096-wide outer blocks, several of them per front; the subtree-sweep schedule).
+* At BASELINE.json's full size (Poisson 100^3, configs[1]) through
+  size-independent properties: residual, cholmod_l_check_factor, the dead upper
+  triangles, and log det(A) = 2 sum log L(j,j) in closed form.
+* The dense partial factorization on a 16 500-row front against LAPACK.
+Everything goes through the C-ABI library; the oracle is only the checker.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleFactor, bind_blas
+from suitesparse_amd import cholmod as ch
+from suitesparse_amd import generators as G
+
+pytestmark = pytest.mark.gpu
+
+TOL_L = 1e-12          # ||L - L_ref||_F / ||L_ref||_F over the lower trapezoids (north_star)
+TOL_RES = 1e-11        # ||Ax-b||_2 / ||b||_2
+
+_WORK = {
+    "p3d_64_nd": lambda: G.poisson3d(64) + (G.geometric_nd(64, 64, 64, 4),),
+    "box42_r3_nd": lambda: G.box_stencil3d(42, 3) + (G.geometric_nd(42, 42, 42, 6, 3),),
+    "p2d_1259_nd": lambda: G.poisson2d(1259) + (G.geometric_nd(1259, 1259, 1, 4),),
+}
+_cache = {}
+
+
+def _oracle(name):
+    """(n, Ap, Ai, Ax, perm, OracleFactor, lower mask): one CPU factorization per
+    workload and test session (BLAS bound by dlopen, as bench.py's cpu_baseline)."""
+    if name not in _cache:
+        bind_blas()
+        n, Ap, Ai, Ax, perm = _WORK[name]()
+        O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+        assert O.factorize(Ax) == 0
+        _cache[name] = (n, Ap, Ai, Ax, perm, O, O.lower_mask())
+    return _cache[name]
+
+
+def _compare(name, session_kwargs=None, expect_nsplit=None, expect_ob4096=False):
+    n, Ap, Ai, Ax, perm, O, mask = _oracle(name)
+    S = ch.Session(**(session_kwargs or {}))
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    for k in ("Perm", "ColCount", "super", "pi", "px", "s"):
+        assert np.array_equal(getattr(fv, k), getattr(O, k)), k
+    assert fv.maxcsize == O.maxcsize and fv.maxesize == O.maxesize
+    assert S.cm.fl == O.fl and S.cm.lnz == O.lnz
+    err = np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask])
+    assert err < TOL_L, err
+    assert np.all(fv.x[~mask] == 0)              # dead upper triangles stay zero
+    assert S.L.cholmod_l_check_factor(Lf, C.byref(S.cm)) == 1
+    chk = S.factor_checks(Lf)
+    assert chk["upper_nonzeros"] == 0 and chk["nonfinite"] == 0 and chk["nonpositive_diag"] == 0
+    assert abs(chk["fro2"] - float(np.dot(O.x[mask], O.x[mask]))) < 1e-12 * chk["fro2"]
+    st = S.hip_stats(Lf)
+    if expect_nsplit is not None:
+        assert st[22] >= expect_nsplit, st[22]
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    r = G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b
+    xo = O.solve(b)
+    ro = G.sym_matvec(n, Ap, Ai, Ax, -1, xo) - b
+    # the attainable residual scales with cond(A) * eps (2D Poisson 1259^2: 5e-11 on
+    # the CPU path as well), so the bar is the reference path's own residual
+    assert np.linalg.norm(r) / np.linalg.norm(b) < max(TOL_RES, 2.0 * np.linalg.norm(ro) / np.linalg.norm(b))
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-10
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
+    return err
+
+
+def test_poisson64_matches_oracle():
+    """Poisson 64^3 under geometric ND: n = 262 144, 12 674 supernodes, 6 545-row root."""
+    _compare("p3d_64_nd")
+
+
+def test_nd24k_standin_matches_oracle():
+    """SURVEY 8d's nd24k stand-in (box stencil r=3 on 42^3, fat supernodes):
+    948 supernodes, root 7 560 x 7 560, fl = 8.0e11."""
+    _compare("box42_r3_nd")
+
+
+def test_g3circuit_standin_matches_oracle():
+    """SURVEY 8d's G3_circuit stand-in (2D Poisson 1259^2, thin supernodes):
+    n = 1 585 081, 114 250 supernodes, 98 % of them through the fused small-front kernel."""
+    _compare("p2d_1259_nd")
+
+
+def test_ob4096_and_subtree_sweep_on_nd24k_standin(monkeypatch):
+    """The code the 200^3 headline runs on: 4096-wide outer block columns (two of
+    them on the 7 560-column root, one on every front >= 3000 rows) and the
+    memory-aware subtree-sweep schedule (nsplit > 1), against the oracle."""
+    monkeypatch.setenv("CHOLMOD_HIP_OB4096_ROWS", "3000")
+    monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", "400")
+    _compare("box42_r3_nd", expect_nsplit=2)
+
+
+def test_ob4096_and_subtree_sweep_on_poisson64(monkeypatch):
+    monkeypatch.setenv("CHOLMOD_HIP_OB4096_ROWS", "2500")
+    monkeypatch.setenv("CHOLMOD_HIP_OB2048_ROWS", "1500")
+    monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", "300")
+    _compare("p3d_64_nd", expect_nsplit=2)
+
+
+def test_generic_kernels_only_on_thin_standin():
+    """The same thin workload without the fused small-front kernel: every front
+    through k_extend_add / potrf / trsm / update (flag CHOLMOD_HIP_NO_SMALL_FRONTS)."""
+    _compare("p2d_1259_nd", session_kwargs={"hip_flags": 16})
+
+
+def test_poisson100_full_size_properties(golden_dir):
+    """BASELINE.json configs[1] at full size (n = 10^6, Lx 10.5 GB): no CPU oracle,
+    so: the recorded symbolic profile of the reference, the
+    check_factor invariants, the dead upper triangles, log det in closed form,
+    and the residual."""
+    rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))
+    m = 100
+    n, Ap, Ai, Ax = G.poisson3d(m)
+    perm = G.geometric_nd(m, m, m, 4)
+    S = ch.Session(factor_on_device=True)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    fv = ch.FactorView(Lf)
+    want = rec["poisson3d_nd"]["100"]           # recorded to three digits
+    assert fv.nsuper == want["nsuper"]
+    assert abs(fv.xsize - want["xsize"]) <= 5e-3 * want["xsize"]
+    assert abs(fv.maxcsize - want["maxcsize"]) <= 5e-3 * want["maxcsize"]
+    assert abs(S.cm.fl - want["fl"]) <= 5e-3 * want["fl"]
+    assert S.L.cholmod_l_check_factor(Lf, C.byref(S.cm)) == 1
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK and ch.FactorView(Lf).minor == n
+    chk = S.factor_checks(Lf)
+    assert chk["upper_nonzeros"] == 0 and chk["nonfinite"] == 0 and chk["nonpositive_diag"] == 0
+    logdet = G.poisson_logdet(m, m, m)
+    assert abs(2.0 * chk["half_logdet"] - logdet) < 1e-11 * logdet
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    r = G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b
+    assert np.linalg.norm(r) / np.linalg.norm(b) < TOL_RES
+    # idempotence: a second factorization of the resident matrix gives the same factor
+    assert S.refactorize_resident(Lf) == 1
+    chk2 = S.factor_checks(Lf)
+    assert abs(chk2["fro2"] - chk["fro2"]) <= 1e-13 * chk["fro2"]
+    assert abs(chk2["half_logdet"] - chk["half_logdet"]) <= 1e-13 * abs(chk["half_logdet"])
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+@pytest.mark.parametrize("ob4096_rows", [None, 10000])
+def test_dense_partial_factor_16500_rows(monkeypatch, ob4096_rows):
+    """One dense front of 16 500 rows, 8 300 eliminated columns (outer block columns
+    2048 wide by default, 4096 wide -- two full ones and a remainder -- when
+    forced), against LAPACK on the host."""
+    import scipy.linalg as sl
+    if ob4096_rows:
+        monkeypatch.setenv("CHOLMOD_HIP_OB4096_ROWS", str(ob4096_rows))
+    L = ch.lib()
+    nsrow, nscol = 16500, 8300
+    rng = np.random.default_rng(16500)
+    W = rng.standard_normal((nsrow, 96))
+    Fm = W @ W.T
+    Fm[np.diag_indices(nsrow)] += 50.0 + np.arange(nsrow) * 1e-3
+    F = np.asfortranarray(Fm.copy())
+    info = C.c_int64(-1)
+    assert L.cholmod_hip_dense_partial_factor(F.ctypes.data, nsrow, nscol, 0, C.byref(info)) == 0
+    assert info.value == 0
+    ref = np.linalg.cholesky(Fm[:nscol, :nscol])
+    assert np.linalg.norm(np.tril(F[:nscol, :nscol]) - ref) / np.linalg.norm(ref) < 1e-13
+    L21 = sl.solve_triangular(ref, Fm[nscol:, :nscol].T, lower=True).T
+    assert np.linalg.norm(F[nscol:, :nscol] - L21) / np.linalg.norm(L21) < 1e-12
+    Sc = np.tril(Fm[nscol:, nscol:] - L21 @ L21.T)
+    assert np.linalg.norm(np.tril(F[nscol:, nscol:]) - Sc) / np.linalg.norm(Sc) < 1e-12
+    assert np.array_equal(np.triu(F[:nscol, :nscol], 1), np.triu(Fm[:nscol, :nscol], 1))
+
+
+# ---- orderings that are not etree postorders --------------------------
+
+@pytest.mark.parametrize("budget_mb", [None, 0.01])
+def test_postorder_off_random_perm(monkeypatch, budget_mb):
+    """Common->postorder = FALSE with a random UserPerm: supernodes are then not
+    numbered in etree postorder, subtrees are not index ranges.  Also with the
+    subtree-sweep schedule forced (nsplit > 1 walks subtrees)."""
+    if budget_mb:
+        monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", str(budget_mb))
+    n, Ap, Ai, Ax = G.poisson2d(45)
+    rng = np.random.default_rng(45)
+    base = G.geometric_nd(45, 45, 1, 3)
+    # a valid but scrambled elimination order: ND with the leaf blocks and the
+    # separators shuffled among themselves keeps fill moderate, kills the postorder
+    perm = base.copy()
+    blocks = np.array_split(np.arange(n), 60)
+    order = rng.permutation(len(blocks) - 6)
+    perm = np.concatenate([base[blocks[i]] for i in order] + [base[b] for b in blocks[-6:]])
+    S = ch.Session(postorder=False)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=False)
+    assert O.factorize(Ax) == 0
+    sparent = O.sparent()
+    # the point of the case: some subtree is not a contiguous index range
+    first = np.arange(O.nsuper)
+    size = np.ones(O.nsuper, dtype=np.int64)
+    for s in range(O.nsuper):
+        p = sparent[s]
+        if p >= 0:
+            first[p] = min(first[p], first[s])
+            size[p] += size[s]
+    assert np.any(size != np.arange(O.nsuper) - first + 1)
+    for k in ("Perm", "super", "pi", "px", "s"):
+        assert np.array_equal(getattr(fv, k), getattr(O, k)), k
+    mask = O.lower_mask()
+    assert np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask]) < TOL_L
+    if budget_mb:
+        assert S.hip_stats(Lf)[22] > 1
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b) / np.linalg.norm(b) < TOL_RES
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+def test_super_numeric_direct_unpacked_unsorted_with_ignored_triangle():
+    """cholmod_l_super_numeric called directly (the expert routine,
+    cholmod_supernodal.h:126) on an unpacked, unsorted lower-stored S that also
+    carries entries in the ignored upper triangle
+    (t_cholmod_super_numeric.c:369-373 skips i < k)."""
+    n, Ap, Ai, Ax = G.poisson3d(8)
+    S = ch.Session(postorder=False)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, None)                      # natural order, no postorder: S = A
+    O = OracleFactor(n, Ap, Ai, -1, perm=None, postorder=False)
+    assert O.factorize(Ax) == 0
+    cap = int(Ap[-1]) + 5 * n
+    A_un = S.L.cholmod_l_allocate_sparse(n, n, cap, 0, 0, -1, ch.REAL, C.byref(S.cm))
+    a = A_un.contents
+    p = ch._view(a.p, n + 1, C.c_int64, np.int64)
+    nz = ch._view(a.nz, n, C.c_int64, np.int64)
+    ai = ch._view(a.i, cap, C.c_int64, np.int64)
+    ax = ch._view(a.x, cap, C.c_double, np.float64)
+    ai[:] = 0
+    ax[:] = np.nan
+    rng = np.random.default_rng(8)
+    pos = 0
+    for j in range(n):
+        rows = list(Ai[Ap[j]:Ap[j + 1]])
+        vals = list(Ax[Ap[j]:Ap[j + 1]])
+        if j > 0:                                # junk above the diagonal: must be ignored
+            rows.append(int(rng.integers(0, j)))
+            vals.append(1e30)
+        o = rng.permutation(len(rows))
+        p[j] = pos
+        nz[j] = len(rows)
+        ai[pos:pos + len(rows)] = np.array(rows)[o]
+        ax[pos:pos + len(rows)] = np.array(vals)[o]
+        pos += len(rows) + 3
+    p[n] = pos
+    beta = (C.c_double * 2)(0.0, 0.0)
+    assert S.L.cholmod_l_super_numeric(A_un, None, C.byref(beta), Lf, C.byref(S.cm)) == 1
+    assert S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    mask = O.lower_mask()
+    assert np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask]) < TOL_L
+    S.free_factor(Lf)
+    S.free_sparse(A_un)
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
