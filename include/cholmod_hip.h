@@ -192,6 +192,13 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
 #define CHOLMOD_HIP_NSTATS 24
 int cholmod_hip_get_stats (cholmod_hip_plan *plan, double *stats) ;
 int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
+/* The launch list of the plan and, after a factorization with profiling on, the
+ * device milliseconds of every launch (tuning; tools/launch_profile.py).
+ * kind: 0 zero, 1 extend-add, 2 potrf, 3 trsm, 4 update(128), 5 update(64),
+ * 7 all-reduce, 8 thin fronts.  Fills at most cap entries of the arrays that are
+ * not NULL, returns the number of launches. */
+int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
+    int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;
 
 /* Dense fp64 C -= A*B' micro-benchmark on the engine's update kernel (used by
  * bench.py to print the measured MFMA rate next to the 78.6 TFLOP/s spec).
@@ -207,6 +214,11 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;
 /* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */
 int cholmod_hip_debug_panel_cycles (long long *out16) ;
+/* Tuning probe (plans created with CHOLMOD_HIP_THIN_TIMING set): shader cycles one
+ * front of thin-front launch `launch` spent per phase: [0] requests + zero, [1] A,
+ * [2] children, [3] panel chain, [4] publish + row solves, [5] store + barrier,
+ * [6] trailing update / contribution block. */
+int cholmod_hip_debug_thin_cycles (cholmod_hip_plan *plan, int64_t launch, long long *out10) ;
 /* Tuning probe: cycles for n repetitions of basic fp64 instruction patterns (one wave). */
 int cholmod_hip_debug_latency (long long *out8, int n) ;
 

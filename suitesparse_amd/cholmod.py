@@ -135,7 +135,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
-    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks",
+    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles",
     "cholmod_hip_version",
 ]
 
@@ -241,6 +241,8 @@ def lib():
     sig("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
     sig("cholmod_hip_factor_checks", C.c_int, [vp, vp])
+    sig("cholmod_hip_get_launch_profile", i64, [vp, i64, vp, vp, vp, vp, vp, vp])
+    sig("cholmod_hip_debug_thin_cycles", C.c_int, [vp, i64, vp])
     sig("cholmod_hip_version", C.c_char_p, [])
     _lib = L
     return L
@@ -373,6 +375,16 @@ class Session:
             raise RuntimeError(f"cholmod_hip_factor_checks failed: {rc}")
         return dict(half_logdet=out[0], upper_nonzeros=int(out[1]), nonfinite=int(out[2]),
                     fro2=out[3], nonpositive_diag=int(out[4]))
+
+    def launch_profile(self, Lf):
+        """Per-launch (kind, grid, aux, ms, flops, bytes) of the last profiled factorization."""
+        plan = Lf.contents.hip_plan
+        nl = self.L.cholmod_hip_get_launch_profile(plan, 0, None, None, None, None, None, None)
+        kind = np.zeros(nl, dtype=np.int32); grid = np.zeros(nl, dtype=np.int32); aux = np.zeros(nl, dtype=np.int32)
+        ms = np.zeros(nl); fl = np.zeros(nl); by = np.zeros(nl)
+        self.L.cholmod_hip_get_launch_profile(plan, nl, kind.ctypes.data, grid.ctypes.data, aux.ctypes.data,
+                                              ms.ctypes.data, fl.ctypes.data, by.ctypes.data)
+        return dict(kind=kind, grid=grid, aux=aux, ms=ms, flops=fl, bytes=by)
 
     def set_profiling(self, Lf, on=True):
         if Lf.contents.hip_plan:

@@ -194,6 +194,7 @@ struct cholmod_hip_plan {
     double *d_solved = nullptr ; i64 solved_cap = 0 ; int max_big_nscol = 0 ;
     double *d_sv_acc = nullptr ; i64 sv_acc_cap = 0 ;
     unsigned int *d_ticket = nullptr ;
+    long long *d_thin_tim = nullptr ;       // CHOLMOD_HIP_THIN_TIMING: 10 cycle counters per launch
     CheckTask *d_chk = nullptr ; i64 nchk = 0 ;     // cholmod_hip_factor_checks task list (lazy)
     double *d_chk_out = nullptr ;
     Schedule sch ;
@@ -219,6 +220,7 @@ struct cholmod_hip_plan {
     // stats
     bool profiling = false ;
     double stats [CHOLMOD_HIP_NSTATS] = {0} ;
+    std::vector<float> launch_ms ;          // per-launch device time of the last profiled factorization
     hipEvent_t ev0 = nullptr, ev1 = nullptr ;
     std::vector<hipEvent_t> evpool ;
 } ;
@@ -977,7 +979,7 @@ static void free_device (cholmod_hip_plan *P)
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out} ;
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1032,6 +1034,11 @@ static int upload_plan (cholmod_hip_plan *P)
         for (const Launch &L : P->sch.launches) if (L.kind == K_ALLREDUCE && L.ar_r0 > 0) mx = std::max (mx, L.ar_cnt) ;
         HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
     }
+    if (getenv ("CHOLMOD_HIP_THIN_TIMING"))
+    {
+        HIPCHK (hipMalloc ((void **) &P->d_thin_tim, (P->sch.launches.size () + 1) * 10 * sizeof (long long))) ;
+        HIPCHK (hipMemset (P->d_thin_tim, 0, (P->sch.launches.size () + 1) * 10 * sizeof (long long))) ;
+    }
     if (P->nsuper > 0)
     {
         int grid = (int) ((P->nsuper * 64 + 255) / 256) ;
@@ -1052,6 +1059,7 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -1067,16 +1075,31 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
             // fronts of <= 64 rows run one wave per front (lane = row, no cross-wave
             // hand-off), wider ones four
-            if (L.aux <= 64)
-                hipLaunchKernelGGL (k_thin_front<1>, dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
+            if (P->d_thin_tim)
+            {
+                // tuning: per-phase shader cycles of one front per launch (CHOLMOD_HIP_THIN_TIMING)
+                long long *tim = P->d_thin_tim + 10 * (size_t) (&L - P->sch.launches.data ()) ;
+                if (L.aux <= 64)
+                    hipLaunchKernelGGL ((k_thin_front<1, true>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
+                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
+                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, tim) ;
+                else
+                    hipLaunchKernelGGL ((k_thin_front<4, true>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
+                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
+                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, tim) ;
+            }
+            else if (L.aux <= 64)
+                hipLaunchKernelGGL ((k_thin_front<1>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
                     P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux, (long long *) nullptr) ;
             else
-                hipLaunchKernelGGL (k_thin_front<4>, dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
+                hipLaunchKernelGGL ((k_thin_front<4>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
                     P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux, (long long *) nullptr) ;
             break ;
         case K_ALLREDUCE:
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
@@ -1221,10 +1244,12 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         float t = 0 ;
         HIPCHK (hipEventElapsedTime (&t, P->evpool [0], P->evpool [1])) ;
         S [13] = t * 1e-3 ;
+        P->launch_ms.assign (nl, 0.0f) ;
         for (size_t q = 0 ; q < nl ; q++)
         {
             const Launch &L = P->sch.launches [q] ;
             HIPCHK (hipEventElapsedTime (&t, P->evpool [2 * (q + 1)], P->evpool [2 * (q + 1) + 1])) ;
+            P->launch_ms [q] = t ;
             double sec = t * 1e-3 ;
             switch (L.kind)
             {
@@ -1645,6 +1670,31 @@ int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
     P->stats [22] = P->nsplit ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
     return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_debug_thin_cycles (cholmod_hip_plan *P, int64_t launch, long long *out10)
+{
+    if (!P || !P->d_thin_tim || launch < 0 || launch >= (i64) P->sch.launches.size ()) return CHOLMOD_HIP_INVALID ;
+    HIPCHK (hipMemcpy (out10, P->d_thin_tim + 10 * launch, 10 * sizeof (long long), hipMemcpyDeviceToHost)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *P, int64_t cap, int32_t *kind, int32_t *grid,
+    int32_t *aux, double *ms, double *flops, double *bytes)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    i64 nl = (i64) P->sch.launches.size () ;
+    for (i64 q = 0 ; q < nl && q < cap ; q++)
+    {
+        const Launch &L = P->sch.launches [q] ;
+        if (kind) kind [q] = L.kind ;
+        if (grid) grid [q] = L.grid ;
+        if (aux) aux [q] = L.aux ;
+        if (ms) ms [q] = q < (i64) P->launch_ms.size () ? P->launch_ms [q] : 0.0 ;
+        if (flops) flops [q] = L.flops ;
+        if (bytes) bytes [q] = L.bytes ;
+    }
+    return nl ;
 }
 
 int cholmod_hip_set_profiling (cholmod_hip_plan *P, int on)

@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
 __host__ __device__ inline size_t thin_front_lds_bytes (int ns_max)
 {
     int nsp = (ns_max + 1) & ~1 ;
-    return (size_t) (ns_max * (ns_max + 1) / 2 + TF_PW) * sizeof (double) + 2 * (size_t) nsp * sizeof (i32) ;
+    return (size_t) (ns_max * (ns_max + 1) / 2) * sizeof (double) + 3 * (size_t) nsp * sizeof (i32) ;
 }
 // (i,j) of the e-th entry of a packed lower triangle of order m
 __device__ __forceinline__ void tri_decode (int e, int m, int &i, int &j)
@@ -979,19 +979,212 @@ __device__ __forceinline__ void tri_decode (int e, int m, int &i, int &j)
     while (st + (m - jj) <= e) { st += m - jj ; jj++ ; }
     j = jj ; i = jj + (e - st) ;
 }
-template <int NW>
-__global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
+// LDS-only barrier of the thin-front workgroup: __syncthreads() would also wait
+// for the global stores in flight (the finished panel columns on their way to
+// Lx), two microseconds per panel.  One wave: LDS operations of a wave are
+// ordered, nothing to wait for.
+template <int NW> __device__ __forceinline__ void tf_barrier ()
+{
+    if constexpr (NW == 1) { asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ; }
+    else asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") ;
+}
+// One PW-column panel (PW = 4, 8, 16 at compile time: no branch inside the
+// elimination; columns pc .. PW-1 do not exist and behave as identity columns).
+// Every wave carries the PW diagonal rows in its lanes 0 .. PW-1 (the same values
+// in all waves) and 64 - PW rows of its own behind them, so each wave runs the
+// whole elimination by itself: pivots and multipliers travel by v_readlane, no
+// wave waits for another, no barrier inside the panel.  On return a [] holds the
+// finished entries L(row, c0 + c) of this thread's row; `own` tells whether this
+// thread is the one that stores them (diagonal rows: wave 0 only).
+template <int PW, int NW>
+__device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
+    int lane, int wave, int &fail, double *Lp)
+{
+    double a [PW] ;
+    const int row = lane < PW ? c0 + lane : c0 + PW + (64 - PW) * wave + (lane - PW) ;
+    const bool rok = row < ns ;
+    const bool own = rok && (lane >= PW || wave == 0) ;
+    const int rr = rok ? row : ns - 1 ;
+    {
+        int o = tri_col (c0, ns) ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            double v = F [o + rr] ;                         // always inside the packed front: no branch
+            v = (rok && row >= c0 + c) ? v : 0.0 ;
+            a [c] = (c < pc) ? v : (lane == c ? 1.0 : 0.0) ;
+            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
+        }
+    }
+    double dv = 1.0 ;                                       // lane c keeps the pivot of column c
+#pragma unroll
+    for (int c = 0 ; c < PW ; c++)
+    {
+        double d = readlane_f64 (a [c], c) ;
+        if (c < pc && fail < 0 && d <= 0.0) fail = c0 + c ;
+        double x = __builtin_amdgcn_rcp (d) ;
+        double e = __builtin_fma (-d, x, 1.0) ;
+        x = __builtin_fma (x, e, x) ;
+        // all multipliers u(c0+c2, c) of the column leave for the scalar registers at
+        // once, next to the reciprocal: one (read-lane, read-lane, fma) triple after the
+        // other through the same scalar pair costs ~70 cycles each
+        // (missing columns pc .. PW-1 collect garbage nobody reads: they sit behind
+        // the real ones, are never a pivot that counts and are never stored)
+        double u [PW] ;
+#pragma unroll
+        for (int c2 = c + 1 ; c2 < PW ; c2++) u [c2] = readlane_f64 (a [c], c2) ;
+        __builtin_amdgcn_sched_barrier (0) ;
+        double t = a [c] * x ;                              // u(row,c) / d
+#pragma unroll
+        for (int c2 = c + 1 ; c2 < PW ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
+        if (lane == c) dv = d ;
+        __builtin_amdgcn_sched_barrier (0) ;
+    }
+    double r, ri ;
+    sqrt_rsqrt (dv, r, ri) ;
+#pragma unroll
+    for (int c = 0 ; c < PW ; c++)
+    {
+        double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
+        a [c] = (lane == c) ? rc : a [c] * ric ;
+        if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
+    }
+    if (wave == 0 && lane == 0) *s_fail = fail ;
+    if (own)
+    {
+        // finished columns: back into the LDS front (operands of the trailing update)
+        // and, straight from the registers, to Lx (Lp = first column of the panel;
+        // columns at / beyond a failed pivot stay zero)
+        int o = tri_col (c0, ns) ;
+        double *Lr = Lp + row ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            if (c < pc && row >= c0 + c)
+            {
+                F [o + row] = a [c] ;
+                if (fail < 0 || c0 + c < fail) Lr [(i64) c * ns] = a [c] ;
+            }
+            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
+        }
+    }
+}
+// G tiles (i0, j0 + 16 g) of the trailing update, G independent MFMA chains:
+// C -= L(:, c0 .. c0+pc) L(:, same)'.  TO_CB: the result is the contribution block
+// (packed, HBM); otherwise it goes back into the LDS front.  All offsets come from
+// 24-bit multiplies and increments (tri_col (j+4) - tri_col (j) = 4 m - 4 j - 10).
+__device__ __forceinline__ int tri_col24 (int j, int m) { return __mul24 (j, m) - (__mul24 (j, j + 1) >> 1) ; }
+template <int G, int KS, bool TO_CB>
+__device__ __forceinline__ void tf_tiles (double *F, int ns, int c0, int pc, int i0, int j0, int lane,
+    double *Co, int nc, int ncb, bool czero)
+{
+    const int lr = lane & 15, lk = lane >> 4 ;
+    const int i = i0 + lr ;
+    const int ir = i < ns ? i : ns - 1 ;
+    int koff [KS] ;                                         // column of k-step s for this lane (k = 4 s + lk)
+    double af [KS] ;
+#pragma unroll
+    for (int s4 = 0 ; s4 < KS ; s4++)
+    {
+        int k = 4 * s4 + lk ;
+        koff [s4] = tri_col24 (c0 + (k < pc ? k : pc - 1), ns) ;
+        double v = F [koff [s4] + ir] ;
+        af [s4] = (k < pc) ? -v : 0.0 ;
+    }
+    // C entries of this lane: (i, j0 + 16 g + lk + 4 r); offsets in the packed front
+    d4 acc [G] ;
+    if (czero)
+    {
+        // a front without children: nothing but zeros behind the panel columns
+#pragma unroll
+        for (int g = 0 ; g < G ; g++) acc [g] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    }
+    else
+    {
+        int j = j0 + lk ;
+        int o = tri_col24 (j < ns ? j : ns - 1, ns) ;
+#pragma unroll
+        for (int g = 0 ; g < G ; g++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                bool ok = (i < ns) && (j <= i) ;
+                double v = F [ok ? o + i : 0] ;
+                acc [g][r] = ok ? v : 0.0 ;
+                o += 4 * ns - 4 * j - 10 ; j += 4 ;
+            }
+    }
+#pragma unroll
+    for (int s4 = 0 ; s4 < KS ; s4++)
+    {
+        int k = 4 * s4 + lk ;
+#pragma unroll
+        for (int g = 0 ; g < G ; g++)
+        {
+            int jr = j0 + 16 * g + lr ; jr = jr < ns ? jr : ns - 1 ;
+            double bv = F [koff [s4] + jr] ;
+            bv = (k < pc) ? bv : 0.0 ;
+            acc [g] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, af [s4], acc [g], 0, 0, 0) ;
+        }
+    }
+    if constexpr (TO_CB)
+    {
+        int j = j0 + lk - nc ;                              // column / row inside the contribution block
+        const int ic = i - nc ;
+        int o = tri_col24 (j < ncb ? j : ncb - 1, ncb) ;
+#pragma unroll
+        for (int g = 0 ; g < G ; g++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                if (i < ns && j <= ic) Co [o + ic] = acc [g][r] ;
+                o += 4 * ncb - 4 * j - 10 ; j += 4 ;
+            }
+    }
+    else
+    {
+        int j = j0 + lk ;
+        int o = tri_col24 (j < ns ? j : ns - 1, ns) ;
+#pragma unroll
+        for (int g = 0 ; g < G ; g++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                if (i < ns && j <= i) F [o + i] = acc [g][r] ;
+                o += 4 * ns - 4 * j - 10 ; j += 4 ;
+            }
+    }
+}
+template <int KS, bool TO_CB>
+__device__ __forceinline__ void tf_tile_row (double *F, int ns, int c0, int pc, int t0, int I, int lane,
+    double *Co, int nc, int ncb, bool czero)
+{
+    const int i0 = t0 + 16 * I ;
+    for (int J = 0 ; J <= I ; )
+    {
+        int left = I + 1 - J, j0 = t0 + 16 * J ;
+        if (left >= 4) { tf_tiles<4, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 4 ; }
+        else if (left >= 2) { tf_tiles<2, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 2 ; }
+        else { tf_tiles<1, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 1 ; }
+    }
+}
+template <int NW, bool TIMED = false>
+__global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (const i32 *fronts,
     const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
     const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
-    double *Lx, double *CB, i32 *info, int ns_max)
+    double *Lx, double *CB, i32 *info, int ns_max, long long *tim = nullptr)
 {
+    long long tc [10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     constexpr int NT = 64 * NW ;
-    constexpr int NLD = 8 ;                                 // child entries in flight per thread
+    constexpr int NLD = 8 ;                                 // child entries in flight per thread and buffer
+    constexpr int NRM = (SM_MAX + NT - 1) / NT ;            // relative-map entries per thread
     extern __shared__ __attribute__((aligned(16))) double tf_lds [] ;
     double *F = tf_lds ;                                    // packed lower triangle of the front
-    double *pv = F + ns_max * (ns_max + 1) / 2 ;            // 1 / L(c,c) of the current panel
-    i32 *rows_l = (i32 *) (pv + TF_PW) ;                    // the front's row list
-    i32 *rm_l = rows_l + ((ns_max + 1) & ~1) ;              // relative map of the current child
+    const int nsp = (ns_max + 1) & ~1 ;
+    i32 *rows_l = (i32 *) (F + ns_max * (ns_max + 1) / 2) ; // the front's row list
+    i32 *rm_l = rows_l + nsp ;                              // relative maps of two children (ping-pong)
     __shared__ int s_fail ;
     const i32 fid = fronts [blockIdx.x] ;
     const FrontD &f = fr [fid] ;
@@ -999,7 +1192,8 @@ __global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     const i64 psx = f.psx, cbo = f.cb ;
     const int T = ns * (ns + 1) / 2 ;
-    // ---- (1) requests first
+    const int cbeg = f.child_begin, cend = f.child_end ;
+    // ---- (1) requests first: row list, column pointers of A, the first child
     i64 rowv = (tid < ns) ? Ls [f.psi + tid] : 0 ;
     i64 p0 = 0, p1 = 0 ;
     const bool asm_col = f.assemble && tid < nc ;
@@ -1008,10 +1202,75 @@ __global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
         i64 col = (i64) k1 + tid ;
         p0 = Sp [col] ; p1 = Snz ? p0 + Snz [col] : Sp [col + 1] ;
     }
+    // children stream: chunk = NLD * NT consecutive entries of one child's packed CB
+    // (or NLD whole columns of a square one, see below); two register buffers
+    struct Cur { int ci, base, m, tot, sq ; const double *src ; } ;
+    auto child_at = [&] (int ci, Cur &c)
+    {
+        const FrontD &cf = fr [child [ci]] ;
+        c.ci = ci ; c.base = 0 ; c.m = cf.ncb ; c.sq = !cf.cbp ;
+        c.tot = cf.cbp ? cf.ncb * (cf.ncb + 1) / 2 : cf.ncb * cf.ncb ;
+        c.src = CB + cf.cb ;
+    } ;
+    auto advance = [&] (Cur &c) -> bool                      // next chunk; false when the stream is over
+    {
+        c.base += NLD * NT ;
+        if (c.base < c.tot) return true ;
+        if (c.ci + 1 >= cend) return false ;
+        child_at (c.ci + 1, c) ;
+        return true ;
+    } ;
+    auto issue = [&] (const Cur &c, double (&v) [NLD], i32 (&rmv) [NRM])
+    {
+        if (c.base == 0)
+        {
+            const i32 *rm = relmap + fr [child [c.ci]].rel ;
+#pragma unroll
+            for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; rmv [q] = rm [e < c.m ? e : c.m - 1] ; }
+        }
+#pragma unroll
+        for (int q = 0 ; q < NLD ; q++)
+        {
+            int e = c.base + tid + NT * q ;
+            v [q] = c.src [e < c.tot ? e : c.tot - 1] ;
+        }
+    } ;
+    auto consume = [&] (const Cur &c, const double (&v) [NLD], const i32 (&rmv) [NRM])
+    {
+        i32 *rmc = rm_l + (c.ci & 1) * nsp ;
+        if (c.base == 0)
+        {
+            // a new child: its map goes to LDS; the barrier also keeps two children
+            // from adding into the same entry at the same time
+#pragma unroll
+            for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; if (e < c.m) rmc [e] = rmv [q] ; }
+            tf_barrier<NW> () ;
+        }
+        // (i, j) of this thread's first entry of the chunk, then NT entries further each time
+        int e = c.base + tid, i, j ;
+        const int m = c.m ;
+        if (c.sq) { j = e / m ; i = e - j * m ; }
+        else tri_decode (e < c.tot ? e : c.tot - 1, m, i, j) ;
+#pragma unroll
+        for (int q = 0 ; q < NLD ; q++)
+        {
+            if (e < c.tot && i >= j) F [tri_col24 (rmc [j], ns) + rmc [i]] += v [q] ;
+            e += NT ; i += NT ;
+            if (c.sq) { while (i >= m) { i -= m ; j++ ; } }
+            else { while (i >= m && j < m - 1) { j++ ; i = i - m + j ; } }
+            if (i >= m || j >= m) { j = m - 1 ; i = m - 1 ; e = c.tot ; }     // past the last entry
+        }
+    } ;
+    double vA [NLD], vB [NLD] ;
+    i32 rmA [NRM], rmB [NRM] ;
+    Cur cA, cB ;
+    bool haveA = cbeg < cend, haveB = false ;
+    if (haveA) { child_at (cbeg, cA) ; issue (cA, vA, rmA) ; }
     for (int e = tid ; e < T ; e += NT) F [e] = 0.0 ;
     if (tid == 0) s_fail = -1 ;
     if (tid < ns) rows_l [tid] = (i32) rowv ;
-    __syncthreads () ;
+    tf_barrier<NW> () ;
+    tick (0) ;
     // ---- A into the panel columns (ASSIGN semantics, entries outside the pattern dropped)
     if (asm_col)
     {
@@ -1038,207 +1297,61 @@ __global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
         }
         if (beta != 0.0) Fc [k] += beta ;
     }
-    __syncthreads () ;
-    // ---- (2) children
-    for (int ci = f.child_begin ; ci < f.child_end ; ci++)
+    tick (1) ;
+    // ---- (2) children: consume one buffer while the next chunk is in flight
+    while (haveA)
     {
-        const FrontD &c = fr [child [ci]] ;
-        const int m = c.ncb ;
-        const i32 *rm = relmap + c.rel ;
-        const double *src = CB + c.cb ;
-        for (int e = tid ; e < m ; e += NT) rm_l [e] = rm [e] ;
-        if (c.cbp)
-        {
-            const int tot = m * (m + 1) / 2 ;
-            for (int base = 0 ; base < tot ; base += NLD * NT)
-            {
-                double v [NLD] ;
-#pragma unroll
-                for (int q = 0 ; q < NLD ; q++)
-                {
-                    int e = base + tid + NT * q ;
-                    v [q] = src [e < tot ? e : tot - 1] ;
-                }
-                if (base == 0) __syncthreads () ;           // rm_l complete
-#pragma unroll
-                for (int q = 0 ; q < NLD ; q++)
-                {
-                    int e = base + tid + NT * q ;
-                    if (e < tot)
-                    {
-                        int i, j ;
-                        tri_decode (e, m, i, j) ;
-                        F [tri_col (rm_l [j], ns) + rm_l [i]] += v [q] ;
-                    }
-                }
-            }
-        }
-        else
-        {
-            // square child (a generic front under a thin parent): column by column
-            __syncthreads () ;
-            for (int j = wave ; j < m ; j += NW)
-            {
-                double *Ft = F + tri_col (rm_l [j], ns) ;
-                const double *sc = src + (i64) j * m ;
-                for (int i = j + lane ; i < m ; i += 64) Ft [rm_l [i]] += sc [i] ;
-            }
-        }
-        __syncthreads () ;
+        cB = cA ; haveB = advance (cB) ;
+        if (haveB) issue (cB, vB, rmB) ;
+        consume (cA, vA, rmA) ;
+        if (!haveB) break ;
+        cA = cB ; haveA = advance (cA) ;
+        if (haveA) issue (cA, vA, rmA) ;
+        consume (cB, vB, rmB) ;
     }
-    // ---- (3), (4): 16-column panels
-    const int lr = lane & 15, lk = lane >> 4 ;
+    tf_barrier<NW> () ;
+    tick (2) ;
+    // ---- (3), (4): panels of up to 16 columns
     int fail = -1 ;
     for (int c0 = 0 ; c0 < nc ; c0 += TF_PW)
     {
         const int pc = nc - c0 < TF_PW ? nc - c0 : TF_PW ;
-        const int row = c0 + tid ;
-        const bool rok = row < ns ;
-        double a [TF_PW] ;
-#pragma unroll
-        for (int c = 0 ; c < TF_PW ; c++)
-            a [c] = (rok && c < pc && row >= c0 + c) ? F [tri_col (c0 + c, ns) + row] : 0.0 ;
-        if (wave == 0)
-        {
-            double dv = 1.0 ;                               // lane c keeps the pivot of column c
-#pragma unroll
-            for (int c = 0 ; c < TF_PW ; c++)
-            {
-                if (c < pc)
-                {
-                    double d = readlane_f64 (a [c], c) ;
-                    if (fail < 0 && d <= 0.0) fail = c0 + c ;
-                    double x = __builtin_amdgcn_rcp (d) ;
-                    double e = __builtin_fma (-d, x, 1.0) ;
-                    x = __builtin_fma (x, e, x) ;
-                    double t = a [c] * x ;                  // u(row,c) / d
-#pragma unroll
-                    for (int c2 = c + 1 ; c2 < TF_PW ; c2++)
-                        if (c2 < pc) a [c2] = __builtin_fma (-t, readlane_f64 (a [c], c2), a [c2]) ;
-                    if (lane == c) dv = d ;
-                }
-            }
-            double r, ri ;
-            sqrt_rsqrt (dv, r, ri) ;
-#pragma unroll
-            for (int c = 0 ; c < TF_PW ; c++)
-            {
-                double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
-                a [c] = (lane == c) ? rc : a [c] * ric ;
-                if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
-            }
-            if (lane < TF_PW) pv [lane] = ri ;
-            if (lane == 0) s_fail = fail ;
-        }
-        if (NW > 1)
-        {
-            // publish the factored 16 x 16 block, then the other waves solve their rows
-            if (wave == 0 && rok)
-            {
-#pragma unroll
-                for (int c = 0 ; c < TF_PW ; c++)
-                    if (c < pc && row >= c0 + c) F [tri_col (c0 + c, ns) + row] = a [c] ;
-            }
-            __syncthreads () ;
-            fail = s_fail ;
-            if (wave > 0)
-            {
-                const int nvalid = fail >= 0 ? fail - c0 : pc ;
-#pragma unroll
-                for (int c = 0 ; c < TF_PW ; c++)
-                {
-                    if (c < pc)
-                    {
-                        double xv = a [c] * pv [c] ;
-                        if (c >= nvalid) xv = 0.0 ;
-                        a [c] = xv ;
-                        const double *Lc = F + tri_col (c0 + c, ns) + c0 ;      // L11(c2, c) at Lc [c2]
-#pragma unroll
-                        for (int c2 = c + 1 ; c2 < TF_PW ; c2++)
-                            if (c2 < pc) a [c2] = __builtin_fma (-xv, Lc [c2], a [c2]) ;
-                    }
-                }
-                if (rok)
-                {
-#pragma unroll
-                    for (int c = 0 ; c < TF_PW ; c++)
-                        if (c < pc) F [tri_col (c0 + c, ns) + row] = a [c] ;
-                }
-            }
-        }
-        else
-        {
-            if (rok)
-            {
-#pragma unroll
-                for (int c = 0 ; c < TF_PW ; c++)
-                    if (c < pc && row >= c0 + c) F [tri_col (c0 + c, ns) + row] = a [c] ;
-            }
-        }
-        // finished columns: registers -> Lx (columns at / beyond a failed pivot stay zero)
-        if (rok)
-        {
-            double *Lr = Lx + psx + row + (i64) c0 * ns ;
-#pragma unroll
-            for (int c = 0 ; c < TF_PW ; c++)
-                if (c < pc && row >= c0 + c && (fail < 0 || c0 + c < fail)) Lr [(i64) c * ns] = a [c] ;
-        }
-        __syncthreads () ;
-        if (NW == 1) fail = s_fail ;
+        double *Lp = Lx + psx + (i64) c0 * ns ;
+        if (pc <= 4) tf_panel<4, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
+        else if (pc <= 8) tf_panel<8, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
+        else if (pc <= 12) tf_panel<12, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
+        else tf_panel<16, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
+        tick (3) ;
+        tf_barrier<NW> () ;
+        tick (4) ;
+        fail = s_fail ;
         if (fail >= 0) break ;
-        // trailing update of rows / columns t0 .. ns-1 with the pc panel columns
+        // trailing update of rows / columns t0 .. ns-1 with the pc panel columns; tile
+        // rows are dealt in pairs (p, nd-1-p) so that every wave gets the same work
         const int t0 = c0 + pc ;
         const bool last = t0 >= nc ;
         const int nd = (ns - t0 + 15) >> 4 ;
-        const int ntile = nd * (nd + 1) / 2 ;
-        for (int u = wave ; u < ntile ; u += NW)
+        double *Co = CB + cbo ;
+        const bool czero = last && c0 == 0 && cbeg == cend ;    // leaf front, single panel
+        for (int pr = wave ; 2 * pr < nd ; pr += NW)
         {
-            int tj = 0, rem = u ;
-            while (rem >= nd - tj) { rem -= nd - tj ; tj++ ; }
-            const int i0 = t0 + 16 * (tj + rem), j0 = t0 + 16 * tj ;
-            const int i = i0 + lr ;
-            const int ir = i < ns ? i : ns - 1 ;
-            const int jr = j0 + lr < ns ? j0 + lr : ns - 1 ;
-            d4 acc ;
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
+            for (int side = 0 ; side < 2 ; side++)
             {
-                int j = j0 + lk + 4 * r ;
-                acc [r] = (i < ns && j <= i) ? F [tri_col (j, ns) + i] : 0.0 ;
-            }
-#pragma unroll
-            for (int kk = 0 ; kk < TF_PW ; kk += 4)
-            {
-                if (kk < pc)
+                int I = side ? nd - 1 - pr : pr ;
+                if (side && I == pr) break ;
+                if (last)
                 {
-                    int k = kk + lk ;
-                    const double *Fk = F + tri_col (c0 + (k < pc ? k : pc - 1), ns) ;
-                    double av = (k < pc) ? -Fk [ir] : 0.0 ;
-                    double bv = (k < pc) ? Fk [jr] : 0.0 ;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, av, acc, 0, 0, 0) ;
+                    if (pc <= 4) tf_tile_row<1, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else if (pc <= 8) tf_tile_row<2, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else if (pc <= 12) tf_tile_row<3, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else tf_tile_row<4, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
                 }
-            }
-            if (last)
-            {
-                double *Co = CB + cbo ;
-#pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                {
-                    int j = j0 + lk + 4 * r ;
-                    if (i < ns && j <= i) Co [tri_col (j - nc, ncb) + (i - nc)] = acc [r] ;
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                {
-                    int j = j0 + lk + 4 * r ;
-                    if (i < ns && j <= i) F [tri_col (j, ns) + i] = acc [r] ;
-                }
+                else        // (only with more than 16 columns: the panel before the last is full)
+                    tf_tile_row<4, false> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
             }
         }
-        if (!last) __syncthreads () ;
+        if (!last) tf_barrier<NW> () ;
+        tick (5) ;
     }
     if (fail >= 0)
     {
@@ -1247,6 +1360,7 @@ __global__ void __launch_bounds__(64 * NW) k_thin_front (const i32 *fronts,
         const int tot = ncb * (ncb + 1) / 2 ;
         for (int e = tid ; e < tot ; e += NT) CB [cbo + e] = 0.0 ;
     }
+    if constexpr (TIMED) { if (tid == 0 && blockIdx.x == gridDim.x / 2) for (int q = 0 ; q < 10 ; q++) tim [q] = tc [q] ; }
 }
 
 // ---- dense update  C -= A * B'  (fp64 MFMA 16x16x4 tiles) -------------------
