@@ -6,7 +6,8 @@
  *
  *   gcc -O2 -I include examples/cholmod_l_demo.c -L suitesparse_amd/lib \
  *       -lcholmod_amd -Wl,-rpath,$PWD/suitesparse_amd/lib -lm -o cholmod_l_demo
- *   ./cholmod_l_demo [perm.txt] < tests/golden/bcsstk01.tri
+ *   ./cholmod_l_demo [perm.txt [cpu]] < tests/golden/bcsstk01.tri
+ * ("cpu" selects Common->useGPU = 0: the CPU supernodal path, BASELINE.json configs[0])
  *
  * An optional file with n integers supplies the fill-reducing permutation
  * (the ordering packages are out of scope; default is the natural ordering
@@ -14,6 +15,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "cholmod.h"
 
 int main (int argc, char **argv)
@@ -21,12 +23,12 @@ int main (int argc, char **argv)
     cholmod_common Common, *cm = &Common ;
     cholmod_l_start (cm) ;
     cm->supernodal = CHOLMOD_SUPERNODAL ;        /* SURVEY.md finding 1 */
-    cm->useGPU = 1 ;
+    cm->useGPU = (argc > 2 && !strcmp (argv [2], "cpu")) ? 0 : 1 ;    /* "cpu": BASELINE.json configs[0] */
     cholmod_sparse *A = cholmod_l_read_sparse (stdin, cm) ;
     if (!A) { printf ("read failed, status %d\n", cm->status) ; return 1 ; }
     if (A->stype == 0 || A->nrow != A->ncol) { printf ("matrix must be symmetric\n") ; return 1 ; }
     size_t n = A->nrow ;
-    printf ("cholmod_l_demo (HIP engine): n %zu nnz %ld stype %d\n", n, (long) cholmod_l_nnz (A, cm), A->stype) ;
+    printf ("cholmod_l_demo: n %zu nnz %ld stype %d\n", n, (long) cholmod_l_nnz (A, cm), A->stype) ;
     SuiteSparse_long *perm = NULL ;
     if (argc > 1)
     {

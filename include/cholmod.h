@@ -168,6 +168,12 @@ typedef struct cholmod_common_struct
     int (*hip_allreduce) (void *dev_ptr, int64_t count_doubles, int group_first,
         int group_size, void *user) ;
     void *hip_allreduce_user ;
+    /* Common->useGPU == 1 but no usable device (none present, or no HBM for this
+     * factor): 0 (default) = fail loudly with CHOLMOD_GPU_PROBLEM / CHOLMOD_OUT_OF_MEMORY;
+     * 1 = degrade to the CPU path with status CHOLMOD_OK, as the reference does
+     * (CHOLMOD/Supernodal/t_cholmod_super_numeric.c:183-192).  The environment
+     * variable CHOLMOD_HIP_CPU_FALLBACK=1 sets it in cholmod_l_start. */
+    int hip_cpu_fallback ;
 } cholmod_common ;
 
 typedef struct cholmod_sparse_struct

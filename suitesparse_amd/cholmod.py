@@ -71,6 +71,7 @@ class Common(C.Structure):
         ("hip_factor_on_device", C.c_int), ("hip_flags", C.c_int), ("hip_profile", C.c_int),
         ("hip_rank", C.c_int), ("hip_world", C.c_int),
         ("hip_allreduce", C.c_void_p), ("hip_allreduce_user", C.c_void_p),
+        ("hip_cpu_fallback", C.c_int),
     ]
 
 

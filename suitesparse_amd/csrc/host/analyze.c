@@ -237,16 +237,15 @@ int cholmod_l_rowcolcounts (cholmod_sparse *A, SuiteSparse_long *fset, size_t fs
 
 /* ---- supernodal symbolic ---------------------------------------------------------------- */
 
-/* resolve Common->useGPU == EMPTY from CHOLMOD_USE_GPU as the reference does
- * (Supernodal/cholmod_super_symbolic.c:257-296); unlike the reference an unset
- * variable selects the GPU, because the HIP engine is this library's only
- * numeric path. */
+/* resolve Common->useGPU == EMPTY from CHOLMOD_USE_GPU exactly as the reference
+ * does (Supernodal/cholmod_super_symbolic.c:257-296): the variable set to a
+ * non-zero number selects the GPU, unset (or 0) the CPU. */
 int ssamd_resolve_use_gpu (cholmod_common *Common)
 {
     if (Common->useGPU == EMPTY)
     {
         const char *e = getenv ("CHOLMOD_USE_GPU") ;
-        Common->useGPU = (e && atoi (e) == 0 && e [0] != '\0') ? 0 : 1 ;
+        Common->useGPU = (e && atoi (e) != 0) ? 1 : 0 ;
         const char *b = getenv ("CHOLMOD_GPU_MEM_BYTES") ;
         if (b) Common->maxGpuMemBytes = (size_t) strtoull (b, NULL, 10) ;
         const char *f = getenv ("CHOLMOD_GPU_MEM_FRACTION") ;

@@ -69,6 +69,10 @@ int cholmod_l_start (cholmod_common *Common)
     Common->fl = EMPTY ; Common->lnz = EMPTY ; Common->anz = EMPTY ; Common->modfl = EMPTY ;
     Common->maxGpuMemFraction = 0.0 ;
     Common->maxGpuMemBytes = 0 ;
+    {
+        const char *e = getenv ("CHOLMOD_HIP_CPU_FALLBACK") ;
+        Common->hip_cpu_fallback = (e && atoi (e) != 0) ? 1 : 0 ;
+    }
     return TRUE ;
 }
 

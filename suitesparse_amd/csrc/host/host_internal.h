@@ -38,4 +38,9 @@ int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cho
 int ssamd_resolve_use_gpu (cholmod_common *Common) ;
 int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common) ;
 
+/* cpu_numeric.c */
+int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common) ;
+void ssamd_cpu_super_solve (int which, const cholmod_factor *L, double *X, Int nrhs, Int ldx) ;
+const char *ssamd_cpu_blas_name (void) ;
+
 #endif

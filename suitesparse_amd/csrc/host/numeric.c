@@ -1,8 +1,10 @@
 /* numeric.c -- cholmod_l_factorize / cholmod_l_super_numeric / cholmod_l_solve
- * and the cholmod_l_gpu_* entry points of the host layer.  All arithmetic is
- * done by the HIP engine behind include/cholmod_hip.h; this file only checks
- * arguments, permutes the input (ptranspose), moves vectors and maps engine
- * return codes to Common->status.  There is deliberately no CPU BLAS path.
+ * and the cholmod_l_gpu_* entry points of the host layer.  With Common->useGPU
+ * the arithmetic is done by the HIP engine behind include/cholmod_hip.h; this
+ * file checks arguments, permutes the input (ptranspose), moves vectors and
+ * maps engine return codes to Common->status.  With Common->useGPU == 0, or when
+ * no device can be used, the CPU path of cpu_numeric.c runs instead, as in the
+ * reference (t_cholmod_super_numeric.c:183-192).
  *
  * Reference files: CHOLMOD/Cholesky/cholmod_factorize.c, cholmod_solve.c;
  * CHOLMOD/Supernodal/cholmod_super_numeric.c, cholmod_super_solve.c;
@@ -172,18 +174,56 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
     if (A->nrow != A->ncol || A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
-    if (ssamd_resolve_use_gpu (Common) != 1)
+    double b = beta ? beta [0] : 0.0 ;
+    /* GPU or CPU (reference t_cholmod_super_numeric.c:183-192: the GPU is used only
+     * if Common->useGPU == 1 and the analysis found one, L->useGPU; a device that
+     * cannot be initialised degrades to the CPU path).  A factor that already lives
+     * on the engine stays there. */
+    int want_gpu = (ssamd_resolve_use_gpu (Common) == 1) ;
+    if (want_gpu && !(L->useGPU || L->hip_plan) && Common->hip_cpu_fallback) want_gpu = FALSE ;
+    if (want_gpu)
     {
-        ERROR (CHOLMOD_NOT_INSTALLED, "Common->useGPU is 0, but this library has no CPU BLAS path; "
-            "set Common->useGPU = 1 (or CHOLMOD_USE_GPU=1)") ;
+        int was_ok = Common->status ;
+        void (*eh) (int, const char *, int, const char *) = Common->error_handler ;
+        Common->error_handler = NULL ;                  /* a failed device probe is not an error yet */
+        int have = ssamd_ensure_plan (L, Common) ;
+        Common->error_handler = eh ;
+        if (have)
+        {
+            int64_t minor = (int64_t) L->n ;
+            int rc = cholmod_hip_factorize ((cholmod_hip_plan *) L->hip_plan, A->p, A->i,
+                A->packed ? NULL : A->nz, A->x, b, Common->quick_return_if_not_posdef, NULL, &minor) ;
+            return finish_numeric (rc, minor, L, Common) ;
+        }
+        /* no device / no HBM for this factor: loud by default; degrade to the CPU path
+         * only if the caller asked for the reference's behaviour (several ranks
+         * cannot degrade on their own) */
+        if (!Common->hip_cpu_fallback || Common->hip_world > 1 || Common->status == CHOLMOD_INVALID
+            || Common->status == CHOLMOD_TOO_LARGE)
+        {
+            int st = Common->status ;
+            Common->status = was_ok ;
+            ERROR (st, "HIP plan creation failed") ;
+            return FALSE ;
+        }
+        Common->status = CHOLMOD_OK ;
+        L->useGPU = 0 ;
+    }
+    /* ---- CPU path */
+    int was_symbolic = (L->x == NULL) ;
+    if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
+    if (!L->x) return FALSE ;           /* out of memory: L is returned symbolic (cholmod_super_numeric.c:235-248) */
+    (void) was_symbolic ;
+    L->xtype = CHOLMOD_REAL ; L->dtype = CHOLMOD_DOUBLE ; L->is_ll = TRUE ;
+    if (!ssamd_cpu_super_numeric (A, b, L, Common))
+    {
+        if (was_symbolic) { cholmod_l_free (L->xsize, sizeof (double), L->x, Common) ; L->x = NULL ; L->xtype = CHOLMOD_PATTERN ; }
         return FALSE ;
     }
-    if (!ssamd_ensure_plan (L, Common)) return FALSE ;
-    double b = beta ? beta [0] : 0.0 ;
-    int64_t minor = (int64_t) L->n ;
-    int rc = cholmod_hip_factorize ((cholmod_hip_plan *) L->hip_plan, A->p, A->i,
-        A->packed ? NULL : A->nz, A->x, b, Common->quick_return_if_not_posdef, NULL, &minor) ;
-    return finish_numeric (rc, minor, L, Common) ;
+    L->hip_on_device = FALSE ;
+    L->hip_host_valid = TRUE ;
+    Common->gpuKernelTime = 0 ; Common->gpuFlops = 0 ; Common->gpuNumKernelLaunches = 0 ;
+    return TRUE ;
 }
 
 int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_common *Common)
@@ -305,6 +345,19 @@ static int factor_on_device (cholmod_factor *L, cholmod_common *Common)
     return TRUE ;
 }
 
+/* the triangular solves run where the factor is: on the host when the values are
+ * in L->x and the engine is not to be used (Common->useGPU == 0, no device, or a
+ * factor the CPU path computed) */
+static int solve_on_host (cholmod_factor *L, cholmod_common *Common)
+{
+    if (L->xtype != CHOLMOD_REAL || !L->is_super || !L->x) return FALSE ;
+    if (L->hip_on_device && !L->hip_host_valid) return FALSE ;      /* current values only in HBM */
+    if (L->hip_on_device) return FALSE ;                            /* resident copy: use it */
+    if (ssamd_resolve_use_gpu (Common) != 1) return TRUE ;
+    /* a GPU was asked for: the host solve is only the opted-in degradation */
+    return Common->hip_cpu_fallback && (!L->useGPU || !cholmod_hip_probe ()) ;
+}
+
 static int super_solve (int which, cholmod_factor *L, cholmod_dense *X, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (FALSE) ;
@@ -313,6 +366,11 @@ static int super_solve (int which, cholmod_factor *L, cholmod_dense *X, cholmod_
     if (X->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "X must be real") ; return FALSE ; }
     if (X->nrow != L->n || X->d < X->nrow) { ERROR (CHOLMOD_INVALID, "X and L dimensions must match") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
+    if (solve_on_host (L, Common))
+    {
+        ssamd_cpu_super_solve (which, L, X->x, (Int) X->ncol, (Int) X->d) ;
+        return Common->blas_ok ;
+    }
     if (!factor_on_device (L, Common)) return FALSE ;
     int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, X->x, (int64_t) X->ncol, (int64_t) X->d) ;
     if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "HIP solve failed") ;
@@ -387,7 +445,8 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
     }
     int which = (sys == CHOLMOD_A || sys == CHOLMOD_LDLt) ? 0
               : (sys == CHOLMOD_L || sys == CHOLMOD_LD) ? 1 : 2 ;
-    if (!factor_on_device (L, Common)) return FALSE ;
+    int on_host = solve_on_host (L, Common) ;
+    if (!on_host && !factor_on_device (L, Common)) return FALSE ;
     cholmod_dense *Y = cholmod_l_allocate_dense (n, nrhs, n, CHOLMOD_REAL, Common) ;
     if (!Y) return FALSE ;
     double *Yx = Y->x ;
@@ -395,8 +454,13 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
         for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [Perm [k] + r*dB] ;
     else
         for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [k + r*dB] ;
-    int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, Yx, nrhs, n) ;
-    int ok = (rc == CHOLMOD_HIP_OK) ? TRUE : map_hip_status (rc, Common, "HIP solve failed") ;
+    int ok = TRUE ;
+    if (on_host) ssamd_cpu_super_solve (which, L, Yx, nrhs, n) ;
+    else
+    {
+        int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, Yx, nrhs, n) ;
+        ok = (rc == CHOLMOD_HIP_OK) ? TRUE : map_hip_status (rc, Common, "HIP solve failed") ;
+    }
     if (ok)
     {
         if (sys == CHOLMOD_A)

@@ -1,0 +1,178 @@
+"""The product's CPU supernodal path (Common->useGPU == 0; reference
+CHOLMOD/Supernodal/t_cholmod_super_numeric.c:183-192, BASELINE.json configs[0]):
+suitesparse_amd/csrc/host/cpu_numeric.c against the oracle -- maps bit-exact,
+factor to 1e-12, residual, the not-positive-definite protocol, the demo driver
+on bcsstk01.  Runs without a GPU, with the dlopen'ed BLAS if one is found and
+with the built-in C kernels."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleFactor
+from suitesparse_amd import cholmod as ch
+from suitesparse_amd import generators as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_L = 1e-12
+
+
+def _case(name, golden_dir):
+    if name == "bcsstk01":
+        rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))["bcsstk01"]
+        return G.read_triplet(os.path.join(golden_dir, "bcsstk01.tri")) + (np.array(rec["Perm"]),)
+    if name == "bcsstk02":
+        return G.read_triplet(os.path.join(golden_dir, "bcsstk02.tri")) + (None,)
+    if name == "p3d_14_nd":
+        return G.poisson3d(14) + (-1, G.geometric_nd(14, 14, 14, 4))
+    if name == "p2d_70_nd":
+        return G.poisson2d(70) + (-1, G.geometric_nd(70, 70, 1, 4))
+    if name == "box8r2_nd":
+        return G.box_stencil3d(8, 2) + (-1, G.geometric_nd(8, 8, 8, 3))
+    if name == "p3d_9x7x11_nat":
+        return G.poisson3d(9, 7, 11) + (-1, None)
+    raise KeyError(name)
+
+
+def _scipy_blas():
+    """LP64 OpenBLAS shipped with scipy, if any (CHOLMOD_BLAS_LIBRARY syntax path:prefix)."""
+    import glob
+    try:
+        import scipy
+    except Exception:
+        return None
+    d = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+    c = glob.glob(os.path.join(d, "libscipy_openblas-*.so"))
+    return c[0] + ":scipy_" if c else None
+
+
+def _run_child(code, env_extra):
+    """The BLAS binding is per process: run the check in a child with the wanted
+    CHOLMOD_BLAS_LIBRARY."""
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    return out.stdout
+
+
+CHECK = r'''
+import sys, json, os
+import numpy as np
+sys.path.insert(0, ".")
+sys.path.insert(0, "tests")
+from oracle.oracle import OracleFactor
+from suitesparse_amd import cholmod as ch, generators as G
+from test_cpu_path import _case
+name = sys.argv[1] if len(sys.argv) > 1 else os.environ["CASE"]
+n, Ap, Ai, Ax, stype, perm = _case(name, "tests/golden")
+S = ch.Session(use_gpu=0)
+A = S.sparse(n, Ap, Ai, Ax, stype)
+Lf = S.analyze(A, perm)
+assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK, S.cm.status
+fv = ch.FactorView(Lf)
+assert fv.x is not None and not Lf.contents.hip_plan        # host factor, no engine involved
+O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+assert O.factorize(Ax) == 0
+for k in ("Perm", "ColCount", "super", "pi", "px", "s"):
+    assert np.array_equal(getattr(fv, k), getattr(O, k)), k
+m = O.lower_mask()
+err = np.linalg.norm((fv.x - O.x)[m]) / np.linalg.norm(O.x[m])
+assert err < 1e-12, err
+assert np.all(fv.x[~m] == 0)
+assert S.L.cholmod_l_check_factor(Lf, __import__("ctypes").byref(S.cm)) == 1
+b = G.demo_rhs(n)
+x = S.solve(Lf, b)
+r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
+assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-11
+rng = np.random.default_rng(1)
+B = rng.standard_normal((3, n))
+assert np.linalg.norm(S.solve(Lf, B, ch.SYS_L) - O.lsolve(B)) < 1e-11 * np.linalg.norm(B)
+assert np.linalg.norm(S.solve(Lf, B, ch.SYS_Lt) - O.ltsolve(B)) < 1e-9 * np.linalg.norm(O.ltsolve(B))
+assert S.cm.cholmod_cpu_potrf_calls == fv.nsuper and S.cm.cholmod_gpu_potrf_calls == 0
+S.free_factor(Lf); S.free_sparse(A)
+assert S.cm.malloc_count == 0
+S.finish()
+print("ok", name, err)
+'''
+
+
+@pytest.mark.parametrize("blas", ["builtin", "dlopen"])
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk02", "p3d_14_nd", "p2d_70_nd", "box8r2_nd", "p3d_9x7x11_nat"])
+def test_cpu_factor_and_solves_match_oracle(name, blas):
+    lib = "none" if blas == "builtin" else _scipy_blas()
+    if lib is None:
+        pytest.skip("no LP64 BLAS with LAPACK found for dlopen")
+    out = _run_child(CHECK, {"CHOLMOD_BLAS_LIBRARY": lib, "CASE": name})
+    assert out.startswith("ok")
+
+
+@pytest.mark.parametrize("quick", [False, True])
+def test_cpu_not_posdef_protocol_matches_oracle(quick):
+    n, Ap, Ai, Ax = G.poisson3d(10)
+    perm = G.geometric_nd(10, 10, 10, 3)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    sup = O.super
+    cand = [s for s in range(O.nsuper // 2, O.nsuper) if sup[s + 1] - sup[s] >= 6]
+    kbad = int(sup[cand[0]] + 3)
+    Ax2 = Ax.copy()
+    Ax2[Ap[int(O.Perm[kbad])]] = -7.0
+    assert O.factorize(Ax2, quick_return=quick) == 1 and O.minor == kbad
+    S = ch.Session(use_gpu=0)
+    S.cm.quick_return_if_not_posdef = int(quick)
+    A = S.sparse(n, Ap, Ai, Ax2, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1               # TRUE, as the reference
+    assert S.cm.status == ch.NOT_POSDEF
+    fv = ch.FactorView(Lf)
+    assert fv.minor == kbad
+    mask = O.lower_mask()
+    assert np.array_equal(fv.x[mask] != 0, (O.x != 0)[mask])
+    assert np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask]) < TOL_L
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+def test_env_default_is_cpu_like_the_reference(monkeypatch):
+    """Common->useGPU == -1 (cholmod_l_start): CHOLMOD_USE_GPU unset selects the CPU
+    (CHOLMOD/Supernodal/cholmod_super_symbolic.c:286-291), =1 the GPU."""
+    n, Ap, Ai, Ax = G.poisson2d(8)
+    for env, want in ((None, 0), ("0", 0), ("1", 1)):
+        if env is None:
+            monkeypatch.delenv("CHOLMOD_USE_GPU", raising=False)
+        else:
+            monkeypatch.setenv("CHOLMOD_USE_GPU", env)
+        S = ch.Session(use_gpu=-1)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.analyze(A)
+        assert S.cm.useGPU == want
+        if want == 0:
+            assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK and not Lf.contents.hip_plan
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+
+
+def test_c_demo_on_cpu_path(golden_dir, tmp_path):
+    """BASELINE.json configs[0]: the demo flow on bcsstk01 with Common->useGPU = 0."""
+    rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))["bcsstk01"]
+    exe = str(tmp_path / "cholmod_l_demo")
+    lib = os.path.join(ROOT, "suitesparse_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "cholmod_l_demo.c"), "-L", lib, "-lcholmod_amd",
+                           f"-Wl,-rpath,{lib}", "-lm", "-o", exe])
+    permfile = tmp_path / "perm.txt"
+    permfile.write_text(" ".join(str(v) for v in rec["Perm"]))
+    with open(os.path.join(golden_dir, "bcsstk01.tri")) as f:
+        out = subprocess.run([exe, str(permfile), "cpu"], stdin=f, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "nsuper 7 ssize 101 xsize 1064 maxcsize 169 maxesize 13" in txt, txt
+    assert "fl 6009 lnz 489" in txt, txt
+    assert "status 0 minor 48" in txt, txt
+    assert float(txt.split("residual")[1].split()[0]) < 1e-12
+    assert "malloc_count 0 memory_inuse 0" in txt

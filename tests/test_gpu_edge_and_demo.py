@@ -124,6 +124,60 @@ def test_upper_stored_and_unpacked_unsorted_input():
     S.finish()
 
 
+def test_device_allocation_failure_is_loud_or_degrades_on_request(monkeypatch):
+    """The reservation of L in HBM fails (test hook): by default the factorization
+    fails with CHOLMOD_OUT_OF_MEMORY and L stays symbolic
+    (CHOLMOD/Supernodal/cholmod_super_numeric.c:235-248); with
+    Common->hip_cpu_fallback it degrades to the CPU path with status OK, as the
+    reference does when its GPU cannot be initialised (t_cholmod_super_numeric.c:183-192)."""
+    n, Ap, Ai, Ax = G.poisson3d(9)
+    perm = G.geometric_nd(9, 9, 9, 3)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    assert O.factorize(Ax) == 0
+    monkeypatch.setenv("CHOLMOD_HIP_TEST_FAIL_ALLOC", "1")
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert Lf.contents.useGPU == 1
+    assert S.factorize(A, Lf) == 0 and S.cm.status == ch.OUT_OF_MEMORY
+    assert not Lf.contents.x and Lf.contents.xtype == ch.PATTERN and not Lf.contents.hip_plan
+    S.cm.hip_cpu_fallback = 1
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    fv = ch.FactorView(Lf)
+    assert not Lf.contents.hip_plan and S.cm.cholmod_cpu_potrf_calls == fv.nsuper
+    m = O.lower_mask()
+    assert np.linalg.norm((fv.x - O.x)[m]) <= 1e-12 * np.linalg.norm(O.x[m])
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b) <= 1e-11 * np.linalg.norm(b)
+    # the device comes back: the same factor object moves to the engine
+    monkeypatch.delenv("CHOLMOD_HIP_TEST_FAIL_ALLOC")
+    Lf.contents.useGPU = 1
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK and Lf.contents.hip_plan
+    assert np.linalg.norm((ch.FactorView(Lf).x - O.x)[m]) <= 1e-12 * np.linalg.norm(O.x[m])
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
+
+
+def test_use_gpu_zero_runs_the_cpu_path_on_a_gpu_box():
+    n, Ap, Ai, Ax = G.poisson3d(8)
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, None)
+    assert Lf.contents.useGPU == 0
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK and not Lf.contents.hip_plan
+    assert S.cm.cholmod_gpu_potrf_calls == 0 and S.cm.cholmod_cpu_potrf_calls == ch.FactorView(Lf).nsuper
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b) <= 1e-11 * np.linalg.norm(b)
+    assert not Lf.contents.hip_plan                          # the solve stayed on the host too
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
 def test_c_demo_driver_on_bcsstk01(golden_dir, tmp_path):
     """BASELINE.json config #1: the demo flow in C against include/cholmod.h."""
     rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))["bcsstk01"]

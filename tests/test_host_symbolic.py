@@ -147,6 +147,8 @@ def test_host_only_plan_schedule_and_levels():
 
 
 def test_numeric_without_gpu_fails_loudly():
+    """Common->useGPU = 1 without a device: loud failure by default; the CPU path
+    only on request (Common->useGPU = 0, or the opted-in degradation)."""
     if ch.lib().cholmod_hip_probe():
         pytest.skip("a GPU is present")
     n, Ap, Ai, Ax = G.poisson2d(6)
@@ -155,11 +157,15 @@ def test_numeric_without_gpu_fails_loudly():
     Lf = S.analyze(A)
     assert S.factorize(A, Lf) == 0
     assert S.cm.status == ch.GPU_PROBLEM
-    S.cm.useGPU = 0
-    assert S.factorize(A, Lf) == 0
-    assert S.cm.status == ch.NOT_INSTALLED
+    assert not Lf.contents.x                                # L is returned symbolic
+    S.cm.hip_cpu_fallback = 1                               # the reference's degradation, opted in
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b) < 1e-12 * np.linalg.norm(b)
     S.free_factor(Lf)
     S.free_sparse(A)
+    assert S.cm.malloc_count == 0
     S.finish()
 
 
