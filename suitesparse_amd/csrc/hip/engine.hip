@@ -1345,6 +1345,7 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     if (!host_only && !cholmod_hip_probe ()) { *status = CHOLMOD_HIP_NO_DEVICE ; return nullptr ; }
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
     if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
+    const double tpc = std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ;
     P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
     P->rank = rank ; P->world = world ;
     P->super.assign (super, super + nsuper + 1) ;
@@ -1368,8 +1369,14 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
                 P->arena_budget = (i64) std::max (1e9, (double) freeb - fixed) ;
         }
     }
+    const bool ptiming = getenv ("CHOLMOD_HIP_PLAN_TIMING") != nullptr ;
+    auto pnow = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
+    double tp0 = pnow () ;
     *status = build_host (P) ;
+    double tp1 = pnow () ;
     if (*status == CHOLMOD_HIP_OK && !host_only) *status = upload_plan (P) ;
+    if (ptiming) fprintf (stderr, "cholmod_hip_plan_create: copy maps %.3f s, build_host %.3f s, upload_plan %.3f s\n",
+        tp0 - tpc, tp1 - tp0, pnow () - tp1) ;
     if (*status != CHOLMOD_HIP_OK)
     {
         free_device (P) ; delete P ; return nullptr ;

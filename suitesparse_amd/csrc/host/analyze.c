@@ -13,6 +13,9 @@
 #include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ---- elimination tree ------------------------------------------------------------ */
 
@@ -430,25 +433,84 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
          * to s receive row k (:786-835).  Lists come out strictly ascending. */
         Ls [0] = 0 ;
         for (Int s = 0 ; s < nsuper ; s++) { fill [s] = Lpi [s] ; seen [s] = EMPTY ; }
-        for (Int s = 0 ; s < nsuper ; s++)
+        /* One supernode's share of the traversal (:786-835): its own columns first,
+         * then column k is appended to every not yet stamped supernode on the etree
+         * paths from the supernodes of A(0:k1-1,k) up towards s.  Everything it
+         * touches lies in the subtree of s. */
+#define SSAMD_LS_OF(s) do { \
+            Int k1_ = Super [s], k2_ = Super [(s)+1] ; \
+            for (Int k = k1_ ; k < k2_ ; k++) Ls [fill [s]++] = k ; \
+            for (Int k = k1_ ; k < k2_ ; k++) \
+            { \
+                seen [s] = k ;          /* stamps are column numbers: unique per k */ \
+                for (Int p = Up [k] ; p < Up [k+1] ; p++) \
+                { \
+                    Int i = Ui [p] ; \
+                    if (i >= k1_) { if (A->sorted) break ; else continue ; } \
+                    for (Int t = col2s [i] ; seen [t] != k ; t = Sparent [t]) \
+                    { \
+                        Ls [fill [t]++] = k ; \
+                        seen [t] = k ; \
+                    } \
+                } \
+            } } while (0)
+        /* Disjoint subtrees of the supernodal etree never touch each other's lists:
+         * cut the tree where a subtree holds less than 1/(8 threads) of all rows,
+         * run the subtrees in parallel (members in ascending order inside each),
+         * then the few supernodes above the cut one after the other.  A list still
+         * receives its rows in ascending order: the columns of an ancestor are
+         * larger than those of any descendant. */
+        Int *wsub = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        Int *owner = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        Int *mlist = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        Int *mptr = cholmod_l_malloc (nsuper + 2, sizeof (Int), Common) ;
+        if (wsub && owner && mlist && mptr)
         {
-            Int k1 = Super [s], k2 = Super [s+1] ;
-            for (Int k = k1 ; k < k2 ; k++) Ls [fill [s]++] = k ;
-            for (Int k = k1 ; k < k2 ; k++)
+            int nth = 1 ;
+#ifdef _OPENMP
+            nth = omp_get_max_threads () ;
+#endif
+            for (Int s = 0 ; s < nsuper ; s++) wsub [s] = Lpi [s+1] - Lpi [s] ;
+            for (Int s = 0 ; s < nsuper ; s++) if (Sparent [s] != EMPTY) wsub [Sparent [s]] += wsub [s] ;
+            Int thr = (nth > 1) ? ssize / (8 * (Int) nth) : ssize + 1 ;
+            /* owner: EMPTY above the cut, else the root of the subtree (parent > child,
+             * so a descending sweep sees parents first) */
+            Int nroots = 0 ;
+            for (Int s = nsuper - 1 ; s >= 0 ; s--)
             {
-                seen [s] = k ;          /* stamps are column numbers: unique per k */
-                for (Int p = Up [k] ; p < Up [k+1] ; p++)
+                Int par = Sparent [s] ;
+                if (wsub [s] > thr) owner [s] = EMPTY ;
+                else if (par == EMPTY || owner [par] == EMPTY) { owner [s] = s ; nroots++ ; }
+                else owner [s] = owner [par] ;
+            }
+            /* members of every subtree in ascending order (counting sort by root) */
+            Int *rootid = wsub ;                    /* reuse: root supernode -> 0 .. nroots-1 */
+            Int nr = 0 ;
+            for (Int s = 0 ; s < nsuper ; s++) if (owner [s] == s) rootid [s] = nr++ ;
+            for (Int r = 0 ; r <= nroots ; r++) mptr [r] = 0 ;
+            for (Int s = 0 ; s < nsuper ; s++) if (owner [s] != EMPTY) mptr [rootid [owner [s]] + 1]++ ;
+            for (Int r = 0 ; r < nroots ; r++) mptr [r+1] += mptr [r] ;
+            {
+                Int *pos = cholmod_l_malloc (nroots + 1, sizeof (Int), Common) ;
+                if (pos)
                 {
-                    Int i = Ui [p] ;
-                    if (i >= k1) { if (A->sorted) break ; else continue ; }
-                    for (Int t = col2s [i] ; seen [t] != k ; t = Sparent [t])
-                    {
-                        Ls [fill [t]++] = k ;
-                        seen [t] = k ;
-                    }
+                    for (Int r = 0 ; r < nroots ; r++) pos [r] = mptr [r] ;
+                    for (Int s = 0 ; s < nsuper ; s++) if (owner [s] != EMPTY) mlist [pos [rootid [owner [s]]]++] = s ;
+                    cholmod_l_free (nroots + 1, sizeof (Int), pos, Common) ;
+#pragma omp parallel for schedule(dynamic, 1)
+                    for (Int r = 0 ; r < nroots ; r++)
+                        for (Int q = mptr [r] ; q < mptr [r+1] ; q++) { Int s = mlist [q] ; SSAMD_LS_OF (s) ; }
+                    for (Int s = 0 ; s < nsuper ; s++) if (owner [s] == EMPTY) SSAMD_LS_OF (s) ;
                 }
+                else ok = FALSE ;
             }
         }
+        else ok = FALSE ;
+        if (wsub) cholmod_l_free (nsuper + 1, sizeof (Int), wsub, Common) ;
+        if (owner) cholmod_l_free (nsuper + 1, sizeof (Int), owner, Common) ;
+        if (mlist) cholmod_l_free (nsuper + 1, sizeof (Int), mlist, Common) ;
+        if (mptr) cholmod_l_free (nsuper + 2, sizeof (Int), mptr, Common) ;
+#undef SSAMD_LS_OF
         for (Int s = 0 ; s < nsuper && ok ; s++) if (fill [s] != Lpi [s+1]) ok = FALSE ;
         if (!ok) ERROR (CHOLMOD_INVALID, "invalid symbolic structure (ColCount/Parent mismatch)") ;
     }
@@ -457,6 +519,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
     {
         /* largest update matrix / largest set of rows below a diagonal block
          * (:907-948): runs of rows belonging to one ancestor supernode */
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max:maxcsize) reduction(max:maxesize)
         for (Int d = 0 ; d < nsuper ; d++)
         {
             Int nscol = Super [d+1] - Super [d] ;
@@ -643,9 +706,14 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
     if (ok)
     {
         Int *Perm = L->Perm, *ColCount = L->ColCount ;
-        ok = ssamd_etree_upper (n, U->p, U->i, Parent)
-            && ssamd_postorder (n, Parent, NULL, Post, work) == n ;
+        double t3a = ssamd_now () ;
+        ok = ssamd_etree_upper (n, U->p, U->i, Parent) ;
+        double t3b = ssamd_now () ;
+        ok = ok && ssamd_postorder (n, Parent, NULL, Post, work) == n ;
+        double t3c = ssamd_now () ;
         if (ok) ssamd_colcounts (n, Lw->p, Lw->i, Parent, Post, ColCount, work) ;
+        if (timing) fprintf (stderr, "cholmod_l_analyze:   etree %.3f s, postorder %.3f s, colcounts %.3f s\n",
+            t3b - t3a, t3c - t3b, ssamd_now () - t3c) ;
         if (ok)
         {
             double fl = 0, lnz = 0 ;
@@ -657,8 +725,10 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
         }
         if (ok && Common->postorder)
         {
+            double t4a = ssamd_now () ;
             if (ssamd_postorder (n, Parent, ColCount, Post, work) == n)
             {
+                double t4b = ssamd_now () ;
                 Int *tmp = work, *inv = work + n ;
                 for (Int k = 0 ; k < n ; k++) tmp [k] = Perm [Post [k]] ;
                 for (Int k = 0 ; k < n ; k++) Perm [k] = tmp [k] ;
@@ -672,9 +742,19 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
                 }
                 for (Int k = 0 ; k < n ; k++) Parent [k] = tmp [k] ;
                 if (L->ordering == CHOLMOD_NATURAL) L->ordering = CHOLMOD_POSTORDERED ;
+                /* only the upper pattern of the final P A P' is needed from here on
+                 * (supernodal row structure); one permuted transpose for a lower-stored A */
                 cholmod_l_free_sparse (&U, Common) ;
                 cholmod_l_free_sparse (&Lw, Common) ;
-                ok = permuted_patterns (A, Perm, &U, &Lw, Common) ;
+                if (A->stype < 0) U = cholmod_l_ptranspose (A, 0, Perm, NULL, 0, Common) ;
+                else
+                {
+                    Lw = cholmod_l_ptranspose (A, 0, Perm, NULL, 0, Common) ;
+                    if (Lw) U = cholmod_l_ptranspose (Lw, 0, NULL, NULL, 0, Common) ;
+                }
+                ok = (U != NULL) ;
+                if (timing) fprintf (stderr, "cholmod_l_analyze:   weighted postorder %.3f s, compose + permuted pattern %.3f s\n",
+                    t4b - t4a, ssamd_now () - t4b) ;
             }
         }
     }

@@ -253,89 +253,102 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
         cholmod_l_free (n + 1, sizeof (Int), w, Common) ;
         return C ;
     }
-    /* symmetric */
+    /* symmetric: C = P A P' with the other triangle stored.  Three parallel passes
+     * (count, scatter with atomic cursors, per-column sort by (row, source
+     * position)), so the output is deterministic and its columns are sorted. */
     int upper_in = A->stype > 0 ;
     int upper_out = !upper_in ;
+    const int packed = A->packed ;
     Int *Pinv = NULL ;
     if (Perm)
     {
         Pinv = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
         if (!Pinv) return NULL ;
+        int bad = 0 ;
+#pragma omp parallel for schedule(static)
         for (Int k = 0 ; k < n ; k++) Pinv [k] = EMPTY ;
+#pragma omp parallel for schedule(static) reduction(|:bad)
         for (Int k = 0 ; k < n ; k++)
         {
             Int j = Perm [k] ;
-            if (j < 0 || j >= n || Pinv [j] != EMPTY)
-            {
-                cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
-                ERROR (CHOLMOD_INVALID, "invalid permutation") ;
-                return NULL ;
-            }
-            Pinv [j] = k ;
+            if (j < 0 || j >= n || !__sync_bool_compare_and_swap (&Pinv [j], (Int) EMPTY, k)) bad |= 1 ;
+        }
+        if (bad)
+        {
+            cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
+            ERROR (CHOLMOD_INVALID, "invalid permutation") ;
+            return NULL ;
         }
     }
-    /* pass 1: count entries per output column and per output row */
-    Int *colcnt = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
-    Int *rowptr = cholmod_l_calloc (n + 2, sizeof (Int), Common) ;
+    Int *cursor = cholmod_l_malloc (n + 1, sizeof (Int), Common) ;
+    if (!cursor) { if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ; return NULL ; }
+#pragma omp parallel for schedule(static)
+    for (Int j = 0 ; j <= n ; j++) cursor [j] = 0 ;
+    /* pass 1: entries per output column */
+#pragma omp parallel for schedule(static)
+    for (Int j = 0 ; j < n ; j++)
+    {
+        Int p = Ap [j], pend = packed ? Ap [j+1] : p + Anz [j] ;
+        Int c = Pinv ? Pinv [j] : j ;
+        for ( ; p < pend ; p++)
+        {
+            Int i = Ai [p] ;
+            if (upper_in ? (i > j) : (i < j)) continue ;    /* ignored triangle */
+            Int r = Pinv ? Pinv [i] : i ;
+            Int lo = r < c ? r : c, hi = r < c ? c : r ;
+            Int col = upper_out ? hi : lo ;
+#pragma omp atomic
+            cursor [col]++ ;
+        }
+    }
     Int nz = 0 ;
-    if (colcnt && rowptr)
+    for (Int j = 0 ; j < n ; j++) { Int c = cursor [j] ; cursor [j] = nz ; nz += c ; }
+    cursor [n] = nz ;
+    cholmod_sparse *C = cholmod_l_allocate_sparse (n, n, nz, TRUE, TRUE, upper_out ? 1 : -1, xtype, Common) ;
+    Int *src = C ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) : NULL ;
+    if (C && src)
     {
+        Int *Cp = C->p, *Ci = C->i ;
+        double *Cx = C->x ;
+#pragma omp parallel for schedule(static)
+        for (Int j = 0 ; j <= n ; j++) Cp [j] = cursor [j] ;
+        /* pass 2: scatter (row, source position) */
+#pragma omp parallel for schedule(static)
         for (Int j = 0 ; j < n ; j++)
         {
-            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
-            for ( ; p < pend ; p++)
-            {
-                Int i = Ai [p] ;
-                if (upper_in ? (i > j) : (i < j)) continue ;    /* ignored triangle */
-                Int r = Pinv ? Pinv [i] : i, c = Pinv ? Pinv [j] : j ;
-                Int lo = r < c ? r : c, hi = r < c ? c : r ;
-                colcnt [upper_out ? hi : lo]++ ;
-                rowptr [(upper_out ? lo : hi) + 1]++ ;
-                nz++ ;
-            }
-        }
-    }
-    cholmod_sparse *C = (colcnt && rowptr) ? cholmod_l_allocate_sparse (n, n, nz, TRUE, TRUE,
-        upper_out ? 1 : -1, xtype, Common) : NULL ;
-    Int *erow = C ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) : NULL ;
-    Int *ecol = C ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (Int), Common) : NULL ;
-    double *eval = (C && xtype == CHOLMOD_REAL) ? cholmod_l_malloc (nz > 0 ? nz : 1, sizeof (double), Common) : NULL ;
-    if (C && erow && ecol && (xtype != CHOLMOD_REAL || eval))
-    {
-        /* pass 2: bucket by output row so that pass 3 emits sorted columns */
-        for (Int i = 0 ; i < n ; i++) rowptr [i+1] += rowptr [i] ;
-        for (Int j = 0 ; j < n ; j++)
-        {
-            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            Int p = Ap [j], pend = packed ? Ap [j+1] : p + Anz [j] ;
+            Int c = Pinv ? Pinv [j] : j ;
             for ( ; p < pend ; p++)
             {
                 Int i = Ai [p] ;
                 if (upper_in ? (i > j) : (i < j)) continue ;
-                Int r = Pinv ? Pinv [i] : i, c = Pinv ? Pinv [j] : j ;
+                Int r = Pinv ? Pinv [i] : i ;
                 Int lo = r < c ? r : c, hi = r < c ? c : r ;
                 Int row = upper_out ? lo : hi, col = upper_out ? hi : lo ;
-                Int q = rowptr [row]++ ;
-                erow [q] = row ; ecol [q] = col ;
-                if (eval) eval [q] = Ax [p] ;
+                Int q ;
+#pragma omp atomic capture
+                q = cursor [col]++ ;
+                Ci [q] = row ; src [q] = p ;
             }
         }
-        Int *Cp = C->p, *Ci = C->i ;
-        double *Cx = C->x ;
-        Cp [0] = 0 ;
-        for (Int j = 0 ; j < n ; j++) { Cp [j+1] = Cp [j] + colcnt [j] ; colcnt [j] = Cp [j] ; }
-        for (Int q = 0 ; q < nz ; q++)
+        /* pass 3: every column sorted by (row, source position), values gathered */
+#pragma omp parallel for schedule(dynamic, 4096)
+        for (Int j = 0 ; j < n ; j++)
         {
-            Int dst = colcnt [ecol [q]]++ ;
-            Ci [dst] = erow [q] ;
-            if (eval) Cx [dst] = eval [q] ;
+            Int b0 = Cp [j], e0 = Cp [j+1] ;
+            for (Int q = b0 + 1 ; q < e0 ; q++)
+            {
+                Int r = Ci [q], sp = src [q], t = q ;
+                while (t > b0 && (Ci [t-1] > r || (Ci [t-1] == r && src [t-1] > sp)))
+                { Ci [t] = Ci [t-1] ; src [t] = src [t-1] ; t-- ; }
+                Ci [t] = r ; src [t] = sp ;
+            }
+            if (xtype == CHOLMOD_REAL) for (Int q = b0 ; q < e0 ; q++) Cx [q] = Ax [src [q]] ;
         }
     }
     else if (C) cholmod_l_free_sparse (&C, Common) ;
-    if (eval) cholmod_l_free (nz > 0 ? nz : 1, sizeof (double), eval, Common) ;
-    if (ecol) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), ecol, Common) ;
-    if (erow) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), erow, Common) ;
-    if (rowptr) cholmod_l_free (n + 2, sizeof (Int), rowptr, Common) ;
-    if (colcnt) cholmod_l_free (n + 1, sizeof (Int), colcnt, Common) ;
+    if (src) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), src, Common) ;
+    cholmod_l_free (n + 1, sizeof (Int), cursor, Common) ;
     if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
     return C ;
 }
