@@ -1982,6 +1982,8 @@ int cholmod_hip_debug_latency (long long *out8, int n)
 double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
 {
     if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    double scale = 1.0 ;                        // 10000 + ...: all-zero operands
+    if (waves_per_simd >= 10000) { scale = 0.0 ; waves_per_simd -= 10000 ; }
     int fill = 0 ;                              // 1000 f + w: filler f between the MFMAs
     if (waves_per_simd >= 1000) { fill = waves_per_simd / 1000 ; waves_per_simd %= 1000 ; }
     bool valu = waves_per_simd < 0 ;            // negative: fp64 VALU FMA loop instead
@@ -1995,20 +1997,19 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
     if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     hipEvent_t e0, e1 ;
     (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
-    if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
-    else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
-    else if (fill == 1) hipLaunchKernelGGL ((k_mfma_peak<8, 1>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
-    else if (fill == 2) hipLaunchKernelGGL ((k_mfma_peak<8, 2>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
-    else if (fill == 3) hipLaunchKernelGGL ((k_mfma_peak<8, 3>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
-    else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, 16) ;
+    auto launch = [&] (int it)
+    {
+        if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, it) ;
+        else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
+        else if (fill == 1) hipLaunchKernelGGL ((k_mfma_peak<8, 1>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
+        else if (fill == 2) hipLaunchKernelGGL ((k_mfma_peak<8, 2>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
+        else if (fill == 3) hipLaunchKernelGGL ((k_mfma_peak<8, 3>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
+        else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
+    } ;
+    launch (16) ;
     (void) hipDeviceSynchronize () ;
     (void) hipEventRecord (e0, 0) ;
-    if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
-    else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
-    else if (fill == 1) hipLaunchKernelGGL ((k_mfma_peak<8, 1>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
-    else if (fill == 2) hipLaunchKernelGGL ((k_mfma_peak<8, 2>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
-    else if (fill == 3) hipLaunchKernelGGL ((k_mfma_peak<8, 3>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
-    else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, iters) ;
+    launch (iters) ;
     (void) hipEventRecord (e1, 0) ;
     (void) hipEventSynchronize (e1) ;
     float ms = 0 ;

@@ -484,11 +484,18 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
                 double x = __builtin_amdgcn_rcp (d) ;
                 double e = __builtin_fma (-d, x, 1.0) ;
                 x = __builtin_fma (x, e, x) ;
+                // the column's multipliers leave for the scalar registers together, next to
+                // the reciprocal: (read-lane, read-lane, fma) triples one behind the other
+                // through one scalar pair cost ~70 cycles each
+                double u [16] ;
+#pragma unroll
+                for (int c2 = c + 1 ; c2 < 16 ; c2++) u [c2] = readlane_f64 (a [c], c2) ;
+                __builtin_amdgcn_sched_barrier (0) ;
                 double t = a [c] * x ;              // u(row,c) / d
 #pragma unroll
-                for (int c2 = c + 1 ; c2 < 16 ; c2++)
-                    a [c2] = __builtin_fma (-t, readlane_f64 (a [c], c2), a [c2]) ;
+                for (int c2 = c + 1 ; c2 < 16 ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
                 if (lane == c) dv = d ;
+                __builtin_amdgcn_sched_barrier (0) ;
             }
             tick (1) ;
             // off the chain: sqrt / rsqrt of the 16 pivots side by side in lanes
@@ -875,10 +882,14 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
 #pragma unroll
         for (int e = 0 ; e < 16 ; e++)
         {
+            double mu [16] ;
+#pragma unroll
+            for (int r = e + 1 ; r < 16 ; r++) mu [r] = readlane_f64 (Lr [e], r) ;
+            __builtin_amdgcn_sched_barrier (0) ;
             y [e] = acc [e] * readlane_f64 (rdv, e) ;
 #pragma unroll
-            for (int r = e + 1 ; r < 16 ; r++)
-                acc [r] = __builtin_fma (readlane_f64 (Lr [e], r), y [e], acc [r]) ;
+            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (mu [r], y [e], acc [r]) ;
+            __builtin_amdgcn_sched_barrier (0) ;
         }
         if (lane < 16)
         {
@@ -2240,7 +2251,7 @@ __global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, 
 // FILL: what sits between two MFMAs -- 0 nothing, 1 s_nop 3, 2 one independent
 // v_fma_f32, 3 one LDS read (the pattern of a real kernel's operand fetch)
 template <int NACC, int FILL = 0>
-__global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
+__global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters, double scale)
 {
     __shared__ double lds_fill [256] ;
     lds_fill [threadIdx.x] = 1.0 ;
@@ -2249,7 +2260,9 @@ __global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters)
     d4 acc [NACC] ;
     double a [4], b [4] ;
 #pragma unroll
-    for (int q = 0 ; q < 4 ; q++) { a [q] = 1.0 + 1e-9 * (threadIdx.x + q) ; b [q] = 1.0 - 1e-9 * (threadIdx.x + 3 * q) ; }
+    // scale = 0: all-zero operands (no toggling in the multipliers: the issue rate
+    // without the power the data costs); scale = 1: full-mantissa operands
+    for (int q = 0 ; q < 4 ; q++) { a [q] = scale * (1.0 + 1e-9 * (threadIdx.x + q)) ; b [q] = scale * (1.0 - 1e-9 * (threadIdx.x + 3 * q)) ; }
 #pragma unroll
     for (int q = 0 ; q < NACC ; q++) acc [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
     for (int it = 0 ; it < iters ; it++)

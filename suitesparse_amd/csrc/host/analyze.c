@@ -391,6 +391,10 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
     Int *seen = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
     Int *Ls = NULL ;
     Int ssize = 0, xsize = 0 ;
+    /* for_whom (:155-160, :662-663, :749-771, :912-913): the numeric sizes (xsize,
+     * px, maxcsize, maxesize) exist for Cholesky and for GPU-accelerated SPQR;
+     * plain SPQR gets the row structure only and px [0] = 123456 as the marker */
+    const int want_px = (for_whom == CHOLMOD_ANALYZE_FOR_CHOLESKY || for_whom == CHOLMOD_ANALYZE_FOR_SPQRGPU) ;
     int ok = Super && Lpi && Lpx && Sparent && fill && seen ;
     if (ok)
     {
@@ -402,8 +406,11 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
             Super [q] = F [s].first ;
             Lpi [q] = ssize ; Lpx [q] = xsize ;
             ssize += F [s].lead_nz ;
-            xsize += F [s].ncols * F [s].lead_nz ;
-            xx += (double) F [s].ncols * (double) F [s].lead_nz ;
+            if (want_px)
+            {
+                xsize += F [s].ncols * F [s].lead_nz ;
+                xx += (double) F [s].ncols * (double) F [s].lead_nz ;
+            }
             if (ssize < 0 || xx > (double) INT64_MAX)
             {
                 ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
@@ -415,6 +422,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
         if (ok)
         {
             Super [nsuper] = n ; Lpi [nsuper] = ssize ; Lpx [nsuper] = xsize ;
+            if (!want_px) Lpx [0] = 123456 ;
             for (Int s = 0 ; s < nsuper ; s++)
                 for (Int k = Super [s] ; k < Super [s+1] ; k++) col2s [k] = s ;
             for (Int s = 0 ; s < nsuper ; s++)
@@ -515,7 +523,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
         if (!ok) ERROR (CHOLMOD_INVALID, "invalid symbolic structure (ColCount/Parent mismatch)") ;
     }
     Int maxcsize = 1, maxesize = 1 ;
-    if (ok)
+    if (ok && want_px)
     {
         /* largest update matrix / largest set of rows below a diagonal block
          * (:907-948): runs of rows belonging to one ancestor supernode */
@@ -535,6 +543,9 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
                 p = q ;
             }
         }
+    }
+    if (ok)
+    {
         L->nsuper = nsuper ;
         L->ssize = ssize > 1 ? ssize : 1 ;
         L->xsize = xsize > 1 ? xsize : 1 ;

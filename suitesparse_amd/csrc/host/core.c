@@ -203,61 +203,21 @@ cholmod_sparse *cholmod_l_copy_sparse (cholmod_sparse *A, cholmod_common *Common
 
 /* ---- transposes (reference: Core/cholmod_transpose.c:871-1139) ----------------- */
 
-/* Symmetric case: C = A(p,p)' with the other triangle stored (stype flips).
- * An entry of the stored triangle of A at (i,j) moves to (Pinv[i], Pinv[j]),
- * is reflected into the triangle C stores, and the columns of C come out
- * sorted (two bucket passes).  Unsymmetric case: plain transpose (Perm/fset
- * are not supported for stype == 0 in this build). */
-cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse_long *Perm,
-    SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
+/* Symmetric permutation C = P A P' (Perm may be NULL), upper_out selects the
+ * triangle C is stored in -- independent of the triangle A is stored in, so a
+ * lower-stored A goes to a lower-stored permuted S in one pass (the reference
+ * takes two transposes for that, Cholesky/cholmod_factorize.c:233-244). */
+cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
+    cholmod_common *Common)
 {
-    RETURN_IF_NULL_COMMON (NULL) ;
-    RETURN_IF_NULL (A, NULL) ;
-    (void) fsize ;
-    Common->status = CHOLMOD_OK ;
-    Int n = (Int) A->nrow, ncol = (Int) A->ncol ;
+    /* C = P A P' of a symmetric A with the wanted triangle stored.  Three parallel passes
+     * (count, scatter with atomic cursors, per-column sort by (row, source
+     * position)), so the output is deterministic and its columns are sorted. */
+    Int n = (Int) A->nrow ;
     Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
     double *Ax = A->x ;
     int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
-    if (A->stype == 0)
-    {
-        if (Perm || fset)
-        {
-            ERROR (CHOLMOD_NOT_INSTALLED, "permuted unsymmetric transpose not built") ;
-            return NULL ;
-        }
-        Int nz = cholmod_l_nnz (A, Common) ;
-        cholmod_sparse *C = cholmod_l_allocate_sparse (ncol, n, nz, TRUE, TRUE, 0, xtype, Common) ;
-        if (!C) return NULL ;
-        Int *Cp = C->p, *Ci = C->i ;
-        double *Cx = C->x ;
-        Int *w = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
-        if (!w) { cholmod_l_free_sparse (&C, Common) ; return NULL ; }
-        for (Int j = 0 ; j < ncol ; j++)
-        {
-            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
-            for ( ; p < pend ; p++) w [Ai [p]]++ ;
-        }
-        Cp [0] = 0 ;
-        for (Int i = 0 ; i < n ; i++) { Cp [i+1] = Cp [i] + w [i] ; w [i] = Cp [i] ; }
-        for (Int j = 0 ; j < ncol ; j++)
-        {
-            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
-            for ( ; p < pend ; p++)
-            {
-                Int q = w [Ai [p]]++ ;
-                Ci [q] = j ;
-                if (xtype == CHOLMOD_REAL) Cx [q] = Ax [p] ;
-            }
-        }
-        cholmod_l_free (n + 1, sizeof (Int), w, Common) ;
-        return C ;
-    }
-    /* symmetric: C = P A P' with the other triangle stored.  Three parallel passes
-     * (count, scatter with atomic cursors, per-column sort by (row, source
-     * position)), so the output is deterministic and its columns are sorted. */
     int upper_in = A->stype > 0 ;
-    int upper_out = !upper_in ;
     const int packed = A->packed ;
     Int *Pinv = NULL ;
     if (Perm)
@@ -351,6 +311,57 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
     cholmod_l_free (n + 1, sizeof (Int), cursor, Common) ;
     if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;
     return C ;
+}
+
+/* reference: Core/cholmod_transpose.c:871.  Symmetric case: C = A(p,p)' with the
+ * other triangle stored (stype flips), columns sorted.  Unsymmetric case: plain
+ * transpose (Perm/fset are not supported for stype == 0 in this build). */
+cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse_long *Perm,
+    SuiteSparse_long *fset, size_t fsize, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (A, NULL) ;
+    (void) fsize ;
+    Common->status = CHOLMOD_OK ;
+    Int n = (Int) A->nrow, ncol = (Int) A->ncol ;
+    Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
+    double *Ax = A->x ;
+    int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
+    if (A->stype == 0)
+    {
+        if (Perm || fset)
+        {
+            ERROR (CHOLMOD_NOT_INSTALLED, "permuted unsymmetric transpose not built") ;
+            return NULL ;
+        }
+        Int nz = cholmod_l_nnz (A, Common) ;
+        cholmod_sparse *C = cholmod_l_allocate_sparse (ncol, n, nz, TRUE, TRUE, 0, xtype, Common) ;
+        if (!C) return NULL ;
+        Int *Cp = C->p, *Ci = C->i ;
+        double *Cx = C->x ;
+        Int *w = cholmod_l_calloc (n + 1, sizeof (Int), Common) ;
+        if (!w) { cholmod_l_free_sparse (&C, Common) ; return NULL ; }
+        for (Int j = 0 ; j < ncol ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++) w [Ai [p]]++ ;
+        }
+        Cp [0] = 0 ;
+        for (Int i = 0 ; i < n ; i++) { Cp [i+1] = Cp [i] + w [i] ; w [i] = Cp [i] ; }
+        for (Int j = 0 ; j < ncol ; j++)
+        {
+            Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int q = w [Ai [p]]++ ;
+                Ci [q] = j ;
+                if (xtype == CHOLMOD_REAL) Cx [q] = Ax [p] ;
+            }
+        }
+        cholmod_l_free (n + 1, sizeof (Int), w, Common) ;
+        return C ;
+    }
+    return ssamd_sym_permute (A, values, Perm, !(A->stype > 0), Common) ;
 }
 
 cholmod_sparse *cholmod_l_transpose (cholmod_sparse *A, int values, cholmod_common *Common)

@@ -27,6 +27,10 @@ typedef SuiteSparse_long Int ;
              if (Common->status != CHOLMOD_OUT_OF_MEMORY) { ERROR (CHOLMOD_INVALID, "argument missing") ; } \
              return (result) ; } } while (0)
 
+/* core.c */
+cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
+    cholmod_common *Common) ;
+
 /* analyze.c */
 int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent) ;
 Int ssamd_postorder (Int n, const Int *Parent, const Int *Weight, Int *Post, Int *work3n) ;

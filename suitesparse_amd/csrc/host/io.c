@@ -129,13 +129,16 @@ int cholmod_l_check_factor (cholmod_factor *L, cholmod_common *Common)
     Int nsuper = (Int) L->nsuper ;
     if (s [0] == EMPTY) BAD ("supernodes not defined") ;
     if (pi [0] != 0 || (pi [nsuper] > 1 ? pi [nsuper] : 1) != (Int) L->ssize) BAD ("invalid pi") ;
-    if (px [0] != 0 || (px [nsuper] > 1 ? px [nsuper] : 1) != (Int) L->xsize) BAD ("invalid px") ;
+    /* px [0] == 123456: a factor analysed for SPQR without the GPU carries no px
+     * (CHOLMOD/Supernodal/cholmod_super_symbolic.c:769, Check/cholmod_check.c:1880) */
+    const int check_px = (px [0] != 123456) ;
+    if (check_px && (px [0] != 0 || (px [nsuper] > 1 ? px [nsuper] : 1) != (Int) L->xsize)) BAD ("invalid px") ;
     for (Int q = 0 ; q < nsuper ; q++)
     {
         Int k1 = Sup [q], k2 = Sup [q+1] ;
         Int nscol = k2 - k1, nsrow = pi [q+1] - pi [q] ;
         if (k1 > k2 || k1 < 0 || k2 > n || nsrow < nscol) BAD ("invalid supernode") ;
-        if (px [q+1] - px [q] != nsrow * nscol) BAD ("invalid supernode") ;
+        if (check_px && px [q+1] - px [q] != nsrow * nscol) BAD ("invalid supernode") ;
         for (Int r = 0 ; r < nsrow ; r++)
         {
             Int i = s [pi [q] + r] ;

@@ -255,7 +255,7 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' factorization not built") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
-    cholmod_sparse *S = NULL, *A1 = NULL ;
+    cholmod_sparse *S = NULL ;
     int natural = (L->ordering == CHOLMOD_NATURAL) ;
     Int *Perm = natural ? NULL : (Int *) L->Perm ;
     if (A->stype > 0)
@@ -268,9 +268,9 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     }
     else
     {
-        A1 = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, Common) ;
-        if (A1) S = cholmod_l_ptranspose (A1, 2, Perm, NULL, 0, Common) ;
-        cholmod_l_free_sparse (&A1, Common) ;
+        /* lower-stored A: the reference transposes twice (:233-244); here one
+         * symmetric permutation lands in the lower triangle directly */
+        S = ssamd_sym_permute (A, 2, Perm, FALSE, Common) ;
     }
     if (!S) return FALSE ;
     double zero [2] = {0, 0} ;

@@ -214,3 +214,33 @@ def test_memory_budget_splits_the_sweep(monkeypatch):
     S.free_factor(Lf)
     S.free_sparse(A)
     S.finish()
+
+
+def test_for_whom_variants_of_super_symbolic():
+    """cholmod_l_analyze_p2's for_whom (CHOLMOD/Supernodal/cholmod_super_symbolic.c:
+    155-160, :662-663, :749-771, :912-913): FOR_SPQRGPU carries the same numeric
+    sizes as FOR_CHOLESKY; plain FOR_SPQR only the row structure, px[0] = 123456."""
+    n, Ap, Ai, Ax = G.poisson3d(9)
+    perm = np.ascontiguousarray(G.geometric_nd(9, 9, 9, 3))
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    views = {}
+    for who in (0, 1, 2):                       # FOR_SPQR, FOR_CHOLESKY, FOR_SPQRGPU
+        Lf = S.L.cholmod_l_analyze_p2(who, A, perm.ctypes.data, None, 0, C.byref(S.cm))
+        assert Lf and S.cm.status == ch.OK
+        assert S.L.cholmod_l_check_factor(Lf, C.byref(S.cm)) == 1
+        fv = ch.FactorView(Lf)
+        views[who] = {k: np.array(getattr(fv, k)) for k in ("Perm", "super", "pi", "px", "s")}
+        views[who].update(xsize=fv.xsize, maxcsize=fv.maxcsize, maxesize=fv.maxesize, useGPU=fv.useGPU)
+        S.free_factor(Lf)
+    for k in ("Perm", "super", "pi", "s"):
+        assert np.array_equal(views[0][k], views[1][k]) and np.array_equal(views[2][k], views[1][k])
+    assert np.array_equal(views[2]["px"], views[1]["px"])
+    assert (views[2]["xsize"], views[2]["maxcsize"], views[2]["maxesize"]) == \
+        (views[1]["xsize"], views[1]["maxcsize"], views[1]["maxesize"])
+    assert views[0]["px"][0] == 123456 and views[0]["xsize"] == 1
+    assert views[0]["maxcsize"] == 1 and views[0]["maxesize"] == 1
+    assert views[0]["useGPU"] == 0 and views[2]["useGPU"] == 0
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
