@@ -101,6 +101,9 @@ def main():
                     help="geometric = the nested dissection SURVEY 8d prescribes for the metric (default); "
                          "builtin = cholmod_l_analyze's own ordering (host/order.c), for information")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) or gloo (ranks sharing a GPU, tests)")
+    ap.add_argument("--exchange", default="native", choices=["native", "callback"],
+                    help="native: the engine calls RCCL itself (default with the nccl backend); callback: "
+                         "torch.distributed all_reduce through the host callback")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,8 +135,12 @@ def main():
         raise RuntimeError("bench.py needs a HIP device; there is no CPU path to measure")
     lib.cholmod_hip_set_device(local_rank)
 
+    # exchange: the engine's native RCCL path (stream-ordered ncclAllReduce on its own
+    # streams) with the nccl backend; the torch.distributed callback with gloo (ranks
+    # sharing a GPU in tests), or on request (--exchange callback)
     allreduce = None
-    if dist is not None:
+    native = dist is not None and args.dist_backend == "nccl" and args.exchange == "native"
+    if dist is not None and not native:
         from suitesparse_amd.dist import make_allreduce
         allreduce = make_allreduce(subgroups=None)     # the plan's own rank groups are created below
     grids = [0] if args.matrix else [args.m] if args.m > 0 else ([200, 160, 100] if args.workload == "poisson3d" else [100])
@@ -179,6 +186,17 @@ def main():
             S.finish()
             continue
         assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+        if native:
+            # one 128-byte RCCL id from rank 0 to everybody, then every rank attaches its plan
+            import torch
+            idb = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                assert S.L.cholmod_hip_rccl_unique_id(idb.ctypes.data) == 0
+            t = torch.from_numpy(idb).cuda()
+            dist.broadcast(t, 0)
+            idb = t.cpu().numpy().copy()
+            rc = S.L.cholmod_hip_rccl_attach(ch.FactorView(Lf).hip_plan, idb.ctypes.data)
+            assert rc == 0, f"cholmod_hip_rccl_attach failed: {rc}"
         if allreduce is not None and world > 1:
             # process groups for the rank ranges this plan shares fronts over
             # (same partition on every rank -> same collective new_group calls)
@@ -331,8 +349,8 @@ def main():
                        "levels": int(stats[3]), "launches_per_step": int(stats[2]),
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} GPUs: etree subtrees per rank + shared top fronts, "
-                       f"{allreduce.stats['n'] // max(args.steps + args.warmup + (0 if args.no_profile_pass else 1), 1)} "
-                       f"block-column all-reduces per factorization ({args.dist_backend})",
+                       f"{int(stats[17])} block-column all-reduces per factorization "
+                       f"({'RCCL, engine-native' if native else args.dist_backend + ' callback'})",
                        "input": "S=tril(PAP') resident in HBM; factor left in HBM"},
             "pct_fp64_mfma_peak_per_gpu": 100.0 * value / world / (1e3 * FP64_MFMA_PEAK_TFLOPS),
             "device_ms_per_step": 1e3 * dev_s / args.steps,
@@ -350,6 +368,11 @@ def main():
         if resid is not None:
             line["residual_2norm"] = resid
             line["factor_checks"] = checks
+        if native:
+            line["exchange"] = {"backend": "rccl (engine-native, stream-ordered)",
+                                "allreduce_calls_per_factorization": int(stats[17]),
+                                "allreduce_GB_per_factorization": 1e-9 * stats[18],
+                                "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
         if allreduce is not None:
             nfac = max(args.steps + args.warmup + (0 if args.no_profile_pass else 1), 1)
             line["exchange"] = {"backend": args.dist_backend, "allreduce_calls_per_factorization": allreduce.stats["n"] // nfac,

@@ -109,6 +109,16 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     const int64_t *s, int flags, int rank, int world, int *status) ;
 int cholmod_hip_set_allreduce (cholmod_hip_plan *plan,
     cholmod_hip_allreduce_fn fn, void *user) ;
+/* Native exchange: instead of the host callback the engine calls RCCL itself
+ * (librccl bound with dlopen), stream-ordered on its own streams -- no host
+ * synchronisation per block column, usable from a plain C caller.  One rank
+ * obtains a 128-byte id with cholmod_hip_rccl_unique_id and hands it to the
+ * others by any means (MPI_Bcast, a file, torch.distributed); every rank then
+ * calls cholmod_hip_rccl_attach on its plan: ncclCommInitRank over the world and
+ * one ncclCommSplit per rank group the plan shares fronts over (collective:
+ * all ranks must call it).  The callback, if set, is then no longer used. */
+int cholmod_hip_rccl_unique_id (void *id128) ;
+int cholmod_hip_rccl_attach (cholmod_hip_plan *plan, const void *id128) ;
 /* owner[s] = rank that factors supernode s, -1 for the shared fronts */
 int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
 /* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it

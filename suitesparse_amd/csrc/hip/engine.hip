@@ -6,6 +6,9 @@
 #include "kernels.hip.h"
 #include "../../../include/cholmod_hip.h"
 
+#include <rccl/rccl.h>      // types only: the library itself is bound with dlopen (cholmod_hip_rccl_attach)
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -154,6 +157,44 @@ template <typename T> static T *dupload (const std::vector<T> &v, hipError_t &er
 
 } // namespace
 
+// ---- RCCL, bound at run time (no link-time dependency: the library also serves
+// single-GPU callers and CPU-only hosts) ------------------------------------------
+namespace {
+struct RcclApi {
+    void *h = nullptr ;
+    ncclResult_t (*GetUniqueId) (ncclUniqueId *) = nullptr ;
+    ncclResult_t (*CommInitRank) (ncclComm_t *, int, ncclUniqueId, int) = nullptr ;
+    ncclResult_t (*CommSplit) (ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr ;
+    ncclResult_t (*AllReduce) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr ;
+    ncclResult_t (*CommDestroy) (ncclComm_t) = nullptr ;
+    const char *(*GetErrorString) (ncclResult_t) = nullptr ;
+} ;
+static RcclApi *rccl_api ()
+{
+    static RcclApi api ;
+    static bool tried = false ;
+    if (tried) return api.h ? &api : nullptr ;
+    tried = true ;
+    const char *names [] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr} ;
+    void *h = nullptr ;
+    for (int q = 0 ; names [q] && !h ; q++) h = dlopen (names [q], RTLD_NOW | RTLD_LOCAL) ;
+    if (!h) return nullptr ;
+    api.GetUniqueId = (decltype (api.GetUniqueId)) dlsym (h, "ncclGetUniqueId") ;
+    api.CommInitRank = (decltype (api.CommInitRank)) dlsym (h, "ncclCommInitRank") ;
+    api.CommSplit = (decltype (api.CommSplit)) dlsym (h, "ncclCommSplit") ;
+    api.AllReduce = (decltype (api.AllReduce)) dlsym (h, "ncclAllReduce") ;
+    api.CommDestroy = (decltype (api.CommDestroy)) dlsym (h, "ncclCommDestroy") ;
+    api.GetErrorString = (decltype (api.GetErrorString)) dlsym (h, "ncclGetErrorString") ;
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.AllReduce || !api.CommDestroy) return nullptr ;
+    api.h = h ;
+    return &api ;
+}
+}
+#define RCCLCHK(call) do { ncclResult_t r_ = (call) ; if (r_ != ncclSuccess) { \
+    fprintf (stderr, "cholmod_hip: %s failed: %s (%s:%d)\n", #call, \
+        (rccl_api () && rccl_api ()->GetErrorString) ? rccl_api ()->GetErrorString (r_) : "?", __FILE__, __LINE__) ; \
+    return CHOLMOD_HIP_GPU_PROBLEM ; } } while (0)
+
 struct cholmod_hip_plan {
     i64 n = 0, nsuper = 0, ssize = 0, xsize = 0 ;
     int flags = 0 ;
@@ -176,6 +217,11 @@ struct cholmod_hip_plan {
     std::vector<i32> my_lvl_ptr, my_lvl_list ;  // this rank's fronts by level
     cholmod_hip_allreduce_fn ar_fn = nullptr ;
     void *ar_user = nullptr ;
+    // native exchange: communicator of the world and one per rank group of the plan
+    // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
+    ncclComm_t nccl_world = nullptr ;
+    std::map<i64, ncclComm_t> nccl_group ;
+    hipEvent_t ar_done = nullptr ;          // all-reduce on the second stream finished
     double *d_xchg = nullptr ;
     double *d_stage = nullptr ;             // packed block-column slab for the all-reduce
     // triangular solves: per level, the supernodes one workgroup handles whole
@@ -976,6 +1022,13 @@ static int build_host (cholmod_hip_plan *P)
 
 static void free_device (cholmod_hip_plan *P)
 {
+    if (RcclApi *R = (P->nccl_world ? rccl_api () : nullptr))
+    {
+        for (auto &g : P->nccl_group) (void) R->CommDestroy (g.second) ;
+        (void) R->CommDestroy (P->nccl_world) ;
+        P->nccl_group.clear () ; P->nccl_world = nullptr ;
+    }
+    if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
@@ -992,6 +1045,9 @@ static void free_device (cholmod_hip_plan *P)
 static int upload_plan (cholmod_hip_plan *P)
 {
     hipError_t e ;
+    const bool ptiming = getenv ("CHOLMOD_HIP_PLAN_TIMING") != nullptr ;
+    auto pnow = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
+    double tu0 = pnow () ;
     HIPCHK (hipStreamCreate (&P->stream)) ;
     HIPCHK (hipStreamCreate (&P->stream2)) ;
     for (int q = 0 ; q < P->sch.nevents ; q++)
@@ -1012,6 +1068,7 @@ static int upload_plan (cholmod_hip_plan *P)
             need / 1e9, freeb / 1e9) ;
         return CHOLMOD_HIP_OUT_OF_MEMORY ;
     }
+    double tu1 = pnow () ;
     P->d_Ls = dupload (P->Ls, e) ; HIPCHK (e) ;
     P->d_fr = dupload (P->fr, e) ; HIPCHK (e) ;
     P->d_supermap = dupload (P->supermap, e) ; HIPCHK (e) ;
@@ -1024,18 +1081,20 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
+    double tu2 = pnow () ;
     HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
     if (getenv ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
-    HIPCHK (hipMalloc ((void **) &P->d_xchg, 2 * (size_t) P->world * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
     {
         i64 mx = 1 ;
         for (const Launch &L : P->sch.launches) if (L.kind == K_ALLREDUCE && L.ar_r0 > 0) mx = std::max (mx, L.ar_cnt) ;
         HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
     }
+    double tu3 = pnow () ;
     if (getenv ("CHOLMOD_HIP_THIN_TIMING"))
     {
         HIPCHK (hipMalloc ((void **) &P->d_thin_tim, (P->sch.launches.size () + 1) * 10 * sizeof (long long))) ;
@@ -1049,6 +1108,8 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipGetLastError ()) ;
         HIPCHK (hipStreamSynchronize (P->stream)) ;
     }
+    if (ptiming) fprintf (stderr, "cholmod_hip upload_plan: streams/events %.3f s, maps + schedule H2D %.3f s, hipMalloc (L %.1f GB, arena %.1f GB) %.3f s, relmap kernel %.3f s\n",
+        tu1 - tu0, tu2 - tu1, 8e-9 * P->xsize, 8e-9 * P->arena, tu3 - tu2, pnow () - tu3) ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -1104,6 +1165,43 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     P->d_Lx, P->d_cb, P->d_info, L.aux, (long long *) nullptr) ;
             break ;
         case K_ALLREDUCE:
+            if (P->nccl_world)
+            {
+                // native exchange: everything stream-ordered, the host never waits.  Ahead
+                // of time (wait_ev >= 0) the pack / all-reduce / unpack run on the second
+                // stream behind the event of the update that completed the slab, while the
+                // main stream goes on with the rest of the trailing update; the main stream
+                // then waits (on the device) for the sum before it touches the slab again.
+                RcclApi *R = rccl_api () ;
+                bool ahead = !serial && L.wait_ev >= 0 && P->stream2 ;
+                hipStream_t cs = ahead ? P->stream2 : st ;
+                if (ahead) HIPCHK (hipStreamWaitEvent (cs, P->sync_ev [L.wait_ev], 0)) ;
+                ncclComm_t comm = P->nccl_world ;
+                if (L.ar_gn != P->world)
+                {
+                    auto it = P->nccl_group.find (((i64) L.ar_g0 << 16) | (i64) L.ar_gn) ;
+                    if (it == P->nccl_group.end ()) return CHOLMOD_HIP_INVALID ;
+                    comm = it->second ;
+                }
+                if (L.ar_r0 == 0)
+                    RCCLCHK (R->AllReduce (P->d_Lx + L.ar_off, P->d_Lx + L.ar_off, (size_t) L.ar_cnt, ncclDouble, ncclSum, comm, cs)) ;
+                else
+                {
+                    size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
+                    double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
+                    HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
+                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
+                    RCCLCHK (R->AllReduce (P->d_stage, P->d_stage, (size_t) L.ar_cnt, ncclDouble, ncclSum, comm, cs)) ;
+                    HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
+                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
+                }
+                if (ahead)
+                {
+                    HIPCHK (hipEventRecord (P->ar_done, cs)) ;
+                    HIPCHK (hipStreamWaitEvent (st, P->ar_done, 0)) ;
+                }
+                break ;
+            }
             if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
             {
                 // ahead of time (wait_ev >= 0): the slab is complete once the event
@@ -1202,24 +1300,51 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta) ;
     }
     if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
+    int poisoned = CHOLMOD_HIP_OK ;
+    int fail_rank = -1 ; long fail_launch = -1 ;
+    if (const char *e = getenv ("CHOLMOD_HIP_TEST_FAIL_LAUNCH")) (void) sscanf (e, "%d:%ld", &fail_rank, &fail_launch) ;
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
-        { int rl = run_launch (P, L, prof) ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+        if (prof && poisoned == CHOLMOD_HIP_OK) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
+        if (poisoned != CHOLMOD_HIP_OK)
+        {
+            // A launch of this rank failed.  The other ranks of its groups are about to
+            // block in the collectives that follow: keep taking part in them (the data no
+            // longer matters) and report the failure through the agreement exchange at
+            // the end, so that every rank returns an error instead of hanging.
+            if (L.kind == K_ALLREDUCE) (void) run_launch (P, L, true) ;
+            continue ;
+        }
+        int rl = run_launch (P, L, prof) ;
+        // test hook "rank:launch": that launch of that rank reports a failure
+        if (fail_rank == P->rank && fail_launch == (long) q) rl = CHOLMOD_HIP_GPU_PROBLEM ;
+        if (rl != CHOLMOD_HIP_OK)
+        {
+            if (P->world == 1) return rl ;
+            poisoned = rl ;
+            continue ;
+        }
         if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1) + 1], st)) ;
     }
-    HIPCHK (hipGetLastError ()) ;
-    HIPCHK (hipEventRecord (P->ev1, st)) ;
+    if (poisoned == CHOLMOD_HIP_OK && hipGetLastError () != hipSuccess) poisoned = CHOLMOD_HIP_GPU_PROBLEM ;
+    if (poisoned != CHOLMOD_HIP_OK && P->world == 1) return poisoned ;
+    (void) hipEventRecord (P->ev1, st) ;
     double th1 = now () ;
     // not-positive-definite protocol (t_cholmod_super_numeric.c:905-968)
-    std::vector<i32> info (std::max<i64> (P->nsuper, 1)) ;
-    HIPCHK (hipMemcpyAsync (info.data (), P->d_info, info.size () * sizeof (i32),
-        hipMemcpyDeviceToHost, st)) ;
-    HIPCHK (hipStreamSynchronize (st)) ;
-    double th2 = now () ;
+    std::vector<i32> info (std::max<i64> (P->nsuper, 1), 0) ;
     float ms = 0 ;
-    HIPCHK (hipEventElapsedTime (&ms, P->ev0, P->ev1)) ;
+    if (poisoned == CHOLMOD_HIP_OK)
+    {
+        if (hipMemcpyAsync (info.data (), P->d_info, info.size () * sizeof (i32), hipMemcpyDeviceToHost, st) != hipSuccess
+            || hipStreamSynchronize (st) != hipSuccess
+            || hipEventElapsedTime (&ms, P->ev0, P->ev1) != hipSuccess)
+        {
+            if (P->world == 1) return CHOLMOD_HIP_GPU_PROBLEM ;
+            poisoned = CHOLMOD_HIP_GPU_PROBLEM ;
+        }
+    }
+    double th2 = now () ;
     if (host_timing)
         fprintf (stderr, "cholmod_hip: host enqueue %.3f ms, wait+info copy %.3f ms, device %.3f ms, %zu launches\n",
             1e3 * (th1 - th0), 1e3 * (th2 - th1), (double) ms, nl) ;
@@ -1241,7 +1366,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
     }
-    if (prof)
+    if (prof && poisoned == CHOLMOD_HIP_OK)
     {
         float t = 0 ;
         HIPCHK (hipEventElapsedTime (&t, P->evpool [0], P->evpool [1])) ;
@@ -1272,13 +1397,21 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         // agree on the first failing supernode: every rank publishes its own
         // candidate in its slot of a small device array, the sum-all-reduce
         // makes all slots visible everywhere
-        if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
-        std::vector<double> x (2 * (size_t) P->world, 0.0) ;
+        if (!P->ar_fn && !P->nccl_world) return CHOLMOD_HIP_INVALID ;
+        std::vector<double> x (3 * (size_t) P->world, 0.0) ;
         x [P->rank] = (double) (sbad >= 0 ? sbad : P->nsuper) ;
         x [P->world + P->rank] = (double) binfo ;
+        x [2 * P->world + P->rank] = (poisoned != CHOLMOD_HIP_OK) ? 1.0 : 0.0 ;     // a launch of this rank failed
         HIPCHK (hipMemcpy (P->d_xchg, x.data (), x.size () * sizeof (double), hipMemcpyHostToDevice)) ;
-        if (P->ar_fn (P->d_xchg, (i64) x.size (), 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        if (P->nccl_world)
+        {
+            RCCLCHK (rccl_api ()->AllReduce (P->d_xchg, P->d_xchg, x.size (), ncclDouble, ncclSum, P->nccl_world, st)) ;
+            HIPCHK (hipStreamSynchronize (st)) ;
+        }
+        else if (P->ar_fn (P->d_xchg, (i64) x.size (), 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
         HIPCHK (hipMemcpy (x.data (), P->d_xchg, x.size () * sizeof (double), hipMemcpyDeviceToHost)) ;
+        for (int r = 0 ; r < P->world ; r++)
+            if (x [2 * P->world + r] != 0.0) return poisoned != CHOLMOD_HIP_OK ? poisoned : CHOLMOD_HIP_GPU_PROBLEM ;
         i64 best = P->nsuper ;
         for (int r = 0 ; r < P->world ; r++)
             if ((i64) x [r] < best) { best = (i64) x [r] ; binfo = (i64) x [P->world + r] ; }
@@ -1419,7 +1552,7 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
 {
     if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
     if (P->world == 1) return CHOLMOD_HIP_OK ;
-    if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
+    if (!P->ar_fn && !P->nccl_world) return CHOLMOD_HIP_INVALID ;
     P->winv_valid = false ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     // Fronts shared by everybody are already complete everywhere.  Of every other
@@ -1442,10 +1575,54 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
         for (i64 off = P->px [q] ; off < P->px [e] ; off += chunk)
         {
             i64 cnt = std::min (chunk, P->px [e] - off) ;
-            if (P->ar_fn (P->d_Lx + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            if (P->nccl_world)
+                RCCLCHK (rccl_api ()->AllReduce (P->d_Lx + off, P->d_Lx + off, (size_t) cnt, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
+            else if (P->ar_fn (P->d_Lx + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
         }
         q = e ;
     }
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+/* ---- native exchange over RCCL ------------------------------------------------- */
+
+int cholmod_hip_rccl_unique_id (void *id128)
+{
+    RcclApi *R = rccl_api () ;
+    if (!R || !id128) return CHOLMOD_HIP_NO_DEVICE ;
+    static_assert (sizeof (ncclUniqueId) == 128, "ncclUniqueId is 128 bytes") ;
+    ncclUniqueId id ;
+    RCCLCHK (R->GetUniqueId (&id)) ;
+    memcpy (id128, &id, sizeof (id)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_rccl_attach (cholmod_hip_plan *P, const void *id128)
+{
+    if (!P || P->host_only || !id128) return CHOLMOD_HIP_INVALID ;
+    RcclApi *R = rccl_api () ;
+    if (!R) return CHOLMOD_HIP_NO_DEVICE ;
+    if (P->nccl_world) return CHOLMOD_HIP_OK ;
+    ncclUniqueId id ;
+    memcpy (&id, id128, sizeof (id)) ;
+    RCCLCHK (R->CommInitRank (&P->nccl_world, P->world, id, P->rank)) ;
+    // one communicator per rank group the plan shares fronts over; every rank of
+    // the world walks the same sorted list (the split is collective over the world)
+    std::map<i64, int> groups ;
+    for (i64 s = 0 ; s < P->nsuper ; s++)
+        if (P->grpn [s] > 1 && P->grpn [s] < P->world) groups [((i64) P->grp0 [s] << 16) | (i64) P->grpn [s]] = 1 ;
+    int color = 0 ;
+    for (auto &g : groups)
+    {
+        int g0 = (int) (g.first >> 16), gn = (int) (g.first & 0xffff) ;
+        bool member = P->rank >= g0 && P->rank < g0 + gn ;
+        ncclComm_t sub = nullptr ;
+        RCCLCHK (R->CommSplit (P->nccl_world, member ? color : NCCL_SPLIT_NOCOLOR, P->rank, &sub, nullptr)) ;
+        if (member) P->nccl_group [g.first] = sub ;
+        color++ ;
+    }
+    if (!P->ar_done) HIPCHK (hipEventCreateWithFlags (&P->ar_done, hipEventDisableTiming)) ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -476,7 +476,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
         {
             int nth = 1 ;
 #ifdef _OPENMP
-            nth = omp_get_max_threads () ;
+            nth = ssamd_host_threads () ;
 #endif
             for (Int s = 0 ; s < nsuper ; s++) wsub [s] = Lpi [s+1] - Lpi [s] ;
             for (Int s = 0 ; s < nsuper ; s++) if (Sparent [s] != EMPTY) wsub [Sparent [s]] += wsub [s] ;
@@ -505,7 +505,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
                     for (Int r = 0 ; r < nroots ; r++) pos [r] = mptr [r] ;
                     for (Int s = 0 ; s < nsuper ; s++) if (owner [s] != EMPTY) mlist [pos [rootid [owner [s]]]++] = s ;
                     cholmod_l_free (nroots + 1, sizeof (Int), pos, Common) ;
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth)
                     for (Int r = 0 ; r < nroots ; r++)
                         for (Int q = mptr [r] ; q < mptr [r+1] ; q++) { Int s = mlist [q] ; SSAMD_LS_OF (s) ; }
                     for (Int s = 0 ; s < nsuper ; s++) if (owner [s] == EMPTY) SSAMD_LS_OF (s) ;
@@ -527,7 +527,7 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
     {
         /* largest update matrix / largest set of rows below a diagonal block
          * (:907-948): runs of rows belonging to one ancestor supernode */
-#pragma omp parallel for schedule(dynamic, 1024) reduction(max:maxcsize) reduction(max:maxesize)
+#pragma omp parallel for schedule(dynamic, 1024) reduction(max:maxcsize) reduction(max:maxesize) num_threads(ssamd_host_threads ())
         for (Int d = 0 ; d < nsuper ; d++)
         {
             Int nscol = Super [d+1] - Super [d] ;

@@ -4,6 +4,9 @@
  * cholmod_sparse.c, cholmod_dense.c, cholmod_triplet.c, cholmod_transpose.c,
  * cholmod_factor.c, cholmod_error.c).  64-bit indices, real double only. */
 #include "host_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 /* ---- error / common ----------------------------------------------------------- */
 
@@ -203,6 +206,21 @@ cholmod_sparse *cholmod_l_copy_sparse (cholmod_sparse *A, cholmod_common *Common
 
 /* ---- transposes (reference: Core/cholmod_transpose.c:871-1139) ----------------- */
 
+/* Threads for the memory-bound analysis loops (scatter with atomics, sorts of
+ * short columns): they stop scaling at a few dozen and lose beyond a socket
+ * (EPYC 9575F x 2, 256 hardware threads: 4x slower than with 32), so the OpenMP
+ * default is capped; CHOLMOD_HOST_THREADS overrides. */
+int ssamd_host_threads (void)
+{
+    int nt = 1 ;
+#ifdef _OPENMP
+    nt = omp_get_max_threads () ;
+#endif
+    const char *e = getenv ("CHOLMOD_HOST_THREADS") ;
+    if (e && atoi (e) > 0) return atoi (e) ;
+    return nt > 32 ? 32 : nt ;
+}
+
 /* Symmetric permutation C = P A P' (Perm may be NULL), upper_out selects the
  * triangle C is stored in -- independent of the triangle A is stored in, so a
  * lower-stored A goes to a lower-stored permuted S in one pass (the reference
@@ -219,15 +237,16 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
     int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
     int upper_in = A->stype > 0 ;
     const int packed = A->packed ;
+    const int nth = ssamd_host_threads () ;
     Int *Pinv = NULL ;
     if (Perm)
     {
         Pinv = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
         if (!Pinv) return NULL ;
         int bad = 0 ;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nth)
         for (Int k = 0 ; k < n ; k++) Pinv [k] = EMPTY ;
-#pragma omp parallel for schedule(static) reduction(|:bad)
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(|:bad)
         for (Int k = 0 ; k < n ; k++)
         {
             Int j = Perm [k] ;
@@ -242,10 +261,10 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
     }
     Int *cursor = cholmod_l_malloc (n + 1, sizeof (Int), Common) ;
     if (!cursor) { if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ; return NULL ; }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nth)
     for (Int j = 0 ; j <= n ; j++) cursor [j] = 0 ;
     /* pass 1: entries per output column */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nth)
     for (Int j = 0 ; j < n ; j++)
     {
         Int p = Ap [j], pend = packed ? Ap [j+1] : p + Anz [j] ;
@@ -270,10 +289,10 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
     {
         Int *Cp = C->p, *Ci = C->i ;
         double *Cx = C->x ;
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nth)
         for (Int j = 0 ; j <= n ; j++) Cp [j] = cursor [j] ;
         /* pass 2: scatter (row, source position) */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(nth)
         for (Int j = 0 ; j < n ; j++)
         {
             Int p = Ap [j], pend = packed ? Ap [j+1] : p + Anz [j] ;
@@ -292,7 +311,7 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
             }
         }
         /* pass 3: every column sorted by (row, source position), values gathered */
-#pragma omp parallel for schedule(dynamic, 4096)
+#pragma omp parallel for schedule(dynamic, 4096) num_threads(nth)
         for (Int j = 0 ; j < n ; j++)
         {
             Int b0 = Cp [j], e0 = Cp [j+1] ;

@@ -28,6 +28,7 @@ typedef SuiteSparse_long Int ;
              return (result) ; } } while (0)
 
 /* core.c */
+int ssamd_host_threads (void) ;
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common) ;
 

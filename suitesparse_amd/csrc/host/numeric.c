@@ -93,12 +93,9 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
     cholmod_hip_plan *P = cholmod_hip_plan_create_dist ((int64_t) L->n, (int64_t) L->nsuper,
         L->super, L->pi, L->px, L->s, Common->hip_flags, world > 1 ? Common->hip_rank : 0, world, &st) ;
     if (!P) return map_hip_status (st ? st : CHOLMOD_HIP_GPU_PROBLEM, Common, "HIP plan creation failed") ;
-    if (world > 1 && !Common->hip_allreduce)
-    {
-        cholmod_hip_plan_destroy (P) ;
-        ERROR (CHOLMOD_INVALID, "Common->hip_world > 1 needs Common->hip_allreduce") ;
-        return FALSE ;
-    }
+    /* (several ranks need an exchange: the Common->hip_allreduce callback, or the
+     * native RCCL path attached to L->hip_plan with cholmod_hip_rccl_attach after
+     * cholmod_l_hip_prepare; without either the factorization returns CHOLMOD_INVALID) */
     if (Common->hip_allreduce)
         cholmod_hip_set_allreduce (P, Common->hip_allreduce, Common->hip_allreduce_user) ;
     L->hip_plan = P ;

@@ -62,6 +62,17 @@ def main():
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)
         ok = S.factorize(A, Lf)
+        if os.environ.get("CHOLMOD_HIP_TEST_FAIL_LAUNCH"):
+            # failure-injection case: every rank must come back with an error (no hang)
+            res.update(ok=int(ok), status=int(S.cm.status))
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            with open(f"{out}.{rank}", "w") as f:
+                json.dump(res, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         fv = ch.FactorView(Lf)
         owner = np.empty(fv.nsuper, dtype=np.int64)
         S.L.cholmod_hip_get_partition(fv.hip_plan, owner.ctypes.data)

@@ -212,6 +212,64 @@ def test_exchange_path_over_rccl_single_rank(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lookahead", [True, False])
+@pytest.mark.parametrize("notposdef", [False, True])
+def test_native_rccl_exchange_single_rank(monkeypatch, lookahead, notposdef):
+    """The engine's own RCCL path (cholmod_hip_rccl_unique_id / _attach: dlopen'ed
+    librccl, ncclCommInitRank, stream-ordered ncclAllReduce on the engine's
+    streams, no host callback, no torch) with the one rank a 1-GPU box can host:
+    CHOLMOD_HIP_SHARE_AS_WORLD marks the fronts a 4-rank run would share, so packing,
+    all-reduce, unpack, the exchange look-ahead on the second stream and the
+    not-posdef agreement all run; the factor must match the oracle."""
+    from oracle.oracle import OracleFactor
+    monkeypatch.setenv("CHOLMOD_HIP_SHARE_AS_WORLD", "4")
+    n, Ap, Ai, Ax = G.poisson3d(20)
+    perm = G.geometric_nd(20, 20, 20, 4)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    if notposdef:
+        kbad = int(O.super[O.nsuper - 3] + 2)
+        Ax = Ax.copy()
+        Ax[Ap[int(O.Perm[kbad])]] = -5.0
+        assert O.factorize(Ax) == 1 and O.minor == kbad
+    else:
+        assert O.factorize(Ax) == 0
+    S = ch.Session(hip_flags=0 if lookahead else 256)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm)) == 1
+    plan = ch.FactorView(Lf).hip_plan
+    idb = np.zeros(128, dtype=np.uint8)
+    assert S.L.cholmod_hip_rccl_unique_id(idb.ctypes.data) == 0
+    assert S.L.cholmod_hip_rccl_attach(plan, idb.ctypes.data) == 0
+    assert S.factorize(A, Lf) == 1
+    st = S.hip_stats(Lf)
+    assert st[17] > 0 and st[18] > 0                     # all-reduce launches really in the schedule
+    fv = ch.FactorView(Lf)
+    m = O.lower_mask()
+    assert np.linalg.norm((fv.x - O.x)[m]) <= 1e-12 * np.linalg.norm(O.x[m])
+    if notposdef:
+        assert S.cm.status == ch.NOT_POSDEF and fv.minor == O.minor
+    else:
+        assert S.cm.status == ch.OK
+        b = G.demo_rhs(n)
+        x = S.solve(Lf, b)
+        assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b) <= 1e-11 * np.linalg.norm(b)
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+@pytest.mark.gpu
+def test_local_failure_does_not_hang_the_other_ranks():
+    """A launch of rank 1 fails in the middle of the factorization (test hook): rank 1
+    keeps taking part in the remaining collectives and the failure travels through
+    the final agreement exchange, so every rank returns CHOLMOD_GPU_PROBLEM."""
+    res = _run_ranks(3, "gpu", "p3d_20", timeout=300, extra_env={"CHOLMOD_HIP_TEST_FAIL_LAUNCH": "1:25"})
+    for r in res:
+        assert r["ok"] == 0 and r["status"] == ch.GPU_PROBLEM, r
+
+
+@pytest.mark.gpu
 def test_distributed_rank_subgroups():
     """Proportional mapping: with 4 ranks the heavy children of the root split its
     group, so block columns are summed over 2-rank sub-groups as well as over
