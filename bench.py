@@ -106,6 +106,12 @@ def main():
                          "torch.distributed all_reduce through the host callback")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries that print there (RCCL's
+    # version banner at communicator creation) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -260,40 +266,50 @@ def main():
         S.set_profiling(Lf, False)
         if ps[6] > 0:
             ach = ps[8] / ps[6] / 1e12
-            traffic, traffic_note = None, None
-            pmc = os.path.join(ROOT, "profiles", "r01j_pmc_summary.json")
-            if os.path.exists(pmc):
-                # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc
-                # passes of this same command (offline; see profiles/README.md)
-                pj = json.load(open(pmc))
-                if pj.get("workload") == wname and world == 1:
-                    traffic = pj["fetch_bytes_per_launch_raw"] + pj["write_bytes_per_launch"]
-                    traffic_note = "rocprofv3 FETCH_SIZE(raw)+WRITE_SIZE per launch, profiles/r01j_pmc_summary.json"
-                else:
-                    big = os.path.join(ROOT, "profiles", "r01k_pmc_summary_poisson190.json")
-                    bj = json.load(open(big)) if os.path.exists(big) else None
-                    traffic_note = ("no PMC pass at this size: rocprofv3 --pmc did not finish a single 200^3 factorization "
-                                    "(9274 update launches of the subtree-sweep schedule) in 25 minutes, three attempts; "
-                                    "the same passes take seconds up to 190^3 (plain level order, 1774 launches)")
-                    if bj:
-                        traffic_note += (f": at 190^3 this kernel fetches {bj['fetch_bytes_per_launch_raw'] / 1e9:.2f} GB (raw) and "
-                                         f"writes {bj['write_bytes_per_launch'] / 1e9:.2f} GB per launch "
-                                         "(profiles/r01k_pmc_summary_poisson190.json; see DESIGN.md section 4 for why the "
-                                         "fetch side exceeds the algorithmic bytes)")
+            traffic, traffic_note, traffic_detail = None, None, None
+            # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc passes of the
+            # same workload (offline, profiles/README.md): FETCH_SIZE x 2 + WRITE_SIZE x 1, the
+            # calibration measured on known-byte kernels
+            lp = S.launch_profile(Lf)
+            upd = np.where(lp["kind"] == 5)[0]
+            pmc_by_workload = {"poisson3d_200^3_geometricND_leaf4": "r02h_pmc_summary_poisson200_top48.json"}
+            pj = None
+            if wname in pmc_by_workload and world == 1:
+                pf = os.path.join(ROOT, "profiles", pmc_by_workload[wname])
+                pj = json.load(open(pf)) if os.path.exists(pf) else None
+            if pj is not None and upd.size >= pj["launches_profiled"]:
+                k = pj["launches_profiled"]
+                top = upd[np.argsort(-lp["ms"][upd])[:k]]       # the same selection: the k longest launches
+                traffic = pj["traffic_bytes_per_launch"]
+                traffic_detail = {
+                    "launches": int(k), "selection": pj["selection"],
+                    "share_of_kernel_time": float(lp["ms"][top].sum() / lp["ms"][upd].sum()),
+                    "ms_per_launch": float(lp["ms"][top].mean()),
+                    "algorithmic_bytes_per_launch": float(lp["bytes"][top].mean()),
+                    "algorithmic_flops_per_launch": float(lp["flops"][top].mean()),
+                    "TFLOPs_on_these_launches": float(lp["flops"][top].sum() / (1e-3 * lp["ms"][top].sum()) / 1e12),
+                    "fetch_bytes_per_launch": pj["fetch_bytes_per_launch"], "write_bytes_per_launch": pj["write_bytes_per_launch"],
+                    "traffic_over_algorithmic": float(pj["traffic_bytes_per_launch"] / lp["bytes"][top].mean()),
+                    "TBps_at_the_memory_side": float(pj["traffic_bytes_per_launch"] / (1e-3 * lp["ms"][top].mean()) / 1e12),
+                    "source": "profiles/" + pmc_by_workload[wname]}
+                traffic_note = ("per launch over the %d longest launches (%.0f %% of this kernel's time): a counter pass over all "
+                                "launches of a 200^3 factorization does not finish" % (k, 100 * traffic_detail["share_of_kernel_time"]))
+            else:
+                traffic_note = "no PMC summary under profiles/ for this workload"
             roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": traffic_note,
+                    "traffic_note": traffic_note, "traffic_detail": traffic_detail,
                     "algorithmic_bytes_per_launch": ps[16] / max(ps[7], 1),
                     "algorithmic_flops_per_launch": ps[8] / max(ps[7], 1),
                     "extend_add": {"algorithmic_GB": ps[10] / 1e9, "seconds_incl_zero": ps[9]},
-                    "small_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
+                    "thin_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
                                            "achieved_GBps": (ps[20] / ps[19] / 1e9) if ps[19] > 0 else None,
                                            "hbm_peak_GBps": 8000.0},
                     "kernel": "k_update2<64,64,16,2,false>", "launches": int(ps[7]),
                     "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
                     "seconds_by_class": {"update64": ps[6], "update64_K_below_512": ps[23], "update128": ps[14], "extend_add+zero": ps[9],
                                          "potrf": ps[11], "trsm": ps[12], "assemble": ps[13],
-                                         "small_fronts_fused": ps[19],
+                                         "thin_fronts_fused": ps[19],
                                          "total_profiled": ps[0]}}
 
     # correctness of what was just timed (outside the timed region): device solve ->
@@ -379,7 +395,8 @@ def main():
                                 "allreduce_GB_per_factorization": 1e-9 * allreduce.stats["bytes"] / nfac,
                                 "allreduce_GB_by_group_size": {str(k): 1e-9 * v / nfac for k, v in sorted(allreduce.stats["by_size"].items())},
                                 "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     S.free_factor(Lf)
     S.free_sparse(A)
     S.finish()

@@ -315,7 +315,38 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
         for (Int j = 0 ; j < n ; j++)
         {
             Int b0 = Cp [j], e0 = Cp [j+1] ;
-            for (Int q = b0 + 1 ; q < e0 ; q++)
+            if (e0 - b0 > 48)
+            {
+                /* long column (dense stencils: hundreds of entries): heap sort in place */
+                Int len = e0 - b0 ;
+                Int *R = Ci + b0, *Sq = src + b0 ;
+#define SSAMD_LESS(x, y) (R [x] < R [y] || (R [x] == R [y] && Sq [x] < Sq [y]))
+#define SSAMD_SWAP(x, y) do { Int t_ = R [x] ; R [x] = R [y] ; R [y] = t_ ; t_ = Sq [x] ; Sq [x] = Sq [y] ; Sq [y] = t_ ; } while (0)
+                for (Int start = len / 2 - 1 ; start >= 0 ; start--)
+                    for (Int root = start ; ; )
+                    {
+                        Int ch = 2 * root + 1 ;
+                        if (ch >= len) break ;
+                        if (ch + 1 < len && SSAMD_LESS (ch, ch + 1)) ch++ ;
+                        if (!SSAMD_LESS (root, ch)) break ;
+                        SSAMD_SWAP (root, ch) ; root = ch ;
+                    }
+                for (Int end = len - 1 ; end > 0 ; end--)
+                {
+                    SSAMD_SWAP (0, end) ;
+                    for (Int root = 0 ; ; )
+                    {
+                        Int ch = 2 * root + 1 ;
+                        if (ch >= end) break ;
+                        if (ch + 1 < end && SSAMD_LESS (ch, ch + 1)) ch++ ;
+                        if (!SSAMD_LESS (root, ch)) break ;
+                        SSAMD_SWAP (root, ch) ; root = ch ;
+                    }
+                }
+#undef SSAMD_LESS
+#undef SSAMD_SWAP
+            }
+            else for (Int q = b0 + 1 ; q < e0 ; q++)
             {
                 Int r = Ci [q], sp = src [q], t = q ;
                 while (t > b0 && (Ci [t-1] > r || (Ci [t-1] == r && src [t-1] > sp)))
