@@ -12,4 +12,4 @@ print(d["config"]["workload"][:16], " ".join(sys.argv[1:]),
       "| GF/s %.0f ms %.2f dev_ms %.2f resid %s launches %d" % (d["value"], d["ms_per_step"], d["device_ms_per_step"],
       ("%.1e" % d["residual_2norm"]) if "residual_2norm" in d else "-", d["config"]["launches_per_step"]),
       "| upd TF %.1f" % r.get("achieved", 0),
-      {k: round(v * 1e3, 2) for k, v in r.get("seconds_by_class", {}).items()}, r.get("small_front_kernel"))
+      {k: round(v * 1e3, 2) for k, v in r.get("seconds_by_class", {}).items()}, r.get("thin_front_kernel"))
