@@ -219,6 +219,10 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
 /* Issue-bound v_mfma_f64_16x16x4_f64 loop without memory traffic: the measured
  * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */
 double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
+/* The same with the update kernel's operand pattern: a ti x tj grid of accumulators
+ * per wave (variant = 100 ti + 10 tj + ldsread; ldsread = 1 refreshes the fragments
+ * from LDS every step), all-zero operands on request. */
+double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands) ;
 
 /* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;

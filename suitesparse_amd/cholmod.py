@@ -134,7 +134,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
-    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak",
+    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
     "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles",
     "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach",
@@ -237,6 +237,7 @@ def lib():
     sig("cholmod_hip_set_profiling", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_bench_update_kernel", dbl, [i64, i64, i64, C.c_int, C.c_int])
     sig("cholmod_hip_bench_mfma_peak", dbl, [C.c_int, C.c_int])
+    sig("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int])
     sig("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int])
     sig("cholmod_hip_debug_potrf_cycles", C.c_int, [vp])
     sig("cholmod_hip_debug_panel_cycles", C.c_int, [vp])

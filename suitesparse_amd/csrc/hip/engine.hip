@@ -2156,6 +2156,42 @@ int cholmod_hip_debug_latency (long long *out8, int n)
     return CHOLMOD_HIP_OK ;
 }
 
+/* issue loops with the update kernel's operand pattern: variant = 100 ti + 10 tj + ldsread */
+double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands)
+{
+    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
+    if (waves_per_simd < 1) waves_per_simd = 1 ;
+    int blocks = 256 * waves_per_simd ;
+    double *d = nullptr ;
+    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    double scale = zero_operands ? 0.0 : 1.0 ;
+    int ti = variant / 100, tj = (variant / 10) % 10, lr = variant % 10 ;
+    auto launch = [&] (int it) -> bool
+    {
+#define P2(TI_, TJ_) if (ti == TI_ && tj == TJ_) { \
+        if (lr) hipLaunchKernelGGL ((k_mfma_peak2<TI_, TJ_, true>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ; \
+        else hipLaunchKernelGGL ((k_mfma_peak2<TI_, TJ_, false>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ; return true ; }
+        P2 (1, 1) P2 (2, 2) P2 (2, 4) P2 (4, 4) P2 (1, 4) P2 (4, 2)
+#undef P2
+        return false ;
+    } ;
+    if (!launch (16)) { (void) hipFree (d) ; return CHOLMOD_HIP_INVALID ; }
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    launch (iters) ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    hipError_t err = hipGetLastError () ;
+    (void) hipFree (d) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    return (double) blocks * 4.0 * iters * (double) (ti * tj) * 2048.0 / (ms * 1e-3) ;
+}
+
 double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
 {
     if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;

@@ -2282,4 +2282,47 @@ __global__ void __launch_bounds__(256) k_mfma_peak (double *out, int iters, doub
     out [blockIdx.x * 256 + threadIdx.x] = sum ;
 }
 
+// second issue-loop family: the operand pattern of the update kernel -- a TI x TJ
+// grid of accumulators per wave, A fragment a[i] shared along a row, B fragment
+// b[j] along a column, fragments refreshed from LDS every k-step (LDSREAD) or kept
+template <int TI, int TJ, bool LDSREAD>
+__global__ void __launch_bounds__(256) k_mfma_peak2 (double *out, int iters, double scale)
+{
+    __shared__ double frag [2][4][128] ;
+    for (int e = threadIdx.x ; e < 2 * 4 * 128 ; e += 256) (&frag [0][0][0]) [e] = scale * (1.0 + 1e-9 * e) ;
+    __syncthreads () ;
+    d4 acc [TI][TJ] ;
+#pragma unroll
+    for (int i = 0 ; i < TI ; i++)
+#pragma unroll
+        for (int j = 0 ; j < TJ ; j++) acc [i][j] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    double a [TI], b [TJ] ;
+    int lane = threadIdx.x & 63 ;
+#pragma unroll
+    for (int i = 0 ; i < TI ; i++) a [i] = frag [0][i & 3][lane] ;
+#pragma unroll
+    for (int j = 0 ; j < TJ ; j++) b [j] = frag [1][j & 3][lane] ;
+    for (int it = 0 ; it < iters ; it++)
+    {
+        if constexpr (LDSREAD)
+        {
+#pragma unroll
+            for (int i = 0 ; i < TI ; i++) a [i] = frag [0][i & 3][(lane + it) & 127] ;
+#pragma unroll
+            for (int j = 0 ; j < TJ ; j++) b [j] = frag [1][j & 3][(lane + it) & 127] ;
+        }
+#pragma unroll
+        for (int i = 0 ; i < TI ; i++)
+#pragma unroll
+            for (int j = 0 ; j < TJ ; j++)
+                acc [i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [j], a [i], acc [i][j], 0, 0, 0) ;
+    }
+    double sum = 0 ;
+#pragma unroll
+    for (int i = 0 ; i < TI ; i++)
+#pragma unroll
+        for (int j = 0 ; j < TJ ; j++) sum += acc [i][j][0] + acc [i][j][1] + acc [i][j][2] + acc [i][j][3] ;
+    out [blockIdx.x * 256 + threadIdx.x] = sum ;
+}
+
 } // namespace sship
