@@ -202,7 +202,19 @@ def main():
             dist.broadcast(t, 0)
             idb = t.cpu().numpy().copy()
             rc = S.L.cholmod_hip_rccl_attach(ch.FactorView(Lf).hip_plan, idb.ctypes.data)
-            assert rc == 0, f"cholmod_hip_rccl_attach failed: {rc}"
+            # every rank must agree that the native path is up; otherwise all of them take the callback
+            flag = torch.tensor([0.0 if rc == 0 else 1.0], device="cuda")
+            dist.all_reduce(flag)
+            if flag.item() > 0:
+                if rank == 0:
+                    print(f"[bench] cholmod_hip_rccl_attach failed on some rank (this rank: {rc}): "
+                          "falling back to the torch.distributed callback", file=sys.stderr)
+                S.L.cholmod_hip_rccl_detach(ch.FactorView(Lf).hip_plan)
+                from suitesparse_amd.dist import make_allreduce
+                native = False
+                allreduce = make_allreduce(subgroups=None)
+                S._keep.append(allreduce)
+                assert S.L.cholmod_hip_set_allreduce(ch.FactorView(Lf).hip_plan, allreduce, None) == 0
         if allreduce is not None and world > 1:
             # process groups for the rank ranges this plan shares fronts over
             # (same partition on every rank -> same collective new_group calls)

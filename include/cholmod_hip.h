@@ -119,6 +119,8 @@ int cholmod_hip_set_allreduce (cholmod_hip_plan *plan,
  * all ranks must call it).  The callback, if set, is then no longer used. */
 int cholmod_hip_rccl_unique_id (void *id128) ;
 int cholmod_hip_rccl_attach (cholmod_hip_plan *plan, const void *id128) ;
+/* back to the callback (destroys the plan's communicators) */
+int cholmod_hip_rccl_detach (cholmod_hip_plan *plan) ;
 /* owner[s] = rank that factors supernode s, -1 for the shared fronts */
 int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
 /* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it

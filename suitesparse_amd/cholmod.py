@@ -137,7 +137,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
     "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles",
-    "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach",
+    "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach", "cholmod_hip_rccl_detach",
     "cholmod_hip_version",
 ]
 
@@ -248,6 +248,7 @@ def lib():
     sig("cholmod_hip_debug_thin_cycles", C.c_int, [vp, i64, vp])
     sig("cholmod_hip_rccl_unique_id", C.c_int, [vp])
     sig("cholmod_hip_rccl_attach", C.c_int, [vp, vp])
+    sig("cholmod_hip_rccl_detach", C.c_int, [vp])
     sig("cholmod_hip_version", C.c_char_p, [])
     _lib = L
     return L

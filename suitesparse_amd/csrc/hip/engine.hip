@@ -1623,6 +1623,38 @@ int cholmod_hip_rccl_attach (cholmod_hip_plan *P, const void *id128)
         color++ ;
     }
     if (!P->ar_done) HIPCHK (hipEventCreateWithFlags (&P->ar_done, hipEventDisableTiming)) ;
+    // self check: a sum of ones over every communicator this rank belongs to must give
+    // the size of its group (catches a wrong split before any factor data moves)
+    {
+        std::vector<std::pair<ncclComm_t, int>> mine ;
+        mine.push_back ({P->nccl_world, P->world}) ;
+        for (auto &g : P->nccl_group) mine.push_back ({g.second, (int) (g.first & 0xffff)}) ;
+        for (auto &c : mine)
+        {
+            double one = 1.0, got = 0.0 ;
+            HIPCHK (hipMemcpyAsync (P->d_xchg, &one, sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
+            RCCLCHK (R->AllReduce (P->d_xchg, P->d_xchg, 1, ncclDouble, ncclSum, c.first, P->stream)) ;
+            HIPCHK (hipMemcpyAsync (&got, P->d_xchg, sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
+            HIPCHK (hipStreamSynchronize (P->stream)) ;
+            if (got != (double) c.second)
+            {
+                fprintf (stderr, "cholmod_hip_rccl_attach: self check failed (sum %g over a group of %d)\n", got, c.second) ;
+                return CHOLMOD_HIP_GPU_PROBLEM ;
+            }
+        }
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_rccl_detach (cholmod_hip_plan *P)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    if (RcclApi *R = (P->nccl_world ? rccl_api () : nullptr))
+    {
+        for (auto &g : P->nccl_group) (void) R->CommDestroy (g.second) ;
+        (void) R->CommDestroy (P->nccl_world) ;
+    }
+    P->nccl_group.clear () ; P->nccl_world = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -733,6 +733,9 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
             Common->anz = (double) ((Int *) U->p) [n] ;
             Common->method [0].fl = fl ; Common->method [0].lnz = lnz ;
             Common->selected = 0 ;
+            /* default strategy (nmethods == 0: the method table is the library's own):
+             * the selected method names the ordering that was actually used */
+            if (Common->nmethods == 0 && L->ordering != CHOLMOD_POSTORDERED) Common->method [0].ordering = L->ordering ;
         }
         if (ok && Common->postorder)
         {
