@@ -340,6 +340,7 @@ def main():
         resid = float(np.linalg.norm(r) / np.linalg.norm(b))
         checks = S.factor_checks(Lf)
         checks["solve_seconds_incl_h2d_d2h"] = t_solve
+        checks["solve_device_ms"] = 1e3 * float(S.hip_stats(Lf)[24])      # L and L' sweeps, kernels only
         if not args.matrix and args.workload in ("poisson3d", "poisson2d"):
             ld = G.poisson_logdet(*([m] * (3 if args.workload == "poisson3d" else 2)))
             checks["logdet_closed_form"] = ld

@@ -199,9 +199,11 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [9] seconds in extend-add kernels    [10] algorithmic bytes of extend-add
  *  [11] seconds in potrf kernels        [12] seconds in trsm kernels
  *  [13] seconds in assemble (memset + A scatter)
+ *  [24] device seconds of the last cholmod_hip_solve (its kernels, without the
+ *       copies of the right-hand side)
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
-#define CHOLMOD_HIP_NSTATS 24
+#define CHOLMOD_HIP_NSTATS 26
 int cholmod_hip_get_stats (cholmod_hip_plan *plan, double *stats) ;
 int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 /* The launch list of the plan and, after a factorization with profiling on, the

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcholmod_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CHOLMOD_MAXMETHODS = 9
-CHOLMOD_HIP_NSTATS = 24
+CHOLMOD_HIP_NSTATS = 26
 
 # constants (include/cholmod.h)
 PATTERN, REAL = 0, 1

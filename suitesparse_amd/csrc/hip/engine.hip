@@ -237,9 +237,17 @@ struct cholmod_hip_plan {
     InvTask *d_inv_tasks = nullptr ;
     double *d_winv = nullptr ;
     bool winv_valid = false ;
-    double *d_solved = nullptr ; i64 solved_cap = 0 ; int max_big_nscol = 0 ;
+    double *d_solved = nullptr ; i64 solved_cap = 0 ;     // side vector Y of the forward walk
     double *d_sv_acc = nullptr ; i64 sv_acc_cap = 0 ;
     unsigned int *d_ticket = nullptr ;
+    // the walk, batched over the big supernodes of a level: step b of a level = one
+    // launch holding block b of every big supernode of the level that has one
+    struct SbLaunch { i32 level, first, ntasks, grid ; } ;
+    std::vector<SolveBlk> sb_tasks, sb_commit ;     // [block tasks by launch], [one commit task per big supernode]
+    std::vector<SbLaunch> sb_launch, sb_commit_launch ;
+    std::vector<i32> sb_lvl_ptr ;                   // level -> range of sb_launch
+    SolveBlk *d_sb_tasks = nullptr, *d_sb_commit = nullptr ;
+    int sb_max_tasks = 0 ;
     long long *d_thin_tim = nullptr ;       // CHOLMOD_HIP_THIN_TIMING: 10 cycle counters per launch
     CheckTask *d_chk = nullptr ; i64 nchk = 0 ;     // cholmod_hip_factor_checks task list (lazy)
     double *d_chk_out = nullptr ;
@@ -266,6 +274,7 @@ struct cholmod_hip_plan {
     // stats
     bool profiling = false ;
     double stats [CHOLMOD_HIP_NSTATS] = {0} ;
+    double solve_seconds = 0 ;              // device time of the last cholmod_hip_solve (kernels only)
     std::vector<float> launch_ms ;          // per-launch device time of the last profiled factorization
     hipEvent_t ev0 = nullptr, ev1 = nullptr ;
     std::vector<hipEvent_t> evpool ;
@@ -876,23 +885,50 @@ static int build_host (cholmod_hip_plan *P)
         {
             i32 sid = P->lvl_list [q] ;
             const FrontD &f = P->fr [sid] ;
-            // one workgroup streams ~50-100 GB/s: anything above ~16 MB of L gets the
+            // one workgroup streams ~50-100 GB/s: anything above 512 KB of L gets the
             // multi-workgroup block walk
-            if (f.nscol > SOLVE_BIG_COLS || (i64) f.nsrow * f.nscol > ((i64) 2 << 20)) P->sv_big [l].push_back (sid) ;
+            if (f.nscol > SOLVE_BIG_COLS || (i64) f.nsrow * f.nscol > ((i64) 1 << 16)) P->sv_big [l].push_back (sid) ;
             else P->sv_tasks.push_back (SolveTask {sid, 0, f.nscol, 1}) ;
         }
         P->sv_ptr [l+1] = (i32) P->sv_tasks.size () ;
     }
-    P->inv_tasks.clear () ; P->inv_first.assign (std::max<i64> (nsuper, 1), -1) ; P->max_big_nscol = 0 ;
+    P->inv_tasks.clear () ; P->inv_first.assign (std::max<i64> (nsuper, 1), -1) ;
+    P->sb_tasks.clear () ; P->sb_commit.clear () ; P->sb_launch.clear () ; P->sb_commit_launch.clear () ;
+    P->sb_lvl_ptr.assign (nlev + 1, 0) ; P->sb_max_tasks = 0 ;
     for (int l = 0 ; l < nlev ; l++)
+    {
+        int maxblk = 0 ;
+        cholmod_hip_plan::SbLaunch Lc {l, (i32) P->sb_commit.size (), 0, 0} ;
         for (i32 sid : P->sv_big [l])
         {
             const FrontD &f = P->fr [sid] ;
             P->inv_first [sid] = (i64) P->inv_tasks.size () ;
-            P->max_big_nscol = std::max (P->max_big_nscol, f.nscol) ;
-            for (int jb = 0 ; jb < f.nscol ; jb += SOLVE_SB)
+            for (int jb = 0 ; jb < f.nscol ; jb += SOLVE_IB)
                 P->inv_tasks.push_back (InvTask {sid, jb, (i64) P->inv_tasks.size () * 8192}) ;
+            maxblk = std::max (maxblk, (f.nscol + SOLVE_SB - 1) / SOLVE_SB) ;
+            P->sb_commit.push_back (SolveBlk {sid, 0, f.nscol, Lc.grid, 0, Lc.ntasks}) ;
+            Lc.grid += (f.nscol + 255) / 256 ; Lc.ntasks++ ;
         }
+        P->sb_commit_launch.push_back (Lc) ;
+        for (int b = 0 ; b < maxblk ; b++)
+        {
+            cholmod_hip_plan::SbLaunch Lb {l, (i32) P->sb_tasks.size (), 0, 0} ;
+            for (i32 sid : P->sv_big [l])
+            {
+                const FrontD &f = P->fr [sid] ;
+                int jb = b * SOLVE_SB ;
+                if (jb >= f.nscol) continue ;
+                int w = std::min (SOLVE_SB, f.nscol - jb) ;
+                int rest = f.nsrow - (jb + w) ;
+                P->sb_tasks.push_back (SolveBlk {sid, jb, w, Lb.grid, (i32) (P->inv_first [sid] + jb / SOLVE_IB), Lb.ntasks}) ;
+                // workgroups: 256-row chunks below the block x 64-column sub-blocks
+                Lb.grid += rest > 0 ? ((rest + 255) / 256) * ((w + 63) / 64) : 0 ; Lb.ntasks++ ;
+            }
+            P->sb_max_tasks = std::max (P->sb_max_tasks, (int) Lb.ntasks) ;
+            P->sb_launch.push_back (Lb) ;
+        }
+        P->sb_lvl_ptr [l+1] = (i32) P->sb_launch.size () ;
+    }
     // launch schedule of this rank
     Schedule &S = P->sch ;
     std::vector<i32> mine_ids ;
@@ -1032,7 +1068,7 @@ static void free_device (cholmod_hip_plan *P)
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim} ;
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1751,25 +1787,27 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
     {
         if (!P->d_winv)
         {
+            hipError_t e ;
             HIPCHK (hipMalloc ((void **) &P->d_winv, P->inv_tasks.size () * 8192 * sizeof (double))) ;
-            HIPCHK (hipMalloc ((void **) &P->d_inv_tasks, P->inv_tasks.size () * sizeof (InvTask))) ;
-            HIPCHK (hipMemcpy (P->d_inv_tasks, P->inv_tasks.data (), P->inv_tasks.size () * sizeof (InvTask), hipMemcpyHostToDevice)) ;
-            HIPCHK (hipMalloc ((void **) &P->d_ticket, sizeof (unsigned int))) ;
-            HIPCHK (hipMemset (P->d_ticket, 0, sizeof (unsigned int))) ;
+            P->d_inv_tasks = dupload (P->inv_tasks, e) ; HIPCHK (e) ;
+            P->d_sb_tasks = dupload (P->sb_tasks, e) ; HIPCHK (e) ;
+            P->d_sb_commit = dupload (P->sb_commit, e) ; HIPCHK (e) ;
+            HIPCHK (hipMalloc ((void **) &P->d_ticket, (size_t) std::max (P->sb_max_tasks, 1) * sizeof (unsigned int))) ;
+            HIPCHK (hipMemset (P->d_ticket, 0, (size_t) std::max (P->sb_max_tasks, 1) * sizeof (unsigned int))) ;
             P->winv_valid = false ;
         }
-        if ((i64) P->max_big_nscol * nrhs > P->solved_cap)
+        if (need > P->solved_cap)
         {
             if (P->d_solved) (void) hipFree (P->d_solved) ;
             P->d_solved = nullptr ;
-            P->solved_cap = (i64) P->max_big_nscol * nrhs ;
+            P->solved_cap = need ;
             HIPCHK (hipMalloc ((void **) &P->d_solved, P->solved_cap * sizeof (double))) ;
         }
-        if (64 * nrhs > P->sv_acc_cap)
+        if ((i64) P->sb_max_tasks * SOLVE_SB * nrhs > P->sv_acc_cap)
         {
             if (P->d_sv_acc) (void) hipFree (P->d_sv_acc) ;
             P->d_sv_acc = nullptr ;
-            P->sv_acc_cap = 64 * nrhs ;
+            P->sv_acc_cap = (i64) P->sb_max_tasks * SOLVE_SB * nrhs ;
             HIPCHK (hipMalloc ((void **) &P->d_sv_acc, P->sv_acc_cap * sizeof (double))) ;
             HIPCHK (hipMemset (P->d_sv_acc, 0, P->sv_acc_cap * sizeof (double))) ;
         }
@@ -1781,6 +1819,7 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         }
     }
     HIPCHK (hipMemcpyAsync (P->d_X, X, need * sizeof (double), hipMemcpyHostToDevice, st)) ;
+    HIPCHK (hipEventRecord (P->ev0, st)) ;
     if (which == 0 || which == 1)
     {
         for (int l = 0 ; l < P->nlevels ; l++)
@@ -1788,40 +1827,32 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
             if (nf) hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
                 P->d_sv + P->sv_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
-            for (i32 sid : P->sv_big [l])
+            for (int q = P->sb_lvl_ptr [l] ; q < P->sb_lvl_ptr [l+1] ; q++)
             {
-                const FrontD &f = P->fr [sid] ;
-                int nblk = (f.nscol + SOLVE_SB - 1) / SOLVE_SB ;
-                for (int b = 0 ; b < nblk ; b++)
-                {
-                    int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
-                    int rest = f.nsrow - (jb + w) ;
-                    hipLaunchKernelGGL (k_solve_fwd_blk, dim3 (std::max (1, (rest + 255) / 256)), dim3 (256), 0, st,
-                        (int) sid, jb, w, P->d_winv + (P->inv_first [sid] + b) * 8192,
-                        P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs,
-                        P->d_solved, (i64) P->max_big_nscol) ;
-                }
-                hipLaunchKernelGGL (k_solve_commit, dim3 ((f.nscol + 255) / 256), dim3 (256), 0, st,
-                    (int) sid, P->d_fr, P->d_X, (i64) ldx, (int) nrhs, P->d_solved, (i64) P->max_big_nscol) ;
+                const auto &B = P->sb_launch [q] ;
+                hipLaunchKernelGGL (k_solve_fwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
+                    P->d_sb_tasks + B.first, P->d_fr, P->d_Lx, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
+                if (B.grid > 0) hipLaunchKernelGGL (k_solve_fwd_apply, dim3 (B.grid), dim3 (256), 0, st,
+                    P->d_sb_tasks + B.first, (int) B.ntasks, P->d_fr, P->d_Ls, P->d_Lx,
+                    P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
             }
+            const auto &Cm = P->sb_commit_launch [l] ;
+            if (Cm.ntasks) hipLaunchKernelGGL (k_solve_commit, dim3 (Cm.grid), dim3 (256), 0, st,
+                P->d_sb_commit + Cm.first, (int) Cm.ntasks, P->d_fr, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
         }
     }
     if (which == 0 || which == 2)
     {
         for (int l = P->nlevels - 1 ; l >= 0 ; l--)
         {
-            for (i32 sid : P->sv_big [l])
+            for (int q = P->sb_lvl_ptr [l+1] - 1 ; q >= P->sb_lvl_ptr [l] ; q--)
             {
-                const FrontD &f = P->fr [sid] ;
-                int nblk = (f.nscol + SOLVE_SB - 1) / SOLVE_SB ;
-                for (int b = nblk - 1 ; b >= 0 ; b--)
-                {
-                    int jb = b * SOLVE_SB, w = std::min (SOLVE_SB, f.nscol - jb) ;
-                    int rest = f.nsrow - (jb + w) ;
-                    hipLaunchKernelGGL (k_solve_bwd_blk, dim3 (std::max (1, (rest + 255) / 256)), dim3 (256), 0, st,
-                        (int) sid, jb, w, P->d_winv + (P->inv_first [sid] + b) * 8192 + 4096,
-                        P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc, P->d_ticket) ;
-                }
+                const auto &B = P->sb_launch [q] ;
+                if (B.grid > 0) hipLaunchKernelGGL (k_solve_bwd_apply, dim3 (B.grid), dim3 (256), 0, st,
+                    P->d_sb_tasks + B.first, (int) B.ntasks, P->d_fr, P->d_Ls, P->d_Lx,
+                    P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
+                hipLaunchKernelGGL (k_solve_bwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
+                    P->d_sb_tasks + B.first, P->d_fr, P->d_Lx, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
             }
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
             if (nf) hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
@@ -1829,8 +1860,13 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         }
     }
     HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipEventRecord (P->ev1, st)) ;
     HIPCHK (hipMemcpyAsync (X, P->d_X, need * sizeof (double), hipMemcpyDeviceToHost, st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
+    {
+        float ms = 0 ;
+        if (hipEventElapsedTime (&ms, P->ev0, P->ev1) == hipSuccess) P->solve_seconds = 1e-3 * ms ;
+    }
     return CHOLMOD_HIP_OK ;
 }
 
@@ -1886,6 +1922,7 @@ int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
     P->stats [4] = 8.0 * P->arena ;
     P->stats [5] = 8.0 * P->xsize ;
     P->stats [22] = P->nsplit ;
+    P->stats [24] = P->solve_seconds ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
     return CHOLMOD_HIP_OK ;
 }

@@ -1882,8 +1882,9 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
 }
 
 // column block of the big-supernode walk (k_solve_fwd_blk / k_solve_bwd_blk below)
-#define SOLVE_SB 64          /* column block of the big-front walk */
-#define SOLVE_BIG_COLS 1024  /* fronts wider than this (or > 16 MB) take the multi-workgroup walk */
+#define SOLVE_IB 64          /* diagonal blocks with an explicit inverse (k_diag_inv64) */
+#define SOLVE_SB 256         /* column block of the big-front walk: four inverse blocks */
+#define SOLVE_BIG_COLS 256   /* fronts wider than this (or > 512 KB) take the multi-workgroup walk */
 
 __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
@@ -1972,20 +1973,21 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
 }
 
 
-// ---- big supernodes, third generation: one launch per 64-column block --------
+// ---- big supernodes: a batched walk in 256-column blocks -----------------------
 // The 64x64 diagonal blocks of the big supernodes are inverted once per
-// factorization (k_diag_inv64, every block independent); the solves then
-// contain no substitution chain at all:
-//   forward  (k_solve_fwd_blk): every workgroup forms x_b = inv(L_bb) x_b itself
-//            (a 64x64 matrix-vector product, 32 KB of inverse out of L2) and
-//            applies it to its 256 rows below, X[rows] -= L[rows, b] x_b;
-//            workgroup 0 stores x_b in a side buffer (the other workgroups of the
-//            launch may still be reading the unsolved x_b), copied back by
-//            k_solve_commit once the supernode is done;
-//   backward (k_solve_bwd_blk): every workgroup adds its rows' share of
-//            L[rows, b]' x[rows] into a 64-entry accumulator; the last one to
-//            arrive (ticket counter) forms x_b = inv(L_bb)' (x_b - acc).
-// Inverse layout (per block, 2 x 4096 doubles): Wm [k*64 + r] = W(r,k) and
+// factorization (k_diag_inv64, every block independent).  The solve walks a big
+// supernode in blocks of SOLVE_SB = 256 columns, and one launch carries the same
+// step of EVERY big supernode of the etree level (they are independent), so the
+// number of dependent launches is the block count of the level's widest
+// supernode, not the sum over its supernodes (Poisson 100^3: 1680 -> 130 per
+// direction):
+//   forward  k_solve_fwd_diag (one workgroup per task) forms x_b = inv(L_bb) x_b, four
+//            64-column sub-blocks with the explicit inverses on the diagonal, into a
+//            side vector; k_solve_fwd_apply (256-row x 64-column workgroups) subtracts
+//            L[rows, b] x_b from the rows below; k_solve_commit copies x_b back per level;
+//   backward k_solve_bwd_apply adds L[rows, b]' x[rows] into the task's accumulator,
+//            k_solve_bwd_diag forms x_b = inv(L_bb)' (x_b - acc).
+// Inverse layout (per 64-block, 2 x 4096 doubles): Wm [k*64 + r] = W(r,k) and
 // WmT [k*64 + c] = W(k,c), both zero outside the lower triangle and
 // identity-padded past the supernode's last column.
 struct InvTask { i32 front ; i32 jb ; i64 w_off ; } ;
@@ -2036,45 +2038,115 @@ __global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const 
     }
 }
 
-__global__ void __launch_bounds__(256) k_solve_fwd_blk (int fid, int jb, int w, const double *Wm,
-    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs,
-    double *solved, i64 ld_solved)
+// One step of the walk for every big supernode of a level at once: task t = block
+// [jb, jb+w) of one supernode, workgroups wg_start .. of the launch belong to it.
+struct SolveBlk { i32 front, jb, w, wg_start, inv, slot ; } ;   // inv: index of its first 64 x 64 inverse
+
+__device__ __forceinline__ int find_solve_task (const SolveBlk *t, int nt, int b)
 {
-    __shared__ double t [64], xs [64], part [4][64] ;
-    const FrontD &f = fr [fid] ;
-    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
-    int r = tid & 63, p = tid >> 6 ;
+    int lo = 0, hi = nt - 1 ;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1 ; if (t [mid].wg_start <= b) lo = mid ; else hi = mid - 1 ; }
+    return lo ;
+}
+
+// forward, step 1 (one workgroup per task): x_b = inv(L_bb) x_b by 64-column
+// sub-blocks -- explicit inverses on the diagonal, matrix-vector products below it.
+// The solved x_b goes to the side vector Y (k_solve_commit copies it back per level).
+__global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
+    const FrontD *fr, const double *Lx, const double *Winv, const double *X, i64 ldx, int nrhs, double *Y)
+{
+    __shared__ double xs [SOLVE_SB], t [64], part [4][64] ;
+    const SolveBlk T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
+    const int nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    const int jb = T.jb, w = T.w, nsub = (w + 63) >> 6 ;
+    const int r = tid & 63, p = tid >> 6 ;
+    const double *L = Lx + f.psx ;
+    // everything this thread will ever need of L_bb leaves for the registers at once
+    // (sub-step k: row 64 k + r, columns == p (mod 4) before the sub-block: 16 k values;
+    // 96 in all, one HBM latency instead of one per sub-step); the chain below then
+    // only waits for LDS and for the 64 x 64 inverses (L2)
+    double l1 [16], l2 [32], l3 [48] ;
+    {
+        const double *Lr = L + (jb + 64 + r) + (i64) jb * nsrow ;
+#pragma unroll
+        for (int u = 0 ; u < 16 ; u++) l1 [u] = (64 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
+        Lr += 64 ;
+#pragma unroll
+        for (int u = 0 ; u < 32 ; u++) l2 [u] = (128 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
+        Lr += 64 ;
+#pragma unroll
+        for (int u = 0 ; u < 48 ; u++) l3 [u] = (192 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
+    }
+    for (int rhs = 0 ; rhs < nrhs ; rhs++)
+    {
+        const double *x = X + (i64) rhs * ldx ;
+        xs [tid] = (tid < w) ? x [k1 + jb + tid] : 0.0 ;
+        __syncthreads () ;
+        for (int k = 0 ; k < nsub ; k++)
+        {
+            // t = x_k - L[k-th row block, columns before it] * (solved part)
+            double a0 = 0.0, a1 = 0.0 ;
+            if (k == 1)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u += 2) { a0 = __builtin_fma (l1 [u], xs [p + 4 * u], a0) ; a1 = __builtin_fma (l1 [u + 1], xs [p + 4 * u + 4], a1) ; }
+            }
+            else if (k == 2)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 32 ; u += 2) { a0 = __builtin_fma (l2 [u], xs [p + 4 * u], a0) ; a1 = __builtin_fma (l2 [u + 1], xs [p + 4 * u + 4], a1) ; }
+            }
+            else if (k == 3)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 48 ; u += 2) { a0 = __builtin_fma (l3 [u], xs [p + 4 * u], a0) ; a1 = __builtin_fma (l3 [u + 1], xs [p + 4 * u + 4], a1) ; }
+            }
+            part [p][r] = a0 + a1 ;
+            __syncthreads () ;
+            if (tid < 64) t [tid] = xs [64 * k + tid] - ((part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid])) ;
+            __syncthreads () ;
+            const double *Wm = Winv + (i64) (T.inv + k) * 8192 ;        // Wm [kk*64 + r] = W(r, kk)
+            double a = 0.0 ;
+#pragma unroll
+            for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (Wm [(p + 4 * u) * 64 + r], t [p + 4 * u], a) ;
+            part [p][r] = a ;
+            __syncthreads () ;
+            if (tid < 64) xs [64 * k + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
+            __syncthreads () ;
+        }
+        if (tid < w) Y [(i64) rhs * ldx + k1 + jb + tid] = xs [tid] ;
+        __syncthreads () ;
+    }
+}
+
+// forward, step 2: X[rows below] -= L[rows, b] x_b ; workgroup = (256-row chunk) x
+// (64-column sub-block), so that a single supernode fills the chip
+__global__ void __launch_bounds__(256) k_solve_fwd_apply (const SolveBlk *tasks, int ntasks,
+    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs, const double *Y)
+{
+    __shared__ double xs [64] ;
+    const SolveBlk T = tasks [find_solve_task (tasks, ntasks, (int) blockIdx.x)] ;
+    const FrontD &f = fr [T.front] ;
+    const int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    const int jb = T.jb, w = T.w, nsub = (w + 63) >> 6 ;
+    const int wgl = (int) blockIdx.x - T.wg_start ;
+    const int q = wgl % nsub, chunk = wgl / nsub ;
+    const int c0 = 64 * q, cw = (w - c0 < 64) ? w - c0 : 64 ;
     const double *L = Lx + f.psx ;
     const i64 *rows = Ls + f.psi ;
-    int i = jb + w + (int) blockIdx.x * 256 + tid ;
-    // the 16 entries of the inverse this thread needs, and its row of L, do not
-    // depend on the right-hand side
-    double wv [16] ;
-#pragma unroll
-    for (int u = 0 ; u < 16 ; u++) wv [u] = Wm [(p + 4 * u) * 64 + r] ;
+    const int i = jb + w + chunk * 256 + tid ;
     for (int rhs = 0 ; rhs < nrhs ; rhs++)
     {
         double *x = X + (i64) rhs * ldx ;
-        if (tid < 64) t [tid] = (tid < w) ? x [k1 + jb + tid] : 0.0 ;
-        __syncthreads () ;
-        double a = 0.0 ;
-#pragma unroll
-        for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (wv [u], t [p + 4 * u], a) ;
-        part [p][r] = a ;
-        __syncthreads () ;
-        if (tid < 64)
-        {
-            double v = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
-            xs [tid] = v ;
-            if (blockIdx.x == 0 && tid < w) solved [rhs * ld_solved + jb + tid] = v ;
-        }
+        if (tid < 64) xs [tid] = (tid < cw) ? Y [(i64) rhs * ldx + k1 + jb + c0 + tid] : 0.0 ;
         __syncthreads () ;
         if (i < nsrow)
         {
-            const double *Li = L + i + (i64) jb * nsrow ;
+            const double *Li = L + i + (i64) (jb + c0) * nsrow ;
             double acc [4] = {0.0, 0.0, 0.0, 0.0} ;
             int c = 0 ;
-            for ( ; c + 16 <= w ; c += 16)
+            for ( ; c + 16 <= cw ; c += 16)
             {
                 double l [16] ;
 #pragma unroll
@@ -2082,104 +2154,161 @@ __global__ void __launch_bounds__(256) k_solve_fwd_blk (int fid, int jb, int w, 
 #pragma unroll
                 for (int u = 0 ; u < 16 ; u++) acc [u & 3] = __builtin_fma (l [u], xs [c + u], acc [u & 3]) ;
             }
-            for ( ; c < w ; c++) acc [0] = __builtin_fma (Li [(i64) c * nsrow], xs [c], acc [0]) ;
-            double s = (acc [0] + acc [1]) + (acc [2] + acc [3]) ;
-            if (i < nscol) x [k1 + i] -= s ;
-            else atomicAdd (&x [rows [i]], -s) ;
+            for ( ; c < cw ; c++) acc [0] = __builtin_fma (Li [(i64) c * nsrow], xs [c], acc [0]) ;
+            double sm = (acc [0] + acc [1]) + (acc [2] + acc [3]) ;
+            // (several column sub-blocks, and siblings of the level, add into the same row)
+            atomicAdd (i < nscol ? &x [k1 + i] : &x [rows [i]], -sm) ;
         }
         __syncthreads () ;
     }
 }
 
-// solved values of columns [0, nscol) of a big supernode back into X
-__global__ void __launch_bounds__(256) k_solve_commit (int fid, const FrontD *fr, double *X, i64 ldx,
-    int nrhs, const double *solved, i64 ld_solved)
+// solved values of the big supernodes of a level back into X (one task per supernode)
+__global__ void __launch_bounds__(256) k_solve_commit (const SolveBlk *tasks, int ntasks, const FrontD *fr,
+    double *X, i64 ldx, int nrhs, const double *Y)
 {
-    const FrontD &f = fr [fid] ;
-    int j = (int) blockIdx.x * 256 + threadIdx.x ;
+    const SolveBlk T = tasks [find_solve_task (tasks, ntasks, (int) blockIdx.x)] ;
+    const FrontD &f = fr [T.front] ;
+    int j = ((int) blockIdx.x - T.wg_start) * 256 + threadIdx.x ;
     if (j >= f.nscol) return ;
-    for (int rhs = 0 ; rhs < nrhs ; rhs++) X [(i64) rhs * ldx + f.k1 + j] = solved [rhs * ld_solved + j] ;
+    for (int rhs = 0 ; rhs < nrhs ; rhs++) X [(i64) rhs * ldx + f.k1 + j] = Y [(i64) rhs * ldx + f.k1 + j] ;
 }
 
-__global__ void __launch_bounds__(256) k_solve_bwd_blk (int fid, int jb, int w, const double *WmT,
-    const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs,
-    double *accbuf, unsigned int *ticket)
+// backward, step 1: acc (task) += L[rows, b]' x[rows] ; workgroup = (256-row chunk) x
+// (64-column sub-block); thread = row, the column sums of a wave go through an LDS
+// transpose, one atomic add per column and wave
+__global__ void __launch_bounds__(256) k_solve_bwd_apply (const SolveBlk *tasks, int ntasks,
+    const FrontD *fr, const i64 *Ls, const double *Lx, const double *X, i64 ldx, int nrhs, double *accbuf)
 {
-    __shared__ double t [64], part [4][64] ;
     __shared__ double Tw [4][64 * 17] ;      // per wave: 64 rows x 16 columns of products
-    __shared__ unsigned int s_last ;
-    const FrontD &f = fr [fid] ;
-    int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
-    int lane = tid & 63, wave = tid >> 6 ;
+    const SolveBlk T = tasks [find_solve_task (tasks, ntasks, (int) blockIdx.x)] ;
+    const FrontD &f = fr [T.front] ;
+    const int nscol = f.nscol, nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    const int lane = tid & 63, wave = tid >> 6 ;
+    const int jb = T.jb, w = T.w, nsub = (w + 63) >> 6 ;
+    const int wgl = (int) blockIdx.x - T.wg_start ;
+    const int qsub = wgl % nsub, chunk = wgl / nsub ;
     const double *L = Lx + f.psx ;
     const i64 *rows = Ls + f.psi ;
-    int r0 = jb + w + (int) blockIdx.x * 256 ;
-    int nr = nsrow - r0 < 256 ? nsrow - r0 : 256 ;
-    if (nr > 0)
+    double *acc = accbuf + (i64) T.slot * nrhs * SOLVE_SB ;
+    const int r0 = jb + w + chunk * 256 ;
+    const int nr = nsrow - r0 < 256 ? nsrow - r0 : 256 ;
+    if (nr <= 0) return ;
+    const int i = r0 + tid ;
+    const bool ok = tid < nr ;
+    const int c16 = lane & 15, seg = lane >> 4 ;
+    for (int rhs = 0 ; rhs < nrhs ; rhs++)
     {
-        // thread = row: its 64 entries of L (coalesced over the threads, all loads
-        // in flight) times its x; the column sums over a wave's 64 rows go through
-        // an LDS transpose (16 columns at a time) instead of cross-lane shuffles
-        int i = r0 + tid ;
-        bool ok = tid < nr ;
-        const double *Li = L + (ok ? i : r0) + (i64) jb * nsrow ;
-        double l [64] ;
-#pragma unroll
-        for (int c = 0 ; c < 64 ; c++) l [c] = Li [(i64) (c < w ? c : w - 1) * nsrow] ;
-        int c16 = lane & 15, seg = lane >> 4 ;
-        for (int rhs = 0 ; rhs < nrhs ; rhs++)
+        const double *x = X + (i64) rhs * ldx ;
+        double y = ok ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
+        for (int q = 4 * qsub ; q < 4 * qsub + 4 ; q++)
         {
-            const double *x = X + (i64) rhs * ldx ;
-            double y = ok ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
+            const double *Li = L + (ok ? i : r0) + (i64) (jb + 16 * q) * nsrow ;
+            double l [16] ;
 #pragma unroll
-            for (int q = 0 ; q < 4 ; q++)
-            {
+            for (int c = 0 ; c < 16 ; c++) l [c] = Li [(i64) (16 * q + c < w ? c : 0) * nsrow] ;
 #pragma unroll
-                for (int c = 0 ; c < 16 ; c++) Tw [wave][lane * 17 + c] = l [16 * q + c] * y ;
-                __builtin_amdgcn_s_waitcnt (0xc07f) ;      // lgkmcnt(0): own wave's LDS writes landed
-                __builtin_amdgcn_wave_barrier () ;
-                double sum = 0.0 ;
+            for (int c = 0 ; c < 16 ; c++) Tw [wave][lane * 17 + c] = (16 * q + c < w) ? l [c] * y : 0.0 ;
+            __builtin_amdgcn_s_waitcnt (0xc07f) ;      // lgkmcnt(0): own wave's LDS writes landed
+            __builtin_amdgcn_wave_barrier () ;
+            double sum = 0.0 ;
 #pragma unroll
-                for (int rr = 0 ; rr < 16 ; rr++) sum += Tw [wave][(seg * 16 + rr) * 17 + c16] ;
-                sum += __shfl_xor (sum, 16) ;
-                sum += __shfl_xor (sum, 32) ;
-                if (seg == 0) part [wave][16 * q + c16] = sum ;
-                __builtin_amdgcn_wave_barrier () ;
-            }
-            __syncthreads () ;
-            if (tid < w) atomicAdd (&accbuf [rhs * 64 + tid], (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid])) ;
-            __syncthreads () ;
+            for (int rr = 0 ; rr < 16 ; rr++) sum += Tw [wave][(seg * 16 + rr) * 17 + c16] ;
+            sum += __shfl_xor (sum, 16) ;
+            sum += __shfl_xor (sum, 32) ;
+            if (seg == 0 && 16 * q + c16 < w) atomicAdd (&acc [rhs * SOLVE_SB + 16 * q + c16], sum) ;
+            __builtin_amdgcn_wave_barrier () ;
         }
     }
-    // the last workgroup to get here finishes the block
-    __threadfence () ;
-    if (tid == 0) s_last = (atomicAdd (ticket, 1u) == gridDim.x - 1) ? 1u : 0u ;
-    __syncthreads () ;
-    if (!s_last) return ;
-    __threadfence () ;
-    int c = tid & 63, p = tid >> 6 ;
-    double wv [16] ;
+}
+
+// backward, step 2 (one workgroup per task): x_b = inv(L_bb)' (x_b - acc) by
+// sub-blocks from the bottom; the accumulator is cleared for the next step
+__global__ void __launch_bounds__(256) k_solve_bwd_diag (const SolveBlk *tasks,
+    const FrontD *fr, const double *Lx, const double *Winv, double *X, i64 ldx, int nrhs, double *accbuf)
+{
+    __shared__ double xs [SOLVE_SB], t [64], part [4][64] ;
+    __shared__ double Tw [4][64 * 17] ;
+    const SolveBlk T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
+    const int nsrow = f.nsrow, k1 = f.k1, tid = threadIdx.x ;
+    const int jb = T.jb, w = T.w, nsub = (w + 63) >> 6 ;
+    const double *L = Lx + f.psx ;
+    double *acc = accbuf + (i64) T.slot * nrhs * SOLVE_SB ;
+    const int r = tid & 63, p = tid >> 6 ;
+    const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, seg = lane >> 4 ;
+    // sub-step k needs L(rows below sub-block k inside the block, its 64 columns):
+    // wave = 16 of the columns, lane = row (coalesced), all 96 values per thread
+    // requested at once
+    double m2 [16], m1 [32], m0 [48] ;
+    {
 #pragma unroll
-    for (int u = 0 ; u < 16 ; u++) wv [u] = WmT [(p + 4 * u) * 64 + c] ;
+        for (int c = 0 ; c < 16 ; c++)
+        {
+            const double *Lc2 = L + jb + (i64) (jb + 128 + 16 * wave + c) * nsrow ;
+            m2 [c] = (192 + lane < w) ? Lc2 [192 + lane] : 0.0 ;
+            const double *Lc1 = L + jb + (i64) (jb + 64 + 16 * wave + c) * nsrow ;
+#pragma unroll
+            for (int j = 0 ; j < 2 ; j++) m1 [2 * c + j] = (128 + 64 * j + lane < w) ? Lc1 [128 + 64 * j + lane] : 0.0 ;
+            const double *Lc0 = L + jb + (i64) (jb + 16 * wave + c) * nsrow ;
+#pragma unroll
+            for (int j = 0 ; j < 3 ; j++) m0 [3 * c + j] = (64 + 64 * j + lane < w) ? Lc0 [64 + 64 * j + lane] : 0.0 ;
+        }
+    }
     for (int rhs = 0 ; rhs < nrhs ; rhs++)
     {
         double *x = X + (i64) rhs * ldx ;
-        if (tid < 64)
+        xs [tid] = (tid < w) ? x [k1 + jb + tid] - acc [rhs * SOLVE_SB + tid] : 0.0 ;
+        acc [rhs * SOLVE_SB + tid] = 0.0 ;
+        __syncthreads () ;
+        for (int k = nsub - 1 ; k >= 0 ; k--)
         {
-            double a = __hip_atomic_load (&accbuf [rhs * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
-            t [tid] = (tid < w) ? x [k1 + jb + tid] - a : 0.0 ;
-            accbuf [rhs * 64 + tid] = 0.0 ;
-        }
-        __syncthreads () ;
-        double a = 0.0 ;
+            // t[c] = xs[64k + c] - sum over the solved rows below (inside the block) of L(row, 64k + c) xs[row]
+            double sm [16] ;
 #pragma unroll
-        for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (wv [u], t [p + 4 * u], a) ;
-        part [p][c] = a ;
-        __syncthreads () ;
-        if (tid < w) x [k1 + jb + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
+            for (int c = 0 ; c < 16 ; c++) sm [c] = 0.0 ;
+            if (k == 2)
+            {
+                double y = xs [192 + lane] ;
+#pragma unroll
+                for (int c = 0 ; c < 16 ; c++) sm [c] = m2 [c] * y ;
+            }
+            else if (k == 1)
+            {
+                double y0 = xs [128 + lane], y1 = xs [192 + lane] ;
+#pragma unroll
+                for (int c = 0 ; c < 16 ; c++) sm [c] = __builtin_fma (m1 [2 * c + 1], y1, m1 [2 * c] * y0) ;
+            }
+            else if (k == 0)
+            {
+                double y0 = xs [64 + lane], y1 = xs [128 + lane], y2 = xs [192 + lane] ;
+#pragma unroll
+                for (int c = 0 ; c < 16 ; c++) sm [c] = __builtin_fma (m0 [3 * c + 2], y2, __builtin_fma (m0 [3 * c + 1], y1, m0 [3 * c] * y0)) ;
+            }
+            // column sums over the wave's 64 rows through an LDS transpose
+#pragma unroll
+            for (int c = 0 ; c < 16 ; c++) Tw [wave][lane * 17 + c] = sm [c] ;
+            __builtin_amdgcn_s_waitcnt (0xc07f) ;
+            __builtin_amdgcn_wave_barrier () ;
+            double sum = 0.0 ;
+#pragma unroll
+            for (int rr = 0 ; rr < 16 ; rr++) sum += Tw [wave][(seg * 16 + rr) * 17 + c16] ;
+            sum += __shfl_xor (sum, 16) ;
+            sum += __shfl_xor (sum, 32) ;
+            if (seg == 0) t [16 * wave + c16] = xs [64 * k + 16 * wave + c16] - sum ;
+            __syncthreads () ;
+            const double *WmT = Winv + (i64) (T.inv + k) * 8192 + 4096 ;     // WmT [kk*64 + c] = W(kk, c)
+            double a = 0.0 ;
+#pragma unroll
+            for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (WmT [(p + 4 * u) * 64 + r], t [p + 4 * u], a) ;
+            part [p][r] = a ;
+            __syncthreads () ;
+            if (tid < 64) xs [64 * k + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
+            __syncthreads () ;
+        }
+        if (tid < w) x [k1 + jb + tid] = xs [tid] ;
         __syncthreads () ;
     }
-    if (tid == 0) *ticket = 0u ;
 }
 
 // gather / scatter by the fill-reducing permutation (cholmod_solve.c:105,:322)
