@@ -350,8 +350,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_m)
-        mf = lib.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
-        mf_big = lib.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 0)
+        pr = ch.probes()            # micro-benchmarks: lib/libcholmod_amd_probes.so, not the product library
+        mf = pr.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
+        mf_big = pr.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 0)
         # issue-bound v_mfma_f64_16x16x4 loops (no memory): waves per SIMD x accumulators per
         # wave x operand data (full-mantissa / all-zero: the multipliers' switching power
         # moves the clock); the ceiling printed is the best any of them -- or the real
@@ -361,7 +362,7 @@ def main():
             for acc in (8, 16):
                 for w in (1, 2, 4, 8):
                     code = (10000 if zero else 0) + (100 if acc == 16 else 0) + w
-                    r = lib.cholmod_hip_bench_mfma_peak(code, 20000 // w)
+                    r = pr.cholmod_hip_bench_mfma_peak(code, 20000 // w)
                     if r > 0:
                         sweep[f"{'zero' if zero else 'data'}_acc{acc}_waves{w}"] = r / 1e12
         mpeak = max(list(sweep.values()) + [mf_big / 1e12 if mf_big > 0 else 0.0]) * 1e12

@@ -32,24 +32,16 @@ extern "C" {
 
 /* plan flags */
 #define CHOLMOD_HIP_PLAN_DEFAULT   0
-#define CHOLMOD_HIP_GEMM_VALU      1    /* debug: VALU instead of MFMA tiles */
 #define CHOLMOD_HIP_TILE128         4    /* tuning: 128x128 update tiles on big regions
                                            (default: 64x64 everywhere, which fills the
                                            256 CUs on mid-size fronts)               */
-#define CHOLMOD_HIP_LOOKAHEAD       8    /* accepted and ignored (a panel look-ahead on a
-                                           second stream was measured and dropped:
-                                           fp64 VALU panel code starves next to fp64
-                                           MFMA waves)                                */
 #define CHOLMOD_HIP_NO_SMALL_FRONTS 16   /* tuning: no fused LDS-resident kernel for
                                            thin fronts (generic kernels everywhere)  */
 #define CHOLMOD_HIP_NO_XCD_SWIZZLE 32    /* tuning: plain block -> tile order          */
 #define CHOLMOD_HIP_FIXED_OB       64    /* tuning: 512-column outer blocks everywhere  */
 #define CHOLMOD_HIP_WIDE_OB       128    /* tests: 2048-column outer blocks everywhere  */
-#define CHOLMOD_HIP_PANEL_LOOKAHEAD 4096  /* accepted and ignored, like CHOLMOD_HIP_LOOKAHEAD */
 #define CHOLMOD_HIP_NO_CB_ASSIGN   2048   /* tuning: zero-fill every contribution block and
                                            extend-add before the dense phase           */
-#define CHOLMOD_HIP_POTRF_VALU    1024    /* debug: single-wave diagonal-block Cholesky  */
-#define CHOLMOD_HIP_TRSM_VALU      512    /* debug: one-thread-per-row panel solve       */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
@@ -214,35 +206,11 @@ int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
     int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;
 
-/* Dense fp64 C -= A*B' micro-benchmark on the engine's update kernel (used by
- * bench.py to print the measured MFMA rate next to the 78.6 TFLOP/s spec).
- * Returns achieved flop/s, or a negative CHOLMOD_HIP_* code. */
-double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
-    int iters, int flags) ;
-
-/* Issue-bound v_mfma_f64_16x16x4_f64 loop without memory traffic: the measured
- * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */
-double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
-/* The same with the update kernel's operand pattern: a ti x tj grid of accumulators
- * per wave (variant = 100 ti + 10 tj + ldsread; ldsread = 1 refreshes the fragments
- * from LDS every step), all-zero operands on request. */
-double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands) ;
-
-/* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
-int cholmod_hip_debug_potrf_cycles (long long *out8) ;
-/* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */
-int cholmod_hip_debug_panel_cycles (long long *out16) ;
 /* Tuning probe (plans created with CHOLMOD_HIP_THIN_TIMING set): shader cycles one
  * front of thin-front launch `launch` spent per phase: [0] requests + zero, [1] A,
  * [2] children, [3] panel chain, [4] publish + row solves, [5] store + barrier,
  * [6] trailing update / contribution block. */
 int cholmod_hip_debug_thin_cycles (cholmod_hip_plan *plan, int64_t launch, long long *out10) ;
-/* Tuning probe: cycles for n repetitions of basic fp64 instruction patterns (one wave). */
-int cholmod_hip_debug_latency (long long *out8, int n) ;
-
-/* Tuning probe: waves 0,1 of every block run the MFMA loop, waves 2,3 a
- * v_fma_f64 loop; returns the seconds the launch took. */
-double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu) ;
 
 /* Test hook: run the engine's dense partial factorization on ONE dense front
  * given on the host (column-major nsrow-by-nsrow, lower; the first nscol

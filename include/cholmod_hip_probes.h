@@ -1,0 +1,42 @@
+/* cholmod_hip_probes.h -- micro-benchmarks and tuning probes of the engine's
+ * kernels.  They live in lib/libcholmod_amd_probes.so (csrc/hip/probes.hip), not
+ * in the product library: bench.py prints their figures beside the spec peak,
+ * tools/ use them for tuning.  flop/s or seconds as stated; negative = a
+ * CHOLMOD_HIP_* error code. */
+#ifndef CHOLMOD_HIP_PROBES_H
+#define CHOLMOD_HIP_PROBES_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Dense fp64 C -= A*B' micro-benchmark on the engine's update kernel k_update2 (used by
+ * bench.py to print the measured MFMA rate next to the 78.6 TFLOP/s spec).
+ * Returns achieved flop/s, or a negative CHOLMOD_HIP_* code. */
+double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
+    int iters, int flags) ;
+
+/* Issue-bound v_mfma_f64_16x16x4_f64 loop without memory traffic: the measured
+ * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */
+double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
+/* The same with the update kernel's operand pattern: a ti x tj grid of accumulators
+ * per wave (variant = 100 ti + 10 tj + ldsread; ldsread = 1 refreshes the fragments
+ * from LDS every step), all-zero operands on request. */
+double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands) ;
+
+/* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
+int cholmod_hip_debug_potrf_cycles (long long *out8) ;
+/* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */
+int cholmod_hip_debug_panel_cycles (long long *out16) ;
+/* Tuning probe: cycles for n repetitions of basic fp64 instruction patterns (one wave). */
+int cholmod_hip_debug_latency (long long *out8, int n) ;
+
+/* Tuning probe: waves 0,1 of every block run the MFMA loop, waves 2,3 a
+ * v_fma_f64 loop; returns the seconds the launch took. */
+double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu) ;
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif

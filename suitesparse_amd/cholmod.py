@@ -27,7 +27,7 @@ NOT_POSDEF = 1
 NATURAL, GIVEN, POSTORDERED = 0, 1, 6
 SIMPLICIAL, AUTO, SUPERNODAL = 0, 1, 2
 SYS_A, SYS_LDLt, SYS_LD, SYS_DLt, SYS_L, SYS_Lt, SYS_D, SYS_P, SYS_Pt = range(9)
-HIP_GEMM_VALU, HIP_PLAN_HOST_ONLY = 1, 2
+HIP_PLAN_HOST_ONLY = 2
 
 
 class Method(C.Structure):
@@ -134,14 +134,22 @@ HIP_SYMBOLS = [
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
-    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
-    "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles", "cholmod_hip_debug_latency",
+    
+    
     "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles",
     "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach", "cholmod_hip_rccl_detach",
     "cholmod_hip_version",
 ]
 
+PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
+PROBE_SYMBOLS = [
+    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
+    "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
+    "cholmod_hip_debug_latency",
+]
+
 _lib = None
+_probes = None
 
 
 def build(force: bool = False) -> str:
@@ -235,13 +243,6 @@ def lib():
     sig("cholmod_hip_get_maps", C.c_int, [vp, vp, vp, vp])
     sig("cholmod_hip_get_stats", C.c_int, [vp, vp])
     sig("cholmod_hip_set_profiling", C.c_int, [vp, C.c_int])
-    sig("cholmod_hip_bench_update_kernel", dbl, [i64, i64, i64, C.c_int, C.c_int])
-    sig("cholmod_hip_bench_mfma_peak", dbl, [C.c_int, C.c_int])
-    sig("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int])
-    sig("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int])
-    sig("cholmod_hip_debug_potrf_cycles", C.c_int, [vp])
-    sig("cholmod_hip_debug_panel_cycles", C.c_int, [vp])
-    sig("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
     sig("cholmod_hip_factor_checks", C.c_int, [vp, vp])
     sig("cholmod_hip_get_launch_profile", i64, [vp, i64, vp, vp, vp, vp, vp, vp])
@@ -251,6 +252,31 @@ def lib():
     sig("cholmod_hip_rccl_detach", C.c_int, [vp])
     sig("cholmod_hip_version", C.c_char_p, [])
     _lib = L
+    return L
+
+
+def probes():
+    """Micro-benchmarks / tuning probes (include/cholmod_hip_probes.h): a library of
+    their own, not part of the product."""
+    global _probes
+    if _probes is not None:
+        return _probes
+    if not os.path.exists(PROBES_PATH):
+        raise RuntimeError(f"{PROBES_PATH} is missing: build it with __graft_entry__.build()")
+    L = C.CDLL(PROBES_PATH)
+    vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
+    for name, res, args in (
+            ("cholmod_hip_bench_update_kernel", dbl, [i64, i64, i64, C.c_int, C.c_int]),
+            ("cholmod_hip_bench_mfma_peak", dbl, [C.c_int, C.c_int]),
+            ("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int]),
+            ("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int]),
+            ("cholmod_hip_debug_potrf_cycles", C.c_int, [vp]),
+            ("cholmod_hip_debug_panel_cycles", C.c_int, [vp]),
+            ("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _probes = L
     return L
 
 

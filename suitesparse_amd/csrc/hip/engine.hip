@@ -289,7 +289,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
     const char *assign_cb = nullptr)
 {
-    bool valu = (flags & CHOLMOD_HIP_GEMM_VALU) != 0 ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
     int maxnscol = 0, maxrows = 0 ;
     for (int q = 0 ; q < nf ; q++)
@@ -373,7 +372,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         // first update of a contribution block nobody zeroed: C = -A*B'
         G.assign = (to_cb && kc == 0 && assign_cb && assign_cb [fid]) ? 1 : 0 ;
         if (split && is_shared (fid)) { G.tile_mul = grpn [fid] ; G.tile_add = rank - grp0 [fid] ; }
-        bool isbig = !valu && use_big && ncols >= BIG && m >= 2 * BIG ;
+        bool isbig = use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
     std::vector<GemmGroup> big, small ;
@@ -483,7 +482,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
                        f.psx + (i0 + nb) + (i64) i0 * f.nsrow, f.nsrow, m, nb,
                        ids [q], i0, blocks} ;
-            blocks += (m + TR_ROWS - 1) / TR_ROWS ;
+            blocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
             S.tg.push_back (G) ;
             Lt.flops += (double) m * nb * nb ;
             Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
@@ -1003,7 +1002,7 @@ static int build_host (cholmod_hip_plan *P)
         // the children's contributions to the PANEL must be in place before it.
         // (Shared fronts keep the zero-fill: a rank writes only its share of the CB
         // tiles, the rest must read as zero in its partial sum.)
-        bool can_assign = !(P->flags & (CHOLMOD_HIP_GEMM_VALU | CHOLMOD_HIP_NO_CB_ASSIGN)) ;
+        bool can_assign = !(P->flags & CHOLMOD_HIP_NO_CB_ASSIGN) ;
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = P->fr [ids [q]] ;
@@ -1154,7 +1153,6 @@ static int raise_lds_limits ()
 {
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
@@ -1272,34 +1270,21 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb) ; break ;
         case K_POTRF:
-            if (P->flags & CHOLMOD_HIP_POTRF_VALU)
-                hipLaunchKernelGGL (k_potrf<false>, dim3 (L.grid), dim3 (64), 0, st,
-                    P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
-            else
-                hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
+            hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (L.grid), dim3 (256), 0, st,
+                P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
             break ;
         case K_TRSM:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            if (P->flags & CHOLMOD_HIP_TRSM_VALU)
-                hipLaunchKernelGGL (k_trsm, dim3 (L.grid), dim3 (TR_ROWS),
-                    (size_t) (L.aux * L.aux + L.aux * TR_ROWS + L.aux * TR_CW) * sizeof (double), st,
-                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux) ;
-            else
-                hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
-                    P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
+            hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
             break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_SMALL:
-            if (P->flags & CHOLMOD_HIP_GEMM_VALU)
-                hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
-            else
-                hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
     }
     if (!serial && L.rec_ev >= 0) HIPCHK (hipEventRecord (P->sync_ev [L.rec_ev], st)) ;
@@ -2013,295 +1998,6 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
     P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ;
     return CHOLMOD_HIP_OK ;
-}
-
-double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int iters, int flags)
-{
-    if (m <= 0 || n <= 0 || k <= 0 || iters <= 0) return CHOLMOD_HIP_INVALID ;
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    // A: m x k, B: n x k (both ld = max(m,n)), C: m x n, all in one "Lx" buffer
-    i64 ld = std::max (m, n) ;
-    i64 a_off = 0, b_off = ld * k, c_off = 2 * ld * k ;
-    i64 total = c_off + m * n ;
-    double *d = nullptr ;
-    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    std::vector<double> h (total) ;
-    unsigned long long sdd = 88172645463325252ull ;
-    for (i64 q = 0 ; q < total ; q++)
-    {
-        sdd ^= sdd << 13 ; sdd ^= sdd >> 7 ; sdd ^= sdd << 17 ;
-        h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
-    }
-    (void) hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice) ;
-    bool small = (flags & CHOLMOD_HIP_TILE128) == 0 ;
-    int T = small ? SMALL : BIG ;
-    GemmGroup G ;
-    memset (&G, 0, sizeof (G)) ;
-    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
-    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
-    int TM = T, TN = T ;
-    if (flags & 2048) { TM = 128 ; TN = 64 ; }      // experimental rectangular tiles (non-tri only)
-    if (flags & 4096) { TM = 64 ; TN = 128 ; }
-    G.ntiles = (i32) (((m + TM - 1) / TM) * ((n + TN - 1) / TN)) ; G.nblk = (G.ntiles + 63) / 64 * 64 ;
-    G.swz = (flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) ? 0 : 1 ;
-    G.mt = (i32) ((m + TM - 1) / TM) ; G.nt = (i32) ((n + TN - 1) / TN) ;
-    GemmGroup *dg = nullptr ;
-    (void) hipMalloc ((void **) &dg, sizeof (G)) ;
-    (void) hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice) ;
-    int grid = G.nblk ;
-    hipEvent_t e0, e1 ;
-    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
-    auto launch = [&] ()
-    {
-        if (flags & CHOLMOD_HIP_GEMM_VALU)
-            hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (small && (flags & 256))
-            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 32, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (small && (flags & 512))
-            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 3, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (small && (flags & 1024))
-            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 16, 2, true>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (flags & 2048)
-            hipLaunchKernelGGL ((k_update2<128, 64, 16, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (flags & 4096)
-            hipLaunchKernelGGL ((k_update2<64, 128, 16, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else if (small)
-            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-        else
-            hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
-    } ;
-    launch () ;
-    (void) hipDeviceSynchronize () ;
-    (void) hipEventRecord (e0, 0) ;
-    for (int it = 0 ; it < iters ; it++) launch () ;
-    (void) hipEventRecord (e1, 0) ;
-    (void) hipEventSynchronize (e1) ;
-    float ms = 0 ;
-    (void) hipEventElapsedTime (&ms, e0, e1) ;
-    hipError_t err = hipGetLastError () ;
-    (void) hipFree (d) ; (void) hipFree (dg) ;
-    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
-    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-    return 2.0 * (double) m * n * k * iters / (ms * 1e-3) ;
-}
-
-/* mixed MFMA+VALU issue test: returns seconds; flops are computed by the caller */
-double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    int blocks = 256 * blocks_per_cu ;
-    double *d = nullptr ;
-    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    hipEvent_t e0, e1 ;
-    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
-    hipLaunchKernelGGL (k_mixed_peak, dim3 (blocks), dim3 (256), 0, 0, d, 4, 4) ;
-    (void) hipDeviceSynchronize () ;
-    (void) hipEventRecord (e0, 0) ;
-    hipLaunchKernelGGL (k_mixed_peak, dim3 (blocks), dim3 (256), 0, 0, d, it_mfma, it_valu) ;
-    (void) hipEventRecord (e1, 0) ;
-    (void) hipEventSynchronize (e1) ;
-    float ms = 0 ;
-    (void) hipEventElapsedTime (&ms, e0, e1) ;
-    (void) hipFree (d) ;
-    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
-    return ms * 1e-3 ;
-}
-
-/* tuning probe: per-phase shader-clock cycles of one 64x64 k_potrf (lane 0):
- * out[0] stage, [1] panel update, [2] publish+barrier, [3] 8x8 factor,
- * [4] row solve+store, [5] barrier, [6] write-back */
-int cholmod_hip_debug_potrf_cycles (long long *out8)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    const int n = 64 ;
-    std::vector<double> A (n * n) ;
-    for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < n ; i++) A [i + j * n] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j)) ;
-    double *d = nullptr ; i32 *dinfo = nullptr ; long long *dt = nullptr ; PfGroup *dg = nullptr ;
-    HIPCHK (hipMalloc ((void **) &d, n * n * sizeof (double))) ;
-    HIPCHK (hipMalloc ((void **) &dinfo, sizeof (i32))) ;
-    HIPCHK (hipMalloc ((void **) &dt, 8 * sizeof (long long))) ;
-    HIPCHK (hipMalloc ((void **) &dg, sizeof (PfGroup))) ;
-    PfGroup G {0, n, n, 0, 0} ;
-    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
-    HIPCHK (hipMemset (dinfo, 0, sizeof (i32))) ;
-    for (int rep = 0 ; rep < 3 ; rep++)
-    {
-        HIPCHK (hipMemcpy (d, A.data (), n * n * sizeof (double), hipMemcpyHostToDevice)) ;
-        hipLaunchKernelGGL (k_potrf<true>, dim3 (1), dim3 (64), 0, 0, dg, d, dinfo, dt) ;
-        HIPCHK (hipDeviceSynchronize ()) ;
-    }
-    HIPCHK (hipMemcpy (out8, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
-    (void) hipFree (d) ; (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ;
-    return CHOLMOD_HIP_OK ;
-}
-
-/* tuning probe: per-phase shader-clock cycles of the matrix-core panel kernels
- * on one 64x64 diagonal block with 64 rows below it.  out16 [0..7]: k_potrf_mfma
- * (stage, column chain, scale+store, barrier, trailing tiles, barrier,
- * write-back); out16 [8..15]: k_trsm_mfma (stage, reciprocals, diagonal
- * inverses, update MFMAs, barrier, diagonal MFMAs + store, barrier). */
-int cholmod_hip_debug_panel_cycles (long long *out16)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-    const int n = 64, m = 128 ;
-    std::vector<double> A ((size_t) m * n) ;
-    for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < m ; i++) A [i + (size_t) j * m] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j)) ;
-    double *d = nullptr ; i32 *dinfo = nullptr ; long long *dt = nullptr ; PfGroup *dg = nullptr ; TrGroup *dtg = nullptr ;
-    HIPCHK (hipMalloc ((void **) &d, A.size () * sizeof (double))) ;
-    HIPCHK (hipMalloc ((void **) &dinfo, sizeof (i32))) ;
-    HIPCHK (hipMalloc ((void **) &dt, 16 * sizeof (long long))) ;
-    HIPCHK (hipMalloc ((void **) &dg, sizeof (PfGroup))) ;
-    HIPCHK (hipMalloc ((void **) &dtg, sizeof (TrGroup))) ;
-    PfGroup G {0, m, n, 0, 0} ;
-    TrGroup T {0, n, m, m - n, n, 0, 0, 0} ;
-    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
-    HIPCHK (hipMemcpy (dtg, &T, sizeof (T), hipMemcpyHostToDevice)) ;
-    HIPCHK (hipMemset (dinfo, 0, sizeof (i32))) ;
-    for (int rep = 0 ; rep < 3 ; rep++)
-    {
-        HIPCHK (hipMemcpy (d, A.data (), A.size () * sizeof (double), hipMemcpyHostToDevice)) ;
-        hipLaunchKernelGGL (k_potrf_mfma<true>, dim3 (1), dim3 (256), 0, 0, dg, d, dinfo, dt) ;
-        hipLaunchKernelGGL (k_trsm_mfma<true>, dim3 (1), dim3 (256), trsm_mfma_lds_bytes (64), 0,
-            dtg, 1, d, dinfo, 64, dt + 8) ;
-        HIPCHK (hipDeviceSynchronize ()) ;
-    }
-    HIPCHK (hipMemcpy (out16, dt, 16 * sizeof (long long), hipMemcpyDeviceToHost)) ;
-    (void) hipFree (d) ;
-    // wall time of whole launches (HIP events, ns): [7] one potrf workgroup,
-    // [15] a trsm over 16 000 rows (250 workgroups) as at the top of Poisson 100^3
-    {
-        const int mm = 16064 ;
-        double *big = nullptr ;
-        HIPCHK (hipMalloc ((void **) &big, (size_t) mm * n * sizeof (double))) ;
-        std::vector<double> Ab ((size_t) mm * n) ;
-        for (int j = 0 ; j < n ; j++) for (int i = 0 ; i < mm ; i++) Ab [i + (size_t) j * mm] = (i == j) ? n + 1.0 : 1.0 / (1.0 + abs (i - j) % 97) ;
-        PfGroup G2 {0, mm, n, 0, 0} ;
-        TrGroup T2 {0, n, mm, mm - n, n, 0, 0, 0} ;
-        HIPCHK (hipMemcpy (dg, &G2, sizeof (G2), hipMemcpyHostToDevice)) ;
-        HIPCHK (hipMemcpy (dtg, &T2, sizeof (T2), hipMemcpyHostToDevice)) ;
-        hipEvent_t e0, e1, e2 ;
-        (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ; (void) hipEventCreate (&e2) ;
-        float best_p = 1e30f, best_t = 1e30f ;
-        for (int rep = 0 ; rep < 5 ; rep++)
-        {
-            HIPCHK (hipMemcpy (big, Ab.data (), Ab.size () * sizeof (double), hipMemcpyHostToDevice)) ;
-            HIPCHK (hipEventRecord (e0, 0)) ;
-            hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (1), dim3 (256), 0, 0, dg, big, dinfo, (long long *) nullptr) ;
-            HIPCHK (hipEventRecord (e1, 0)) ;
-            hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 ((mm - n + TRM_ROWS - 1) / TRM_ROWS), dim3 (256),
-                trsm_mfma_lds_bytes (64), 0, dtg, 1, big, dinfo, 64, (long long *) nullptr) ;
-            HIPCHK (hipEventRecord (e2, 0)) ;
-            HIPCHK (hipDeviceSynchronize ()) ;
-            float a = 0, b = 0 ;
-            HIPCHK (hipEventElapsedTime (&a, e0, e1)) ;
-            HIPCHK (hipEventElapsedTime (&b, e1, e2)) ;
-            best_p = std::min (best_p, a) ; best_t = std::min (best_t, b) ;
-        }
-        out16 [7] = (long long) (best_p * 1e6) ;
-        out16 [15] = (long long) (best_t * 1e6) ;
-        (void) hipFree (big) ;
-        (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ; (void) hipEventDestroy (e2) ;
-    }
-    (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ; (void) hipFree (dtg) ;
-    return CHOLMOD_HIP_OK ;
-}
-
-/* tuning probe: cycles per repetition of the basic fp64 instruction patterns of
- * the panel kernels, one wave (see k_latency_probe); out8 [v] = cycles for n reps */
-int cholmod_hip_debug_latency (long long *out8, int n)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    double *sink = nullptr ; long long *dt = nullptr ;
-    HIPCHK (hipMalloc ((void **) &sink, 64 * sizeof (double))) ;
-    HIPCHK (hipMalloc ((void **) &dt, 8 * sizeof (long long))) ;
-    for (int rep = 0 ; rep < 2 ; rep++)
-    {
-        hipLaunchKernelGGL (k_latency_probe, dim3 (1), dim3 (64), 0, 0, sink, dt, n) ;
-        HIPCHK (hipDeviceSynchronize ()) ;
-    }
-    HIPCHK (hipMemcpy (out8, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
-    (void) hipFree (sink) ; (void) hipFree (dt) ;
-    return CHOLMOD_HIP_OK ;
-}
-
-/* issue loops with the update kernel's operand pattern: variant = 100 ti + 10 tj + ldsread */
-double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    if (waves_per_simd < 1) waves_per_simd = 1 ;
-    int blocks = 256 * waves_per_simd ;
-    double *d = nullptr ;
-    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    double scale = zero_operands ? 0.0 : 1.0 ;
-    int ti = variant / 100, tj = (variant / 10) % 10, lr = variant % 10 ;
-    auto launch = [&] (int it) -> bool
-    {
-#define P2(TI_, TJ_) if (ti == TI_ && tj == TJ_) { \
-        if (lr) hipLaunchKernelGGL ((k_mfma_peak2<TI_, TJ_, true>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ; \
-        else hipLaunchKernelGGL ((k_mfma_peak2<TI_, TJ_, false>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ; return true ; }
-        P2 (1, 1) P2 (2, 2) P2 (2, 4) P2 (4, 4) P2 (1, 4) P2 (4, 2)
-#undef P2
-        return false ;
-    } ;
-    if (!launch (16)) { (void) hipFree (d) ; return CHOLMOD_HIP_INVALID ; }
-    hipEvent_t e0, e1 ;
-    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
-    (void) hipDeviceSynchronize () ;
-    (void) hipEventRecord (e0, 0) ;
-    launch (iters) ;
-    (void) hipEventRecord (e1, 0) ;
-    (void) hipEventSynchronize (e1) ;
-    float ms = 0 ;
-    (void) hipEventElapsedTime (&ms, e0, e1) ;
-    hipError_t err = hipGetLastError () ;
-    (void) hipFree (d) ;
-    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
-    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-    return (double) blocks * 4.0 * iters * (double) (ti * tj) * 2048.0 / (ms * 1e-3) ;
-}
-
-double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
-{
-    if (!cholmod_hip_probe ()) return CHOLMOD_HIP_NO_DEVICE ;
-    double scale = 1.0 ;                        // 10000 + ...: all-zero operands
-    if (waves_per_simd >= 10000) { scale = 0.0 ; waves_per_simd -= 10000 ; }
-    int fill = 0 ;                              // 1000 f + w: filler f between the MFMAs
-    if (waves_per_simd >= 1000) { fill = waves_per_simd / 1000 ; waves_per_simd %= 1000 ; }
-    bool valu = waves_per_simd < 0 ;            // negative: fp64 VALU FMA loop instead
-    if (valu) waves_per_simd = -waves_per_simd ;
-    bool acc16 = waves_per_simd >= 100 ;        // 100 + w: sixteen accumulators per wave
-    if (acc16) waves_per_simd -= 100 ;
-    if (waves_per_simd < 1) waves_per_simd = 1 ;
-    if (iters < 1) iters = 1 ;
-    int blocks = 256 * waves_per_simd ;         // 256 CUs x (4 waves per block = 1 per SIMD)
-    double *d = nullptr ;
-    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    hipEvent_t e0, e1 ;
-    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
-    auto launch = [&] (int it)
-    {
-        if (valu) hipLaunchKernelGGL ((k_valu_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, it) ;
-        else if (acc16) hipLaunchKernelGGL ((k_mfma_peak<16>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
-        else if (fill == 1) hipLaunchKernelGGL ((k_mfma_peak<8, 1>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
-        else if (fill == 2) hipLaunchKernelGGL ((k_mfma_peak<8, 2>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
-        else if (fill == 3) hipLaunchKernelGGL ((k_mfma_peak<8, 3>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
-        else hipLaunchKernelGGL ((k_mfma_peak<8>), dim3 (blocks), dim3 (256), 0, 0, d, it, scale) ;
-    } ;
-    launch (16) ;
-    (void) hipDeviceSynchronize () ;
-    (void) hipEventRecord (e0, 0) ;
-    launch (iters) ;
-    (void) hipEventRecord (e1, 0) ;
-    (void) hipEventSynchronize (e1) ;
-    float ms = 0 ;
-    (void) hipEventElapsedTime (&ms, e0, e1) ;
-    hipError_t err = hipGetLastError () ;
-    (void) hipFree (d) ;
-    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
-    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-    if (valu) return (double) blocks * 256.0 * iters * 16.0 * 2.0 / (ms * 1e-3) ;
-    return (double) blocks * 4.0 * iters * (acc16 ? 16.0 : 8.0) * 2048.0 / (ms * 1e-3) ;
 }
 
 } // extern "C"

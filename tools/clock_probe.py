@@ -16,7 +16,7 @@ def sampler():
 print("idle:", subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout[-900:])
 th = threading.Thread(target=sampler); th.start()
 t0 = time.time()
-r = L.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 40, 0)
+r = ch.probes().cholmod_hip_bench_update_kernel(16384, 16384, 4096, 40, 0)
 t1 = time.time()
 stop = True; th.join()
 print("update kernel", r / 1e12, "TFLOP/s over", t1 - t0, "s")

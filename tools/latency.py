@@ -10,7 +10,7 @@ from suitesparse_amd import cholmod as ch
 L = ch.lib()
 n = 4096
 out = np.zeros(8, dtype=np.int64)
-print("rc", L.cholmod_hip_debug_latency(out.ctypes.data, n))
+print("rc", ch.probes().cholmod_hip_debug_latency(out.ctypes.data, n))
 names = ["dependent v_fma_f64", "8 independent v_fma_f64 (per 8)", "dependent v_rcp_f64",
          "8 x (readlane pair + fma) (per 8)", "readlane -> fma dependent", "dependent v_mul_f64",
          "dependent mfma_f64_16x16x4", "LDS read -> fma dependent"]

@@ -4,7 +4,7 @@ from suitesparse_amd import cholmod as ch
 L = ch.lib()
 for bpc in (2, 4):
     for (im, iv) in [(20000, 0), (0, 220000), (20000, 220000), (20000, 110000), (20000, 440000)]:
-        t = L.cholmod_hip_bench_mixed(bpc, im, iv)
+        t = ch.probes().cholmod_hip_bench_mixed(bpc, im, iv)
         blocks = 256 * bpc
         fm = blocks * 2 * im * 8 * 2048.0
         fv = blocks * 2 * 64 * iv * 16 * 2.0

@@ -9,7 +9,7 @@ from suitesparse_amd import cholmod as ch
 
 L = ch.lib()
 out = np.zeros(16, dtype=np.int64)
-print("rc", L.cholmod_hip_debug_panel_cycles(out.ctypes.data))
+print("rc", ch.probes().cholmod_hip_debug_panel_cycles(out.ctypes.data))
 pn = ["stage", "column chain (4 panels)", "scale+store", "barrier", "trailing MFMA tiles", "barrier", "write-back", "-"]
 tn = ["stage L11/B", "reciprocals", "diag inverses", "update MFMAs", "barrier", "diag MFMAs+store", "barrier", "-"]
 for title, names, v in (("k_potrf_mfma", pn, out[:8]), ("k_trsm_mfma", tn, out[8:])):

@@ -6,4 +6,4 @@ L = ch.lib()
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 fl = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-print(L.cholmod_hip_bench_update_kernel(m, m, k, 2, fl) / 1e12, "TFLOP/s")
+print(ch.probes().cholmod_hip_bench_update_kernel(m, m, k, 2, fl) / 1e12, "TFLOP/s")
