@@ -174,6 +174,8 @@ typedef struct cholmod_common_struct
      * (CHOLMOD/Supernodal/t_cholmod_super_numeric.c:183-192).  The environment
      * variable CHOLMOD_HIP_CPU_FALLBACK=1 sets it in cholmod_l_start. */
     int hip_cpu_fallback ;
+    int prefer_zomplex ;            /* X of cholmod_l_solve: zomplex instead of complex
+                                     * (reference cholmod_core.h, Cholesky/cholmod_solve.c:1112) */
 } cholmod_common ;
 
 typedef struct cholmod_sparse_struct
@@ -214,6 +216,10 @@ typedef struct cholmod_factor_struct
     void *hip_plan ;
     int hip_on_device ;     /* numeric values currently valid in HBM */
     int hip_host_valid ;    /* L->x holds the current numeric values */
+    /* complex factors (L->xtype == CHOLMOD_COMPLEX): the real supernodal factor of the
+     * 2n x 2n embedding [re -im ; im re] the engine actually computes; the complex
+     * L->x is its even columns */
+    void *cx_twin ;
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

@@ -38,6 +38,11 @@ def lib():
                               C.c_void_p, C.c_void_p]
     L.orc_factorize.restype = C.c_int
     L.orc_factorize.argtypes = [C.c_void_p, I64P, I64P, F64P, C.c_int, C.c_double, C.c_int]
+    L.orc_factorize_complex.restype = C.c_int
+    L.orc_factorize_complex.argtypes = [C.c_void_p, I64P, I64P, F64P, C.c_void_p, C.c_int, C.c_double, C.c_int]
+    L.orc_solve_complex.argtypes = [C.c_void_p, F64P, F64P, C.c_int64]
+    L.orc_bind_blas_complex.restype = C.c_int
+    L.orc_bind_blas_complex.argtypes = [C.c_char_p, C.c_char_p]
     L.orc_free.argtypes = [C.c_void_p]
     for name in ("orc_lsolve", "orc_ltsolve"):
         getattr(L, name).argtypes = [C.c_void_p, F64P, C.c_int64]
@@ -131,6 +136,31 @@ class OracleFactor:
         return lib().orc_factorize(self._h, Ap, Ai, np.ascontiguousarray(Ax, dtype=np.float64),
                                    st, float(beta), int(quick_return))
 
+    def factorize_complex(self, Ax, beta=0.0, quick_return=False, zomplex=False):
+        """Hermitian A with complex values (numpy complex128 array, one value per stored
+        entry); zomplex=True hands the real and imaginary parts over as two arrays, as
+        CHOLMOD_ZOMPLEX does.  L.x becomes complex (see xc)."""
+        Ax = np.ascontiguousarray(Ax, dtype=np.complex128)
+        if zomplex:
+            re = np.ascontiguousarray(Ax.real)
+            im = np.ascontiguousarray(Ax.imag)
+            st = lib().orc_factorize_complex(self._h, self.Ap, self.Ai, re, im.ctypes.data,
+                                             self.stype, float(beta), int(quick_return))
+        else:
+            st = lib().orc_factorize_complex(self._h, self.Ap, self.Ai, Ax.view(np.float64), None,
+                                             self.stype, float(beta), int(quick_return))
+        self._complex = True
+        return st
+
+    xc = property(lambda s: _arr(lib().orc_x(s._h), 2 * s.xsize, np.float64).view(np.complex128))
+
+    def solve_complex(self, b):
+        b = np.ascontiguousarray(b, dtype=np.complex128)
+        nrhs = 1 if b.ndim == 1 else b.shape[0]
+        x = np.empty_like(b)
+        lib().orc_solve_complex(self._h, b.view(np.float64).reshape(-1), x.view(np.float64).reshape(-1), nrhs)
+        return x
+
     def solve(self, b):
         b = np.ascontiguousarray(b, dtype=np.float64)
         nrhs = 1 if b.ndim == 1 else b.shape[0]
@@ -196,6 +226,7 @@ def bind_blas():
     for path, prefix in cands:
         try:
             if lib().orc_bind_blas(path.encode(), prefix):
+                lib().orc_bind_blas_complex(path.encode(), prefix)
                 return f"{os.path.basename(path)} (prefix '{prefix.decode()}')"
         except Exception:
             continue

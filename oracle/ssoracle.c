@@ -314,9 +314,21 @@ static void d_trsm (Int m, Int n, const double *L, Int ldl, double *B, Int ldb)
  * NULL (identity).  Tx may be NULL (pattern only).  Caller frees Tp/Ti/Tx.
  * Follows the permuted-transpose used at Cholesky/cholmod_factorize.c:225-244
  * and Cholesky/cholmod_analyze.c:174-298 (permute_matrices). */
+static int sym_permute_e (Int n, const Int *Ap, const Int *Ai, const double *Ax,
+    int stype, const Int *Perm, int upper, Int **Tp_out, Int **Ti_out,
+    double **Tx_out, int E) ;
 static int sym_permute (Int n, const Int *Ap, const Int *Ai, const double *Ax,
     int stype, const Int *Perm, int upper, Int **Tp_out, Int **Ti_out,
     double **Tx_out)
+{
+    return sym_permute_e (n, Ap, Ai, Ax, stype, Perm, upper, Tp_out, Ti_out, Tx_out, 1) ;
+}
+/* E = 1: real values; E = 2: complex (interleaved) values of a Hermitian matrix --
+ * an entry that lands in the other triangle is conjugated (the conjugate permuted
+ * transpose, `values = 2`, of Cholesky/cholmod_factorize.c:225-244). */
+static int sym_permute_e (Int n, const Int *Ap, const Int *Ai, const double *Ax,
+    int stype, const Int *Perm, int upper, Int **Tp_out, Int **Ti_out,
+    double **Tx_out, int E)
 {
     Int *Pinv = malloc ((n+1) * sizeof (Int)) ;
     Int *cnt = calloc (n+1, sizeof (Int)) ;
@@ -339,13 +351,13 @@ static int sym_permute (Int n, const Int *Ap, const Int *Ai, const double *Ax,
     Tp [0] = 0 ;
     for (Int j = 0 ; j < n ; j++) Tp [j+1] = Tp [j] + cnt [j] ;
     Int *Ti = malloc ((nz > 0 ? nz : 1) * sizeof (Int)) ;
-    double *Tx = Ax ? malloc ((nz > 0 ? nz : 1) * sizeof (double)) : NULL ;
+    double *Tx = Ax ? malloc ((nz > 0 ? nz : 1) * E * sizeof (double)) : NULL ;
     /* two-pass bucket sort by row to get sorted columns: first bucket the
      * entries by their row index, then sweep rows in order */
     Int *rp = calloc (n+2, sizeof (Int)) ;
     Int *ecol = malloc ((nz > 0 ? nz : 1) * sizeof (Int)) ;
     Int *erow = malloc ((nz > 0 ? nz : 1) * sizeof (Int)) ;
-    double *eval = Ax ? malloc ((nz > 0 ? nz : 1) * sizeof (double)) : NULL ;
+    double *eval = Ax ? malloc ((nz > 0 ? nz : 1) * E * sizeof (double)) : NULL ;
     if (!Ti || !rp || !ecol || !erow || (Ax && (!Tx || !eval))) return 0 ;
     for (Int j = 0 ; j < n ; j++)
         for (Int p = Ap [j] ; p < Ap [j+1] ; p++)
@@ -367,7 +379,12 @@ static int sym_permute (Int n, const Int *Ap, const Int *Ai, const double *Ax,
             Int row = upper ? lo : hi, col = upper ? hi : lo ;
             Int q = rp [row]++ ;
             erow [q] = row ; ecol [q] = col ;
-            if (Ax) eval [q] = Ax [p] ;
+            if (Ax && E == 1) eval [q] = Ax [p] ;
+            else if (Ax)
+            {
+                eval [2*q] = Ax [2*p] ;
+                eval [2*q+1] = (row == r) ? Ax [2*p+1] : -Ax [2*p+1] ;
+            }
         }
     memset (cnt, 0, (n+1) * sizeof (Int)) ;
     for (Int q = 0 ; q < nz ; q++)
@@ -375,7 +392,7 @@ static int sym_permute (Int n, const Int *Ap, const Int *Ai, const double *Ax,
         Int col = ecol [q] ;
         Int dst = Tp [col] + cnt [col]++ ;
         Ti [dst] = erow [q] ;
-        if (Ax) Tx [dst] = eval [q] ;
+        if (Ax) for (int e = 0 ; e < E ; e++) Tx [E*dst+e] = eval [E*q+e] ;
     }
     free (rp) ; free (ecol) ; free (erow) ; free (eval) ;
     free (Pinv) ; free (cnt) ;
@@ -1072,6 +1089,382 @@ void orc_solve (const orc_factor *L, const double *B, double *X, Int nrhs)
     orc_ltsolve (L, Y, nrhs) ;
     for (Int r = 0 ; r < nrhs ; r++)
         for (Int k = 0 ; k < n ; k++) X [L->Perm [k] + r*n] = Y [k + r*n] ;
+    free (Y) ;
+}
+
+/* ------------------------------------------------------------------------ */
+/* complex / zomplex input: L and C are complex (interleaved)                 */
+/* ------------------------------------------------------------------------ */
+/* reference: Supernodal/t_cholmod_super_numeric.c:41-83 (L_ENTRY = 2, the
+ * L_ASSIGN / L_ASSEMBLE / L_ASSEMBLESUB macros of the complex and zomplex
+ * templates), BLAS_zherk / BLAS_zgemm :682-717, LAPACK_zpotrf :864-867,
+ * BLAS_ztrsm :997-1002; Supernodal/t_cholmod_super_solve.c with ztrsv/zgemv. */
+
+typedef void (*zgemm_f) (const char *, const char *, const int *, const int *,
+    const int *, const double *, const double *, const int *, const double *,
+    const int *, const double *, double *, const int *) ;
+typedef void (*zherk_f) (const char *, const char *, const int *, const int *,
+    const double *, const double *, const int *, const double *, double *,
+    const int *) ;
+typedef void (*ztrsm_f) (const char *, const char *, const char *, const char *,
+    const int *, const int *, const double *, const double *, const int *,
+    double *, const int *) ;
+typedef void (*zpotrf_f) (const char *, const int *, double *, const int *, int *) ;
+static zgemm_f  x_zgemm  = NULL ;
+static zherk_f  x_zherk  = NULL ;
+static ztrsm_f  x_ztrsm  = NULL ;
+static zpotrf_f x_zpotrf = NULL ;
+
+int orc_bind_blas_complex (const char *path, const char *prefix)
+{
+    void *h = dlopen (path, RTLD_NOW | RTLD_LOCAL) ;
+    if (!h) return 0 ;
+    char name [256] ;
+    snprintf (name, sizeof name, "%szgemm_", prefix) ;
+    zgemm_f g = (zgemm_f) dlsym (h, name) ;
+    snprintf (name, sizeof name, "%szherk_", prefix) ;
+    zherk_f s = (zherk_f) dlsym (h, name) ;
+    snprintf (name, sizeof name, "%sztrsm_", prefix) ;
+    ztrsm_f t = (ztrsm_f) dlsym (h, name) ;
+    snprintf (name, sizeof name, "%szpotrf_", prefix) ;
+    zpotrf_f q = (zpotrf_f) dlsym (h, name) ;
+    if (!g || !s || !t || !q) return 0 ;
+    x_zgemm = g ; x_zherk = s ; x_ztrsm = t ; x_zpotrf = q ;
+    return 1 ;
+}
+
+/* C(m,n) = A(m,k) * B(n,k)^H, complex interleaved (zgemm "N","C") */
+static void z_gemm (Int m, Int n, Int k, const double *A, Int lda,
+    const double *B, Int ldb, double *C, Int ldc)
+{
+    if (x_zgemm)
+    {
+        int M = (int) m, N = (int) n, K = (int) k, LDA = (int) lda,
+            LDB = (int) ldb, LDC = (int) ldc ;
+        double one [2] = {1, 0}, zero [2] = {0, 0} ;
+        x_zgemm ("N", "C", &M, &N, &K, one, A, &LDA, B, &LDB, zero, C, &LDC) ;
+        return ;
+    }
+    for (Int j = 0 ; j < n ; j++)
+        for (Int i = 0 ; i < m ; i++)
+        {
+            double cr = 0, ci = 0 ;
+            for (Int l = 0 ; l < k ; l++)
+            {
+                double ar = A [2*(i + l*lda)], ai = A [2*(i + l*lda)+1] ;
+                double br = B [2*(j + l*ldb)], bi = B [2*(j + l*ldb)+1] ;
+                cr += ar * br + ai * bi ;
+                ci += ai * br - ar * bi ;
+            }
+            C [2*(i + j*ldc)] = cr ; C [2*(i + j*ldc)+1] = ci ;
+        }
+}
+
+/* lower triangle of C(n,n) = A(n,k) * A(n,k)^H (zherk "L","N") */
+static void z_herk (Int n, Int k, const double *A, Int lda, double *C, Int ldc)
+{
+    if (x_zherk)
+    {
+        int N = (int) n, K = (int) k, LDA = (int) lda, LDC = (int) ldc ;
+        double one = 1, zero = 0 ;
+        x_zherk ("L", "N", &N, &K, &one, A, &LDA, &zero, C, &LDC) ;
+        return ;
+    }
+    for (Int j = 0 ; j < n ; j++)
+        z_gemm (n - j, 1, k, A + 2*j, lda, A + 2*j, lda, C + 2*(j + j*ldc), ldc) ;
+    for (Int j = 0 ; j < n ; j++) C [2*(j + j*ldc)+1] = 0 ;
+}
+
+/* zpotrf "L": info as LAPACK (first pivot <= 0, imaginary parts of the diagonal ignored) */
+static Int z_potrf (Int n, double *A, Int lda)
+{
+    if (x_zpotrf)
+    {
+        int N = (int) n, LDA = (int) lda, info = 0 ;
+        x_zpotrf ("L", &N, A, &LDA, &info) ;
+        return info ;
+    }
+    for (Int j = 0 ; j < n ; j++)
+    {
+        double ajj = A [2*(j + j*lda)] ;
+        for (Int l = 0 ; l < j ; l++)
+        {
+            double r = A [2*(j + l*lda)], im = A [2*(j + l*lda)+1] ;
+            ajj -= r * r + im * im ;
+        }
+        if (ajj <= 0.0) { A [2*(j + j*lda)] = ajj ; return j + 1 ; }
+        ajj = sqrt (ajj) ;
+        A [2*(j + j*lda)] = ajj ; A [2*(j + j*lda)+1] = 0 ;
+        for (Int i = j + 1 ; i < n ; i++)
+        {
+            double vr = A [2*(i + j*lda)], vi = A [2*(i + j*lda)+1] ;
+            for (Int l = 0 ; l < j ; l++)
+            {
+                double ar = A [2*(i + l*lda)], ai = A [2*(i + l*lda)+1] ;
+                double br = A [2*(j + l*lda)], bi = A [2*(j + l*lda)+1] ;
+                vr -= ar * br + ai * bi ;
+                vi -= ai * br - ar * bi ;
+            }
+            A [2*(i + j*lda)] = vr / ajj ; A [2*(i + j*lda)+1] = vi / ajj ;
+        }
+    }
+    return 0 ;
+}
+
+/* B(m,n) := B * inv(L)^H, L(n,n) lower non-unit (ztrsm "R","L","C","N") */
+static void z_trsm (Int m, Int n, const double *L, Int ldl, double *B, Int ldb)
+{
+    if (x_ztrsm)
+    {
+        int M = (int) m, N = (int) n, LDL = (int) ldl, LDB = (int) ldb ;
+        double one [2] = {1, 0} ;
+        x_ztrsm ("R", "L", "C", "N", &M, &N, one, L, &LDL, B, &LDB) ;
+        return ;
+    }
+    for (Int jj = 0 ; jj < n ; jj++)
+    {
+        double *bj = B + 2*jj*ldb ;
+        for (Int l = 0 ; l < jj ; l++)
+        {
+            double fr = L [2*(jj + l*ldl)], fi = -L [2*(jj + l*ldl)+1] ;   /* conj (L(jj,l)) */
+            const double *bl = B + 2*l*ldb ;
+            for (Int i = 0 ; i < m ; i++)
+            {
+                bj [2*i]   -= bl [2*i] * fr - bl [2*i+1] * fi ;
+                bj [2*i+1] -= bl [2*i] * fi + bl [2*i+1] * fr ;
+            }
+        }
+        double d = L [2*(jj + jj*ldl)] ;
+        for (Int i = 0 ; i < m ; i++) { bj [2*i] /= d ; bj [2*i+1] /= d ; }
+    }
+}
+
+/* As orc_factorize, for a Hermitian A with complex (Az == NULL: Ax interleaved)
+ * or zomplex (Ax real parts, Az imaginary parts) values; L->x is complex
+ * interleaved, 2*xsize doubles (t_cholmod_super_numeric.c:41-83: "A and F are
+ * complex or zomplex, L and C are complex").  beta is real (:421-431, b[0]). */
+int orc_factorize_complex (orc_factor *L, const Int *Ap, const Int *Ai,
+    const double *Ax, const double *Az, int stype, double beta,
+    int quick_return_if_not_posdef)
+{
+    Int n = L->n, nsuper = L->nsuper ;
+    const Int *Super = L->super, *Lpi = L->pi, *Lpx = L->px, *Ls = L->s ;
+    Int *Sp = NULL, *Si = NULL ;
+    double *Sx = NULL, *Axz = NULL ;
+    if (Az)
+    {
+        Int nz = Ap [n] ;
+        Axz = malloc ((nz > 0 ? nz : 1) * 2 * sizeof (double)) ;
+        if (!Axz) return (L->status = ORC_OUT_OF_MEMORY) ;
+        for (Int p = 0 ; p < nz ; p++) { Axz [2*p] = Ax [p] ; Axz [2*p+1] = Az [p] ; }
+        Ax = Axz ;
+    }
+    if (!sym_permute_e (n, Ap, Ai, Ax, stype, L->Perm, 0, &Sp, &Si, &Sx, 2))
+        return (L->status = ORC_OUT_OF_MEMORY) ;
+    free (Axz) ;
+    free (L->x) ;
+    L->x = malloc ((L->xsize > 0 ? L->xsize : 1) * 2 * sizeof (double)) ;
+    double *C = malloc ((L->maxcsize > 0 ? L->maxcsize : 1) * 2 * sizeof (double)) ;
+    Int *SuperMap = malloc ((n+1) * sizeof (Int)) ;
+    Int *RelativeMap = malloc ((n+1) * sizeof (Int)) ;
+    Int *Map = malloc ((n+1) * sizeof (Int)) ;
+    Int *Next = malloc ((nsuper+1) * sizeof (Int)) ;
+    Int *Lpos = malloc ((nsuper+1) * sizeof (Int)) ;
+    Int *Next_save = malloc ((nsuper+1) * sizeof (Int)) ;
+    Int *Lpos_save = malloc ((nsuper+1) * sizeof (Int)) ;
+    Int *Head = malloc ((nsuper+1) * sizeof (Int)) ;
+    if (!L->x || !C || !SuperMap || !RelativeMap || !Map || !Next || !Lpos
+        || !Next_save || !Lpos_save || !Head)
+        return (L->status = ORC_OUT_OF_MEMORY) ;
+    double *Lx = L->x ;
+    L->minor = n ;
+    L->status = ORC_OK ;
+    L->exec_flops = 0 ;
+    for (int t = 0 ; t < 4 ; t++) L->calls [t] = 0 ;
+    for (Int s = 0 ; s < nsuper ; s++)
+        for (Int k = Super [s] ; k < Super [s+1] ; k++) SuperMap [k] = s ;
+    for (Int s = 0 ; s < nsuper ; s++) Head [s] = EMPTY ;
+    for (Int i = 0 ; i < n ; i++) Map [i] = EMPTY ;
+
+    int repeat_supernode = 0 ;
+    Int nscol_new = 0 ;
+    for (Int s = 0 ; s < nsuper ; s++)
+    {
+        Int k1 = Super [s], k2 = Super [s+1] ;
+        Int nscol = k2 - k1 ;
+        Int psi = Lpi [s], psend = Lpi [s+1], psx = Lpx [s] ;
+        Int nsrow = psend - psi ;
+        Int pend = psx + nsrow * nscol ;
+        for (Int p = 2*psx ; p < 2*pend ; p++) Lx [p] = 0 ;             /* L_CLEAR */
+        for (Int k = 0 ; k < nsrow ; k++) Map [Ls [psi + k]] = k ;
+        for (Int k = k1 ; k < k2 ; k++)
+            for (Int p = Sp [k] ; p < Sp [k+1] ; p++)
+            {
+                Int i = Si [p] ;
+                if (i >= k)
+                {
+                    Int imap = Map [i] ;
+                    if (imap >= 0 && imap < nsrow)
+                    {
+                        Int q = imap + (psx + (k-k1)*nsrow) ;            /* L_ASSIGN */
+                        Lx [2*q] = Sx [2*p] ; Lx [2*q+1] = Sx [2*p+1] ;
+                    }
+                }
+            }
+        if (beta != 0.0)
+        {
+            Int pk = psx ;
+            for (Int k = k1 ; k < k2 ; k++) { Lx [2*pk] += beta ; pk += nsrow + 1 ; }   /* L_ASSEMBLE */
+        }
+        if (!repeat_supernode)
+            for (Int d = Head [s] ; d != EMPTY ; d = Next [d])
+            { Lpos_save [d] = Lpos [d] ; Next_save [d] = Next [d] ; }
+        else
+            for (Int d = Head [s] ; d != EMPTY ; d = Next [d])
+            { Lpos [d] = Lpos_save [d] ; Next [d] = Next_save [d] ; }
+        Int dnext ;
+        for (Int d = Head [s] ; d != EMPTY ; d = dnext)
+        {
+            Int kd1 = Super [d], kd2 = Super [d+1] ;
+            Int ndcol = kd2 - kd1 ;
+            Int pdi = Lpi [d], pdend = Lpi [d+1], pdx = Lpx [d] ;
+            Int ndrow = pdend - pdi ;
+            Int p = Lpos [d] ;
+            Int pdi1 = pdi + p ;
+            Int pdx1 = pdx + p ;
+            Int pdi2 ;
+            for (pdi2 = pdi1 ; pdi2 < pdend && Ls [pdi2] < k2 ; pdi2++) ;
+            Int ndrow1 = pdi2 - pdi1 ;
+            Int ndrow2 = pdend - pdi1 ;
+            Int ndrow3 = ndrow2 - ndrow1 ;
+            dnext = Next [d] ;
+            z_herk (ndrow1, ndcol, Lx + 2*pdx1, ndrow, C, ndrow2) ;
+            L->calls [0]++ ;
+            L->exec_flops += 4.0 * ndrow1 * ndrow1 * ndcol ;
+            if (ndrow3 > 0)
+            {
+                z_gemm (ndrow3, ndrow1, ndcol, Lx + 2*(pdx1 + ndrow1), ndrow,
+                    Lx + 2*pdx1, ndrow, C + 2*ndrow1, ndrow2) ;
+                L->calls [1]++ ;
+                L->exec_flops += 8.0 * ndrow3 * ndrow1 * ndcol ;
+            }
+            for (Int i = 0 ; i < ndrow2 ; i++)
+                RelativeMap [i] = Map [Ls [pdi1 + i]] ;
+            for (Int j = 0 ; j < ndrow1 ; j++)
+            {
+                Int px = psx + RelativeMap [j] * nsrow ;
+                for (Int i = j ; i < ndrow2 ; i++)
+                {
+                    Int q = px + RelativeMap [i] ;                       /* L_ASSEMBLESUB */
+                    Lx [2*q]   -= C [2*(i + ndrow2*j)] ;
+                    Lx [2*q+1] -= C [2*(i + ndrow2*j)+1] ;
+                }
+            }
+            Lpos [d] = pdi2 - pdi ;
+            if (Lpos [d] < ndrow)
+            {
+                Int dancestor = SuperMap [Ls [pdi2]] ;
+                Next [d] = Head [dancestor] ;
+                Head [dancestor] = d ;
+            }
+        }
+        Int nscol2 = repeat_supernode ? nscol_new : nscol ;
+        Int info = z_potrf (nscol2, Lx + 2*psx, nsrow) ;
+        L->calls [2]++ ;
+        L->exec_flops += 4.0 * nscol2 * nscol2 * nscol2 / 3.0 ;
+        if (repeat_supernode)
+        {
+            info = 0 ;
+            for (Int p = 2*(psx + nsrow * nscol_new) ; p < 2*(psx + nsrow * nscol) ; p++) Lx [p] = 0 ;
+        }
+        if (info != 0)
+        {
+            L->status = ORC_NOT_POSDEF ;
+            L->minor = k1 + info - 1 ;
+            for (Int ss = s+1 ; ss < nsuper ; ss++) Head [ss] = EMPTY ;
+            for (Int p = 2*psx ; p < 2*L->xsize ; p++) Lx [p] = 0 ;
+            if (info == 1 || quick_return_if_not_posdef) { Head [s] = EMPTY ; goto done ; }
+            repeat_supernode = 1 ;
+            nscol_new = info - 1 ;
+            s-- ;
+            continue ;
+        }
+        Int nsrow2 = nsrow - nscol2 ;
+        if (nsrow2 > 0)
+        {
+            z_trsm (nsrow2, nscol2, Lx + 2*psx, nsrow, Lx + 2*(psx + nscol2), nsrow) ;
+            L->calls [3]++ ;
+            L->exec_flops += 4.0 * nsrow2 * nscol2 * nscol2 ;
+            if (!repeat_supernode)
+            {
+                Lpos [s] = nscol ;
+                Int sparent = SuperMap [Ls [psi + nscol]] ;
+                Next [s] = Head [sparent] ;
+                Head [sparent] = s ;
+            }
+        }
+        Head [s] = EMPTY ;
+        if (repeat_supernode) goto done ;
+    }
+done:
+    free (C) ; free (SuperMap) ; free (RelativeMap) ; free (Map) ; free (Next) ;
+    free (Lpos) ; free (Next_save) ; free (Lpos_save) ; free (Head) ;
+    free (Sp) ; free (Si) ; free (Sx) ;
+    return L->status ;
+}
+
+/* x = P^T L^-H L^-1 P b, complex interleaved B and X (n-by-nrhs, ld n).
+ * reference: Supernodal/t_cholmod_super_solve.c (complex template: ztrsv
+ * "L","N","N" + zgemv "N" forward, zgemv "C" + ztrsv "L","C","N" backward). */
+void orc_solve_complex (const orc_factor *L, const double *B, double *X, Int nrhs)
+{
+    Int n = L->n ;
+    const Int *Super = L->super, *Lpi = L->pi, *Lpx = L->px, *Ls = L->s ;
+    const double *Lx = L->x ;
+    double *Y = malloc ((n > 0 ? n : 1) * 2 * sizeof (double)) ;
+    for (Int r = 0 ; r < nrhs ; r++)
+    {
+        for (Int k = 0 ; k < n ; k++)
+        { Y [2*k] = B [2*(L->Perm [k] + r*n)] ; Y [2*k+1] = B [2*(L->Perm [k] + r*n)+1] ; }
+        for (Int s = 0 ; s < L->nsuper ; s++)
+        {
+            Int k1 = Super [s], nscol = Super [s+1] - k1 ;
+            Int psi = Lpi [s], nsrow = Lpi [s+1] - psi, psx = Lpx [s] ;
+            for (Int j = 0 ; j < nscol ; j++)
+            {
+                double d = Lx [2*(psx + j + j*nsrow)] ;
+                double vr = Y [2*(k1+j)] / d, vi = Y [2*(k1+j)+1] / d ;
+                Y [2*(k1+j)] = vr ; Y [2*(k1+j)+1] = vi ;
+                for (Int i = j+1 ; i < nsrow ; i++)
+                {
+                    double lr = Lx [2*(psx + i + j*nsrow)], li = Lx [2*(psx + i + j*nsrow)+1] ;
+                    Int row = Ls [psi + i] ;
+                    Y [2*row]   -= lr * vr - li * vi ;
+                    Y [2*row+1] -= lr * vi + li * vr ;
+                }
+            }
+        }
+        for (Int s = L->nsuper - 1 ; s >= 0 ; s--)
+        {
+            Int k1 = Super [s], nscol = Super [s+1] - k1 ;
+            Int psi = Lpi [s], nsrow = Lpi [s+1] - psi, psx = Lpx [s] ;
+            for (Int j = nscol - 1 ; j >= 0 ; j--)
+            {
+                double vr = Y [2*(k1+j)], vi = Y [2*(k1+j)+1] ;
+                for (Int i = j+1 ; i < nsrow ; i++)
+                {
+                    double lr = Lx [2*(psx + i + j*nsrow)], li = -Lx [2*(psx + i + j*nsrow)+1] ;
+                    Int row = Ls [psi + i] ;
+                    vr -= lr * Y [2*row] - li * Y [2*row+1] ;
+                    vi -= lr * Y [2*row+1] + li * Y [2*row] ;
+                }
+                double d = Lx [2*(psx + j + j*nsrow)] ;
+                Y [2*(k1+j)] = vr / d ; Y [2*(k1+j)+1] = vi / d ;
+            }
+        }
+        for (Int k = 0 ; k < n ; k++)
+        { X [2*(L->Perm [k] + r*n)] = Y [2*k] ; X [2*(L->Perm [k] + r*n)+1] = Y [2*k+1] ; }
+    }
     free (Y) ;
 }
 

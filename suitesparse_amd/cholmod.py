@@ -18,10 +18,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libcholmod_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CHOLMOD_MAXMETHODS = 9
-CHOLMOD_HIP_NSTATS = 26
+CHOLMOD_HIP_NSTATS = 32
 
 # constants (include/cholmod.h)
-PATTERN, REAL = 0, 1
+PATTERN, REAL, COMPLEX, ZOMPLEX = 0, 1, 2, 3
 OK, NOT_INSTALLED, OUT_OF_MEMORY, TOO_LARGE, INVALID, GPU_PROBLEM = 0, -1, -2, -3, -4, -5
 NOT_POSDEF = 1
 NATURAL, GIVEN, POSTORDERED = 0, 1, 6
@@ -71,7 +71,7 @@ class Common(C.Structure):
         ("hip_factor_on_device", C.c_int), ("hip_flags", C.c_int), ("hip_profile", C.c_int),
         ("hip_rank", C.c_int), ("hip_world", C.c_int),
         ("hip_allreduce", C.c_void_p), ("hip_allreduce_user", C.c_void_p),
-        ("hip_cpu_fallback", C.c_int),
+        ("hip_cpu_fallback", C.c_int), ("prefer_zomplex", C.c_int),
     ]
 
 
@@ -100,7 +100,8 @@ class Factor(C.Structure):
                 ("ordering", C.c_int), ("is_ll", C.c_int), ("is_super", C.c_int),
                 ("is_monotonic", C.c_int), ("itype", C.c_int), ("xtype", C.c_int),
                 ("dtype", C.c_int), ("useGPU", C.c_int),
-                ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int)]
+                ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
+                ("cx_twin", C.c_void_p)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare
@@ -329,30 +330,53 @@ class Session:
         self.L.cholmod_l_finish(C.byref(self.cm))
 
     # ---- object helpers
-    def sparse(self, n, Ap, Ai, Ax, stype):
-        """Copy numpy CSC arrays into a library-owned cholmod_sparse."""
+    def sparse(self, n, Ap, Ai, Ax, stype, zomplex=False):
+        """Copy numpy CSC arrays into a library-owned cholmod_sparse.  Complex values
+        (numpy complex128) make a CHOLMOD_COMPLEX matrix, or CHOLMOD_ZOMPLEX on request."""
         nz = int(Ap[-1])
-        A = self.L.cholmod_l_allocate_sparse(n, n, max(nz, 1), 1, 1, stype, REAL, C.byref(self.cm))
+        cx = np.iscomplexobj(Ax)
+        xtype = (ZOMPLEX if zomplex else COMPLEX) if cx else REAL
+        A = self.L.cholmod_l_allocate_sparse(n, n, max(nz, 1), 1, 1, stype, xtype, C.byref(self.cm))
         if not A:
             raise MemoryError("cholmod_l_allocate_sparse")
         a = A.contents
         _view(a.p, n + 1, C.c_int64, np.int64)[:] = Ap
         if nz:
             _view(a.i, nz, C.c_int64, np.int64)[:] = Ai
-            _view(a.x, nz, C.c_double, np.float64)[:] = Ax
+            if not cx:
+                _view(a.x, nz, C.c_double, np.float64)[:] = Ax
+            elif zomplex:
+                _view(a.x, nz, C.c_double, np.float64)[:] = np.real(Ax)
+                _view(a.z, nz, C.c_double, np.float64)[:] = np.imag(Ax)
+            else:
+                _view(a.x, 2 * nz, C.c_double, np.float64)[:] = np.ascontiguousarray(Ax, dtype=np.complex128).view(np.float64)
         return A
 
-    def dense(self, arr):
-        arr = np.asarray(arr, dtype=np.float64)
+    def dense(self, arr, zomplex=False):
+        cx = np.iscomplexobj(arr)
+        arr = np.asarray(arr, dtype=np.complex128 if cx else np.float64)
         n = arr.shape[-1] if arr.ndim > 1 else arr.shape[0]
         nrhs = arr.shape[0] if arr.ndim > 1 else 1
-        X = self.L.cholmod_l_allocate_dense(n, nrhs, n, REAL, C.byref(self.cm))
-        _view(X.contents.x, n * nrhs, C.c_double, np.float64)[:] = arr.reshape(-1)
+        xtype = (ZOMPLEX if zomplex else COMPLEX) if cx else REAL
+        X = self.L.cholmod_l_allocate_dense(n, nrhs, n, xtype, C.byref(self.cm))
+        if not cx:
+            _view(X.contents.x, n * nrhs, C.c_double, np.float64)[:] = arr.reshape(-1)
+        elif zomplex:
+            _view(X.contents.x, n * nrhs, C.c_double, np.float64)[:] = arr.real.reshape(-1)
+            _view(X.contents.z, n * nrhs, C.c_double, np.float64)[:] = arr.imag.reshape(-1)
+        else:
+            _view(X.contents.x, 2 * n * nrhs, C.c_double, np.float64)[:] = arr.reshape(-1).view(np.float64)
         return X
 
     def dense_to_numpy(self, X):
         x = X.contents
-        out = _view(x.x, x.d * x.ncol, C.c_double, np.float64).copy()
+        if x.xtype == COMPLEX:
+            out = _view(x.x, 2 * x.d * x.ncol, C.c_double, np.float64).copy().view(np.complex128)
+        elif x.xtype == ZOMPLEX:
+            out = (_view(x.x, x.d * x.ncol, C.c_double, np.float64)
+                   + 1j * _view(x.z, x.d * x.ncol, C.c_double, np.float64))
+        else:
+            out = _view(x.x, x.d * x.ncol, C.c_double, np.float64).copy()
         return out.reshape(x.ncol, x.d)[:, :x.nrow] if x.ncol > 1 else out[:x.nrow]
 
     def free_sparse(self, A):
@@ -383,8 +407,8 @@ class Session:
         b = (C.c_double * 2)(beta, 0.0)
         return self.L.cholmod_l_refactorize_resident(C.byref(b), Lf, C.byref(self.cm))
 
-    def solve(self, Lf, b, sys=SYS_A):
-        B = self.dense(b)
+    def solve(self, Lf, b, sys=SYS_A, zomplex=False):
+        B = self.dense(b, zomplex=zomplex)
         X = self.L.cholmod_l_solve(sys, Lf, B, C.byref(self.cm))
         self.free_dense(B)
         if not X:
@@ -439,5 +463,9 @@ class FactorView:
         self.pi = _view(f.pi, self.nsuper + 1, C.c_int64, np.int64)
         self.px = _view(f.px, self.nsuper + 1, C.c_int64, np.int64)
         self.s = _view(f.s, self.ssize, C.c_int64, np.int64)
-        self.x = _view(f.x, self.xsize, C.c_double, np.float64) if f.x else None
+        if f.x and f.xtype == COMPLEX:      # interleaved (re, im) pairs
+            self.x = _view(f.x, 2 * self.xsize, C.c_double, np.float64).view(np.complex128)
+        else:
+            self.x = _view(f.x, self.xsize, C.c_double, np.float64) if f.x else None
         self.hip_plan = f.hip_plan
+        self.cx_twin = f.cx_twin

@@ -136,9 +136,9 @@ cholmod_sparse *cholmod_l_allocate_sparse (size_t nrow, size_t ncol, size_t nzma
         ERROR (CHOLMOD_INVALID, "rectangular matrix with stype != 0 invalid") ;
         return NULL ;
     }
-    if (xtype != CHOLMOD_PATTERN && xtype != CHOLMOD_REAL)
+    if (xtype < CHOLMOD_PATTERN || xtype > CHOLMOD_ZOMPLEX)
     {
-        ERROR (CHOLMOD_INVALID, "xtype invalid (only pattern and real are built)") ;
+        ERROR (CHOLMOD_INVALID, "xtype invalid") ;
         return NULL ;
     }
     Common->status = CHOLMOD_OK ;
@@ -152,7 +152,10 @@ cholmod_sparse *cholmod_l_allocate_sparse (size_t nrow, size_t ncol, size_t nzma
     A->p = cholmod_l_calloc (ncol + 1, sizeof (Int), Common) ;
     if (!packed) A->nz = cholmod_l_calloc (ncol > 0 ? ncol : 1, sizeof (Int), Common) ;
     A->i = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
-    if (xtype == CHOLMOD_REAL) A->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    /* complex: interleaved (re, im) pairs in x; zomplex: real parts in x, imaginary in z
+     * (reference Core/cholmod_complex.c) */
+    if (xtype != CHOLMOD_PATTERN) A->x = cholmod_l_malloc (nzmax, SSAMD_XENT (xtype) * sizeof (double), Common) ;
+    if (xtype == CHOLMOD_ZOMPLEX) A->z = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
     if (Common->status < CHOLMOD_OK) { cholmod_l_free_sparse (&A, Common) ; return NULL ; }
     return A ;
 }
@@ -165,7 +168,8 @@ int cholmod_l_free_sparse (cholmod_sparse **AH, cholmod_common *Common)
     cholmod_l_free (A->ncol + 1, sizeof (Int), A->p, Common) ;
     if (A->nz) cholmod_l_free (A->ncol > 0 ? A->ncol : 1, sizeof (Int), A->nz, Common) ;
     cholmod_l_free (A->nzmax, sizeof (Int), A->i, Common) ;
-    if (A->x) cholmod_l_free (A->nzmax, sizeof (double), A->x, Common) ;
+    if (A->x) cholmod_l_free (A->nzmax, SSAMD_XENT (A->xtype) * sizeof (double), A->x, Common) ;
+    if (A->z) cholmod_l_free (A->nzmax, sizeof (double), A->z, Common) ;
     cholmod_l_free (1, sizeof (cholmod_sparse), A, Common) ;
     *AH = NULL ;
     return TRUE ;
@@ -198,7 +202,9 @@ cholmod_sparse *cholmod_l_copy_sparse (cholmod_sparse *A, cholmod_common *Common
         if (pend > p)
         {
             memcpy ((Int *) C->i + p, (Int *) A->i + p, (pend - p) * sizeof (Int)) ;
-            if (A->x) memcpy ((double *) C->x + p, (double *) A->x + p, (pend - p) * sizeof (double)) ;
+            size_t e = SSAMD_XENT (A->xtype) ;
+            if (A->x) memcpy ((double *) C->x + e * p, (double *) A->x + e * p, (pend - p) * e * sizeof (double)) ;
+            if (A->z) memcpy ((double *) C->z + p, (double *) A->z + p, (pend - p) * sizeof (double)) ;
         }
     }
     return C ;
@@ -233,8 +239,9 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
      * position)), so the output is deterministic and its columns are sorted. */
     Int n = (Int) A->nrow ;
     Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
-    double *Ax = A->x ;
-    int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
+    double *Ax = A->x, *Az = A->z ;
+    int xtype = values ? A->xtype : CHOLMOD_PATTERN ;
+    const double csign = (values == 2) ? -1.0 : 1.0 ;     /* 2: conjugate transpose, 1: array transpose */
     int upper_in = A->stype > 0 ;
     const int packed = A->packed ;
     const int nth = ssamd_host_threads () ;
@@ -307,7 +314,8 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
                 Int q ;
 #pragma omp atomic capture
                 q = cursor [col]++ ;
-                Ci [q] = row ; src [q] = p ;
+                /* (source position, moved to the other triangle = transposed) */
+                Ci [q] = row ; src [q] = (p << 1) | (row != r) ;
             }
         }
         /* pass 3: every column sorted by (row, source position), values gathered */
@@ -353,7 +361,21 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
                 { Ci [t] = Ci [t-1] ; src [t] = src [t-1] ; t-- ; }
                 Ci [t] = r ; src [t] = sp ;
             }
-            if (xtype == CHOLMOD_REAL) for (Int q = b0 ; q < e0 ; q++) Cx [q] = Ax [src [q]] ;
+            if (xtype == CHOLMOD_REAL) for (Int q = b0 ; q < e0 ; q++) Cx [q] = Ax [src [q] >> 1] ;
+            else if (xtype == CHOLMOD_COMPLEX)
+                for (Int q = b0 ; q < e0 ; q++)
+                {
+                    Int p = src [q] >> 1 ;
+                    Cx [2*q] = Ax [2*p] ;
+                    Cx [2*q+1] = (src [q] & 1) ? csign * Ax [2*p+1] : Ax [2*p+1] ;
+                }
+            else if (xtype == CHOLMOD_ZOMPLEX)
+                for (Int q = b0 ; q < e0 ; q++)
+                {
+                    Int p = src [q] >> 1 ;
+                    Cx [q] = Ax [p] ;
+                    ((double *) C->z) [q] = (src [q] & 1) ? csign * Az [p] : Az [p] ;
+                }
         }
     }
     else if (C) cholmod_l_free_sparse (&C, Common) ;
@@ -375,8 +397,9 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
     Common->status = CHOLMOD_OK ;
     Int n = (Int) A->nrow, ncol = (Int) A->ncol ;
     Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
-    double *Ax = A->x ;
-    int xtype = (values && A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_PATTERN ;
+    double *Ax = A->x, *Az = A->z ;
+    int xtype = values ? A->xtype : CHOLMOD_PATTERN ;
+    const double csign = (values == 2) ? -1.0 : 1.0 ;
     if (A->stype == 0)
     {
         if (Perm || fset)
@@ -406,6 +429,8 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
                 Int q = w [Ai [p]]++ ;
                 Ci [q] = j ;
                 if (xtype == CHOLMOD_REAL) Cx [q] = Ax [p] ;
+                else if (xtype == CHOLMOD_COMPLEX) { Cx [2*q] = Ax [2*p] ; Cx [2*q+1] = csign * Ax [2*p+1] ; }
+                else if (xtype == CHOLMOD_ZOMPLEX) { Cx [q] = Ax [p] ; ((double *) C->z) [q] = csign * Az [p] ; }
             }
         }
         cholmod_l_free (n + 1, sizeof (Int), w, Common) ;
@@ -538,29 +563,37 @@ cholmod_dense *cholmod_l_allocate_dense (size_t nrow, size_t ncol, size_t d, int
 {
     RETURN_IF_NULL_COMMON (NULL) ;
     if (d < nrow) { ERROR (CHOLMOD_INVALID, "leading dimension invalid") ; return NULL ; }
-    if (xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "xtype invalid") ; return NULL ; }
+    if (xtype < CHOLMOD_REAL || xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "xtype invalid") ; return NULL ; }
     Common->status = CHOLMOD_OK ;
     cholmod_dense *X = cholmod_l_calloc (1, sizeof (cholmod_dense), Common) ;
     if (!X) return NULL ;
     size_t nzmax = d * ncol ; nzmax = nzmax > 1 ? nzmax : 1 ;
     X->nrow = nrow ; X->ncol = ncol ; X->nzmax = nzmax ; X->d = d ;
     X->xtype = xtype ; X->dtype = CHOLMOD_DOUBLE ;
-    X->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
-    if (!X->x) { cholmod_l_free (1, sizeof (cholmod_dense), X, Common) ; return NULL ; }
+    X->x = cholmod_l_malloc (nzmax, SSAMD_XENT (xtype) * sizeof (double), Common) ;
+    if (X->x && xtype == CHOLMOD_ZOMPLEX) X->z = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    if (!X->x || (xtype == CHOLMOD_ZOMPLEX && !X->z)) { cholmod_l_free_dense (&X, Common) ; return NULL ; }
     return X ;
 }
 
 cholmod_dense *cholmod_l_zeros (size_t nrow, size_t ncol, int xtype, cholmod_common *Common)
 {
     cholmod_dense *X = cholmod_l_allocate_dense (nrow, ncol, nrow, xtype, Common) ;
-    if (X) memset (X->x, 0, X->nzmax * sizeof (double)) ;
+    if (X) memset (X->x, 0, X->nzmax * SSAMD_XENT (xtype) * sizeof (double)) ;
+    if (X && X->z) memset (X->z, 0, X->nzmax * sizeof (double)) ;
     return X ;
 }
 
 cholmod_dense *cholmod_l_ones (size_t nrow, size_t ncol, int xtype, cholmod_common *Common)
 {
     cholmod_dense *X = cholmod_l_allocate_dense (nrow, ncol, nrow, xtype, Common) ;
-    if (X) { double *x = X->x ; for (size_t k = 0 ; k < X->nzmax ; k++) x [k] = 1.0 ; }
+    if (X)
+    {
+        double *x = X->x ;
+        if (xtype == CHOLMOD_COMPLEX) for (size_t k = 0 ; k < X->nzmax ; k++) { x [2*k] = 1.0 ; x [2*k+1] = 0.0 ; }
+        else for (size_t k = 0 ; k < X->nzmax ; k++) x [k] = 1.0 ;
+        if (X->z) memset (X->z, 0, X->nzmax * sizeof (double)) ;
+    }
     return X ;
 }
 
@@ -569,7 +602,8 @@ cholmod_dense *cholmod_l_copy_dense (cholmod_dense *X, cholmod_common *Common)
     RETURN_IF_NULL_COMMON (NULL) ;
     RETURN_IF_NULL (X, NULL) ;
     cholmod_dense *Y = cholmod_l_allocate_dense (X->nrow, X->ncol, X->d, X->xtype, Common) ;
-    if (Y) memcpy (Y->x, X->x, X->d * X->ncol * sizeof (double)) ;
+    if (Y) memcpy (Y->x, X->x, X->d * X->ncol * SSAMD_XENT (X->xtype) * sizeof (double)) ;
+    if (Y && X->z) memcpy (Y->z, X->z, X->d * X->ncol * sizeof (double)) ;
     return Y ;
 }
 
@@ -578,7 +612,8 @@ int cholmod_l_free_dense (cholmod_dense **XH, cholmod_common *Common)
     RETURN_IF_NULL_COMMON (FALSE) ;
     if (!XH || !*XH) return TRUE ;
     cholmod_dense *X = *XH ;
-    cholmod_l_free (X->nzmax, sizeof (double), X->x, Common) ;
+    if (X->x) cholmod_l_free (X->nzmax, SSAMD_XENT (X->xtype) * sizeof (double), X->x, Common) ;
+    if (X->z) cholmod_l_free (X->nzmax, sizeof (double), X->z, Common) ;
     cholmod_l_free (1, sizeof (cholmod_dense), X, Common) ;
     *XH = NULL ;
     return TRUE ;
@@ -600,7 +635,8 @@ int cholmod_l_free_factor (cholmod_factor **LH, cholmod_common *Common)
     if (L->pi) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->pi, Common) ;
     if (L->px) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->px, Common) ;
     if (L->s) cholmod_l_free (L->ssize, sizeof (Int), L->s, Common) ;
-    if (L->x) cholmod_l_free (L->xsize, sizeof (double), L->x, Common) ;
+    if (L->cx_twin) cholmod_l_free_factor ((cholmod_factor **) &L->cx_twin, Common) ;
+    if (L->x) cholmod_l_free (L->xsize, SSAMD_XENT (L->xtype) * sizeof (double), L->x, Common) ;
     cholmod_l_free (1, sizeof (cholmod_factor), L, Common) ;
     *LH = NULL ;
     return TRUE ;

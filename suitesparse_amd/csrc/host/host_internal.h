@@ -15,6 +15,10 @@
 typedef SuiteSparse_long Int ;
 #define EMPTY (-1)
 
+/* doubles per entry of an x array (complex: interleaved pairs; zomplex keeps its
+ * imaginary parts in a z array of its own) */
+#define SSAMD_XENT(xtype) ((size_t) ((xtype) == CHOLMOD_COMPLEX ? 2 : 1))
+
 #define ERROR(status, msg) cholmod_l_error (status, __FILE__, __LINE__, msg, Common)
 
 #define RETURN_IF_NULL_COMMON(result) \
@@ -42,6 +46,11 @@ void ssamd_colcounts (Int n, const Int *Lp, const Int *Li, const Int *Parent, co
 int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cholmod_common *Common) ;
 int ssamd_resolve_use_gpu (cholmod_common *Common) ;
 int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common) ;
+
+/* complex.c: complex / zomplex input through the real embedding */
+int ssamd_complex_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common) ;
+int ssamd_complex_sync_host (cholmod_factor *L, cholmod_common *Common) ;
+cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common) ;
 
 /* cpu_numeric.c */
 int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common) ;

@@ -163,15 +163,20 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (A, FALSE) ;
     (void) F ;
-    if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "A must be real") ; return FALSE ; }
-    if (L->xtype != CHOLMOD_PATTERN && L->xtype != CHOLMOD_REAL)
-    { ERROR (CHOLMOD_INVALID, "invalid xtype of L") ; return FALSE ; }
+    if (A->xtype < CHOLMOD_REAL || A->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "A must be numeric") ; return FALSE ; }
+    /* a numeric L keeps its kind: real for real A, complex for complex or zomplex A
+     * (reference cholmod_super_numeric.c:160-175) */
+    const int want = (A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_COMPLEX ;
+    if (L->xtype != CHOLMOD_PATTERN && L->xtype != want)
+    { ERROR (CHOLMOD_INVALID, "complex type mismatch") ; return FALSE ; }
     if (A->stype > 0) { ERROR (CHOLMOD_INVALID, "symmetric upper case not supported") ; return FALSE ; }
     if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "unsymmetric (A*F) case not built") ; return FALSE ; }
     if (A->nrow != A->ncol || A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
     double b = beta ? beta [0] : 0.0 ;
+    /* complex / zomplex A: the real factorization of the embedded matrix (complex.c) */
+    if (want == CHOLMOD_COMPLEX) return ssamd_complex_super_numeric (A, b, L, Common) ;
     /* GPU or CPU (reference t_cholmod_super_numeric.c:183-192: the GPU is used only
      * if Common->useGPU == 1 and the analysis found one, L->useGPU; a device that
      * cannot be initialised degrades to the CPU path).  A factor that already lives
@@ -227,6 +232,17 @@ int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_
 {
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
+    if (L->cx_twin)
+    {
+        cholmod_factor *T = L->cx_twin ;
+        if (!cholmod_l_refactorize_resident (beta, T, Common)) return FALSE ;
+        int status = Common->status ;
+        L->minor = (T->minor >= T->n) ? L->n : T->minor / 2 ;
+        L->hip_on_device = T->hip_on_device ; L->hip_host_valid = FALSE ;
+        if (T->x && T->hip_host_valid && !ssamd_complex_sync_host (L, Common)) return FALSE ;
+        Common->status = status ;
+        return TRUE ;
+    }
     if (!L->hip_plan) { ERROR (CHOLMOD_INVALID, "no resident matrix") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
     int64_t minor = (int64_t) L->n ;
@@ -247,7 +263,7 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     RETURN_IF_NULL (A, FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     (void) fset ; (void) fsize ;
-    if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "A must be real") ; return FALSE ; }
+    if (A->xtype < CHOLMOD_REAL || A->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "A must be numeric") ; return FALSE ; }
     if (A->nrow != L->n || A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
     if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' factorization not built") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
@@ -287,6 +303,7 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common)
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     if (L->hip_host_valid) return TRUE ;
+    if (L->cx_twin) return ssamd_complex_sync_host (L, Common) ;
     if (!L->hip_plan || !L->hip_on_device) { ERROR (CHOLMOD_INVALID, "no numeric factor") ; return FALSE ; }
     if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
     if (!L->x) return FALSE ;
@@ -302,6 +319,7 @@ int cholmod_l_hip_prepare (cholmod_factor *L, cholmod_common *Common)
     RETURN_IF_NULL (L, FALSE) ;
     if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
+    if (L->cx_twin) return ssamd_ensure_plan ((cholmod_factor *) L->cx_twin, Common) ;
     return ssamd_ensure_plan (L, Common) ;
 }
 
@@ -309,6 +327,7 @@ int cholmod_l_gather_factor (cholmod_factor *L, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
+    if (L->cx_twin) return cholmod_l_gather_factor ((cholmod_factor *) L->cx_twin, Common) ;
     if (!L->hip_plan || !L->hip_on_device) { ERROR (CHOLMOD_INVALID, "no numeric factor") ; return FALSE ; }
     int rc = cholmod_hip_gather_factor ((cholmod_hip_plan *) L->hip_plan) ;
     if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "factor gather failed") ;
@@ -320,6 +339,7 @@ int cholmod_l_hip_stats (cholmod_factor *L, double *stats, cholmod_common *Commo
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (stats, FALSE) ;
+    if (L->cx_twin) L = (cholmod_factor *) L->cx_twin ;
     if (!L->hip_plan) { ERROR (CHOLMOD_INVALID, "no plan") ; return FALSE ; }
     return cholmod_hip_get_stats ((cholmod_hip_plan *) L->hip_plan, stats) == CHOLMOD_HIP_OK ;
 }
@@ -360,16 +380,29 @@ static int super_solve (int which, cholmod_factor *L, cholmod_dense *X, cholmod_
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (X, FALSE) ;
-    if (X->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "X must be real") ; return FALSE ; }
-    if (X->nrow != L->n || X->d < X->nrow) { ERROR (CHOLMOD_INVALID, "X and L dimensions must match") ; return FALSE ; }
+    /* L and X must be of the same kind (reference cholmod_super_solve.c:70-75); a complex
+     * X against a complex L is the real system of the twin on the same bytes (complex.c) */
+    Int ldx = (Int) X->d ;
+    if (L->xtype == CHOLMOD_COMPLEX && L->cx_twin)
+    {
+        if (X->xtype != CHOLMOD_COMPLEX) { ERROR (CHOLMOD_INVALID, "L and X must both be complex") ; return FALSE ; }
+        if (X->nrow != L->n || X->d < X->nrow) { ERROR (CHOLMOD_INVALID, "X and L dimensions must match") ; return FALSE ; }
+        L = (cholmod_factor *) L->cx_twin ;
+        ldx *= 2 ;
+    }
+    else
+    {
+        if (X->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "X must be real") ; return FALSE ; }
+        if (X->nrow != L->n || X->d < X->nrow) { ERROR (CHOLMOD_INVALID, "X and L dimensions must match") ; return FALSE ; }
+    }
     Common->status = CHOLMOD_OK ;
     if (solve_on_host (L, Common))
     {
-        ssamd_cpu_super_solve (which, L, X->x, (Int) X->ncol, (Int) X->d) ;
+        ssamd_cpu_super_solve (which, L, X->x, (Int) X->ncol, ldx) ;
         return Common->blas_ok ;
     }
     if (!factor_on_device (L, Common)) return FALSE ;
-    int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, X->x, (int64_t) X->ncol, (int64_t) X->d) ;
+    int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, X->x, (int64_t) X->ncol, (int64_t) ldx) ;
     if (rc != CHOLMOD_HIP_OK) return map_hip_status (rc, Common, "HIP solve failed") ;
     return Common->blas_ok ;
 }
@@ -399,6 +432,23 @@ cholmod_dense *cholmod_l_solve (int sys, cholmod_factor *L, cholmod_dense *B, ch
     return X ;
 }
 
+/* entry (k, r) of a dense matrix of any numeric kind */
+static inline void dense_get (const cholmod_dense *B, Int k, Int r, double *re, double *im)
+{
+    size_t q = (size_t) k + (size_t) r * B->d ;
+    const double *x = B->x ;
+    if (B->xtype == CHOLMOD_COMPLEX) { *re = x [2*q] ; *im = x [2*q+1] ; }
+    else { *re = x [q] ; *im = (B->xtype == CHOLMOD_ZOMPLEX) ? ((const double *) B->z) [q] : 0.0 ; }
+}
+
+static inline void dense_put (cholmod_dense *X, Int k, Int r, double re, double im)
+{
+    size_t q = (size_t) k + (size_t) r * X->d ;
+    double *x = X->x ;
+    if (X->xtype == CHOLMOD_COMPLEX) { x [2*q] = re ; x [2*q+1] = im ; }
+    else { x [q] = re ; if (X->xtype == CHOLMOD_ZOMPLEX) ((double *) X->z) [q] = im ; }
+}
+
 int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_sparse *Bset,
     cholmod_dense **X_Handle, cholmod_sparse **Xset_Handle, cholmod_dense **Y_Handle,
     cholmod_dense **E_Handle, cholmod_common *Common)
@@ -410,61 +460,78 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
     (void) Xset_Handle ; (void) Y_Handle ; (void) E_Handle ;
     if (Bset) { ERROR (CHOLMOD_NOT_INSTALLED, "sparse right-hand-side subsets not built") ; return FALSE ; }
     if (sys < CHOLMOD_A || sys > CHOLMOD_Pt) { ERROR (CHOLMOD_INVALID, "invalid system") ; return FALSE ; }
-    if (B->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_INVALID, "B must be real") ; return FALSE ; }
+    if (B->xtype < CHOLMOD_REAL || B->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "B must be numeric") ; return FALSE ; }
     if (B->d < L->n || B->nrow != L->n) { ERROR (CHOLMOD_INVALID, "dimensions of L and B do not match") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
     Int n = (Int) L->n, nrhs = (Int) B->ncol ;
+    const int Lcomplex = (L->xtype == CHOLMOD_COMPLEX) ;
+    const int Bcomplex = (B->xtype != CHOLMOD_REAL) ;
+    /* kind of X (reference cholmod_solve.c:1112-1134): real if L and B are real (P, Pt:
+     * if B is real), else the preferred complex kind */
+    const int ctype = Common->prefer_zomplex ? CHOLMOD_ZOMPLEX : CHOLMOD_COMPLEX ;
+    int xtype = (sys == CHOLMOD_P || sys == CHOLMOD_Pt) ? (Bcomplex ? ctype : CHOLMOD_REAL)
+              : (!Lcomplex && !Bcomplex) ? CHOLMOD_REAL : ctype ;
     cholmod_dense *X = *X_Handle ;
-    if (!X || X->nrow != (size_t) n || X->ncol != (size_t) nrhs || X->xtype != CHOLMOD_REAL)
+    if (!X || X->nrow != (size_t) n || X->ncol != (size_t) nrhs || X->xtype != xtype)
     {
         cholmod_l_free_dense (X_Handle, Common) ;
-        X = cholmod_l_allocate_dense (n, nrhs, n, CHOLMOD_REAL, Common) ;
+        X = cholmod_l_allocate_dense (n, nrhs, n, xtype, Common) ;
         if (!X) return FALSE ;
         *X_Handle = X ;
     }
     const Int *Perm = L->Perm ;
-    double *Bx = B->x, *Xx = X->x ;
-    Int dB = (Int) B->d, dX = (Int) X->d ;
-    if (sys == CHOLMOD_P)
+    double re, im ;
+    if (sys == CHOLMOD_P || sys == CHOLMOD_Pt || sys == CHOLMOD_D)
     {
-        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Bx [Perm [k] + r*dB] ;
-        return TRUE ;
-    }
-    if (sys == CHOLMOD_Pt)
-    {
-        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [Perm [k] + r*dX] = Bx [k + r*dB] ;
-        return TRUE ;
-    }
-    if (sys == CHOLMOD_D)
-    {
-        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Bx [k + r*dB] ;
+        for (Int r = 0 ; r < nrhs ; r++)
+            for (Int k = 0 ; k < n ; k++)
+            {
+                dense_get (B, sys == CHOLMOD_P ? Perm [k] : k, r, &re, &im) ;
+                dense_put (X, sys == CHOLMOD_Pt ? Perm [k] : k, r, re, im) ;
+            }
         return TRUE ;
     }
     int which = (sys == CHOLMOD_A || sys == CHOLMOD_LDLt) ? 0
               : (sys == CHOLMOD_L || sys == CHOLMOD_LD) ? 1 : 2 ;
-    int on_host = solve_on_host (L, Common) ;
-    if (!on_host && !factor_on_device (L, Common)) return FALSE ;
-    cholmod_dense *Y = cholmod_l_allocate_dense (n, nrhs, n, CHOLMOD_REAL, Common) ;
+    /* the system the engine sees: a complex L is the real twin of order 2n acting on
+     * interleaved vectors (complex.c); a real L against a complex B solves the real and
+     * the imaginary parts as 2 nrhs real right-hand sides (the reference's "dual" Y,
+     * cholmod_solve.c:1553) */
+    cholmod_factor *Lr = L ;
+    if (Lcomplex)
+    {
+        if (!L->cx_twin) { ERROR (CHOLMOD_INVALID, "complex L without its engine factor") ; return FALSE ; }
+        Lr = (cholmod_factor *) L->cx_twin ;
+    }
+    const Int yn = Lcomplex ? 2 * n : n ;
+    const Int ycols = (!Lcomplex && Bcomplex) ? 2 * nrhs : nrhs ;
+    int on_host = solve_on_host (Lr, Common) ;
+    if (!on_host && !factor_on_device (Lr, Common)) return FALSE ;
+    cholmod_dense *Y = cholmod_l_allocate_dense (yn, ycols, yn, CHOLMOD_REAL, Common) ;
     if (!Y) return FALSE ;
     double *Yx = Y->x ;
-    if (sys == CHOLMOD_A)
-        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [Perm [k] + r*dB] ;
-    else
-        for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Yx [k + r*n] = Bx [k + r*dB] ;
+    for (Int r = 0 ; r < nrhs ; r++)
+        for (Int k = 0 ; k < n ; k++)
+        {
+            dense_get (B, sys == CHOLMOD_A ? Perm [k] : k, r, &re, &im) ;
+            if (Lcomplex) { Yx [2*k + r*yn] = re ; Yx [2*k+1 + r*yn] = im ; }
+            else { Yx [k + r*yn] = re ; if (Bcomplex) Yx [k + (nrhs + r)*yn] = im ; }
+        }
     int ok = TRUE ;
-    if (on_host) ssamd_cpu_super_solve (which, L, Yx, nrhs, n) ;
+    if (on_host) ssamd_cpu_super_solve (which, Lr, Yx, ycols, yn) ;
     else
     {
-        int rc = cholmod_hip_solve ((cholmod_hip_plan *) L->hip_plan, which, Yx, nrhs, n) ;
+        int rc = cholmod_hip_solve ((cholmod_hip_plan *) Lr->hip_plan, which, Yx, ycols, yn) ;
         ok = (rc == CHOLMOD_HIP_OK) ? TRUE : map_hip_status (rc, Common, "HIP solve failed") ;
     }
     if (ok)
-    {
-        if (sys == CHOLMOD_A)
-            for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [Perm [k] + r*dX] = Yx [k + r*n] ;
-        else
-            for (Int r = 0 ; r < nrhs ; r++) for (Int k = 0 ; k < n ; k++) Xx [k + r*dX] = Yx [k + r*n] ;
-    }
+        for (Int r = 0 ; r < nrhs ; r++)
+            for (Int k = 0 ; k < n ; k++)
+            {
+                if (Lcomplex) { re = Yx [2*k + r*yn] ; im = Yx [2*k+1 + r*yn] ; }
+                else { re = Yx [k + r*yn] ; im = Bcomplex ? Yx [k + (nrhs + r)*yn] : 0.0 ; }
+                dense_put (X, sys == CHOLMOD_A ? Perm [k] : k, r, re, im) ;
+            }
     cholmod_l_free_dense (&Y, Common) ;
     return ok ;
 }
