@@ -43,7 +43,7 @@ static inline ObThresholds outer_block_thresholds ()
 struct PersistCfg { i64 min_tiles ; int tile, sr, sc, wpc, groups ; } ;
 static inline PersistCfg persist_cfg ()
 {
-    PersistCfg c {32768, 64, 8, 8, 4, 2} ;
+    PersistCfg c {32768, 64, 8, 20, 5, 1} ;
     if (const char *e = getenv ("CHOLMOD_HIP_PERSIST_TILES")) c.min_tiles = atoll (e) ;
     if (const char *e = getenv ("CHOLMOD_HIP_PERSIST_SHAPE"))
     {
@@ -325,7 +325,9 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     } ;
     (void) maxrows ;
     const PersistCfg pcfg = persist_cfg () ;
-    const bool persist_on = !(flags & CHOLMOD_HIP_NO_PERSISTENT_UPDATE) ;
+    // opt-in (flag, or the test / tuning variable CHOLMOD_HIP_PERSIST_TILES): measured 3.6 %
+    // slower than independent tiles at the headline size, see DESIGN.md section 4
+    const bool persist_on = (flags & CHOLMOD_HIP_PERSISTENT_UPDATE) || getenv ("CHOLMOD_HIP_PERSIST_TILES") ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
         for (int pass = 0 ; pass < 2 ; pass++)

@@ -270,48 +270,14 @@ __device__ __forceinline__ double readlane_f64 (double v, int l)
     hi = __builtin_amdgcn_readlane (hi, l) ;
     return __hiloint2double (hi, lo) ;
 }
-template <bool TIMED>
-__global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info, long long *tim)
+// The elimination of a <= 64 x 64 block held k-major in LDS (T [k * PF2_LD + i] = A(i,k),
+// identity-padded to nblk 16-column panels).
+// *s_fail (preset to -1) receives the first column with a pivot <= 0.  All 256
+// threads of the workgroup call it; it ends with a barrier.
+template <typename Tick>
+__device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, int tid, Tick tick)
 {
-    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
-    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
-    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
-    __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;   // T[k][i] = L(i,k)
-    __shared__ int s_fail ;
-    __builtin_amdgcn_s_setprio (3) ;
-    PfGroup G = g [blockIdx.x] ;
-    double *A = Lx + G.off ;
-    int nb = G.nb, lda = G.lda ;
-    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
-    if (info [G.front] != 0)
-    {
-        for (int k = wave ; k < nb ; k += 4)
-            if (lane >= k && lane < nb) A [lane + (i64) k * lda] = 0.0 ;
-        return ;
-    }
-    int nbp = (nb + 15) / 16 * 16 ;
-    int nblk = nbp / 16 ;
-    // stage: thread = (row i, columns wave + 4 q), all 16 loads in flight
-    {
-        int i = lane ;
-        int ic = i < nb ? i : nb - 1 ;
-        double tmp [16] ;
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++)
-        {
-            int k = wave + 4 * q ;
-            tmp [q] = A [ic + (i64) (k < nb ? k : nb - 1) * lda] ;
-        }
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++)
-        {
-            int k = wave + 4 * q ;
-            T [k * PF2_LD + i] = (i < nb && k < nb) ? tmp [q] : (i == k ? 1.0 : 0.0) ;
-        }
-    }
-    if (tid == 0) s_fail = -1 ;
-    __syncthreads () ;
-    tick (0) ;
+    const int lane = tid & 63, wave = tid >> 6 ;
     int lr = lane & 15, lk = lane >> 4 ;
     for (int jb = 0 ; jb < nblk ; jb++)
     {
@@ -367,12 +333,12 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
 #pragma unroll
                 for (int c = 0 ; c < 16 ; c++) T [(c0 + c) * PF2_LD + row] = a [c] ;
             }
-            if (fail >= 0 && lane == 0) s_fail = fail ;
+            if (fail >= 0 && lane == 0) (*s_fail) = fail ;
             tick (2) ;
         }
         __syncthreads () ;
         tick (3) ;
-        if (s_fail >= 0) break ;
+        if ((*s_fail) >= 0) break ;
         // trailing tiles (ti >= tj > jb), dealt round-robin to the waves
         int nt = nblk - 1 - jb ;
         int ntile = nt * (nt + 1) / 2 ;
@@ -400,6 +366,51 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
         __syncthreads () ;
         tick (5) ;
     }
+}
+
+template <bool TIMED>
+__global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info, long long *tim)
+{
+    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
+    __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;   // T[k][i] = L(i,k)
+    __shared__ int s_fail ;
+    __builtin_amdgcn_s_setprio (3) ;
+    PfGroup G = g [blockIdx.x] ;
+    double *A = Lx + G.off ;
+    int nb = G.nb, lda = G.lda ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    if (info [G.front] != 0)
+    {
+        for (int k = wave ; k < nb ; k += 4)
+            if (lane >= k && lane < nb) A [lane + (i64) k * lda] = 0.0 ;
+        return ;
+    }
+    int nbp = (nb + 15) / 16 * 16 ;
+    int nblk = nbp / 16 ;
+    // stage: thread = (row i, columns wave + 4 q), all 16 loads in flight
+    {
+        int i = lane ;
+        int ic = i < nb ? i : nb - 1 ;
+        double tmp [16] ;
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = wave + 4 * q ;
+            tmp [q] = A [ic + (i64) (k < nb ? k : nb - 1) * lda] ;
+        }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            int k = wave + 4 * q ;
+            T [k * PF2_LD + i] = (i < nb && k < nb) ? tmp [q] : (i == k ? 1.0 : 0.0) ;
+        }
+    }
+    if (tid == 0) s_fail = -1 ;
+    __syncthreads () ;
+    tick (0) ;
+    pf_eliminate (T, nblk, &s_fail, tid, tick) ;
     int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + fail + 1 ;
     // write-back of the lower triangle (columns at / beyond a failed pivot: zero)
@@ -434,6 +445,102 @@ __host__ __device__ inline size_t trsm_mfma_lds_bytes (int ldl)
 {
     return (size_t) (ldl * ldl + (ldl / 16) * 256) * sizeof (double) ;
 }
+// The two inner stages of the panel solve.
+// Ls [k * ldl + c] = -L11(c,k) below the diagonal, L11(k,k) on it (identity-padded);
+// Wd [b][k][c] receives inv(L_bb)(c,k) of the 16 x 16 diagonal blocks (wave b).
+template <typename Tick>
+__device__ __forceinline__ void trsm_diag_inverses (const double *Ls, int ldl, double *Wd, int nblk,
+    int lane, int wave, Tick tick)
+{
+    if (wave < nblk)
+    {
+        int b = wave ;
+        int rl = lane & 15 ;
+        double Lr [16], acc [16], y [16] ;
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++) Lr [e] = Ls [(16 * b + e) * ldl + 16 * b + rl] ;   // -L_bb(rl,e), diag +
+        double rdv = 0.0 ;
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++) if (rl == e) rdv = Lr [e] ;
+        {
+            // 1 / diagonal: v_rcp_f64 + two Newton steps
+            double x = __builtin_amdgcn_rcp (rdv) ;
+            double t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
+            t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
+            rdv = x ;
+        }
+        tick (1) ;
+#pragma unroll
+        for (int r = 0 ; r < 16 ; r++) acc [r] = (r == rl) ? 1.0 : 0.0 ;
+#pragma unroll
+        for (int e = 0 ; e < 16 ; e++)
+        {
+            double mu [16] ;
+#pragma unroll
+            for (int r = e + 1 ; r < 16 ; r++) mu [r] = readlane_f64 (Lr [e], r) ;
+            __builtin_amdgcn_sched_barrier (0) ;
+            y [e] = acc [e] * readlane_f64 (rdv, e) ;
+#pragma unroll
+            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (mu [r], y [e], acc [r]) ;
+            __builtin_amdgcn_sched_barrier (0) ;
+        }
+        if (lane < 16)
+        {
+#pragma unroll
+            for (int r = 0 ; r < 16 ; r++) Wd [b * 256 + lane * 16 + r] = y [r] ;     // Wd[b][k=q][c=r]
+        }
+    }
+}
+
+// bj [jj][r] = B(row lr of the wave's 16 rows, column 16 jj + lk + 4 r) in the
+// accumulator layout; solves X = B inv(L11)' block column by block column and stores it.
+template <typename Tick>
+__device__ __forceinline__ void trsm_solve_rows (const d4 (&bj) [4], int nblk, const double *Ls, int ldl,
+    const double *Wd, int lane, int nvalid, bool rok, int nb, double *B, i64 lda, Tick tick)
+{
+    const int lr = lane & 15, lk = lane >> 4 ;
+    d4 xr [4] ;
+#pragma unroll
+    for (int j = 0 ; j < 4 ; j++)
+    {
+        if (j < nblk)
+        {
+            d4 acc = bj [j] ;
+#pragma unroll
+            for (int i = 0 ; i < 4 ; i++)
+            {
+                if (i < j)
+                {
+#pragma unroll
+                    for (int s4 = 0 ; s4 < 4 ; s4++)
+                    {
+                        double b = Ls [(16 * i + 4 * s4 + lk) * ldl + 16 * j + lr] ;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, xr [i][s4], acc, 0, 0, 0) ;
+                    }
+                }
+            }
+            tick (3) ;
+            d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
+#pragma unroll
+            for (int s4 = 0 ; s4 < 4 ; s4++)
+            {
+                double b = Wd [j * 256 + (4 * s4 + lk) * 16 + lr] ;
+                x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, acc [s4], x, 0, 0, 0) ;
+            }
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int c = 16 * j + lk + 4 * r ;
+                double v = (c < nvalid) ? x [r] : 0.0 ;
+                x [r] = v ;
+                if (rok && c < nb) B [(i64) c * lda] = v ;
+            }
+            xr [j] = x ;
+            tick (5) ;
+        }
+    }
+}
+
 template <bool TIMED>
 __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     double *Lx, const i32 *info, int ldl, long long *tim)
@@ -503,90 +610,14 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     // inverse of the 16x16 diagonal blocks: wave b; lane r < 16 holds row r of
     // the block in registers and solves column r of the inverse by forward
     // substitution, the (lane-uniform) multipliers travelling by v_readlane
-    if (wave < nblk)
-    {
-        int b = wave ;
-        int rl = lane & 15 ;
-        double Lr [16], acc [16], y [16] ;
-#pragma unroll
-        for (int e = 0 ; e < 16 ; e++) Lr [e] = Ls [(16 * b + e) * ldl + 16 * b + rl] ;   // -L_bb(rl,e), diag +
-        double rdv = 0.0 ;
-#pragma unroll
-        for (int e = 0 ; e < 16 ; e++) if (rl == e) rdv = Lr [e] ;
-        {
-            // 1 / diagonal: v_rcp_f64 + two Newton steps
-            double x = __builtin_amdgcn_rcp (rdv) ;
-            double t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
-            t = __builtin_fma (-rdv, x, 1.0) ; x = __builtin_fma (x, t, x) ;
-            rdv = x ;
-        }
-        tick (1) ;
-#pragma unroll
-        for (int r = 0 ; r < 16 ; r++) acc [r] = (r == rl) ? 1.0 : 0.0 ;
-#pragma unroll
-        for (int e = 0 ; e < 16 ; e++)
-        {
-            double mu [16] ;
-#pragma unroll
-            for (int r = e + 1 ; r < 16 ; r++) mu [r] = readlane_f64 (Lr [e], r) ;
-            __builtin_amdgcn_sched_barrier (0) ;
-            y [e] = acc [e] * readlane_f64 (rdv, e) ;
-#pragma unroll
-            for (int r = e + 1 ; r < 16 ; r++) acc [r] = __builtin_fma (mu [r], y [e], acc [r]) ;
-            __builtin_amdgcn_sched_barrier (0) ;
-        }
-        if (lane < 16)
-        {
-#pragma unroll
-            for (int r = 0 ; r < 16 ; r++) Wd [b * 256 + lane * 16 + r] = y [r] ;     // Wd[b][k=q][c=r]
-        }
-    }
+    trsm_diag_inverses (Ls, ldl, Wd, nblk, lane, wave, tick) ;
     __syncthreads () ;
     tick (2) ;
     // The accumulator layout of v_mfma_f64_16x16x4 (lane (lr,lk) holds columns
     // lk + 4 r, r = 0..3) IS its A-operand layout for the k-steps s = r (k = 4 s +
     // lk): a solved block X_i and the intermediate B_j - sum feed the next MFMAs
     // straight from registers, no LDS round trip, no barrier.
-    d4 xr [4] ;
-#pragma unroll
-    for (int j = 0 ; j < 4 ; j++)
-    {
-        if (j < nblk)
-        {
-            d4 acc = bj [j] ;
-#pragma unroll
-            for (int i = 0 ; i < 4 ; i++)
-            {
-                if (i < j)
-                {
-#pragma unroll
-                    for (int s4 = 0 ; s4 < 4 ; s4++)
-                    {
-                        double b = Ls [(16 * i + 4 * s4 + lk) * ldl + 16 * j + lr] ;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, xr [i][s4], acc, 0, 0, 0) ;
-                    }
-                }
-            }
-            tick (3) ;
-            d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
-#pragma unroll
-            for (int s4 = 0 ; s4 < 4 ; s4++)
-            {
-                double b = Wd [j * 256 + (4 * s4 + lk) * 16 + lr] ;
-                x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, acc [s4], x, 0, 0, 0) ;
-            }
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
-            {
-                int c = 16 * j + lk + 4 * r ;
-                double v = (c < nvalid) ? x [r] : 0.0 ;
-                x [r] = v ;
-                if (rok && c < nb) B [(i64) c * lda] = v ;
-            }
-            xr [j] = x ;
-            tick (5) ;
-        }
-    }
+    trsm_solve_rows (bj, nblk, Ls, ldl, Wd, lane, nvalid, rok, nb, B, lda, tick) ;
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
@@ -1091,7 +1122,7 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
 // contraction and the read-modify-write (or assignment) of the target.
 template <int BM, int BN, int BK, bool DB>
 __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
-    double *Lx, double *CB, double *sm)
+    double *Lx, double *CB, double *sm, int tid)
 {
     constexpr int LDT = BM + 16 ;
     constexpr int LDU = BN + 16 ;
@@ -1103,7 +1134,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     int mrem = G.m - row0, nrem = G.n - col0 ;
     i64 lda = G.lda ;
     int K = G.k ;
-    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    int lane = tid & 63, wave = tid >> 6 ;
     int wm = wave & 1, wn = wave >> 1 ;
 
     // element (idx % BM, idx / BM) of a slab, idx = tid + 256 q: the row is the
@@ -1233,7 +1264,7 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     int I, J ;
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
-    update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm) ;
+    update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm, (int) threadIdx.x) ;
 }
 
 // ---- dense update, persistent form for the big top-of-tree regions -------------
@@ -1308,7 +1339,13 @@ __global__ void __launch_bounds__(256, MINW) k_update2p (const GemmGroup *g,
         }
         const int I = a * G.p_sr + slot % G.p_sr, J = b * G.p_sc + slot / G.p_sr ;
         if (I >= G.mt || J >= G.nt || (G.tri && I < J)) continue ;
-        update_tile<BM, BN, BK, false> (G, I, J, Lx, CB, sm) ;
+        // the thread index through an opaque move: everything derived from it (LDS
+        // addresses, row clamps, epilogue indices) then belongs to this iteration and is
+        // not hoisted out of the ticket loop, where it would stay live across the whole
+        // tile (124 instead of 88 VGPRs, one wave per SIMD less)
+        int tid ;
+        asm volatile ("v_mov_b32 %0, %1" : "=v" (tid) : "v" ((int) threadIdx.x)) ;
+        update_tile<BM, BN, BK, false> (G, I, J, Lx, CB, sm, tid) ;
     }
 }
 
