@@ -283,7 +283,7 @@ def main():
             # same workload (offline, profiles/README.md): FETCH_SIZE x 2 + WRITE_SIZE x 1, the
             # calibration measured on known-byte kernels
             lp = S.launch_profile(Lf)
-            upd = np.where((lp["kind"] == 5) | (lp["kind"] == 9))[0]
+            upd = np.where(lp["kind"] == 5)[0]
             pmc_by_workload = {"poisson3d_200^3_geometricND_leaf4": "r02h_pmc_summary_poisson200_top48.json"}
             pj = None
             if wname in pmc_by_workload and world == 1:

@@ -42,10 +42,6 @@ extern "C" {
 #define CHOLMOD_HIP_WIDE_OB       128    /* tests: 2048-column outer blocks everywhere  */
 #define CHOLMOD_HIP_NO_CB_ASSIGN   2048   /* tuning: zero-fill every contribution block and
                                            extend-add before the dense phase           */
-#define CHOLMOD_HIP_PERSISTENT_UPDATE 512 /* tuning: the big top-of-tree update regions (>= 32768
-                                          * tiles) through the persistent, XCD-lockstep form of
-                                          * the update kernel (k_update2p): a fraction of the HBM
-                                          * traffic, 3.6 % slower at Poisson 200^3 */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
@@ -197,8 +193,6 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [13] seconds in assemble (memset + A scatter)
  *  [24] device seconds of the last cholmod_hip_solve (its kernels, without the
  *       copies of the right-hand side)
- *  [26] persistent update launches (k_update2p; they are also counted in [6]-[8],
- *       [16])   [27] their flops   [28] their algorithmic bytes   [29] their seconds
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
 #define CHOLMOD_HIP_NSTATS 32
@@ -207,7 +201,7 @@ int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 /* The launch list of the plan and, after a factorization with profiling on, the
  * device milliseconds of every launch (tuning; tools/launch_profile.py).
  * kind: 0 zero, 1 extend-add, 2 potrf, 3 trsm, 4 update(128), 5 update(64),
- * 7 all-reduce, 8 thin fronts, 9 persistent update.  Fills at most cap entries of the arrays that are
+ * 7 all-reduce, 8 thin fronts.  Fills at most cap entries of the arrays that are
  * not NULL, returns the number of launches. */
 int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
     int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;

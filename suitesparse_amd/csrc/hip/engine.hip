@@ -38,29 +38,13 @@ static inline ObThresholds outer_block_thresholds ()
     const char *e3 = getenv ("CHOLMOD_HIP_OB4096_ROWS") ;
     return ObThresholds {e1 ? atoi (e1) : 4000, e2 ? atoi (e2) : 8000, e3 ? atoi (e3) : 24000} ;
 }
-// Persistent form of the update kernel (k_update2p) for regions of at least
-// `min_tiles` 64 x 64 tiles: super-tile shape in tiles, workgroups per CU.
-struct PersistCfg { i64 min_tiles ; int tile, sr, sc, wpc, groups ; } ;
-static inline PersistCfg persist_cfg ()
-{
-    PersistCfg c {32768, 64, 8, 20, 5, 1} ;
-    if (const char *e = getenv ("CHOLMOD_HIP_PERSIST_TILES")) c.min_tiles = atoll (e) ;
-    if (const char *e = getenv ("CHOLMOD_HIP_PERSIST_SHAPE"))
-    {
-        int t = 0, a = 0, b = 0, w = 0, g = 1 ;
-        if (sscanf (e, "%d:%dx%d:%d:%d", &t, &a, &b, &w, &g) >= 4 && (t == 64 || t == 128) && a > 0 && b > 0 && w > 0
-            && g >= 1 && g <= UPD_MAX_LISTS / 8)
-        { c.tile = t ; c.sr = a ; c.sc = b ; c.wpc = w ; c.groups = g ; }
-    }
-    return c ;
-}
 static inline int outer_block (int maxrows, const ObThresholds &t)
 {
     return maxrows >= t.t3 ? 4096 : maxrows >= t.t2 ? 2048 : maxrows >= t.t1 ? 1024 : MB ;
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_UPD_PERSIST, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -76,7 +60,6 @@ struct Launch {
     int ar_ld = 0, ar_r0 = 0, ar_nc = 0 ;   // ar_off (column o0), ld ar_ld, rows >= ar_r0 of ar_nc columns
     int ar_g0 = 0, ar_gn = 1 ;              // ... over the ranks [ar_g0, ar_g0+ar_gn)
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
-    int tile = 0 ;                  // K_UPD_PERSIST: tile size (SMALL or BIG)
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -160,7 +143,6 @@ struct Schedule {
     std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
     int nevents = 0 ;
-    int npersist = 0 ;              // K_UPD_PERSIST launches (one ticket-counter block each)
 } ;
 
 template <typename T> static T *dupload (const std::vector<T> &v, hipError_t &err)
@@ -282,11 +264,11 @@ struct cholmod_hip_plan {
     double *d_Lx = nullptr, *d_cb = nullptr ;
     ZeroGroup *d_zg = nullptr ; EaGroup *d_eg = nullptr ; PfGroup *d_pg = nullptr ;
     TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ; i32 *d_sm = nullptr ;
-    unsigned int *d_heads = nullptr ;       // ticket counters of the persistent update launches
     double cur_beta = 0 ;
     // resident input matrix
     i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
     i64 s_nz = 0 ; bool s_unpacked = false ;
+    i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace
     double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
     i64 *d_perm = nullptr ;
@@ -324,10 +306,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow, obt) ;
     } ;
     (void) maxrows ;
-    const PersistCfg pcfg = persist_cfg () ;
-    // opt-in (flag, or the test / tuning variable CHOLMOD_HIP_PERSIST_TILES): measured 3.6 %
-    // slower than independent tiles at the headline size, see DESIGN.md section 4
-    const bool persist_on = (flags & CHOLMOD_HIP_PERSISTENT_UPDATE) || getenv ("CHOLMOD_HIP_PERSIST_TILES") ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
         for (int pass = 0 ; pass < 2 ; pass++)
@@ -337,15 +315,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             int T = pass ? SMALL : BIG ;
             Launch L {pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
             i64 tiles = 0 ;
-            std::vector<GemmGroup> pers ;
             for (auto &G : v)
             {
-                // the big top-of-tree regions: one persistent launch each (k_update2p)
-                {
-                    i64 mt = (G.m + SMALL - 1) / SMALL, nt = (G.n + SMALL - 1) / SMALL ;
-                    i64 c64 = G.tri ? nt * (nt + 1) / 2 + (mt - nt) * nt : mt * nt ;
-                    if (persist_on && c64 >= pcfg.min_tiles) { pers.push_back (G) ; continue ; }
-                }
                 G.mt = (G.m + T - 1) / T ; G.nt = (G.n + T - 1) / T ;
                 i64 cnt = G.tri ? (i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt
                                 : (i64) G.mt * G.nt ;
@@ -378,31 +349,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             L.ng = (int) (S.gg.size () - L.goff) ;
             L.grid = (int) tiles ;
             if (L.ng) S.launches.push_back (L) ;
-            for (auto &G : pers)
-            {
-                const int PT = pcfg.tile ;
-                G.mt = (G.m + PT - 1) / PT ; G.nt = (G.n + PT - 1) / PT ;
-                G.p_sr = pcfg.sr ; G.p_sc = pcfg.sc ; G.p_groups = pcfg.groups ;
-                const i64 AT = (G.mt + G.p_sr - 1) / G.p_sr, BT = (G.nt + G.p_sc - 1) / G.p_sc ;
-                i64 nst = 0 ;
-                if (!G.tri) nst = AT * BT ;
-                else for (i64 b = 0 ; b < BT ; b++) nst += AT - (b * G.p_sc) / G.p_sr ;
-                G.p_nst = (i32) nst ;
-                i64 mine = nst > G.tile_add ? (nst - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
-                if (mine == 0) continue ;
-                G.p_head = S.npersist++ ;
-                G.swz = 2 ;
-                Launch Lq {K_UPD_PERSIST, 256 * pcfg.wpc, 1, S.gg.size (), 0, 0} ;
-                Lq.tile = PT ;
-                double elems = G.tri ? (double) G.n * (G.n + 1) / 2 + (double) (G.m - G.n) * G.n
-                                     : (double) G.m * G.n ;
-                double share = G.tile_mul == 1 ? 1.0 : std::min (1.0, (double) mine / (double) nst) ;
-                Lq.flops = 2.0 * elems * G.k * share ;
-                Lq.aux = (int) G.k ;
-                Lq.bytes = ((G.assign ? 8.0 : 16.0) * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
-                S.gg.push_back (G) ;
-                S.launches.push_back (Lq) ;
-            }
             v.clear () ;
         }
     } ;
@@ -1121,8 +1067,8 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_heads} ;
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1169,8 +1115,6 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_pg = dupload (P->sch.pg, e) ; HIPCHK (e) ;
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
-    if (P->sch.npersist > 0)
-        HIPCHK (hipMalloc ((void **) &P->d_heads, (size_t) P->sch.npersist * UPD_MAX_LISTS * UPD_HEAD_STRIDE * sizeof (unsigned int))) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
     double tu2 = pnow () ;
@@ -1343,14 +1287,6 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
-        case K_UPD_PERSIST:
-            if (L.tile == BIG)
-                hipLaunchKernelGGL ((k_update2p<BIG, BIG, BKK, 2>), dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_gg + L.goff, P->d_Lx, P->d_cb, P->d_heads) ;
-            else
-                hipLaunchKernelGGL ((k_update2p<SMALL, SMALL, BKK, 2>), dim3 (L.grid), dim3 (256), 0, st,
-                    P->d_gg + L.goff, P->d_Lx, P->d_cb, P->d_heads) ;
-            break ;
     }
     if (!serial && L.rec_ev >= 0) HIPCHK (hipEventRecord (P->sync_ev [L.rec_ev], st)) ;
     return CHOLMOD_HIP_OK ;
@@ -1379,12 +1315,23 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
-    if (P->d_heads) HIPCHK (hipMemsetAsync (P->d_heads, 0, (size_t) P->sch.npersist * UPD_MAX_LISTS * UPD_HEAD_STRIDE * sizeof (unsigned int), st)) ;
-    if (P->n > 0)
+    if (P->n > 0 && P->amap_valid)
     {
+        // the resident S was assembled before: stream it through its map
+        if (P->s_nz > 0)
+            hipLaunchKernelGGL (k_assemble_mapped, dim3 ((unsigned) ((P->s_nz + 255) / 256)), dim3 (256), 0, st,
+                P->s_nz, P->d_amap, P->d_Sx, P->d_Lx) ;
+        if (beta != 0.0)
+            hipLaunchKernelGGL (k_add_beta, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+                P->n, P->d_supermap, P->d_fr, P->d_Lx, beta) ;
+    }
+    else if (P->n > 0)
+    {
+        HIPCHK (hipMemsetAsync (P->d_amap, 0xFF, std::max<i64> (P->s_nz, 1) * sizeof (i64), st)) ;     // -1: not in L
         hipLaunchKernelGGL (k_assemble, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
             P->n, P->d_Sp, P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx,
-            P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta) ;
+            P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta, P->d_amap) ;
+        P->amap_valid = true ;
     }
     if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
     int poisoned = CHOLMOD_HIP_OK ;
@@ -1446,8 +1393,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_SMALL || L.kind == K_UPD_PERSIST) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
-        if (L.kind == K_UPD_PERSIST) { S [26] += 1 ; S [27] += L.flops ; S [28] += L.bytes ; }
+        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
@@ -1469,7 +1415,6 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             switch (L.kind)
             {
                 case K_UPD_SMALL: S [6] += sec ; if (L.aux < MB) { S [23] += sec ; } break ;
-                case K_UPD_PERSIST: S [6] += sec ; S [29] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;
@@ -1764,12 +1709,13 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int
     else nz = Sp [n] ;
     if (nz > P->s_nz || !P->d_Sp)
     {
-        if (P->d_Sp) { (void) hipFree (P->d_Sp) ; (void) hipFree (P->d_Si) ; (void) hipFree (P->d_Sx) ; (void) hipFree (P->d_Snz) ; }
-        P->d_Sp = P->d_Si = P->d_Snz = nullptr ; P->d_Sx = nullptr ;
+        if (P->d_Sp) { (void) hipFree (P->d_Sp) ; (void) hipFree (P->d_Si) ; (void) hipFree (P->d_Sx) ; (void) hipFree (P->d_Snz) ; (void) hipFree (P->d_amap) ; }
+        P->d_Sp = P->d_Si = P->d_Snz = P->d_amap = nullptr ; P->d_Sx = nullptr ;
         HIPCHK (hipMalloc ((void **) &P->d_Sp, (n + 1) * sizeof (i64))) ;
         HIPCHK (hipMalloc ((void **) &P->d_Snz, std::max<i64> (n, 1) * sizeof (i64))) ;
         HIPCHK (hipMalloc ((void **) &P->d_Si, std::max<i64> (nz, 1) * sizeof (i64))) ;
         HIPCHK (hipMalloc ((void **) &P->d_Sx, std::max<i64> (nz, 1) * sizeof (double))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_amap, std::max<i64> (nz, 1) * sizeof (i64))) ;
         P->s_nz = nz ;
     }
     HIPCHK (hipMemcpyAsync (P->d_Sp, Sp, (n + 1) * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
@@ -1778,6 +1724,7 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int
     if (nz) HIPCHK (hipMemcpyAsync (P->d_Sx, Sx, nz * sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     P->s_unpacked = (Snz != nullptr) ;
+    P->amap_valid = false ;         // a new pattern may have come with the new values
     return CHOLMOD_HIP_OK ;
 }
 
@@ -2045,12 +1992,6 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.d_pg = dupload (S.pg, e) ; HIPCHK (e) ;
     P.d_tg = dupload (S.tg, e) ; HIPCHK (e) ;
     P.d_gg = dupload (S.gg, e) ; HIPCHK (e) ;
-    if (S.npersist > 0)
-    {
-        size_t hb = (size_t) S.npersist * UPD_MAX_LISTS * UPD_HEAD_STRIDE * sizeof (unsigned int) ;
-        HIPCHK (hipMalloc ((void **) &P.d_heads, hb)) ;
-        HIPCHK (hipMemset (P.d_heads, 0, hb)) ;
-    }
     HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
     if (ncb > 0)
         HIPCHK (hipMemcpy2D (P.d_cb, ncb * sizeof (double), F + nscol + nscol * nsrow,
@@ -2070,7 +2011,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     free_device (&P) ;
     P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
-    P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ; P.d_heads = nullptr ;
+    P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

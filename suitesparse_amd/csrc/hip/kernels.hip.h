@@ -59,9 +59,6 @@ struct GemmGroup {
     i32 nblk;                   // blocks this launch spends on the group (this rank)
     i32 swz;                    // 1: XCD-aware super-tile walk (big groups)
     i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
-    i32 p_sr, p_sc;             // persistent form (k_update2p): super-tile of p_sr x p_sc tiles,
-    i32 p_nst, p_head;          // p_nst super-tiles in the region (all ranks), ticket counter block
-    i32 p_groups, p_pad;        // phase groups per XCD (1..4)
 };
 
 // Contribution blocks of the generic fronts are stored as full squares, ld = ncb
@@ -120,7 +117,7 @@ __global__ void __launch_bounds__(256) k_relmap (int nsuper, const FrontD *fr,
 // in the symbolic pattern are dropped, beta added to the diagonal).
 __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     const i64 *Snz, const i64 *Si, const double *Sx, const i32 *supermap,
-    const FrontD *fr, const i64 *Ls, double *Lx, double beta)
+    const FrontD *fr, const i64 *Ls, double *Lx, double beta, i64 *amap)
 {
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
@@ -137,9 +134,36 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
         if (i < k) continue ;
         int lo = 0, hi = nsrow ;
         while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows [mid] < i) lo = mid + 1 ; else hi = mid ; }
-        if (lo < nsrow && rows [lo] == i) col [lo] = Sx [p] ;
+        if (lo < nsrow && rows [lo] == i)
+        {
+            col [lo] = Sx [p] ;
+            // remember where this entry of S lives in Lx: later factorizations of the same
+            // resident S stream through the map instead of searching (k_assemble_mapped)
+            amap [p] = (col - Lx) + lo ;
+        }
     }
     if (beta != 0.0) col [k - k1] += beta ;
+}
+
+// The same scatter for a matrix whose map is known: 8 B of map + 8 B of value in,
+// 8 B out per entry, no search (the binary searches of k_assemble cost ~1.5 GB of
+// uncoalesced Ls reads at Poisson 100^3, 1.7 ms; this pass: 0.1 ms).
+__global__ void __launch_bounds__(256) k_assemble_mapped (i64 nz, const i64 *amap, const double *Sx, double *Lx)
+{
+    i64 p = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (p >= nz) return ;
+    i64 q = amap [p] ;
+    if (q >= 0) Lx [q] = Sx [p] ;
+}
+
+// Lx(k,k) += beta for the columns this rank's k_assemble owns (after k_assemble_mapped)
+__global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, const FrontD *fr, double *Lx, double beta)
+{
+    i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (k >= n) return ;
+    const FrontD &f = fr [supermap [k]] ;
+    if (f.assemble != 1) return ;
+    Lx [f.psx + (i64) (k - f.k1) * (f.nsrow + 1)] += beta ;
 }
 
 // ---- zero the contribution blocks of a level --------------------------------
@@ -1122,7 +1146,7 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
 // contraction and the read-modify-write (or assignment) of the target.
 template <int BM, int BN, int BK, bool DB>
 __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
-    double *Lx, double *CB, double *sm, int tid)
+    double *Lx, double *CB, double *sm)
 {
     constexpr int LDT = BM + 16 ;
     constexpr int LDU = BN + 16 ;
@@ -1134,7 +1158,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     int mrem = G.m - row0, nrem = G.n - col0 ;
     i64 lda = G.lda ;
     int K = G.k ;
-    int lane = tid & 63, wave = tid >> 6 ;
+    int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     int wm = wave & 1, wn = wave >> 1 ;
 
     // element (idx % BM, idx / BM) of a slab, idx = tid + 256 q: the row is the
@@ -1264,89 +1288,7 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     int I, J ;
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
-    update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm, (int) threadIdx.x) ;
-}
-
-// ---- dense update, persistent form for the big top-of-tree regions -------------
-// A K = 4096 update of a 40 000-row region re-reads its operand panels ~100 times
-// when every 64 x 64 tile is a workgroup of its own: the ~160 tiles an XCD holds
-// at a time drift apart in k, and a K = 4096 slab pair of an 8 x 8 super-tile
-// (16.8 MB) does not stay in a 4 MB L2 (measured: 12x the algorithmic bytes at
-// the memory side, profiles/r02h_pmc_summary_poisson200_top48.json).  Here the
-// grid is one chip-load of workgroups (256 CUs x a few) that stay resident and
-// pull tiles through one ticket counter per XCD: the region is cut into
-// super-tiles of p_sr x p_sc tiles dealt round-robin to 8 p_groups lists, one per XCD
-// (HW_REG_XCC_ID -- a speed matter only, any placement gives the same result) and
-// phase group; ticket t of a list is tile t % (p_sr p_sc) of its super-tile t / (p_sr p_sc).
-// The workgroups of an XCD therefore work on ONE super-tile at a time and, having
-// started together, walk k together: the leaders take the L2 misses, the others
-// hit, which keeps them in step.  Nobody waits for anybody (no co-residency
-// assumption, no spin): an XCD whose list is exhausted pulls from the next one's.
-#define UPD_HEAD_STRIDE 32     /* unsigneds between two ticket counters (128 B) */
-#define UPD_MAX_LISTS 32       /* 8 XCDs x at most 4 phase groups */
-template <int BM, int BN, int BK, int MINW>
-__global__ void __launch_bounds__(256, MINW) k_update2p (const GemmGroup *g,
-    double *Lx, double *CB, unsigned int *heads)
-{
-    __shared__ double sm [BK * (BM + 16 + BN + 16)] ;
-    __shared__ unsigned int s_t ;
-    GemmGroup G = g [0] ;
-    // Phase groups: were ALL workgroups of the chip in step, they would also all sit in
-    // the read-modify-write epilogue of their tiles at the same time with the matrix
-    // cores idle (measured: -4.8 % against independent tiles).  The workgroups of an XCD
-    // therefore form p_groups groups (by dispatch order: consecutive 32 workgroups of an
-    // XCD land on its 32 CUs, so every CU hosts members of every group), each with a
-    // super-tile list and a ticket counter of its own, started 1/p_groups of a tile
-    // time apart: one group's epilogue runs under the other groups' MFMA streams.
-    const int NG = G.p_groups, NL = 8 * NG ;
-    unsigned int *hd = heads + (size_t) G.p_head * UPD_MAX_LISTS * UPD_HEAD_STRIDE ;
-    const int slots = G.p_sr * G.p_sc ;
-    const int AT = (G.mt + G.p_sr - 1) / G.p_sr ;
-    // super-tiles of this rank: L = l * tile_mul + tile_add < p_nst
-    const int my_nst = G.p_nst > G.tile_add ? (G.p_nst - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
-    const int grp = (int) ((blockIdx.x >> 8) % (unsigned) NG) ;
-    int cur = (__builtin_amdgcn_s_getreg (6164) & 7) * NG + grp ;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    // a tile takes ~0.135 us per unit of k; s_sleep 127 = 8128 cycles ~ 3.4 us
-    for (int q = grp * G.k / (25 * NG) ; q > 0 ; q--) __builtin_amdgcn_s_sleep (127) ;
-    int exhausted = 0 ;
-    for ( ; ; )
-    {
-        __syncthreads () ;          // everybody is done with s_t and with the LDS slabs
-        if (threadIdx.x == 0)
-            s_t = __hip_atomic_fetch_add (hd + cur * UPD_HEAD_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
-        __syncthreads () ;
-        const unsigned int t = (unsigned int) __builtin_amdgcn_readfirstlane ((int) s_t) ;    // uniform: tile indices stay in SGPRs
-        const int o = (int) (t / (unsigned) slots), slot = (int) (t - (unsigned) o * (unsigned) slots) ;
-        const int l = o * NL + cur ;
-        if (l >= my_nst)
-        {
-            if (++exhausted == NL) break ;
-            cur = cur + 1 == NL ? 0 : cur + 1 ;
-            continue ;
-        }
-        int L = l * G.tile_mul + G.tile_add, a, b ;
-        if (!G.tri) { b = L / AT ; a = L - b * AT ; }
-        else
-        {
-            int a0 ;
-            for (b = 0 ; ; b++)
-            {
-                a0 = (b * G.p_sc) / G.p_sr ;
-                if (L < AT - a0) break ;
-                L -= AT - a0 ;
-            }
-            a = a0 + L ;
-        }
-        const int I = a * G.p_sr + slot % G.p_sr, J = b * G.p_sc + slot / G.p_sr ;
-        if (I >= G.mt || J >= G.nt || (G.tri && I < J)) continue ;
-        // the thread index through an opaque move: everything derived from it (LDS
-        // addresses, row clamps, epilogue indices) then belongs to this iteration and is
-        // not hoisted out of the ticket loop, where it would stay live across the whole
-        // tile (124 instead of 88 VGPRs, one wave per SIMD less)
-        int tid ;
-        asm volatile ("v_mov_b32 %0, %1" : "=v" (tid) : "v" ((int) threadIdx.x)) ;
-        update_tile<BM, BN, BK, false> (G, I, J, Lx, CB, sm, tid) ;
-    }
+    update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm) ;
 }
 
 // ---- triangular solves with the device-resident factor (nrhs columns) -------

@@ -54,18 +54,6 @@ def test_dense_partial_factorization(L, nsrow, nscol, flags):
     assert np.array_equal(np.triu(F[:nscol, :nscol], 1), np.triu(Fm[:nscol, :nscol], 1))
 
 
-@pytest.mark.parametrize("shape", ["64:8x16:4:1", "64:8x8:4:2", "64:2x3:4:2", "64:3x2:2:4", "64:1x1:1", "128:2x2:2:2"])
-@pytest.mark.parametrize("nsrow,nscol", [(700, 530), (1500, 1100), (2500, 900)])
-def test_dense_partial_factorization_persistent_update(L, monkeypatch, shape, nsrow, nscol):
-    """The persistent form of the update kernel (k_update2p: ticket counters per XCD,
-    super-tiles of tiles) forced onto every update region of at least 4 tiles, with
-    super-tile shapes that do and do not divide the region."""
-    monkeypatch.setenv("CHOLMOD_HIP_PERSIST_TILES", "4")
-    monkeypatch.setenv("CHOLMOD_HIP_PERSIST_SHAPE", shape)
-    test_dense_partial_factorization(L, nsrow, nscol, 0)
-    test_dense_partial_factorization(L, nsrow, nscol, 2048)
-
-
 def test_dense_not_posdef_info(L):
     n = 150
     rng = np.random.default_rng(3)

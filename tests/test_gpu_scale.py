@@ -46,7 +46,7 @@ def _oracle(name):
     return _cache[name]
 
 
-def _compare(name, session_kwargs=None, expect_nsplit=None, expect_ob4096=False, expect_persistent=False):
+def _compare(name, session_kwargs=None, expect_nsplit=None, expect_ob4096=False):
     n, Ap, Ai, Ax, perm, O, mask = _oracle(name)
     S = ch.Session(**(session_kwargs or {}))
     A = S.sparse(n, Ap, Ai, Ax, -1)
@@ -67,8 +67,6 @@ def _compare(name, session_kwargs=None, expect_nsplit=None, expect_ob4096=False,
     st = S.hip_stats(Lf)
     if expect_nsplit is not None:
         assert st[22] >= expect_nsplit, st[22]
-    if expect_persistent:
-        assert st[26] >= 4, st[26]          # launches of the persistent update kernel
     b = G.demo_rhs(n)
     x = S.solve(Lf, b)
     r = G.sym_matvec(n, Ap, Ai, Ax, -1, x) - b
@@ -116,23 +114,6 @@ def test_ob4096_and_subtree_sweep_on_poisson64(monkeypatch):
     monkeypatch.setenv("CHOLMOD_HIP_OB2048_ROWS", "1500")
     monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", "300")
     _compare("p3d_64_nd", expect_nsplit=2)
-
-
-def test_persistent_update_kernel_on_nd24k_standin(monkeypatch):
-    """k_update2p (the form the top-of-tree regions of the 200^3 headline run in)
-    forced onto every region of at least 64 tiles of a complete sparse
-    factorization, 4096-wide outer blocks and the subtree sweep included."""
-    monkeypatch.setenv("CHOLMOD_HIP_PERSIST_TILES", "64")
-    monkeypatch.setenv("CHOLMOD_HIP_OB4096_ROWS", "3000")
-    monkeypatch.setenv("CHOLMOD_HIP_ARENA_BUDGET_MB", "400")
-    err = _compare("box42_r3_nd", expect_nsplit=2, expect_persistent=True)
-    assert err < TOL_L
-
-
-def test_persistent_update_kernel_on_poisson64(monkeypatch):
-    monkeypatch.setenv("CHOLMOD_HIP_PERSIST_TILES", "256")
-    monkeypatch.setenv("CHOLMOD_HIP_PERSIST_SHAPE", "64:4x8:4:4")
-    _compare("p3d_64_nd", expect_persistent=True)
 
 
 def test_generic_kernels_only_on_thin_standin():

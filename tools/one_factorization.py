@@ -9,12 +9,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="poisson3d")
 ap.add_argument("--grid", type=int, default=200)
 ap.add_argument("--repeat", type=int, default=0, help="extra factorizations of the resident matrix")
+ap.add_argument("--hip-flags", type=int, default=0)
 ap.add_argument("--checks", action="store_true",
                 help="also run cholmod_hip_factor_checks: k_factor_checks reads Lx exactly once with 8 B/lane "
                      "loads (8*xsize bytes) -- the known-byte kernel the FETCH_SIZE counter is calibrated on")
 a = ap.parse_args()
 n, Ap, Ai, Ax, stype, perm, name = build_workload(a.workload, a.grid)
-S = ch.Session(factor_on_device=True)
+S = ch.Session(factor_on_device=True, hip_flags=a.hip_flags)
 A = S.sparse(n, Ap, Ai, Ax, stype)
 Lf = S.analyze(A, perm)
 t = time.perf_counter()
