@@ -1312,6 +1312,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     }
     P->winv_valid = false ;                 // the diagonal-block inverses follow the factor
     HIPCHK (hipEventRecord (P->ev0, st)) ;
+    int poisoned = CHOLMOD_HIP_OK ;
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
@@ -1334,7 +1335,6 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         P->amap_valid = true ;
     }
     if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
-    int poisoned = CHOLMOD_HIP_OK ;
     int fail_rank = -1 ; long fail_launch = -1 ;
     if (const char *e = getenv ("CHOLMOD_HIP_TEST_FAIL_LAUNCH")) (void) sscanf (e, "%d:%ld", &fail_rank, &fail_launch) ;
     for (size_t q = 0 ; q < nl ; q++)

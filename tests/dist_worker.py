@@ -40,6 +40,8 @@ def main():
             n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)
         elif case == "p3d_32":
             n, Ap, Ai, Ax = G.poisson3d(32); perm = G.geometric_nd(32, 32, 32, 4)
+        elif case == "p3d_48":
+            n, Ap, Ai, Ax = G.poisson3d(48); perm = G.geometric_nd(48, 48, 48, 4)
         elif case == "p2d_90":
             n, Ap, Ai, Ax = G.poisson2d(90); perm = G.geometric_nd(90, 90, 1, 4)
         elif case == "box10":
