@@ -44,7 +44,7 @@ static inline int outer_block (int maxrows, const ObThresholds &t)
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_UPD_PF, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -306,14 +306,15 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow, obt) ;
     } ;
     (void) maxrows ;
+    std::vector<GemmGroup> pfv ;        // narrow updates whose first tile is factored on the spot (k_update2f)
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
-        for (int pass = 0 ; pass < 2 ; pass++)
+        for (int pass = 0 ; pass < 3 ; pass++)
         {
-            std::vector<GemmGroup> &v = pass ? small : big ;
+            std::vector<GemmGroup> &v = pass == 2 ? pfv : pass ? small : big ;
             if (v.empty ()) continue ;
             int T = pass ? SMALL : BIG ;
-            Launch L {pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
+            Launch L {pass == 2 ? K_UPD_PF : pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
             i64 tiles = 0 ;
             for (auto &G : v)
             {
@@ -357,7 +358,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     auto is_shared = [&] (int fid) { return owner && owner [fid] < 0 ; } ;
     auto add_update = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small,
         const FrontD &f, int fid, int r0, int kc, int kk, int m, int ncols, bool to_cb,
-        bool split = false)
+        bool split = false, bool factor_first = false)
     {
         // target region: rows r0.., cols r0.. of the front (starts on the diagonal)
         if (m <= 0 || ncols <= 0 || kk <= 0) return ;
@@ -373,6 +374,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         // first update of a contribution block nobody zeroed: C = -A*B'
         G.assign = (to_cb && kc == 0 && assign_cb && assign_cb [fid]) ? 1 : 0 ;
         if (split && is_shared (fid)) { G.tile_mul = grpn [fid] ; G.tile_add = rank - grp0 [fid] ; }
+        if (factor_first) { G.pf_next = 1 ; G.pf_col0 = r0 ; pfv.push_back (G) ; return ; }
         bool isbig = use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
@@ -390,6 +392,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the chip busy.  early [q] = block column of front q already summed this way.
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
+    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
+    std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     auto emit_ar = [&] (int q, int c0, int c1, int wait_ev)
     {
         const FrontD &f = fr [ids [q]] ;
@@ -428,7 +432,11 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             int c0 = x.t0 ;
             bool ahead = any_next && x.wide && is_shared (ids [x.q]) && x.t1 > x.t0 ;
             if (ahead) c0 = std::min (x.t0 + MB, x.t1) ;
-            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide) ;
+            // a narrow update of the panel chain ends on the next diagonal block: its first
+            // tile is that block, and the workgroup that updates it factors it (k_update2f)
+            bool ff = fuse_potrf && !x.wide && !x.cb && c0 == x.t0 && f.nscol - x.t0 >= NB && x.t1 - c0 >= NB ;
+            if (ff) pf_done [x.q] = x.t0 ;
+            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
             if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
         }
         flush_updates (big, small) ;
@@ -463,6 +471,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         {
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= i0) continue ;
+            if (pf_done [q] == i0) continue ;       // factored by the update that preceded it
             int nb = std::min (NB, f.nscol - i0) ;
             PfGroup G {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, nb, ids [q], i0} ;
             S.pg.push_back (G) ;
@@ -1287,6 +1296,10 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
+        case K_UPD_PF:
+            hipLaunchKernelGGL (k_update2f, dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
+            break ;
     }
     if (!serial && L.rec_ev >= 0) HIPCHK (hipEventRecord (P->sync_ev [L.rec_ev], st)) ;
     return CHOLMOD_HIP_OK ;
@@ -1393,7 +1406,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
+        if (L.kind == K_UPD_SMALL || L.kind == K_UPD_PF) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
+        if (L.kind == K_UPD_PF) S [26] += 1 ;
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
@@ -1415,6 +1429,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             switch (L.kind)
             {
                 case K_UPD_SMALL: S [6] += sec ; if (L.aux < MB) { S [23] += sec ; } break ;
+                case K_UPD_PF: S [6] += sec ; S [23] += sec ; S [27] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;

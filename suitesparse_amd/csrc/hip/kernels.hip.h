@@ -59,6 +59,8 @@ struct GemmGroup {
     i32 nblk;                   // blocks this launch spends on the group (this rank)
     i32 swz;                    // 1: XCD-aware super-tile walk (big groups)
     i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
+    i32 pf_next, pf_col0;       // k_update2f: tile (0,0) of the region is the next 64 x 64 diagonal block of
+                                // the front (its first column: pf_col0) and is factored by the workgroup that updates it
 };
 
 // Contribution blocks of the generic fronts are stored as full squares, ld = ncb
@@ -1144,7 +1146,7 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
 //  * DB = true double-buffers the LDS slabs (one barrier per slab).
 // One BM x BN tile of an update region (tile row I, tile column J): the whole
 // contraction and the read-modify-write (or assignment) of the target.
-template <int BM, int BN, int BK, bool DB>
+template <int BM, int BN, int BK, bool DB, bool TO_LDS = false>
 __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     double *Lx, double *CB, double *sm)
 {
@@ -1261,6 +1263,33 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
         }
     }
     double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    if constexpr (TO_LDS)
+    {
+        // k_update2f, a full BM x BN tile on the diagonal: the updated block goes to LDS,
+        // k-major (sm [j * BM + i], zero above the diagonal), for the elimination that follows
+        static_assert (BM == BN && !DB, "diagonal tile") ;
+        double cv [TI][TJ][4] ;
+#pragma unroll
+        for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                    cv [a][b][r] = C [wm * WM + a * 16 + (lane & 15) + (i64) (wn * WN + b * 16 + (lane >> 4) + 4 * r) * G.ldc] ;
+        __syncthreads () ;          // the operand slabs in sm are dead
+#pragma unroll
+        for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int i = wm * WM + a * 16 + (lane & 15) ;
+                    int j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
+                    sm [j * BM + i] = (i >= j) ? cv [a][b][r] - acc [a][b][r] : 0.0 ;
+                }
+        return ;
+    }
 #pragma unroll
     for (int a = 0 ; a < TI ; a++)
 #pragma unroll
@@ -1289,6 +1318,56 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
     update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm) ;
+}
+
+// ---- trailing update that also factors the next diagonal block ------------------
+// The narrow (K < 512) updates of the panel chain are followed, on the same stream, by
+// the dpotrf of the block they have just finished updating: tile (0,0) of their region.
+// Here the workgroup that owns that tile keeps it in LDS and eliminates it on the spot
+// (pf_eliminate, as k_potrf_mfma) while the other workgroups of the launch finish their
+// tiles -- one launch of ~17 us less per 64 columns of the chain (potrf -> trsm -> update,
+// ~43 us per step, is half the time of a mid-size factorization).  Everything else in
+// the launch is k_update2<64,64,16,2,false>.
+__global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng,
+    double *Lx, double *CB, i32 *info)
+{
+    __shared__ __attribute__((aligned(16))) double sm [PF_NB * PF2_LD] ;   // operand slabs, then the diagonal block
+    __shared__ int s_fail ;
+    static_assert (PF_NB == 64 && PF2_LD == 64 && 16 * (64 + 16 + 64 + 16) <= PF_NB * PF2_LD, "slabs fit") ;
+    int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
+    GemmGroup G = g [gi] ;
+    int I, J ;
+    if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
+    if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
+    if (!(G.pf_next && I == 0 && J == 0))
+    {
+        update_tile<64, 64, 16, false> (G, I, J, Lx, CB, sm) ;
+        return ;
+    }
+    __builtin_amdgcn_s_setprio (3) ;
+    update_tile<64, 64, 16, false, true> (G, 0, 0, Lx, CB, sm) ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    if (tid == 0) s_fail = -1 ;
+    __syncthreads () ;
+    double *A = Lx + G.c_off ;
+    const i64 lda = G.ldc ;
+    if (info [G.front] != 0)
+    {
+        // an earlier pivot of this front failed: its remaining columns are zero
+        for (int k = wave ; k < PF_NB ; k += 4)
+            if (lane >= k) A [lane + (i64) k * lda] = 0.0 ;
+        return ;
+    }
+    auto tick = [] (int) {} ;
+    pf_eliminate (sm, PF_NB / 16, &s_fail, tid, tick) ;
+    const int fail = s_fail ;
+    if (fail >= 0 && tid == 0) info [G.front] = G.pf_col0 + fail + 1 ;
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++)
+    {
+        const int k = wave + 4 * q, i = lane ;
+        if (i >= k) A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : sm [k * PF2_LD + i] ;
+    }
 }
 
 // ---- triangular solves with the device-resident factor (nrhs columns) -------

@@ -44,7 +44,7 @@ def main():
             n = int(rng.integers(2, 3000)); Ap, Ai, Ax = rand_spd(rng, n, rng.uniform(1.0, 8.0) / n, bool(rng.integers(2)))
         omode = ("natural", "nesdis", "random")[int(rng.integers(3))]
         perm = rng.permutation(n).astype(np.int64) if omode == "random" else None
-        flags = int(rng.choice([0, 0, 0, 64, 128, 16, 2048]))
+        flags = int(rng.choice([0, 0, 0, 64, 128, 16, 2048, 512]))
         S = ch.Session(ordering=omode if omode != "random" else "natural", hip_flags=flags)
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)

@@ -32,7 +32,7 @@ def rel_err_lower(x, xref, mask):
 
 @pytest.mark.parametrize("nsrow,nscol", [(7, 7), (40, 13), (64, 64), (65, 64), (200, 100),
                                          (333, 129), (700, 530), (900, 64), (1500, 1100), (2500, 1700)])
-@pytest.mark.parametrize("flags", [0, 4, 32, 64, 128, 2048, 64 | 2048])   # tile128, no swizzle, 512- / 2048-wide outer blocks, zero-filled CBs
+@pytest.mark.parametrize("flags", [0, 4, 32, 64, 128, 2048, 64 | 2048, 512, 512 | 128])   # tile128, no swizzle, 512- / 2048-wide outer blocks, zero-filled CBs, potrf launches of their own
 def test_dense_partial_factorization(L, nsrow, nscol, flags):
     rng = np.random.default_rng(nsrow * 1000 + nscol)
     M = rng.standard_normal((nsrow, nsrow))
@@ -168,7 +168,7 @@ def test_relative_maps_bit_exact(L, golden_dir):
 def test_plan_flag_variants_agree(L, golden_dir):
     n, Ap, Ai, Ax, stype, perm = _case("p3d_24_nd", golden_dir)
     xs = []
-    for flags in (0, 4, 16, 32, 64, 128, 2048):
+    for flags in (0, 4, 16, 32, 64, 128, 2048, 512):
         S = ch.Session(hip_flags=flags)
         A = S.sparse(n, Ap, Ai, Ax, stype)
         Lf = S.analyze(A, perm)

@@ -116,6 +116,12 @@ def test_ob4096_and_subtree_sweep_on_poisson64(monkeypatch):
     _compare("p3d_64_nd", expect_nsplit=2)
 
 
+def test_separate_potrf_launches_on_nd24k_standin():
+    """The schedule without k_update2f (flag CHOLMOD_HIP_NO_FUSED_POTRF): every diagonal
+    block through a k_potrf_mfma launch of its own."""
+    _compare("box42_r3_nd", session_kwargs={"hip_flags": 512})
+
+
 def test_generic_kernels_only_on_thin_standin():
     """The same thin workload without the fused small-front kernel: every front
     through k_extend_add / potrf / trsm / update (flag CHOLMOD_HIP_NO_SMALL_FRONTS)."""
