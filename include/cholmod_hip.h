@@ -195,8 +195,9 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [13] seconds in assemble (memset + A scatter)
  *  [24] device seconds of the last cholmod_hip_solve (its kernels, without the
  *       copies of the right-hand side)
- *  [26] trailing-update launches that also factor the next diagonal block (k_update2f;
- *       counted in [6]-[8], [16], [23] too)   [27] their seconds
+ *  [26] trailing-update launches that also factor the next diagonal block (k_update2f: the
+ *       K < 512 updates of the panel chain; NOT counted in [6]-[8], [16], [23])
+ *  [27] their seconds   [28] their flops   [29] their algorithmic bytes
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
 #define CHOLMOD_HIP_NSTATS 32

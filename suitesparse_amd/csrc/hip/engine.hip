@@ -1406,8 +1406,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
-        if (L.kind == K_UPD_SMALL || L.kind == K_UPD_PF) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
-        if (L.kind == K_UPD_PF) S [26] += 1 ;
+        if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
+        if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
@@ -1429,7 +1429,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             switch (L.kind)
             {
                 case K_UPD_SMALL: S [6] += sec ; if (L.aux < MB) { S [23] += sec ; } break ;
-                case K_UPD_PF: S [6] += sec ; S [23] += sec ; S [27] += sec ; break ;
+                case K_UPD_PF: S [27] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;

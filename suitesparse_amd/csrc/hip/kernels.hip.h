@@ -223,8 +223,18 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
             if (tc < Pnscol) { dst = Lx + Ppsx + (i64) tc * Pnsrow ; roff = 0 ; }
             else { dst = CB + Pcb + (i64) (tc - Pnscol) * Pncb ; roff = Pnscol ; }
             const double *sc = Cc.cbp ? src + tri_col (j, nc) : src + (i64) j * nc ;
-            // four independent gather / read-modify-write chains in flight per wave
+            // eight, then four independent gather / read-modify-write chains in flight per wave
             int i = j + lane ;
+            for ( ; i + 448 < nc ; i += 512)
+            {
+                int r [8] ; double v [8], d [8] ;
+#pragma unroll
+                for (int q = 0 ; q < 8 ; q++) { r [q] = rm [i + 64 * q] - roff ; v [q] = sc [i + 64 * q] ; }
+#pragma unroll
+                for (int q = 0 ; q < 8 ; q++) d [q] = dst [r [q]] ;
+#pragma unroll
+                for (int q = 0 ; q < 8 ; q++) dst [r [q]] = d [q] + v [q] ;
+            }
             for ( ; i + 192 < nc ; i += 256)
             {
                 int r0 = rm [i] - roff, r1 = rm [i + 64] - roff, r2 = rm [i + 128] - roff, r3 = rm [i + 192] - roff ;

@@ -111,8 +111,8 @@ static void absorb_stats (cholmod_factor *L, cholmod_common *Common)
     Common->gpuKernelTime = s [0] ;
     Common->gpuFlops = (SuiteSparse_long) s [1] ;
     Common->gpuNumKernelLaunches = (int) s [2] ;
-    Common->cholmod_gpu_syrk_time = s [6] + s [14] ;
-    Common->cholmod_gpu_syrk_calls = (size_t) s [7] ;
+    Common->cholmod_gpu_syrk_time = s [6] + s [14] + s [27] ;
+    Common->cholmod_gpu_syrk_calls = (size_t) (s [7] + s [26]) ;
     Common->cholmod_gpu_gemm_time = 0 ; Common->cholmod_gpu_gemm_calls = 0 ;
     Common->cholmod_gpu_potrf_time = s [11] ;
     Common->cholmod_gpu_trsm_time = s [12] ;
