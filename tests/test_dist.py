@@ -117,10 +117,9 @@ def test_partition_is_consistent_and_balanced(world):
 def test_partition_balance_at_the_headline_size():
     """The metric's multi-GPU workload itself (Poisson 200^3, 8 M dof, geometric ND) through the
     host-only plan of every rank: the same partition everywhere and the flop loads the
-    proportional mapping estimates within its own tolerance of the mean (a group is only
-    split between heavy children when no part ends up more than 10 % above the mean,
-    CHOLMOD_HIP_SPLIT_TOL) at 2, 4 and 8 ranks -- measured: 8 ranks within 3 %, 4 ranks
-    -3.4 % .. +7.7 %, 2 ranks within 1 %."""
+    proportional mapping estimates within 5 % of the mean at 2, 4 and 8 ranks (measured:
+    within 1.4 % at 8, 1.2 % at 4, 0.6 % at 2 ranks; a front is shared while its subtree
+    outweighs 1 / (6 world) of the factorization)."""
     m = 200
     n, Ap, Ai, Ax = G.poisson3d(m)
     perm = G.geometric_nd(m, m, m, 4)
@@ -137,7 +136,7 @@ def test_partition_balance_at_the_headline_size():
                                              / gn[shared & (g0 <= r) & (r < g0 + gn)]).sum()
                           for r in range(world)])
         print("world", world, "loads / mean", np.round(loads / loads.mean(), 4), "shared fronts", int(shared.sum()))
-        assert loads.max() <= 1.10 * loads.mean() and loads.min() >= 0.90 * loads.mean(), loads / loads.mean()
+        assert loads.max() <= 1.05 * loads.mean() and loads.min() >= 0.95 * loads.mean(), loads / loads.mean()
         assert int(shared.sum()) <= 64                  # a handful of shared fronts, the rest private subtrees
 
 
