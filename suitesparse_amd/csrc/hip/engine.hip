@@ -268,6 +268,7 @@ struct cholmod_hip_plan {
     // resident input matrix
     i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
     i64 s_nz = 0 ; bool s_unpacked = false ;
+    int *d_first_fail = nullptr ;           // k_first_fail result
     i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace
     double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
@@ -1083,7 +1084,7 @@ static void free_device (cholmod_hip_plan *P)
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit} ;
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1135,6 +1136,7 @@ static int upload_plan (cholmod_hip_plan *P)
     double tu2 = pnow () ;
     HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_first_fail, sizeof (int))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
     if (getenv ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
@@ -1384,14 +1386,27 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     if (poisoned != CHOLMOD_HIP_OK && P->world == 1) return poisoned ;
     (void) hipEventRecord (P->ev1, st) ;
     double th1 = now () ;
-    // not-positive-definite protocol (t_cholmod_super_numeric.c:905-968)
-    std::vector<i32> info (std::max<i64> (P->nsuper, 1), 0) ;
+    // not-positive-definite protocol (t_cholmod_super_numeric.c:905-968): the first
+    // failing supernode and its info, reduced on the device
     float ms = 0 ;
+    i64 sbad = -1, binfo = 0 ;
     if (poisoned == CHOLMOD_HIP_OK)
     {
-        if (hipMemcpyAsync (info.data (), P->d_info, info.size () * sizeof (i32), hipMemcpyDeviceToHost, st) != hipSuccess
-            || hipStreamSynchronize (st) != hipSuccess
-            || hipEventElapsedTime (&ms, P->ev0, P->ev1) != hipSuccess)
+        int first = (int) P->nsuper ;
+        i32 inf = 0 ;
+        bool ok = hipMemcpyAsync (P->d_first_fail, &first, sizeof (int), hipMemcpyHostToDevice, st) == hipSuccess ;
+        if (ok && P->nsuper > 0)
+            hipLaunchKernelGGL (k_first_fail, dim3 ((unsigned) ((P->nsuper + 255) / 256)), dim3 (256), 0, st,
+                P->nsuper, P->d_info, P->d_first_fail) ;
+        ok = ok && hipMemcpyAsync (&first, P->d_first_fail, sizeof (int), hipMemcpyDeviceToHost, st) == hipSuccess
+            && hipStreamSynchronize (st) == hipSuccess
+            && hipEventElapsedTime (&ms, P->ev0, P->ev1) == hipSuccess ;
+        if (ok && first < (int) P->nsuper)
+        {
+            ok = hipMemcpy (&inf, P->d_info + first, sizeof (i32), hipMemcpyDeviceToHost) == hipSuccess ;
+            sbad = first ; binfo = inf ;
+        }
+        if (!ok)
         {
             if (P->world == 1) return CHOLMOD_HIP_GPU_PROBLEM ;
             poisoned = CHOLMOD_HIP_GPU_PROBLEM ;
@@ -1444,9 +1459,6 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             }
         }
     }
-    i64 sbad = -1 ;
-    for (i64 s = 0 ; s < P->nsuper ; s++) if (info [s] != 0) { sbad = s ; break ; }
-    i64 binfo = sbad >= 0 ? info [sbad] : 0 ;
     if (P->world > 1 || P->force_shared)
     {
         // agree on the first failing supernode: every rank publishes its own

@@ -1380,6 +1380,16 @@ __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng
     }
 }
 
+// ---- first failing supernode (not-positive-definite protocol) ---------------------
+// out [0] = smallest supernode with info != 0 (nsuper if none), so that the host reads
+// 4 bytes per factorization instead of the whole info array (G3_circuit stand-in:
+// 114 250 supernodes, 457 KB into pageable memory per refactorization).
+__global__ void __launch_bounds__(256) k_first_fail (i64 nsuper, const i32 *info, int *out)
+{
+    i64 s = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (s < nsuper && info [s] != 0) atomicMin (out, (int) s) ;
+}
+
 // ---- triangular solves with the device-resident factor (nrhs columns) -------
 // Level-scheduled restatement of cholmod_l_super_lsolve / _ltsolve
 // (t_cholmod_super_solve.c:14-220, :222-411).  One workgroup per supernode of
