@@ -20,12 +20,25 @@
  *     CHOLMOD/Include/cholmod_check.h     (:110 gpu_stats), cholmod_matrixops.h
  *
  * Only the 64-bit integer flavour exists (the reference's GPU path is
- * cholmod_l_* only, CHOLMOD/Include/cholmod_internal.h:250-251); only real
- * double matrices.  The numeric factorization always runs on the HIP engine
- * (include/cholmod_hip.h): there is no CPU BLAS path in this library, and
- * cholmod_l_super_numeric fails with CHOLMOD_GPU_PROBLEM when no device or no
- * engine is available.  The struct members carry the reference's names; the
- * structs are this library's own (compile against this header).
+ * cholmod_l_* only, CHOLMOD/Include/cholmod_internal.h:250-251); double
+ * precision; real, complex and zomplex matrices (complex input is carried by the
+ * real embedding, csrc/host/complex.c).  Common->useGPU selects the numeric path
+ * as in the reference: 1 = the HIP engine (include/cholmod_hip.h), 0 = the CPU
+ * supernodal path (csrc/host/cpu_numeric.c), -1 = decided by CHOLMOD_USE_GPU
+ * (unset: CPU).  The struct members carry the reference's names; the structs are
+ * this library's own (compile against this header).
+ *
+ * Where this library deliberately differs from the reference:
+ *  - Common->supernodal = CHOLMOD_AUTO always picks the supernodal path (the
+ *    simplicial branch is not built; CHOLMOD_SIMPLICIAL: CHOLMOD_NOT_INSTALLED);
+ *  - orderings: UserPerm, natural, or the built-in nested dissection (any request
+ *    for AMD / METIS / NESDIS / COLAMD maps to it, L->ordering = CHOLMOD_NESDIS);
+ *  - a GPU request that cannot be served fails loudly (CHOLMOD_GPU_PROBLEM /
+ *    CHOLMOD_OUT_OF_MEMORY) unless Common->hip_cpu_fallback asks for the
+ *    reference's silent degradation to the CPU path;
+ *  - the supernode partition is the CPU one on both paths (no devBuffSize splits);
+ *  - A*A' (stype 0) factorization, update/downdate, Bset solves, complex triplets
+ *    and complex Matrix Market files: CHOLMOD_NOT_INSTALLED / CHOLMOD_INVALID.
  */
 #ifndef CHOLMOD_AMD_H
 #define CHOLMOD_AMD_H
