@@ -1,6 +1,8 @@
 """Randomised parity run against the oracle (GPU box): random sparse SPD patterns,
 random / built-in / natural orderings, random not-positive-definite injections,
-unpacked inputs, 1-3 right-hand sides.  Prints one line per failure and a summary."""
+unpacked inputs, 1-3 right-hand sides; every fourth case with complex or zomplex Hermitian
+values (random phases on the off-diagonal entries) against the oracle's complex template.
+Prints one line per failure and a summary."""
 import os
 import sys
 
@@ -45,8 +47,16 @@ def main():
         omode = ("natural", "nesdis", "random")[int(rng.integers(3))]
         perm = rng.permutation(n).astype(np.int64) if omode == "random" else None
         flags = int(rng.choice([0, 0, 0, 64, 128, 16, 2048, 512]))
-        S = ch.Session(ordering=omode if omode != "random" else "natural", hip_flags=flags)
-        A = S.sparse(n, Ap, Ai, Ax, -1)
+        cx = (it % 4 == 3)
+        zomplex = cx and bool(rng.integers(2))
+        if cx:
+            Ax = Ax.astype(np.complex128)
+            cols = np.repeat(np.arange(n), np.diff(Ap))
+            off = Ai != cols
+            Ax[off] *= np.exp(1j * rng.uniform(0, 2 * np.pi, int(off.sum())))
+        S = ch.Session(ordering=omode if omode != "random" else "natural", hip_flags=flags,
+                       use_gpu=int(os.environ.get("FUZZ_USE_GPU", "1")))      # 0: the product's CPU path
+        A = S.sparse(n, Ap, Ai, Ax, -1, zomplex=zomplex)
         Lf = S.analyze(A, perm)
         fv = ch.FactorView(Lf)
         Pfinal = fv.Perm.copy()
@@ -56,10 +66,11 @@ def main():
             k = int(rng.integers(n))
             Axx[Ap[k]] = -abs(Axx[Ap[k]])            # negative diagonal somewhere
             S.free_sparse(A)
-            A = S.sparse(n, Ap, Ai, Axx, -1)
+            A = S.sparse(n, Ap, Ai, Axx, -1, zomplex=zomplex)
         ok = S.factorize(A, Lf)
         O = OracleFactor(n, Ap, Ai, -1, perm=Pfinal, postorder=True)
-        st = O.factorize(Axx)
+        st = O.factorize_complex(Axx, zomplex=zomplex) if cx else O.factorize(Axx)
+        Ox = O.xc if cx else O.x
         fv = ch.FactorView(Lf)
         msg = []
         for key in ("Perm", "super", "pi", "px", "s"):
@@ -70,21 +81,26 @@ def main():
         if st != 0 and fv.minor != O.minor:
             msg.append(f"minor {fv.minor} vs {O.minor}")
         mk = O.lower_mask()
-        den = np.linalg.norm(O.x[mk])
-        err = np.linalg.norm((fv.x - O.x)[mk]) / (den if den > 0 else 1.0)
+        den = np.linalg.norm(Ox[mk])
+        err = np.linalg.norm((fv.x - Ox)[mk]) / (den if den > 0 else 1.0)
         if not (err < 1e-11):
             msg.append(f"L err {err:.2e}")
         if st == 0:
             nr = int(rng.integers(1, 4))
             b = rng.standard_normal((nr, n)) if nr > 1 else rng.standard_normal(n)
-            x = S.solve(Lf, b)
+            if cx:
+                b = b + 1j * rng.standard_normal(b.shape)
+                Al = sp.csc_matrix((Axx, Ai, Ap), shape=(n, n))
+                Af = (Al + sp.tril(Al, -1).conj().T).tocsr()
+            x = S.solve(Lf, b, zomplex=zomplex)
             for bb, xx in zip(np.atleast_2d(b), np.atleast_2d(x)):
-                r = G.sym_matvec(n, Ap, Ai, Axx, -1, xx) - bb
+                r = (Af @ xx if cx else G.sym_matvec(n, Ap, Ai, Axx, -1, xx)) - bb
                 if not (np.linalg.norm(r) <= 1e-9 * np.linalg.norm(bb)):
                     msg.append(f"resid {np.linalg.norm(r) / np.linalg.norm(bb):.2e}")
         if msg:
             bad += 1
-            print(f"FAIL case {it} kind {kind} n {n} order {omode} flags {flags} inject {inject}: " + "; ".join(msg), flush=True)
+            print(f"FAIL case {it} kind {kind} n {n} order {omode} flags {flags} inject {inject} complex {cx} zomplex {zomplex}: "
+                  + "; ".join(msg), flush=True)
         S.free_factor(Lf)
         S.free_sparse(A)
         if S.cm.malloc_count != 0:

@@ -16,3 +16,11 @@ def test_randomised_parity(seed):
                          capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "40 cases, 0 failures" in out.stdout, out.stdout[-2000:]
+
+
+def test_randomised_parity_cpu_path():
+    """The same run through the product's CPU path (Common->useGPU = 0), complex cases included."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_runner.py"), "16", "5"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, FUZZ_USE_GPU="0"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "16 cases, 0 failures" in out.stdout, out.stdout[-2000:]
