@@ -233,6 +233,12 @@ typedef struct cholmod_factor_struct
      * 2n x 2n embedding [re -im ; im re] the engine actually computes; the complex
      * L->x is its even columns */
     void *cx_twin ;
+    /* pattern of the last matrix cholmod_l_factorize handed to the engine (hash of its
+     * p / i arrays, its nnz): a call with the same pattern only refreshes the values of
+     * the resident matrix (cholmod_hip_refresh_values) */
+    uint64_t hip_apat_hash ;
+    size_t hip_apat_nnz ;
+    int hip_apat_valid ;
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

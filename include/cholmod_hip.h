@@ -143,6 +143,18 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *plan, const int64_t *Sp,
 int cholmod_hip_factorize_resident (cholmod_hip_plan *plan, double beta,
     int quick_return_if_not_posdef, int64_t *minor) ;
 
+/* New values for the resident S when only the VALUES of the caller's matrix changed
+ * (cholmod_l_factorize called again with the same pattern: the common case of a
+ * nonlinear or time-stepping loop).  cholmod_hip_set_value_map hands over, once per
+ * upload, where every entry of the resident packed S came from in the caller's value
+ * array: src [q] in [0, nvalues).  cholmod_hip_refresh_values then copies the caller's
+ * nvalues doubles to the device and gathers Sx [q] = values [src [q]] there -- no
+ * host-side permutation, no pattern upload, the assembly map stays valid.
+ * Both return CHOLMOD_HIP_INVALID without a resident packed S of snz entries. */
+int cholmod_hip_set_value_map (cholmod_hip_plan *plan, const int64_t *src, int64_t snz,
+    int64_t nvalues) ;
+int cholmod_hip_refresh_values (cholmod_hip_plan *plan, const double *values, int64_t nvalues) ;
+
 /* Copy the device-resident packed Lx (xsize doubles) to the host. */
 int cholmod_hip_download_factor (cholmod_hip_plan *plan, double *Lx_host) ;
 /* Replace the device-resident Lx by host values (e.g. a factor computed

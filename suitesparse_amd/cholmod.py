@@ -101,7 +101,8 @@ class Factor(C.Structure):
                 ("is_monotonic", C.c_int), ("itype", C.c_int), ("xtype", C.c_int),
                 ("dtype", C.c_int), ("useGPU", C.c_int),
                 ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
-                ("cx_twin", C.c_void_p)]
+                ("cx_twin", C.c_void_p), ("hip_apat_hash", C.c_uint64), ("hip_apat_nnz", C.c_size_t),
+                ("hip_apat_valid", C.c_int)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare
@@ -133,6 +134,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_get_groups",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
+    "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
     "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     

@@ -269,6 +269,8 @@ struct cholmod_hip_plan {
     i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
     i64 s_nz = 0 ; bool s_unpacked = false ;
     int *d_first_fail = nullptr ;           // k_first_fail result
+    i64 *d_vsrc = nullptr ; double *d_vals = nullptr ;      // value map of the resident S (cholmod_hip_set_value_map)
+    i64 vsrc_nz = 0, vals_n = 0, s_cur_nz = 0 ;
     i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace
     double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
@@ -1084,7 +1086,7 @@ static void free_device (cholmod_hip_plan *P)
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
-        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail} ;
+        P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
     for (auto e : P->sync_ev) (void) hipEventDestroy (e) ;
@@ -1758,6 +1760,33 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     P->s_unpacked = (Snz != nullptr) ;
     P->amap_valid = false ;         // a new pattern may have come with the new values
+    P->s_cur_nz = nz ;
+    P->vsrc_nz = 0 ;                // ... and the value map of the previous one is void
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_set_value_map (cholmod_hip_plan *P, const int64_t *src, int64_t snz, int64_t nvalues)
+{
+    if (!P || P->host_only || !src || !P->d_Sp || P->s_unpacked || snz != P->s_cur_nz || nvalues < 0) return CHOLMOD_HIP_INVALID ;
+    for (i64 q = 0 ; q < snz ; q++) if (src [q] < 0 || src [q] >= nvalues) return CHOLMOD_HIP_INVALID ;
+    if (P->d_vsrc) { (void) hipFree (P->d_vsrc) ; P->d_vsrc = nullptr ; }
+    if (P->d_vals) { (void) hipFree (P->d_vals) ; P->d_vals = nullptr ; }
+    HIPCHK (hipMalloc ((void **) &P->d_vsrc, std::max<i64> (snz, 1) * sizeof (i64))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_vals, std::max<i64> (nvalues, 1) * sizeof (double))) ;
+    if (snz) HIPCHK (hipMemcpy (P->d_vsrc, src, snz * sizeof (i64), hipMemcpyHostToDevice)) ;
+    P->vsrc_nz = snz ; P->vals_n = nvalues ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_refresh_values (cholmod_hip_plan *P, const double *values, int64_t nvalues)
+{
+    if (!P || P->host_only || !values || !P->d_vsrc || P->vsrc_nz != P->s_cur_nz || nvalues != P->vals_n)
+        return CHOLMOD_HIP_INVALID ;
+    if (nvalues) HIPCHK (hipMemcpyAsync (P->d_vals, values, nvalues * sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
+    if (P->vsrc_nz)
+        hipLaunchKernelGGL (k_gather_values, dim3 ((unsigned) ((P->vsrc_nz + 255) / 256)), dim3 (256), 0, P->stream,
+            P->vsrc_nz, P->d_vsrc, P->d_vals, P->d_Sx) ;
+    HIPCHK (hipStreamSynchronize (P->stream)) ;     // the caller may reuse `values` at once
     return CHOLMOD_HIP_OK ;
 }
 

@@ -158,6 +158,13 @@ __global__ void __launch_bounds__(256) k_assemble_mapped (i64 nz, const i64 *ama
     if (q >= 0) Lx [q] = Sx [p] ;
 }
 
+// Sx [q] = values [src [q]]: new values of the caller's matrix into the resident S
+__global__ void __launch_bounds__(256) k_gather_values (i64 nz, const i64 *src, const double *values, double *Sx)
+{
+    i64 q = blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (q < nz) Sx [q] = values [src [q]] ;
+}
+
 // Lx(k,k) += beta for the columns this rank's k_assemble owns (after k_assemble_mapped)
 __global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, const FrontD *fr, double *Lx, double beta)
 {

@@ -234,6 +234,16 @@ int ssamd_host_threads (void)
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common)
 {
+    return ssamd_sym_permute_src (A, values, Perm, upper_out, NULL, Common) ;
+}
+
+/* The same; *src_out (if not NULL) receives, for every entry q of C, the position in A it
+ * came from (nnz(C) entries, cholmod_l_malloc'ed, the caller frees): the value map that lets
+ * a later factorization of a matrix with the same pattern skip this permutation
+ * (cholmod_l_factorize_p, cholmod_hip_set_value_map). */
+cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
+    SuiteSparse_long **src_out, cholmod_common *Common)
+{
     /* C = P A P' of a symmetric A with the wanted triangle stored.  Three parallel passes
      * (count, scatter with atomic cursors, per-column sort by (row, source
      * position)), so the output is deterministic and its columns are sorted. */
@@ -379,6 +389,14 @@ cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_lo
         }
     }
     else if (C) cholmod_l_free_sparse (&C, Common) ;
+    if (src_out) *src_out = NULL ;
+    if (src && C && src_out)
+    {
+#pragma omp parallel for schedule(static) num_threads(nth)
+        for (Int q = 0 ; q < nz ; q++) src [q] >>= 1 ;      /* drop the transposed-entry flag */
+        *src_out = src ;
+        src = NULL ;
+    }
     if (src) cholmod_l_free (nz > 0 ? nz : 1, sizeof (Int), src, Common) ;
     cholmod_l_free (n + 1, sizeof (Int), cursor, Common) ;
     if (Pinv) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), Pinv, Common) ;

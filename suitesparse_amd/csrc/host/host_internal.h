@@ -35,6 +35,8 @@ typedef SuiteSparse_long Int ;
 int ssamd_host_threads (void) ;
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common) ;
+cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
+    SuiteSparse_long **src_out, cholmod_common *Common) ;
 
 /* analyze.c */
 int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent) ;

@@ -253,6 +253,33 @@ int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_
 
 /* ---- cholmod_l_factorize ---------------------------------------------------------------- */
 
+/* 64-bit hash of a packed pattern (dimensions, stype, p, i): the key under which the
+ * engine's value map of a matrix is remembered */
+static uint64_t pattern_hash (cholmod_sparse *A)
+{
+    const Int *Ap = A->p, *Ai = A->i ;
+    const Int ncol = (Int) A->ncol, nz = Ap [ncol] ;
+    const int nth = ssamd_host_threads () ;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t) A->nrow * 0xff51afd7ed558ccdull) ^ ((uint64_t) (A->stype + 2) << 56) ;
+    uint64_t hp = 0, hi = 0 ;
+    /* position-dependent mixing, order-independent combination: parallel and deterministic */
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp)
+    for (Int j = 0 ; j <= ncol ; j++)
+    {
+        uint64_t x = (uint64_t) Ap [j] + 0x9E3779B97F4A7C15ull * (uint64_t) (j + 1) ;
+        x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
+        hp += x ;
+    }
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hi)
+    for (Int p = 0 ; p < nz ; p++)
+    {
+        uint64_t x = (uint64_t) Ai [p] + 0xD1B54A32D192ED03ull * (uint64_t) (p + 1) ;
+        x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
+        hi += x ;
+    }
+    return h ^ hp ^ (hi * 0x2545F4914F6CDD1Dull) ;
+}
+
 /* reference: Cholesky/cholmod_factorize.c:97-300, supernodal symmetric branch
  * (:177-288): S = tril(P A P') by one permuted transpose when A is stored
  * upper (:225-232) or two when it is stored lower (:233-244). */
@@ -268,26 +295,67 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' factorization not built") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
+    double zero [2] = {0, 0} ;
+    /* Same pattern as the matrix the engine already holds (hash of p / i, nnz): only the
+     * values travel -- H2D of A->x and a gather into the resident S on the device; the
+     * host-side permutation, the pattern upload and the assembly search are skipped. */
+    const int vmap_ok = (A->xtype == CHOLMOD_REAL && A->packed && L->hip_plan && Common->hip_world <= 1
+        && ssamd_resolve_use_gpu (Common) == 1) ;
+    uint64_t hash = vmap_ok ? pattern_hash (A) : 0 ;
+    size_t annz = vmap_ok ? (size_t) ((Int *) A->p) [A->ncol] : 0 ;
+    if (vmap_ok && L->hip_apat_valid && L->hip_apat_hash == hash && L->hip_apat_nnz == annz
+        && (L->xtype == CHOLMOD_REAL || L->xtype == CHOLMOD_PATTERN))
+    {
+        int rc = cholmod_hip_refresh_values ((cholmod_hip_plan *) L->hip_plan, A->x, (int64_t) annz) ;
+        if (rc == CHOLMOD_HIP_OK)
+        {
+            int64_t minor = (int64_t) L->n ;
+            rc = cholmod_hip_factorize_resident ((cholmod_hip_plan *) L->hip_plan, beta ? beta [0] : 0.0,
+                Common->quick_return_if_not_posdef, &minor) ;
+            return finish_numeric (rc, minor, L, Common) ;
+        }
+        L->hip_apat_valid = FALSE ;         /* no usable map after all: the long way */
+    }
     cholmod_sparse *S = NULL ;
+    Int *src = NULL ;
     int natural = (L->ordering == CHOLMOD_NATURAL) ;
     Int *Perm = natural ? NULL : (Int *) L->Perm ;
-    if (A->stype > 0)
-    {
-        S = cholmod_l_ptranspose (A, 2, Perm, NULL, 0, Common) ;
-    }
-    else if (natural && A->packed)
+    if (natural && A->packed && A->stype < 0)
     {
         S = A ;
     }
     else
     {
-        /* lower-stored A: the reference transposes twice (:233-244); here one
-         * symmetric permutation lands in the lower triangle directly */
-        S = ssamd_sym_permute (A, 2, Perm, FALSE, Common) ;
+        /* S = tril (P A P'): upper-stored A by the conjugate permuted transpose of the
+         * reference (:225-232); lower-stored A: the reference transposes twice (:233-244),
+         * here one symmetric permutation lands in the lower triangle directly */
+        S = ssamd_sym_permute_src (A, 2, Perm, FALSE, vmap_ok || (A->xtype == CHOLMOD_REAL && A->packed) ? &src : NULL, Common) ;
     }
     if (!S) return FALSE ;
-    double zero [2] = {0, 0} ;
+    L->hip_apat_valid = FALSE ;
     int ok = cholmod_l_super_numeric (S, NULL, beta ? beta : zero, L, Common) ;
+    /* the engine now holds S: tell it where S's values come from in A */
+    if (ok && L->hip_plan && L->hip_on_device && A->xtype == CHOLMOD_REAL && A->packed && Common->hip_world <= 1
+        && (S == A || src))
+    {
+        size_t snz = (size_t) ((Int *) S->p) [S->ncol] ;
+        size_t an = (size_t) ((Int *) A->p) [A->ncol] ;
+        Int *id = NULL ;
+        if (S == A)
+        {
+            id = cholmod_l_malloc (snz > 0 ? snz : 1, sizeof (Int), Common) ;
+            if (id) for (size_t q = 0 ; q < snz ; q++) id [q] = (Int) q ;
+        }
+        if ((S == A ? id : src) && cholmod_hip_set_value_map ((cholmod_hip_plan *) L->hip_plan,
+                S == A ? id : src, (int64_t) snz, (int64_t) an) == CHOLMOD_HIP_OK)
+        {
+            L->hip_apat_hash = vmap_ok ? hash : pattern_hash (A) ;
+            L->hip_apat_nnz = an ;
+            L->hip_apat_valid = TRUE ;
+        }
+        if (id) cholmod_l_free (snz > 0 ? snz : 1, sizeof (Int), id, Common) ;
+    }
+    if (src) cholmod_l_free (((Int *) S->p) [S->ncol] > 0 ? ((Int *) S->p) [S->ncol] : 1, sizeof (Int), src, Common) ;
     if (S != A) cholmod_l_free_sparse (&S, Common) ;
     return ok ;
 }

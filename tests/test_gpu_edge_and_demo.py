@@ -266,3 +266,59 @@ def test_random_sparse_spd(seed, n, density):
     T = sp.tril(Asym).tocsc()
     T.sort_indices()
     _check(n, T.indptr.astype(np.int64), T.indices.astype(np.int64), T.data.astype(np.float64), -1, tol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stype", [-1, 1])
+def test_factorize_again_with_new_values_and_with_a_new_pattern(stype):
+    """cholmod_l_factorize called repeatedly on one L: the same pattern with new values takes
+    the values-only path (hash of p / i; H2D of A->x + gather into the resident S), a changed
+    pattern the full path again; every result against the oracle."""
+    import scipy.sparse as sp
+    n, Ap, Ai, Ax = G.poisson3d(14)
+    perm = G.geometric_nd(14, 14, 14, 4)
+    if stype > 0:                                   # the same matrix, upper triangle stored
+        U = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n)).T.tocsc()
+        U.sort_indices()
+        Ap, Ai, Ax = U.indptr.astype(np.int64), U.indices.astype(np.int64), U.data.copy()
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    Lf = S.analyze(A, perm)
+    O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+    mask = O.lower_mask()
+    rng = np.random.default_rng(5)
+    a = A.contents
+    for it in range(4):
+        vals = Ax * (1.0 + 0.3 * it)
+        diag = Ai == np.repeat(np.arange(n), np.diff(Ap))
+        vals[diag] += rng.uniform(0.0, 1.0, int(diag.sum()))
+        ch._view(a.x, len(vals), C.c_double, np.float64)[:] = vals
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        assert Lf.contents.hip_apat_valid == 1
+        assert O.factorize(vals) == 0
+        fv = ch.FactorView(Lf)
+        assert np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask]) < 1e-12, it
+        b = G.demo_rhs(n)
+        x = S.solve(Lf, b)
+        assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, vals, stype, x) - b) / np.linalg.norm(b) < 1e-11
+    # a different pattern (one off-diagonal entry removed everywhere it is stored) on the same L:
+    # entries outside the old pattern are not a concern, fewer entries are simply absent
+    keep = np.ones(len(Ai), dtype=bool)
+    off = np.where(~diag)[0]
+    keep[off[len(off) // 2]] = False
+    cols = np.repeat(np.arange(n), np.diff(Ap))[keep]
+    Ap2 = np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=n))]).astype(np.int64)
+    Ai2, Ax2 = Ai[keep].copy(), vals[keep].copy()
+    A2 = S.sparse(n, Ap2, Ai2, Ax2, stype)
+    h_before = Lf.contents.hip_apat_hash
+    assert S.factorize(A2, Lf) == 1 and S.cm.status == ch.OK
+    assert Lf.contents.hip_apat_hash != h_before
+    O2 = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)      # L's symbolic structure is the old one
+    assert O2.factorize(Ax2, Ap=Ap2, Ai=Ai2) == 0
+    fv = ch.FactorView(Lf)
+    assert np.linalg.norm((fv.x - O2.x)[mask]) / np.linalg.norm(O2.x[mask]) < 1e-12
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.free_sparse(A2)
+    assert S.cm.malloc_count == 0
+    S.finish()
