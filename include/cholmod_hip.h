@@ -157,6 +157,11 @@ int cholmod_hip_refresh_values (cholmod_hip_plan *plan, const double *values, in
 
 /* Copy the device-resident packed Lx (xsize doubles) to the host. */
 int cholmod_hip_download_factor (cholmod_hip_plan *plan, double *Lx_host) ;
+/* Even columns only, packed (xsize / 2 doubles): for a plan built on the doubled
+ * structure of a complex factor (the real embedding, csrc/host/complex.c) these are the
+ * interleaved complex columns of L, i.e. the reference's complex L->x, gathered on the
+ * device. */
+int cholmod_hip_download_even_columns (cholmod_hip_plan *plan, double *out_host) ;
 /* Replace the device-resident Lx by host values (e.g. a factor computed
  * elsewhere), so the device solves can be used with it. */
 int cholmod_hip_upload_factor (cholmod_hip_plan *plan, const double *Lx_host) ;

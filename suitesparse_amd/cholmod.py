@@ -135,7 +135,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
-    "cholmod_hip_download_factor", "cholmod_hip_upload_factor", "cholmod_hip_solve",
+    "cholmod_hip_download_factor", "cholmod_hip_download_even_columns", "cholmod_hip_upload_factor", "cholmod_hip_solve",
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     
     

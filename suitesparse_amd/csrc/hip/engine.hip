@@ -1932,21 +1932,14 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
     return CHOLMOD_HIP_OK ;
 }
 
+static int ensure_check_tasks (cholmod_hip_plan *P) ;
+
 int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
 {
     if (!P || P->host_only || !out5) return CHOLMOD_HIP_INVALID ;
     for (int q = 0 ; q < 5 ; q++) out5 [q] = 0 ;
     if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
-    if (!P->d_chk)
-    {
-        std::vector<CheckTask> t ;
-        for (i64 s = 0 ; s < P->nsuper ; s++)
-            for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS) t.push_back (CheckTask {(i32) s, c0}) ;
-        hipError_t e ;
-        P->d_chk = dupload (t, e) ; HIPCHK (e) ;
-        P->nchk = (i64) t.size () ;
-        HIPCHK (hipMalloc ((void **) &P->d_chk_out, 5 * sizeof (double))) ;
-    }
+    { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }
     HIPCHK (hipMemsetAsync (P->d_chk_out, 0, 5 * sizeof (double), P->stream)) ;
     hipLaunchKernelGGL (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
         P->d_chk, P->d_fr, P->d_Lx, P->d_chk_out) ;
@@ -1954,6 +1947,36 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     return CHOLMOD_HIP_OK ;
+}
+
+static int ensure_check_tasks (cholmod_hip_plan *P)
+{
+    if (P->d_chk) return CHOLMOD_HIP_OK ;
+    std::vector<CheckTask> t ;
+    for (i64 s = 0 ; s < P->nsuper ; s++)
+        for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS) t.push_back (CheckTask {(i32) s, c0}) ;
+    hipError_t e ;
+    P->d_chk = dupload (t, e) ; HIPCHK (e) ;
+    P->nchk = (i64) t.size () ;
+    HIPCHK (hipMalloc ((void **) &P->d_chk_out, 5 * sizeof (double))) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_download_even_columns (cholmod_hip_plan *P, double *out_host)
+{
+    if (!P || P->host_only || !out_host) return CHOLMOD_HIP_INVALID ;
+    if (P->nsuper == 0 || P->xsize == 0) return CHOLMOD_HIP_OK ;
+    { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }
+    double *tmp = nullptr ;
+    const size_t bytes = (size_t) (P->xsize / 2) * sizeof (double) ;
+    if (hipMalloc ((void **) &tmp, bytes) != hipSuccess) { (void) hipGetLastError () ; return CHOLMOD_HIP_OUT_OF_MEMORY ; }
+    hipLaunchKernelGGL (k_even_columns, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
+        P->d_chk, P->d_fr, P->d_Lx, tmp) ;
+    hipError_t e = hipGetLastError () ;
+    if (e == hipSuccess) e = hipMemcpyAsync (out_host, tmp, bytes, hipMemcpyDeviceToHost, P->stream) ;
+    if (e == hipSuccess) e = hipStreamSynchronize (P->stream) ;
+    (void) hipFree (tmp) ;
+    return e == hipSuccess ? CHOLMOD_HIP_OK : CHOLMOD_HIP_GPU_PROBLEM ;
 }
 
 int cholmod_hip_get_maps (cholmod_hip_plan *P, int64_t *sparent, int64_t *level, int64_t *relmap)

@@ -1938,6 +1938,25 @@ __global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
 // == w (mod 4), lanes stride the rows (coalesced).
 #define CHK_COLS 64
 struct CheckTask { i32 front ; i32 c0 ; } ;
+// ---- even columns of the factor (complex input through the real embedding) ---------
+// The engine factors the 2n x 2n embedding of a complex matrix (host/complex.c); the
+// interleaved complex column j of a supernode is the even column 2j of the real one.
+// out (packed: supernode s at px [s] / 2, i.e. 2 * nsrow_c * nscol_c doubles) receives
+// them, the imaginary part of the diagonal as the exact zero zpotrf leaves.
+__global__ void __launch_bounds__(256) k_even_columns (const CheckTask *tasks, const FrontD *fr,
+    const double *Lx, double *out)
+{
+    const CheckTask T = tasks [blockIdx.x] ;
+    const FrontD &f = fr [T.front] ;
+    const int nsrow = f.nsrow, nscol = f.nscol ;
+    const double *L = Lx + f.psx ;
+    double *O = out + f.psx / 2 ;
+    const int c1 = T.c0 + CHK_COLS < nscol ? T.c0 + CHK_COLS : nscol ;
+    for (int c = T.c0 + (T.c0 & 1) ; c < c1 ; c += 2)
+        for (int i = threadIdx.x ; i < nsrow ; i += 256)
+            O [(i64) (c >> 1) * nsrow + i] = (i == c + 1) ? 0.0 : L [(i64) c * nsrow + i] ;
+}
+
 __global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, const FrontD *fr,
     const double *Lx, double *out)
 {

@@ -162,6 +162,17 @@ int ssamd_complex_sync_host (cholmod_factor *L, cholmod_common *Common)
     cholmod_factor *T = (cholmod_factor *) L->cx_twin ;
     if (!T) { ERROR (CHOLMOD_INVALID, "no numeric factor") ; return FALSE ; }
     if (L->hip_host_valid) return TRUE ;
+    if (T->hip_plan && T->hip_on_device && !T->hip_host_valid)
+    {
+        /* gathered on the device: half the bytes cross PCIe, no host copy of the twin */
+        if (!L->x) L->x = cholmod_l_malloc (L->xsize, 2 * sizeof (double), Common) ;
+        if (!L->x) return FALSE ;
+        if (cholmod_hip_download_even_columns ((cholmod_hip_plan *) T->hip_plan, L->x) == CHOLMOD_HIP_OK)
+        {
+            L->hip_host_valid = TRUE ;
+            return TRUE ;
+        }
+    }
     if (!cholmod_l_factor_to_host (T, Common)) return FALSE ;
     if (!gather_even_columns (L, T, Common)) return FALSE ;
     L->hip_host_valid = TRUE ;
@@ -176,8 +187,12 @@ int ssamd_complex_super_numeric (cholmod_sparse *A, double beta, cholmod_factor 
     cholmod_sparse *S2 = embed_lower (A, Common) ;
     if (!S2) return FALSE ;
     double b [2] = {beta, 0} ;
-    /* the host copy of the twin is only a stepping stone to the complex L->x */
+    /* on the engine the twin stays in HBM (the complex L->x is gathered there, below);
+     * on the CPU path its host values are the stepping stone to the complex L->x */
+    const int keep = Common->hip_factor_on_device ;
+    Common->hip_factor_on_device = TRUE ;
     int ok = cholmod_l_super_numeric (S2, NULL, b, T, Common) ;
+    Common->hip_factor_on_device = keep ;
     cholmod_l_free_sparse (&S2, Common) ;
     if (!ok || T->xtype != CHOLMOD_REAL)
     {
@@ -191,7 +206,12 @@ int ssamd_complex_super_numeric (cholmod_sparse *A, double beta, cholmod_factor 
     L->useGPU = T->useGPU ;
     L->hip_on_device = T->hip_on_device ;
     L->hip_host_valid = FALSE ;
-    if (T->x && (T->hip_host_valid || !T->hip_on_device))
+    if (T->hip_on_device && !keep)
+    {
+        if (Common->hip_world > 1 && !cholmod_l_gather_factor (T, Common)) return FALSE ;
+        if (!ssamd_complex_sync_host (L, Common)) return FALSE ;
+    }
+    else if (T->x && (T->hip_host_valid || !T->hip_on_device))
     {
         if (!gather_even_columns (L, T, Common)) return FALSE ;
         L->hip_host_valid = TRUE ;

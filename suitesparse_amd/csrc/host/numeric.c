@@ -235,11 +235,15 @@ int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_
     if (L->cx_twin)
     {
         cholmod_factor *T = L->cx_twin ;
-        if (!cholmod_l_refactorize_resident (beta, T, Common)) return FALSE ;
+        const int keep = Common->hip_factor_on_device ;
+        Common->hip_factor_on_device = TRUE ;       /* the complex L->x is gathered on the device */
+        int ok = cholmod_l_refactorize_resident (beta, T, Common) ;
+        Common->hip_factor_on_device = keep ;
+        if (!ok) return FALSE ;
         int status = Common->status ;
         L->minor = (T->minor >= T->n) ? L->n : T->minor / 2 ;
         L->hip_on_device = T->hip_on_device ; L->hip_host_valid = FALSE ;
-        if (T->x && T->hip_host_valid && !ssamd_complex_sync_host (L, Common)) return FALSE ;
+        if (!keep && !ssamd_complex_sync_host (L, Common)) return FALSE ;
         Common->status = status ;
         return TRUE ;
     }
@@ -578,13 +582,18 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
     cholmod_dense *Y = cholmod_l_allocate_dense (yn, ycols, yn, CHOLMOD_REAL, Common) ;
     if (!Y) return FALSE ;
     double *Yx = Y->x ;
+    const int nth = ssamd_host_threads () ;
     for (Int r = 0 ; r < nrhs ; r++)
+    {
+#pragma omp parallel for schedule(static) num_threads(nth) if (n > 100000)
         for (Int k = 0 ; k < n ; k++)
         {
+            double re, im ;
             dense_get (B, sys == CHOLMOD_A ? Perm [k] : k, r, &re, &im) ;
             if (Lcomplex) { Yx [2*k + r*yn] = re ; Yx [2*k+1 + r*yn] = im ; }
             else { Yx [k + r*yn] = re ; if (Bcomplex) Yx [k + (nrhs + r)*yn] = im ; }
         }
+    }
     int ok = TRUE ;
     if (on_host) ssamd_cpu_super_solve (which, Lr, Yx, ycols, yn) ;
     else
@@ -594,12 +603,16 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
     }
     if (ok)
         for (Int r = 0 ; r < nrhs ; r++)
+        {
+#pragma omp parallel for schedule(static) num_threads(nth) if (n > 100000)
             for (Int k = 0 ; k < n ; k++)
             {
+                double re, im ;
                 if (Lcomplex) { re = Yx [2*k + r*yn] ; im = Yx [2*k+1 + r*yn] ; }
                 else { re = Yx [k + r*yn] ; im = Bcomplex ? Yx [k + (nrhs + r)*yn] : 0.0 ; }
                 dense_put (X, sys == CHOLMOD_A ? Perm [k] : k, r, re, im) ;
             }
+        }
     cholmod_l_free_dense (&Y, Common) ;
     return ok ;
 }
