@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcholmod_amd.so")
+LIB_PATH = os.environ.get("CHOLMOD_AMD_LIB") or os.path.join(_HERE, "lib", "libcholmod_amd.so")   # (override: A/B builds while tuning)
 CSRC = os.path.join(_HERE, "csrc")
 
 CHOLMOD_MAXMETHODS = 9

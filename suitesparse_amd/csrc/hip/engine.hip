@@ -271,6 +271,7 @@ struct cholmod_hip_plan {
     int *d_first_fail = nullptr ;           // k_first_fail result
     i64 *d_vsrc = nullptr ; double *d_vals = nullptr ;      // value map of the resident S (cholmod_hip_set_value_map)
     i64 vsrc_nz = 0, vals_n = 0, s_cur_nz = 0 ;
+    int cur_mapped = 0 ;
     i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace
     double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
@@ -1181,6 +1182,12 @@ static int raise_lds_limits ()
     return CHOLMOD_HIP_OK ;
 }
 
+static int thin_minw ()
+{
+    static const int v = [] () { const char *e = getenv ("CHOLMOD_HIP_THIN_MINW") ; int w = e ? atoi (e) : 6 ; return (w == 4 || w == 5) ? w : 6 ; } () ;
+    return v ;
+}
+
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
@@ -1200,23 +1207,37 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     hipLaunchKernelGGL ((k_thin_front<1, true>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
                         P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                         P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, tim) ;
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim) ;
                 else
                     hipLaunchKernelGGL ((k_thin_front<4, true>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
                         P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                         P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, tim) ;
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim) ;
+            }
+            else if (L.aux <= 64 && thin_minw () != 6)
+            {
+                // tuning (CHOLMOD_HIP_THIN_MINW = 4 / 5): the one-wave kernel with a larger register budget
+                if (thin_minw () == 5)
+                    hipLaunchKernelGGL ((k_thin_front<1, false, 5>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
+                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
+                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
+                else
+                    hipLaunchKernelGGL ((k_thin_front<1, false, 4>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
+                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
+                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
             }
             else if (L.aux <= 64)
                 hipLaunchKernelGGL ((k_thin_front<1>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
                     P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux, (long long *) nullptr) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
             else
                 hipLaunchKernelGGL ((k_thin_front<4>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
                     P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux, (long long *) nullptr) ;
+                    P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
             break ;
         case K_ALLREDUCE:
             if (P->nccl_world)
@@ -1325,6 +1346,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     auto now = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
     double th0 = now () ;
     P->cur_beta = beta ;
+    P->cur_mapped = P->amap_valid ? 1 : 0 ;     // thin fronts: A through the map the first assembly recorded
     size_t nl = P->sch.launches.size () ;
     if (prof)
     {
@@ -1336,6 +1358,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     P->winv_valid = false ;                 // the diagonal-block inverses follow the factor
     HIPCHK (hipEventRecord (P->ev0, st)) ;
     int poisoned = CHOLMOD_HIP_OK ;
+    bool building_map = false ;
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
@@ -1355,7 +1378,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         hipLaunchKernelGGL (k_assemble, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
             P->n, P->d_Sp, P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx,
             P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta, P->d_amap) ;
-        P->amap_valid = true ;
+        building_map = true ;       // (the thin-front kernels record their part; valid once every launch has run)
     }
     if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
     int fail_rank = -1 ; long fail_launch = -1 ;
@@ -1413,6 +1436,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             if (P->world == 1) return CHOLMOD_HIP_GPU_PROBLEM ;
             poisoned = CHOLMOD_HIP_GPU_PROBLEM ;
         }
+        else if (building_map) P->amap_valid = true ;
     }
     double th2 = now () ;
     if (host_timing)

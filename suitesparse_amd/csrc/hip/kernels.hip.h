@@ -725,9 +725,101 @@ template <int NW> __device__ __forceinline__ void tf_barrier ()
 // wave waits for another, no barrier inside the panel.  On return a [] holds the
 // finished entries L(row, c0 + c) of this thread's row; `own` tells whether this
 // thread is the one that stores them (diagonal rows: wave 0 only).
+#ifdef TF_PANEL_LDS
+// Variant: pivots and multipliers travel through a 16-double LDS scratch of the wave
+// (one ds_write_b64 by the diagonal rows, broadcast ds_read_b128 pairs by everybody)
+// instead of two v_readlane per value: (PW-1-c) + 7 vector instructions per column
+// instead of 3 (PW-1-c) + 10.  LDS operations of one wave execute in order, so the
+// read behind the write needs no barrier; bc = this wave's scratch (128 doubles, 16-byte
+// aligned).
+typedef double d2 __attribute__((ext_vector_type(2))) ;
 template <int PW, int NW>
 __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
-    int lane, int wave, int &fail, double *Lp)
+    int lane, int wave, int &fail, double *Lp, double *bc)
+{
+    double a [PW] ;
+    const int row = lane < PW ? c0 + lane : c0 + PW + (64 - PW) * wave + (lane - PW) ;
+    const bool rok = row < ns ;
+    const bool own = rok && (lane >= PW || wave == 0) ;
+    const int rr = rok ? row : ns - 1 ;
+    {
+        int o = tri_col (c0, ns) ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            double v = F [o + rr] ;
+            v = (rok && row >= c0 + c) ? v : 0.0 ;
+            a [c] = (c < pc) ? v : (lane == c ? 1.0 : 0.0) ;
+            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
+        }
+    }
+    double dv = 1.0 ;                                       // lane c keeps the pivot of column c
+#pragma unroll
+    for (int c = 0 ; c < PW ; c++)
+    {
+        bc [lane] = a [c] ;                                 // (every lane: no exec mask to set up; rows 0 .. PW-1 matter)
+        asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+        double u [PW] ;
+#pragma unroll
+        for (int c2 = c & ~1 ; c2 < PW ; c2 += 2)
+        {
+            d2 v = *(const d2 *) (bc + c2) ;
+            u [c2] = v.x ; u [c2 + 1] = v.y ;
+        }
+        asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+        double d = u [c] ;
+        double x = __builtin_amdgcn_rcp (d) ;
+        double e = __builtin_fma (-d, x, 1.0) ;
+        x = __builtin_fma (x, e, x) ;
+        double t = a [c] * x ;                              // u(row,c) / d
+#pragma unroll
+        for (int c2 = c + 1 ; c2 < PW ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
+        if (lane == c) dv = d ;
+        // (without this the scheduler defers the updates of columns c+2 .. and keeps every
+        // column's multipliers alive: 235 registers)
+        __builtin_amdgcn_sched_barrier (0) ;
+    }
+    // first failing pivot of the panel: lane c holds pivot c (NaN does not trip)
+    if (fail < 0)
+    {
+        unsigned long long bad = __ballot (lane < pc && dv <= 0.0) ;
+        if (bad) fail = c0 + (int) __builtin_ctzll (bad) ;
+    }
+    double r, ri ;
+    sqrt_rsqrt (dv, r, ri) ;
+    bc [lane] = r ; bc [64 + lane] = ri ;
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+#pragma unroll
+    for (int c = 0 ; c < PW ; c += 2)
+    {
+        d2 rv = *(const d2 *) (bc + c), iv = *(const d2 *) (bc + 64 + c) ;
+        a [c] = (lane == c) ? rv.x : a [c] * iv.x ;
+        a [c + 1] = (lane == c + 1) ? rv.y : a [c + 1] * iv.y ;
+        if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
+        if (fail >= 0 && c0 + c + 1 >= fail) a [c + 1] = 0.0 ;
+    }
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+    if (wave == 0 && lane == 0) *s_fail = fail ;
+    if (own)
+    {
+        int o = tri_col (c0, ns) ;
+        double *Lr = Lp + row ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            if (c < pc && row >= c0 + c)
+            {
+                F [o + row] = a [c] ;
+                if (fail < 0 || c0 + c < fail) Lr [(i64) c * ns] = a [c] ;
+            }
+            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
+        }
+    }
+}
+#else
+template <int PW, int NW>
+__device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
+    int lane, int wave, int &fail, double *Lp, double *)
 {
     double a [PW] ;
     const int row = lane < PW ? c0 + lane : c0 + PW + (64 - PW) * wave + (lane - PW) ;
@@ -798,6 +890,7 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
         }
     }
 }
+#endif
 // G tiles (i0, j0 + 16 g) of the trailing update, G independent MFMA chains:
 // C -= L(:, c0 .. c0+pc) L(:, same)'.  TO_CB: the result is the contribution block
 // (packed, HBM); otherwise it goes back into the LDS front.  All offsets come from
@@ -897,11 +990,11 @@ __device__ __forceinline__ void tf_tile_row (double *F, int ns, int c0, int pc, 
         else { tf_tiles<1, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 1 ; }
     }
 }
-template <int NW, bool TIMED = false>
-__global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (const i32 *fronts,
+template <int NW, bool TIMED = false, int MINW = (NW == 1 ? 6 : 2)>
+__global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts,
     const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
     const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
-    double *Lx, double *CB, i32 *info, int ns_max, long long *tim = nullptr)
+    double *Lx, double *CB, i32 *info, int ns_max, i64 *amap, int mapped, long long *tim = nullptr)
 {
     long long tc [10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
     auto tick = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
@@ -915,6 +1008,7 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
     i32 *rows_l = (i32 *) (F + ns_max * (ns_max + 1) / 2) ; // the front's row list
     i32 *rm_l = rows_l + nsp ;                              // relative maps of two children (ping-pong)
     __shared__ int s_fail ;
+    __shared__ __attribute__((aligned(16))) double s_bc [128 * NW] ;    // panel broadcast scratch (TF_PANEL_LDS)
     const i32 fid = fronts [blockIdx.x] ;
     const FrontD &f = fr [fid] ;
     const int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
@@ -925,7 +1019,17 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
     // ---- (1) requests first: row list, column pointers of A, the first child
     i64 rowv = (tid < ns) ? Ls [f.psi + tid] : 0 ;
     i64 p0 = 0, p1 = 0 ;
-    const bool asm_col = f.assemble && tid < nc ;
+    // A of a packed S whose map is known (every factorization of a resident S after the
+    // first): the entries of the front's columns are one contiguous range of S, lanes
+    // stride it; amap [p] = -2 - (offset in the packed front), -1 = not in L
+    const bool flat = mapped && !Snz && f.assemble ;
+    const bool asm_col = !flat && f.assemble && tid < nc ;
+    i64 fq = -1 ; double fx = 0.0 ;
+    if (flat)
+    {
+        p0 = Sp [k1] + tid ; p1 = Sp [k1 + nc] ;
+        if (p0 < p1) { fq = amap [p0] ; fx = Sx [p0] ; }
+    }
     if (asm_col)
     {
         i64 col = (i64) k1 + tid ;
@@ -957,9 +1061,12 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
 #pragma unroll
             for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; rmv [q] = rm [e < c.m ? e : c.m - 1] ; }
         }
+        // (chunks past the end of a small block are neither loaded nor decoded: a leaf's
+        // block of 105 entries is two of the eight slots of a one-wave chunk)
 #pragma unroll
         for (int q = 0 ; q < NLD ; q++)
         {
+            if (q > 0 && c.base + NT * q >= c.tot) break ;
             int e = c.base + tid + NT * q ;
             v [q] = c.src [e < c.tot ? e : c.tot - 1] ;
         }
@@ -983,7 +1090,11 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
 #pragma unroll
         for (int q = 0 ; q < NLD ; q++)
         {
-            if (e < c.tot && i >= j) F [tri_col24 (rmc [j], ns) + rmc [i]] += v [q] ;
+            if (q > 0 && c.base + NT * q >= c.tot) break ;
+            // (ds_add_f64: one LDS instruction instead of read / add / write; two entries of
+            // one child never meet in the same entry, the barrier above separates children)
+            if (e < c.tot && i >= j)
+                (void) __hip_atomic_fetch_add (&F [tri_col24 (rmc [j], ns) + rmc [i]], v [q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
             e += NT ; i += NT ;
             if (c.sq) { while (i >= m) { i -= m ; j++ ; } }
             else { while (i >= m && j < m - 1) { j++ ; i = i - m + j ; } }
@@ -1001,6 +1112,20 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
     tf_barrier<NW> () ;
     tick (0) ;
     // ---- A into the panel columns (ASSIGN semantics, entries outside the pattern dropped)
+    if (flat)
+    {
+        if (fq <= -2) F [(int) (-2 - fq)] = fx ;
+        for (i64 p = p0 + NT ; p < p1 ; p += NT)
+        {
+            i64 q = amap [p] ;
+            if (q <= -2) F [(int) (-2 - q)] = Sx [p] ;
+        }
+        if (beta != 0.0)
+        {
+            tf_barrier<NW> () ;
+            if (tid < nc) F [tri_col (tid, ns) + tid] += beta ;
+        }
+    }
     if (asm_col)
     {
         const int k = tid ;
@@ -1021,7 +1146,11 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
                 if (p + u >= p1 || ii [u] < col) continue ;
                 int lo = k, hi = ns ;
                 while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows_l [mid] < (i32) ii [u]) lo = mid + 1 ; else hi = mid ; }
-                if (lo < ns && rows_l [lo] == (i32) ii [u]) Fc [lo] = xx [u] ;
+                if (lo < ns && rows_l [lo] == (i32) ii [u])
+                {
+                    Fc [lo] = xx [u] ;
+                    if (!Snz) amap [p + u] = -2 - (i64) (tri_col (k, ns) + lo) ;
+                }
             }
         }
         if (beta != 0.0) Fc [k] += beta ;
@@ -1046,10 +1175,10 @@ __global__ void __launch_bounds__(64 * NW, (NW == 1 ? 6 : 2)) k_thin_front (cons
     {
         const int pc = nc - c0 < TF_PW ? nc - c0 : TF_PW ;
         double *Lp = Lx + psx + (i64) c0 * ns ;
-        if (pc <= 4) tf_panel<4, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
-        else if (pc <= 8) tf_panel<8, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
-        else if (pc <= 12) tf_panel<12, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
-        else tf_panel<16, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp) ;
+        if (pc <= 4) tf_panel<4, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else if (pc <= 8) tf_panel<8, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else if (pc <= 12) tf_panel<12, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else tf_panel<16, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
         tick (3) ;
         tf_barrier<NW> () ;
         tick (4) ;
