@@ -322,7 +322,7 @@ def main():
                     "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
                     "seconds_by_class": {"update64": ps[6], "update64_K_below_512": ps[23],
                                          "update64_plus_potrf_of_next_block": ps[27], "update128": ps[14], "extend_add+zero": ps[9],
-                                         "potrf": ps[11], "trsm": ps[12], "assemble": ps[13],
+                                         "potrf": ps[11], "trsm": ps[12], "trsm_plus_K64_update_plus_potrf": ps[30], "assemble": ps[13],
                                          "thin_fronts_fused": ps[19],
                                          "total_profiled": ps[0]}}
 

@@ -44,6 +44,8 @@ extern "C" {
                                            extend-add before the dense phase           */
 #define CHOLMOD_HIP_NO_FUSED_POTRF 512   /* tuning: every diagonal block through a k_potrf_mfma
                                          * launch of its own (no k_update2f)                 */
+#define CHOLMOD_HIP_NO_FUSED_TRSM 1024   /* tuning: the K = 64 steps of the panel chain as separate
+                                         * solve and update launches (no k_trsm_upd)               */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
@@ -215,6 +217,8 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [26] trailing-update launches that also factor the next diagonal block (k_update2f: the
  *       K < 512 updates of the panel chain; NOT counted in [6]-[8], [16], [23])
  *  [27] their seconds   [28] their flops   [29] their algorithmic bytes
+ *  [30] seconds of the fused solve + K = 64 update + factorization launches (k_trsm_upd)
+ *  [31] their number
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
 #define CHOLMOD_HIP_NSTATS 32
@@ -223,7 +227,8 @@ int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 /* The launch list of the plan and, after a factorization with profiling on, the
  * device milliseconds of every launch (tuning; tools/launch_profile.py).
  * kind: 0 zero, 1 extend-add, 2 potrf, 3 trsm, 4 update(128), 5 update(64),
- * 7 all-reduce, 8 thin fronts, 9 update + factorization of the next diagonal block.  Fills at most cap entries of the arrays that are
+ * 7 all-reduce, 8 thin fronts, 9 update + factorization of the next diagonal block,
+ * 10 solve + K = 64 update + factorization of the next diagonal block.  Fills at most cap entries of the arrays that are
  * not NULL, returns the number of launches. */
 int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
     int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;

@@ -44,7 +44,7 @@ static inline int outer_block (int maxrows, const ObThresholds &t)
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_UPD_PF, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -397,6 +397,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
     const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
+    const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     auto emit_ar = [&] (int q, int c0, int c1, int wait_ev)
     {
@@ -485,13 +486,46 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         }
         Lp.ng = Lp.grid = (int) (S.pg.size () - Lp.goff) ;
         if (Lp.ng) S.launches.push_back (Lp) ;
+        // Fronts whose step is "solve, K = 64 update of the next 64 columns, factor the next
+        // diagonal block" (every other step of the doubling schedule) take all three in one
+        // launch (k_trsm_upd): a full panel, a full next block inside the same outer block
+        // column, the front not shared between ranks.
+        std::vector<char> fused (nf, 0) ;
+        if (fuse_trsm)
+        {
+            Launch Lf_ {K_TRSM_UPD, 0, 0, S.tg.size (), 0, 0} ;
+            int fblocks = 0 ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol < i0 + 2 * NB || is_shared (ids [q])) continue ;
+                int OBq = ob_of (f) ;
+                int o0 = (i0 / OBq) * OBq ;
+                int o1 = std::min (o0 + OBq, f.nscol) ;
+                if (i0 + 2 * NB > o1) continue ;             // the next block belongs to the outer update
+                int e = (i0 - o0) / NB + 1 ;
+                if ((e & -e) != 1) continue ;               // p = 1 steps only
+                int m = f.nsrow - (i0 + NB) ;
+                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
+                           f.psx + (i0 + NB) + (i64) i0 * f.nsrow, f.nsrow, m, NB,
+                           ids [q], i0, fblocks} ;
+                fblocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
+                S.tg.push_back (G) ;
+                Lf_.flops += (double) m * NB * NB + 2.0 * ((double) m * NB - (double) NB * (NB - 1) / 2) * NB + (double) NB * NB * NB / 3.0 ;
+                Lf_.bytes += 8.0 * (3.0 * m * NB) ;
+                fused [q] = 1 ;
+                pf_done [q] = i0 + NB ;
+            }
+            Lf_.ng = (int) (S.tg.size () - Lf_.goff) ; Lf_.grid = fblocks ; Lf_.aux = NB ;
+            if (Lf_.ng) S.launches.push_back (Lf_) ;
+        }
         // trsm of the rows below
         Launch Lt {K_TRSM, 0, 0, S.tg.size (), 0, 0} ;
         int blocks = 0 ;
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
-            if (f.nscol <= i0) continue ;
+            if (f.nscol <= i0 || fused [q]) continue ;
             int nb = std::min (NB, f.nscol - i0) ;
             int m = f.nsrow - (i0 + nb) ;
             if (m <= 0) continue ;
@@ -516,7 +550,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
-            if (f.nscol <= i0) continue ;
+            if (f.nscol <= i0 || fused [q]) continue ;
             int OBq = ob_of (f) ;
             int o0 = (i0 / OBq) * OBq ;
             int o1 = std::min (o0 + OBq, f.nscol) ;
@@ -1176,16 +1210,31 @@ static int raise_lds_limits ()
     if (done) return CHOLMOD_HIP_OK ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
 
-static int thin_minw ()
+// waves per SIMD the one-wave thin-front kernel is compiled for, by size class (<= 32 / 48 / 64
+// rows); CHOLMOD_HIP_THIN_MINW = "a" or "a,b,c" overrides (3 .. 6)
+static int thin_minw (int cls)
 {
-    static const int v = [] () { const char *e = getenv ("CHOLMOD_HIP_THIN_MINW") ; int w = e ? atoi (e) : 6 ; return (w == 4 || w == 5) ? w : 6 ; } () ;
-    return v ;
+    static int v [3] = {4, 4, 3} ;      // (measured on the 2D 1259^2 problem: 6 everywhere 1.044 ms, 4 / 4 / 3 1.004 ms)
+    static const bool init = [] ()
+    {
+        if (const char *e = getenv ("CHOLMOD_HIP_THIN_MINW"))
+        {
+            int a = 0, b = 0, c = 0 ;
+            int k = sscanf (e, "%d,%d,%d", &a, &b, &c) ;
+            if (k == 1) b = c = a ;
+            if (k == 1 || k == 3) { int w [3] = {a, b, c} ; for (int q = 0 ; q < 3 ; q++) if (w [q] >= 3 && w [q] <= 6) v [q] = w [q] ; }
+        }
+        return true ;
+    } () ;
+    (void) init ;
+    return v [cls] ;
 }
 
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
@@ -1199,45 +1248,29 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
             // fronts of <= 64 rows run one wave per front (lane = row, no cross-wave
             // hand-off), wider ones four
-            if (P->d_thin_tim)
             {
                 // tuning: per-phase shader cycles of one front per launch (CHOLMOD_HIP_THIN_TIMING)
-                long long *tim = P->d_thin_tim + 10 * (size_t) (&L - P->sch.launches.data ()) ;
-                if (L.aux <= 64)
-                    hipLaunchKernelGGL ((k_thin_front<1, true>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
-                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim) ;
+                long long *tim = P->d_thin_tim ? P->d_thin_tim + 10 * (size_t) (&L - P->sch.launches.data ()) : nullptr ;
+#define THIN_LAUNCH(NW_, TIMED_, MINW_) \
+                hipLaunchKernelGGL ((k_thin_front<NW_, TIMED_, MINW_>), dim3 (L.grid), dim3 (64 * NW_), thin_front_lds_bytes (L.aux), st, \
+                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp, \
+                    P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta, \
+                    P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim)
+                if (tim) { if (L.aux <= 64) THIN_LAUNCH (1, true, 6) ; else THIN_LAUNCH (4, true, 2) ; }
+                else if (L.aux > 64) THIN_LAUNCH (4, false, 2) ;
                 else
-                    hipLaunchKernelGGL ((k_thin_front<4, true>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
-                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim) ;
+                {
+                    // one wave per front: the register budget (waves per SIMD the compiler must
+                    // allow) by size class -- the LDS of the wider classes caps the occupancy
+                    // anyway (9.6 / 16.9 KB per front), and 80 registers spill
+                    const int w = thin_minw (L.aux <= 32 ? 0 : L.aux <= 48 ? 1 : 2) ;
+                    if (w == 6) THIN_LAUNCH (1, false, 6) ;
+                    else if (w == 5) THIN_LAUNCH (1, false, 5) ;
+                    else if (w == 3) THIN_LAUNCH (1, false, 3) ;
+                    else THIN_LAUNCH (1, false, 4) ;
+                }
+#undef THIN_LAUNCH
             }
-            else if (L.aux <= 64 && thin_minw () != 6)
-            {
-                // tuning (CHOLMOD_HIP_THIN_MINW = 4 / 5): the one-wave kernel with a larger register budget
-                if (thin_minw () == 5)
-                    hipLaunchKernelGGL ((k_thin_front<1, false, 5>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
-                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
-                else
-                    hipLaunchKernelGGL ((k_thin_front<1, false, 4>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
-                        P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
-            }
-            else if (L.aux <= 64)
-                hipLaunchKernelGGL ((k_thin_front<1>), dim3 (L.grid), dim3 (64), thin_front_lds_bytes (L.aux), st,
-                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                    P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
-            else
-                hipLaunchKernelGGL ((k_thin_front<4>), dim3 (L.grid), dim3 (256), thin_front_lds_bytes (L.aux), st,
-                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp,
-                    P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta,
-                    P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr) ;
             break ;
         case K_ALLREDUCE:
             if (P->nccl_world)
@@ -1318,6 +1351,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
             hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
                 P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
+            break ;
+        case K_TRSM_UPD:
+            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+            hipLaunchKernelGGL (k_trsm_upd, dim3 (L.grid), dim3 (256), trsm_upd_lds_bytes (), st,
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info) ;
             break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
@@ -1455,6 +1493,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         const Launch &L = P->sch.launches [q] ;
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
+        if (L.kind == K_TRSM_UPD) S [31] += 1 ;
         if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
@@ -1482,6 +1521,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_POTRF: S [11] += sec ; break ;
                 case K_SMALL: S [19] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
+                case K_TRSM_UPD: S [30] += sec ; break ;
             }
         }
     }

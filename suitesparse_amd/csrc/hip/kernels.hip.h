@@ -537,12 +537,12 @@ __device__ __forceinline__ void trsm_diag_inverses (const double *Ls, int ldl, d
 
 // bj [jj][r] = B(row lr of the wave's 16 rows, column 16 jj + lk + 4 r) in the
 // accumulator layout; solves X = B inv(L11)' block column by block column and stores it.
+// xr [j] receives the solved block j, again in the accumulator (= A-operand) layout.
 template <typename Tick>
 __device__ __forceinline__ void trsm_solve_rows (const d4 (&bj) [4], int nblk, const double *Ls, int ldl,
-    const double *Wd, int lane, int nvalid, bool rok, int nb, double *B, i64 lda, Tick tick)
+    const double *Wd, int lane, int nvalid, bool rok, int nb, double *B, i64 lda, Tick tick, d4 (&xr) [4])
 {
     const int lr = lane & 15, lk = lane >> 4 ;
-    d4 xr [4] ;
 #pragma unroll
     for (int j = 0 ; j < 4 ; j++)
     {
@@ -660,7 +660,8 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     // lk + 4 r, r = 0..3) IS its A-operand layout for the k-steps s = r (k = 4 s +
     // lk): a solved block X_i and the intermediate B_j - sum feed the next MFMAs
     // straight from registers, no LDS round trip, no barrier.
-    trsm_solve_rows (bj, nblk, Ls, ldl, Wd, lane, nvalid, rok, nb, B, lda, tick) ;
+    d4 xr [4] ;
+    trsm_solve_rows (bj, nblk, Ls, ldl, Wd, lane, nvalid, rok, nb, B, lda, tick, xr) ;
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
@@ -717,21 +718,20 @@ template <int NW> __device__ __forceinline__ void tf_barrier ()
     if constexpr (NW == 1) { asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ; }
     else asm volatile ("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory") ;
 }
-// One PW-column panel (PW = 4, 8, 16 at compile time: no branch inside the
+// One PW-column panel (PW = 4, 8, 12, 16 at compile time: no branch inside the
 // elimination; columns pc .. PW-1 do not exist and behave as identity columns).
 // Every wave carries the PW diagonal rows in its lanes 0 .. PW-1 (the same values
 // in all waves) and 64 - PW rows of its own behind them, so each wave runs the
-// whole elimination by itself: pivots and multipliers travel by v_readlane, no
-// wave waits for another, no barrier inside the panel.  On return a [] holds the
-// finished entries L(row, c0 + c) of this thread's row; `own` tells whether this
-// thread is the one that stores them (diagonal rows: wave 0 only).
-#ifdef TF_PANEL_LDS
-// Variant: pivots and multipliers travel through a 16-double LDS scratch of the wave
-// (one ds_write_b64 by the diagonal rows, broadcast ds_read_b128 pairs by everybody)
-// instead of two v_readlane per value: (PW-1-c) + 7 vector instructions per column
-// instead of 3 (PW-1-c) + 10.  LDS operations of one wave execute in order, so the
-// read behind the write needs no barrier; bc = this wave's scratch (128 doubles, 16-byte
-// aligned).
+// whole elimination by itself: no wave waits for another, no barrier inside the
+// panel.  Pivots and multipliers travel through a 64-double LDS scratch of the wave
+// (one ds_write_b64 by every lane, broadcast ds_read_b128 pairs by everybody): (PW-1-c)
+// + 7 vector instructions per column where two v_readlane per value cost 3 (PW-1-c)
+// + 10 (thin fronts of the 2D 1259^2 problem 1.012 -> 0.982 ms; the kernel is bound
+// by instruction issue).  LDS operations of one wave execute in order, so the read
+// behind the write needs no barrier; bc = this wave's scratch (128 doubles, 16-byte
+// aligned).  On return a [] holds the finished entries L(row, c0 + c) of this
+// thread's row; `own` tells whether this thread is the one that stores them
+// (diagonal rows: wave 0 only).
 typedef double d2 __attribute__((ext_vector_type(2))) ;
 template <int PW, int NW>
 __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
@@ -816,81 +816,6 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
         }
     }
 }
-#else
-template <int PW, int NW>
-__device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
-    int lane, int wave, int &fail, double *Lp, double *)
-{
-    double a [PW] ;
-    const int row = lane < PW ? c0 + lane : c0 + PW + (64 - PW) * wave + (lane - PW) ;
-    const bool rok = row < ns ;
-    const bool own = rok && (lane >= PW || wave == 0) ;
-    const int rr = rok ? row : ns - 1 ;
-    {
-        int o = tri_col (c0, ns) ;
-#pragma unroll
-        for (int c = 0 ; c < PW ; c++)
-        {
-            double v = F [o + rr] ;                         // always inside the packed front: no branch
-            v = (rok && row >= c0 + c) ? v : 0.0 ;
-            a [c] = (c < pc) ? v : (lane == c ? 1.0 : 0.0) ;
-            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
-        }
-    }
-    double dv = 1.0 ;                                       // lane c keeps the pivot of column c
-#pragma unroll
-    for (int c = 0 ; c < PW ; c++)
-    {
-        double d = readlane_f64 (a [c], c) ;
-        if (c < pc && fail < 0 && d <= 0.0) fail = c0 + c ;
-        double x = __builtin_amdgcn_rcp (d) ;
-        double e = __builtin_fma (-d, x, 1.0) ;
-        x = __builtin_fma (x, e, x) ;
-        // all multipliers u(c0+c2, c) of the column leave for the scalar registers at
-        // once, next to the reciprocal: one (read-lane, read-lane, fma) triple after the
-        // other through the same scalar pair costs ~70 cycles each
-        // (missing columns pc .. PW-1 collect garbage nobody reads: they sit behind
-        // the real ones, are never a pivot that counts and are never stored)
-        double u [PW] ;
-#pragma unroll
-        for (int c2 = c + 1 ; c2 < PW ; c2++) u [c2] = readlane_f64 (a [c], c2) ;
-        __builtin_amdgcn_sched_barrier (0) ;
-        double t = a [c] * x ;                              // u(row,c) / d
-#pragma unroll
-        for (int c2 = c + 1 ; c2 < PW ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
-        if (lane == c) dv = d ;
-        __builtin_amdgcn_sched_barrier (0) ;
-    }
-    double r, ri ;
-    sqrt_rsqrt (dv, r, ri) ;
-#pragma unroll
-    for (int c = 0 ; c < PW ; c++)
-    {
-        double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
-        a [c] = (lane == c) ? rc : a [c] * ric ;
-        if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
-    }
-    if (wave == 0 && lane == 0) *s_fail = fail ;
-    if (own)
-    {
-        // finished columns: back into the LDS front (operands of the trailing update)
-        // and, straight from the registers, to Lx (Lp = first column of the panel;
-        // columns at / beyond a failed pivot stay zero)
-        int o = tri_col (c0, ns) ;
-        double *Lr = Lp + row ;
-#pragma unroll
-        for (int c = 0 ; c < PW ; c++)
-        {
-            if (c < pc && row >= c0 + c)
-            {
-                F [o + row] = a [c] ;
-                if (fail < 0 || c0 + c < fail) Lr [(i64) c * ns] = a [c] ;
-            }
-            if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
-        }
-    }
-}
-#endif
 // G tiles (i0, j0 + 16 g) of the trailing update, G independent MFMA chains:
 // C -= L(:, c0 .. c0+pc) L(:, same)'.  TO_CB: the result is the contribution block
 // (packed, HBM); otherwise it goes back into the LDS front.  All offsets come from
@@ -1001,14 +926,14 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     constexpr int NT = 64 * NW ;
     constexpr int NLD = 8 ;                                 // child entries in flight per thread and buffer
-    constexpr int NRM = (SM_MAX + NT - 1) / NT ;            // relative-map entries per thread
+    constexpr int NRM = ((NW == 1 ? 64 : SM_MAX) + NT - 1) / NT ;   // relative-map entries per thread (one wave: fronts, hence child blocks, of <= 64 rows)
     extern __shared__ __attribute__((aligned(16))) double tf_lds [] ;
     double *F = tf_lds ;                                    // packed lower triangle of the front
     const int nsp = (ns_max + 1) & ~1 ;
     i32 *rows_l = (i32 *) (F + ns_max * (ns_max + 1) / 2) ; // the front's row list
     i32 *rm_l = rows_l + nsp ;                              // relative maps of two children (ping-pong)
     __shared__ int s_fail ;
-    __shared__ __attribute__((aligned(16))) double s_bc [128 * NW] ;    // panel broadcast scratch (TF_PANEL_LDS)
+    __shared__ __attribute__((aligned(16))) double s_bc [128 * NW] ;    // panel broadcast scratch
     const i32 fid = fronts [blockIdx.x] ;
     const FrontD &f = fr [fid] ;
     const int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
@@ -1513,6 +1438,154 @@ __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng
     {
         const int k = wave + 4 * q, i = lane ;
         if (i >= k) A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : sm [k * PF2_LD + i] ;
+    }
+}
+
+// ---- panel solve + the K = 64 update of the next block column + its dpotrf ---------
+// Every other step of the panel chain (recursive doubling, p = 1) is: dtrsm of the rows
+// below a 64 x 64 diagonal block, then the K = 64 update of the NEXT 64 columns with
+// exactly those solved rows, then the dpotrf of the next diagonal block -- two launches
+// (k_trsm_mfma, k_update2f) of ~15 + ~25 us whose work is a few microseconds.  Here one
+// launch does all three: a workgroup solves its 64 rows X_b (as k_trsm_mfma: the solved
+// blocks stay in registers, in the A-operand layout of v_mfma_f64_16x16x4) and, beside
+// them, the 64 rows X_0 of the next diagonal block (redundantly: no cross-workgroup
+// hand-off, which costs an L2 write-back on this part); -X_0 goes to LDS k-major, and
+// C_b -= X_b X_0' (64 MFMAs per wave, four independent chains) is read-modified-written
+// from the accumulator layout.  Workgroup 0 owns the next diagonal block: it keeps the
+// updated block in LDS and eliminates it on the spot (pf_eliminate, as k_update2f).
+// Conditions (checked by the scheduler): a full 64-column panel, a full next block,
+// the front not shared between ranks.  TrGroup: l_off = the factored diagonal block,
+// b_off = first row below it (same columns), m rows, col0 = its first column.
+#define TU_LDX 80
+__host__ __device__ inline size_t trsm_upd_lds_bytes ()
+{
+    return (size_t) (64 * 64 + 4 * 256 + 64 * TU_LDX) * sizeof (double) ;
+}
+__global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, double *Lx, i32 *info)
+{
+    extern __shared__ __attribute__((aligned(16))) double tu_lds [] ;
+    double *Ls = tu_lds ;                           // [64][64]  -L11 k-major; later the next diagonal block
+    double *Wd = Ls + 64 * 64 ;                     // [4][16][16] inverses of the 16 x 16 diagonal blocks
+    double *X0s = Wd + 4 * 256 ;                    // [64][TU_LDX]  -X_0 k-major
+    __shared__ int s_fail ;
+    __builtin_amdgcn_s_setprio (3) ;
+    const int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
+    const TrGroup G = g [gi] ;
+    const i64 lda = G.lda ;
+    const int ldl = 64 ;
+    const double *L11 = Lx + G.l_off ;
+    const int inf = info [G.front] ;
+    int nvalid = 64 ;
+    if (inf != 0)
+    {
+        nvalid = inf - 1 - G.col0 ;
+        if (nvalid < 0) nvalid = 0 ;
+        if (nvalid > 64) nvalid = 64 ;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
+    const int lr = lane & 15, lk = lane >> 4 ;
+    const int blk = (int) blockIdx.x - G.blk_start ;
+    const int row = blk * TRM_ROWS + wave * 16 + lr ;
+    const bool rok = row < G.m ;
+    double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;          // this lane's row of the rows below
+    double *B0 = Lx + G.b_off + wave * 16 + lr ;                // its row of the next diagonal block's rows
+    double *Cr = B + 64 * lda ;                                 // the same row, 64 columns to the right
+    d4 bj [4], b0 [4], cj [4] ;
+    {
+        const int j = tid & 63 ;
+        double tmp [16] ;
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++) tmp [q] = L11 [j + (i64) ((tid >> 6) + 4 * q) * lda] ;
+#pragma unroll
+        for (int jj = 0 ; jj < 4 ; jj++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                const i64 co = (i64) (16 * jj + lk + 4 * r) * lda ;
+                bj [jj][r] = B [co] ;
+                b0 [jj][r] = B0 [co] ;
+                cj [jj][r] = Cr [co] ;
+            }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            const int k = (tid >> 6) + 4 * q ;
+            double v = (j == k) ? 1.0 : 0.0 ;
+            if (j < nvalid && k < j) v = -tmp [q] ;
+            if (j < nvalid && k == j) v = tmp [q] ;
+            Ls [k * ldl + j] = v ;
+        }
+    }
+    if (tid == 0) s_fail = -1 ;
+    __syncthreads () ;
+    auto tick = [] (int) {} ;
+    trsm_diag_inverses (Ls, ldl, Wd, 4, lane, wave, tick) ;
+    __syncthreads () ;
+    d4 xr [4], x0 [4] ;
+    trsm_solve_rows (bj, 4, Ls, ldl, Wd, lane, nvalid, rok, 64, B, lda, tick, xr) ;
+    if (blk == 0)
+    {
+#pragma unroll
+        for (int j = 0 ; j < 4 ; j++) x0 [j] = xr [j] ;
+    }
+    else trsm_solve_rows (b0, 4, Ls, ldl, Wd, lane, nvalid, false, 64, B0, lda, tick, x0) ;
+    // -X_0 k-major: X0s [k][j] = -X_0 (j, k); block jj, element r of the accumulator layout is
+    // (row lr of the wave's 16 rows, column 16 jj + lk + 4 r)
+#pragma unroll
+    for (int jj = 0 ; jj < 4 ; jj++)
+#pragma unroll
+        for (int r = 0 ; r < 4 ; r++)
+            X0s [(16 * jj + lk + 4 * r) * TU_LDX + wave * 16 + lr] = -x0 [jj][r] ;
+    __syncthreads () ;                      // (also: every wave is done with Ls and Wd)
+    // C (row, 16 jt + lk + 4 r) -= sum_k X (row, k) X_0 (16 jt + .., k)
+#pragma unroll
+    for (int i = 0 ; i < 4 ; i++)
+#pragma unroll
+        for (int s4 = 0 ; s4 < 4 ; s4++)
+#pragma unroll
+            for (int jt = 0 ; jt < 4 ; jt++)
+            {
+                double bv = X0s [(16 * i + 4 * s4 + lk) * TU_LDX + 16 * jt + lr] ;
+                cj [jt] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, xr [i][s4], cj [jt], 0, 0, 0) ;
+            }
+    if (blk != 0)
+    {
+        if (rok)
+        {
+#pragma unroll
+            for (int jt = 0 ; jt < 4 ; jt++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++) Cr [(i64) (16 * jt + lk + 4 * r) * lda] = cj [jt][r] ;
+        }
+        return ;
+    }
+    // workgroup 0: the updated tile is the next diagonal block
+    double *A = Lx + G.b_off + 64 * lda ;
+    if (inf != 0)
+    {
+        // an earlier pivot of this front failed: its remaining columns are zero
+        for (int k = wave ; k < PF_NB ; k += 4)
+            if (lane >= k) A [lane + (i64) k * lda] = 0.0 ;
+        return ;
+    }
+    double *T = Ls ;                                // T [k * PF2_LD + i] = A (i, k), zero above the diagonal
+#pragma unroll
+    for (int jt = 0 ; jt < 4 ; jt++)
+#pragma unroll
+        for (int r = 0 ; r < 4 ; r++)
+        {
+            const int i = wave * 16 + lr, j = 16 * jt + lk + 4 * r ;
+            T [j * PF2_LD + i] = (i >= j) ? cj [jt][r] : 0.0 ;
+        }
+    __syncthreads () ;
+    pf_eliminate (T, PF_NB / 16, &s_fail, tid, tick) ;
+    const int fail = s_fail ;
+    if (fail >= 0 && tid == 0) info [G.front] = G.col0 + 64 + fail + 1 ;
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++)
+    {
+        const int k = wave + 4 * q, i = lane ;
+        if (i >= k) A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
     }
 }
 

@@ -234,6 +234,33 @@ def test_beta_refactorize_and_device_resident_mode(L, golden_dir):
     S.finish()
 
 
+def test_thin_fronts_through_the_assembly_map_with_beta(L):
+    """2D grid (nearly every front is a thin one): the first factorization of a resident S
+    searches the row lists and records the map, the later ones stream A through it
+    (k_thin_front `mapped`); beta on the diagonal in both modes, each against the oracle."""
+    n, Ap, Ai, Ax = G.poisson2d(48)
+    perm = G.geometric_nd(48, 48, 1, 4)
+    S = ch.Session(factor_on_device=True)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    mask = O.lower_mask()
+    assert S.factorize(A, Lf, beta=0.125) == 1                  # search path, records the map
+    for beta in (0.125, 0.25, 0.0):                             # mapped path
+        if beta != 0.125:
+            assert S.refactorize_resident(Lf, beta=beta) == 1
+        assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+        assert O.factorize(Ax, beta=beta) == 0
+        assert rel_err_lower(ch.FactorView(Lf).x, O.x, mask) < TOL_L, beta
+        if beta == 0.125:
+            assert S.refactorize_resident(Lf, beta=beta) == 1   # the same beta once more, now through the map
+            assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+            assert rel_err_lower(ch.FactorView(Lf).x, O.x, mask) < TOL_L
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
 def test_triangular_solves_match_oracle(L, golden_dir):
     n, Ap, Ai, Ax, stype, perm = _case("p3d_12_nd", golden_dir)
     S = ch.Session()
