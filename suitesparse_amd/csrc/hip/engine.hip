@@ -264,6 +264,7 @@ struct cholmod_hip_plan {
     double *d_Lx = nullptr, *d_cb = nullptr ;
     ZeroGroup *d_zg = nullptr ; EaGroup *d_eg = nullptr ; PfGroup *d_pg = nullptr ;
     TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ; i32 *d_sm = nullptr ;
+    i32 *d_tu_cnt = nullptr ;       // k_trsm_upd: per group, workgroups that have read the rows workgroup 0 overwrites
     double cur_beta = 0 ;
     // resident input matrix
     i64 *d_Sp = nullptr, *d_Si = nullptr, *d_Snz = nullptr ; double *d_Sx = nullptr ;
@@ -1119,7 +1120,7 @@ static void free_device (cholmod_hip_plan *P)
     }
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
-        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_gg, P->d_sm,
+        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
@@ -1167,6 +1168,7 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_eg = dupload (P->sch.eg, e) ; HIPCHK (e) ;
     P->d_pg = dupload (P->sch.pg, e) ; HIPCHK (e) ;
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P->d_tu_cnt, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32))) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
@@ -1355,7 +1357,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
         case K_TRSM_UPD:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
             hipLaunchKernelGGL (k_trsm_upd, dim3 (L.grid), dim3 (256), trsm_upd_lds_bytes (), st,
-                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info) ;
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, P->d_tu_cnt + L.goff) ;
             break ;
         case K_UPD_BIG:
             hipLaunchKernelGGL ((k_update2<BIG, BIG, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
@@ -1400,6 +1402,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
+    HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
     if (P->n > 0 && P->amap_valid)
     {
         // the resident S was assembled before: stream it through its map
@@ -2140,6 +2143,8 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     HIPCHK (hipMemset (P.d_info, 0, sizeof (i32))) ;
     P.d_pg = dupload (S.pg, e) ; HIPCHK (e) ;
     P.d_tg = dupload (S.tg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P.d_tu_cnt, std::max<size_t> (S.tg.size (), 1) * sizeof (i32))) ;
+    HIPCHK (hipMemset (P.d_tu_cnt, 0, std::max<size_t> (S.tg.size (), 1) * sizeof (i32))) ;
     P.d_gg = dupload (S.gg, e) ; HIPCHK (e) ;
     HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
     if (ncb > 0)
@@ -2160,7 +2165,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     free_device (&P) ;
     P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
-    P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ;
+    P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ; P.d_tu_cnt = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -344,7 +344,7 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
                 // zeroed below, and nothing flows back into earlier columns)
                 double x = __builtin_amdgcn_rcp (d) ;
                 double e = __builtin_fma (-d, x, 1.0) ;
-                x = __builtin_fma (x, e, x) ;
+                double t0 = a [c] * x ;             // beside e, off the chain: t = a x (1 + e)
                 // the column's multipliers leave for the scalar registers together, next to
                 // the reciprocal: (read-lane, read-lane, fma) triples one behind the other
                 // through one scalar pair cost ~70 cycles each
@@ -352,7 +352,7 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
 #pragma unroll
                 for (int c2 = c + 1 ; c2 < 16 ; c2++) u [c2] = readlane_f64 (a [c], c2) ;
                 __builtin_amdgcn_sched_barrier (0) ;
-                double t = a [c] * x ;              // u(row,c) / d
+                double t = __builtin_fma (t0, e, t0) ;      // u(row,c) / d: rcp -> e -> t -> fma, one multiply less on the chain
 #pragma unroll
                 for (int c2 = c + 1 ; c2 < 16 ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
                 if (lane == c) dv = d ;
@@ -1461,7 +1461,7 @@ __host__ __device__ inline size_t trsm_upd_lds_bytes ()
 {
     return (size_t) (64 * 64 + 4 * 256 + 64 * TU_LDX) * sizeof (double) ;
 }
-__global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, double *Lx, i32 *info)
+__global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, double *Lx, i32 *info, i32 *cnt)
 {
     extern __shared__ __attribute__((aligned(16))) double tu_lds [] ;
     double *Ls = tu_lds ;                           // [64][64]  -L11 k-major; later the next diagonal block
@@ -1520,7 +1520,28 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     __syncthreads () ;
     auto tick = [] (int) {} ;
     trsm_diag_inverses (Ls, ldl, Wd, 4, lane, wave, tick) ;
+    // The solve is in place: workgroup 0 overwrites the rows of the next diagonal block
+    // that every other workgroup of the group reads (b0).  A write-after-read hazard,
+    // no data passes through memory: the others count themselves in once their loads
+    // have arrived, workgroup 0 stores only when all are in.  (Blocks are dispatched in
+    // order and only workgroup 0 ever waits, for workgroups right behind it: no
+    // deadlock; the wait is bounded all the same.)
+    const int nwg = (G.m + TRM_ROWS - 1) / TRM_ROWS ;
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
     __syncthreads () ;
+    if (tid == 0 && nwg > 1)
+    {
+        if (blk != 0) (void) __hip_atomic_fetch_add (cnt + gi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+        else
+        {
+            for (int it = 0 ; it < (1 << 22) ; it++)
+            {
+                if (__hip_atomic_load (cnt + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg - 1) break ;
+                __builtin_amdgcn_s_sleep (4) ;
+            }
+        }
+    }
+    if (blk == 0) __syncthreads () ;
     d4 xr [4], x0 [4] ;
     trsm_solve_rows (bj, 4, Ls, ldl, Wd, lane, nvalid, rok, 64, B, lda, tick, xr) ;
     if (blk == 0)
