@@ -46,6 +46,8 @@ extern "C" {
                                          * launch of its own (no k_update2f)                 */
 #define CHOLMOD_HIP_NO_FUSED_TRSM 1024   /* tuning: the K = 64 steps of the panel chain as separate
                                          * solve and update launches (no k_trsm_upd)               */
+#define CHOLMOD_HIP_NO_LEAF_PAIRS 4096    /* tuning: leaf fronts one per wave like every other thin
+                                         * front (no k_leaf_pair)                                */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device

@@ -60,6 +60,8 @@ struct Launch {
     int ar_ld = 0, ar_r0 = 0, ar_nc = 0 ;   // ar_off (column o0), ld ar_ld, rows >= ar_r0 of ar_nc columns
     int ar_g0 = 0, ar_gn = 1 ;              // ... over the ranks [ar_g0, ar_g0+ar_gn)
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
+    int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
+    int leaf_pw = 0 ;               // K_SMALL: every front is a leaf of <= 32 rows and <= leaf_pw (4/8/12/16) columns: two per wave (k_leaf_pair)
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -1028,12 +1030,16 @@ static int build_host (cholmod_hip_plan *P)
             {
                 if (bucket [c].empty ()) continue ;
                 Launch Ls_ {K_SMALL, (int) bucket [c].size (), (int) bucket [c].size (), S.sm.size (), 0, 0} ;
-                int mx = 0 ;
+                int mx = 0, mxc = 0, mxt = 0 ;
+                bool leaves = !(P->flags & CHOLMOD_HIP_NO_LEAF_PAIRS) ;
                 for (i32 sid : bucket [c])
                 {
                     FrontD &f = P->fr [sid] ;
                     if (f.assemble == 1) f.assemble = 2 ;
                     mx = std::max (mx, f.nsrow) ;
+                    mxc = std::max (mxc, f.nscol) ;
+                    mxt = std::max (mxt, f.nscol * f.nsrow - f.nscol * (f.nscol - 1) / 2) ;
+                    if (f.child_end != f.child_begin) leaves = false ;
                     double cc = f.nscol, r = f.ncb ;
                     Ls_.flops += cc * cc * cc / 3.0 + r * cc * cc + r * r * cc ;
                     Ls_.bytes += 8.0 * (f.nsrow * cc + r * (r + 1) / 2) ;
@@ -1045,6 +1051,7 @@ static int build_host (cholmod_hip_plan *P)
                     S.sm.push_back (sid) ;
                 }
                 Ls_.aux = mx ;                              // widest member: LDS sizing, waves per front
+                if (leaves && mx <= 32 && mxc <= 16) { Ls_.leaf_pw = (mxc + 3) / 4 * 4 ; Ls_.leaf_T = (mxt + 31) / 32 * 32 ; }
                 S.launches.push_back (Ls_) ;
             }
         }
@@ -1258,7 +1265,22 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp, \
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta, \
                     P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim)
-                if (tim) { if (L.aux <= 64) THIN_LAUNCH (1, true, 6) ; else THIN_LAUNCH (4, true, 2) ; }
+                if (L.leaf_pw && P->cur_mapped && !P->s_unpacked && !tim)
+                {
+                    // leaf fronts two to a wave, once the assembly map of the resident S exists
+#define LEAF_LAUNCH(PW_, MINW_) \
+                    hipLaunchKernelGGL ((k_leaf_pair<PW_, MINW_>), dim3 ((L.grid + 1) / 2), dim3 (64), (size_t) (2 * L.leaf_T + 128) * sizeof (double), st, \
+                        P->d_sm + L.goff, L.grid, P->d_fr, P->d_Sp, P->d_Sx, P->d_amap, P->cur_beta, P->d_Lx, P->d_cb, P->d_info, L.leaf_T)
+                    static const int lw = [] () { const char *e = getenv ("CHOLMOD_HIP_LEAF_MINW") ; int w = e ? atoi (e) : 4 ; return (w == 2 || w == 3 || w == 5 || w == 6) ? w : 4 ; } () ;
+#define LEAF_PW(MINW_) \
+                    { if (L.leaf_pw <= 4) LEAF_LAUNCH (4, MINW_) ; else if (L.leaf_pw <= 8) LEAF_LAUNCH (8, MINW_) ; \
+                      else if (L.leaf_pw <= 12) LEAF_LAUNCH (12, MINW_) ; else LEAF_LAUNCH (16, MINW_) ; }
+                    // (measured on the 2D 1259^2 leaf level: 4 waves per SIMD 0.112 ms, 5: 0.191, 6: 0.245)
+                    if (lw == 2) LEAF_PW (2) else if (lw == 3) LEAF_PW (3) else if (lw == 5) LEAF_PW (5) else if (lw == 6) LEAF_PW (6) else LEAF_PW (4)
+#undef LEAF_PW
+#undef LEAF_LAUNCH
+                }
+                else if (tim) { if (L.aux <= 64) THIN_LAUNCH (1, true, 6) ; else THIN_LAUNCH (4, true, 2) ; }
                 else if (L.aux > 64) THIN_LAUNCH (4, false, 2) ;
                 else
                 {

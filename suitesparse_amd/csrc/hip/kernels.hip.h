@@ -986,14 +986,20 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
 #pragma unroll
             for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; rmv [q] = rm [e < c.m ? e : c.m - 1] ; }
         }
-        // (chunks past the end of a small block are neither loaded nor decoded: a leaf's
-        // block of 105 entries is two of the eight slots of a one-wave chunk)
-#pragma unroll
-        for (int q = 0 ; q < NLD ; q++)
+        // a thread takes NLD CONSECUTIVE entries of the chunk (the wave still covers one
+        // contiguous 4 KB piece): (i, j) is decoded once per chunk and then advances by one
+        // -- a stride of NT entries crosses several short columns and costs a loop of
+        // 25 - 60 instructions per entry.  Waves wholly past the end of a small block
+        // (a leaf's 105 entries are 14 threads' worth) neither load nor decode.
+        const int e0 = c.base + NLD * tid ;
+        if (__builtin_amdgcn_readfirstlane (e0) < c.tot)
         {
-            if (q > 0 && c.base + NT * q >= c.tot) break ;
-            int e = c.base + tid + NT * q ;
-            v [q] = c.src [e < c.tot ? e : c.tot - 1] ;
+#pragma unroll
+            for (int q = 0 ; q < NLD ; q++)
+            {
+                int e = e0 + q ;
+                v [q] = c.src [e < c.tot ? e : c.tot - 1] ;
+            }
         }
     } ;
     auto consume = [&] (const Cur &c, const double (&v) [NLD], const i32 (&rmv) [NRM])
@@ -1007,23 +1013,23 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
             for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; if (e < c.m) rmc [e] = rmv [q] ; }
             tf_barrier<NW> () ;
         }
-        // (i, j) of this thread's first entry of the chunk, then NT entries further each time
-        int e = c.base + tid, i, j ;
+        int e = c.base + NLD * tid, i, j ;
+        if (__builtin_amdgcn_readfirstlane (e) >= c.tot) return ;
         const int m = c.m ;
         if (c.sq) { j = e / m ; i = e - j * m ; }
         else tri_decode (e < c.tot ? e : c.tot - 1, m, i, j) ;
 #pragma unroll
         for (int q = 0 ; q < NLD ; q++)
         {
-            if (q > 0 && c.base + NT * q >= c.tot) break ;
             // (ds_add_f64: one LDS instruction instead of read / add / write; two entries of
             // one child never meet in the same entry, the barrier above separates children)
             if (e < c.tot && i >= j)
                 (void) __hip_atomic_fetch_add (&F [tri_col24 (rmc [j], ns) + rmc [i]], v [q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
-            e += NT ; i += NT ;
-            if (c.sq) { while (i >= m) { i -= m ; j++ ; } }
-            else { while (i >= m && j < m - 1) { j++ ; i = i - m + j ; } }
-            if (i >= m || j >= m) { j = m - 1 ; i = m - 1 ; e = c.tot ; }     // past the last entry
+            e++ ; i++ ;
+            const bool wrap = i >= m ;                      // next column (branch-free)
+            j = wrap ? j + 1 : j ;
+            i = wrap ? (c.sq ? 0 : j) : i ;
+            if (j >= m) { j = m - 1 ; i = m - 1 ; e = c.tot ; }     // past the last entry
         }
     } ;
     double vA [NLD], vB [NLD] ;
@@ -1144,6 +1150,170 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
         for (int e = tid ; e < tot ; e += NT) CB [cbo + e] = 0.0 ;
     }
     if constexpr (TIMED) { if (tid == 0 && blockIdx.x == gridDim.x / 2) for (int q = 0 ; q < 10 ; q++) tim [q] = tc [q] ; }
+}
+
+// ---- leaf fronts, two per wave -----------------------------------------------------
+// The thin-front kernel is bound by instruction issue, and a leaf front of a 2D / circuit
+// problem (26 rows, 12 columns) uses 26 of the 64 lanes of its wave.  Fronts without
+// children, of <= 32 rows and <= 16 columns (one panel), therefore go two to a wave once
+// the assembly map of the resident S exists: lanes 0..31 carry the rows of one front,
+// lanes 32..63 those of the other, and every vector instruction of the scatter of A, of
+// the elimination and of the stores of L serves both.  What makes this possible is the
+// LDS broadcast of tf_panel: the multipliers of a column are read from an address that
+// differs between the two halves, where a v_readlane would be wave-wide.  The
+// contribution blocks are then computed front by front on the matrix cores (tf_tiles,
+// uniform parameters).  Same packed-triangle LDS layout and same map encoding as
+// k_thin_front, which runs the first factorization of a resident S (and records the map).
+// LDS: the panel columns of the two packed fronts (LP_T doubles each: the launch's largest
+// nscol * nsrow - nscol (nscol - 1) / 2, rounded up to a multiple of 32) + 128 doubles of
+// broadcast scratch -- 5 KB per wave for 26 x 12 leaves, so that the occupancy is set by
+// the registers (the kernel is latency-bound: four dependent loads in front of the work).
+template <int PW, int MINW>
+__global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int nfronts, const FrontD *fr,
+    const i64 *Sp, const double *Sx, const i64 *amap, double beta, double *Lx, double *CB, i32 *info, int LP_T)
+{
+    extern __shared__ __attribute__((aligned(16))) double lp_lds [] ;
+    double *Fs = lp_lds ;
+    double *bc = lp_lds + 2 * LP_T ;
+    const int lane = threadIdx.x, h = lane >> 5, l = lane & 31 ;
+    const int b = blockIdx.x ;
+    const bool twin = 2 * b + 1 < nfronts ;
+    const i32 fida = fronts [2 * b], fidb = fronts [twin ? 2 * b + 1 : 2 * b] ;
+    const FrontD &fa = fr [fida], &fb = fr [fidb] ;
+    const int nsA = fa.nsrow, ncA = fa.nscol, nsB = fb.nsrow, ncB = fb.nscol ;
+    const bool live = h == 0 || twin ;
+    const int ns = h ? nsB : nsA, nc = h ? ncB : ncA ;
+    const i64 psx = h ? fb.psx : fa.psx ;
+    const bool asmb = live && (h ? fb.assemble : fa.assemble) != 0 ;
+    double *F = Fs + h * LP_T ;
+    // ---- requests first: this half's range of S and its first entries
+    i64 p0, p1 ;
+    {
+        const i64 a0 = Sp [fa.k1], a1 = Sp [fa.k1 + ncA], b0 = Sp [fb.k1], b1 = Sp [fb.k1 + ncB] ;
+        p0 = (h ? b0 : a0) + l ; p1 = h ? b1 : a1 ;
+    }
+    if (!asmb) p1 = p0 ;
+    i64 fq = -1 ; double fx = 0.0 ;
+    if (p0 < p1) { fq = amap [p0] ; fx = Sx [p0] ; }
+    // ---- zero the panel columns of both packed fronts
+    for (int k = 0 ; k < LP_T ; k += 32) F [l + k] = 0.0 ;
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+    // ---- A through the map (ASSIGN semantics, entries outside the pattern have no map entry)
+    if (fq <= -2) F [(int) (-2 - fq)] = fx ;
+    p0 += 32 ;
+    while (__any (p0 < p1))
+    {
+        if (p0 < p1)
+        {
+            const i64 q = amap [p0] ;
+            if (q <= -2) F [(int) (-2 - q)] = Sx [p0] ;
+        }
+        p0 += 32 ;
+    }
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+    if (beta != 0.0 && asmb && l < nc) F [l * ns - ((l * (l - 1)) >> 1)] += beta ;
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+    // ---- the panel: lane = row l of its half's front
+    const bool rok = live && l < ns ;
+    const int rr = l < ns ? l : ns - 1 ;
+    double a [PW] ;
+    {
+        int o = 0 ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            const bool in = c < nc ;
+            double v = F [in ? o + rr : 0] ;
+            v = (in && rok && l >= c) ? v : 0.0 ;
+            a [c] = in ? v : (l == c ? 1.0 : 0.0) ;
+            o += ns - c - 1 ;
+        }
+    }
+    const double *bch = bc + 32 * h ;
+    double dv = 1.0 ;
+#pragma unroll
+    for (int c = 0 ; c < PW ; c++)
+    {
+        bc [lane] = a [c] ;
+        asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+        double u [PW] ;
+#pragma unroll
+        for (int c2 = c & ~1 ; c2 < PW ; c2 += 2)
+        {
+            d2 v = *(const d2 *) (bch + c2) ;
+            u [c2] = v.x ; u [c2 + 1] = v.y ;
+        }
+        asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+        const double d = u [c] ;
+        double x = __builtin_amdgcn_rcp (d) ;
+        const double e = __builtin_fma (-d, x, 1.0) ;
+        x = __builtin_fma (x, e, x) ;
+        const double t = a [c] * x ;
+#pragma unroll
+        for (int c2 = c + 1 ; c2 < PW ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
+        if (l == c) dv = d ;
+        __builtin_amdgcn_sched_barrier (0) ;
+    }
+    // first failing pivot of each front (NaN does not trip)
+    const unsigned long long bad = __ballot (live && l < nc && dv <= 0.0) ;
+    const unsigned int badA = (unsigned int) bad, badB = (unsigned int) (bad >> 32) ;
+    const int failA = badA ? (int) __builtin_ctz (badA) : -1 ;
+    const int failB = badB ? (int) __builtin_ctz (badB) : -1 ;
+    const int fail = h ? failB : failA ;
+    double r, ri ;
+    sqrt_rsqrt (dv, r, ri) ;
+    bc [lane] = r ; bc [64 + lane] = ri ;
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+#pragma unroll
+    for (int c = 0 ; c < PW ; c += 2)
+    {
+        d2 rv = *(const d2 *) (bch + c), iv = *(const d2 *) (bch + 64 + c) ;
+        a [c] = (l == c) ? rv.x : a [c] * iv.x ;
+        a [c + 1] = (l == c + 1) ? rv.y : a [c + 1] * iv.y ;
+        if (fail >= 0 && c >= fail) a [c] = 0.0 ;
+        if (fail >= 0 && c + 1 >= fail) a [c + 1] = 0.0 ;
+    }
+    // finished columns: to Lx from the registers, and back into the LDS fronts (operands of
+    // the contribution blocks)
+    {
+        int o = 0 ;
+        double *Lr = Lx + psx + l ;
+#pragma unroll
+        for (int c = 0 ; c < PW ; c++)
+        {
+            if (rok && c < nc && l >= c)
+            {
+                F [o + l] = a [c] ;
+                if (fail < 0 || c < fail) Lr [(i64) c * ns] = a [c] ;
+            }
+            o += ns - c - 1 ;
+        }
+    }
+    asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+    // ---- contribution blocks, front by front (uniform parameters, all 64 lanes)
+    for (int hh = 0 ; hh < (twin ? 2 : 1) ; hh++)
+    {
+        const FrontD &f = hh ? fb : fa ;
+        const int ns_ = f.nsrow, nc_ = f.nscol, ncb_ = f.ncb ;
+        const int fail_ = hh ? failB : failA ;
+        double *Fh = Fs + hh * LP_T ;
+        double *Co = CB + f.cb ;
+        if (fail_ >= 0)
+        {
+            if (lane == 0) info [hh ? fidb : fida] = fail_ + 1 ;
+            const int tot = ncb_ * (ncb_ + 1) / 2 ;
+            for (int e = lane ; e < tot ; e += 64) Co [e] = 0.0 ;
+            continue ;
+        }
+        const int nd = (ncb_ + 15) >> 4 ;
+        for (int I = 0 ; I < nd ; I++)
+        {
+            if (nc_ <= 4) tf_tile_row<1, true> (Fh, ns_, 0, nc_, nc_, I, lane, Co, nc_, ncb_, true) ;
+            else if (nc_ <= 8) tf_tile_row<2, true> (Fh, ns_, 0, nc_, nc_, I, lane, Co, nc_, ncb_, true) ;
+            else if (nc_ <= 12) tf_tile_row<3, true> (Fh, ns_, 0, nc_, nc_, I, lane, Co, nc_, ncb_, true) ;
+            else tf_tile_row<4, true> (Fh, ns_, 0, nc_, nc_, I, lane, Co, nc_, ncb_, true) ;
+        }
+    }
 }
 
 // ---- dense update  C -= A * B'  (fp64 MFMA 16x16x4 tiles) -------------------

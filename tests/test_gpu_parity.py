@@ -32,7 +32,7 @@ def rel_err_lower(x, xref, mask):
 
 @pytest.mark.parametrize("nsrow,nscol", [(7, 7), (40, 13), (64, 64), (65, 64), (200, 100),
                                          (333, 129), (700, 530), (900, 64), (1500, 1100), (2500, 1700)])
-@pytest.mark.parametrize("flags", [0, 4, 32, 64, 128, 2048, 64 | 2048, 512, 512 | 128])   # tile128, no swizzle, 512- / 2048-wide outer blocks, zero-filled CBs, potrf launches of their own
+@pytest.mark.parametrize("flags", [0, 4, 32, 64, 128, 2048, 64 | 2048, 512, 512 | 128, 1024, 1024 | 128])   # tile128, no swizzle, 512- / 2048-wide outer blocks, zero-filled CBs, potrf launches of their own, no fused solve + update steps
 def test_dense_partial_factorization(L, nsrow, nscol, flags):
     rng = np.random.default_rng(nsrow * 1000 + nscol)
     M = rng.standard_normal((nsrow, nsrow))
@@ -168,7 +168,7 @@ def test_relative_maps_bit_exact(L, golden_dir):
 def test_plan_flag_variants_agree(L, golden_dir):
     n, Ap, Ai, Ax, stype, perm = _case("p3d_24_nd", golden_dir)
     xs = []
-    for flags in (0, 4, 16, 32, 64, 128, 2048, 512):
+    for flags in (0, 4, 16, 32, 64, 128, 2048, 512, 1024, 4096):
         S = ch.Session(hip_flags=flags)
         A = S.sparse(n, Ap, Ai, Ax, stype)
         Lf = S.analyze(A, perm)
@@ -206,6 +206,43 @@ def test_not_posdef_protocol_matches_oracle(L, quick):
     nz = O.x != 0
     assert np.array_equal(fv.x[mask] != 0, nz[mask])
     assert rel_err_lower(fv.x, O.x, mask) < TOL_L
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+
+
+def test_not_posdef_inside_a_leaf_front_on_the_mapped_path(L):
+    """A pivot fails inside a leaf front during a refactorization of a resident S (new values,
+    same pattern): the leaf level then runs two fronts to a wave (k_leaf_pair) -- minor, the
+    zero pattern and the values against the oracle's repeat-supernode pass."""
+    n, Ap, Ai, Ax = G.poisson2d(40)
+    perm = G.geometric_nd(40, 40, 1, 4)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    sup, par = O.super, O.sparent()
+    parents = set(int(p) for p in par if p >= 0)
+    leaves = [s for s in range(O.nsuper) if s not in parents and sup[s + 1] - sup[s] >= 3]
+    assert len(leaves) > 4
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK            # first factorization: records the map
+    for sbad in (leaves[len(leaves) // 2], leaves[1]):
+        kbad = int(sup[sbad] + 1)
+        Ax2 = Ax.copy()
+        Ax2[Ap[int(O.Perm[kbad])]] = -7.0
+        assert O.factorize(Ax2) == 1 and O.minor == kbad
+        ch._view(A.contents.x, len(Ax2), C.c_double, np.float64)[:] = Ax2
+        assert S.factorize(A, Lf) == 1                                  # TRUE, as the reference
+        assert S.cm.status == ch.NOT_POSDEF
+        fv = ch.FactorView(Lf)
+        assert fv.minor == kbad
+        mask = O.lower_mask()
+        assert np.array_equal(fv.x[mask] != 0, (O.x != 0)[mask])
+        assert rel_err_lower(fv.x, O.x, mask) < TOL_L
+    ch._view(A.contents.x, len(Ax), C.c_double, np.float64)[:] = Ax     # and positive definite again
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    assert O.factorize(Ax) == 0
+    assert rel_err_lower(ch.FactorView(Lf).x, O.x, O.lower_mask()) < TOL_L
     S.free_factor(Lf)
     S.free_sparse(A)
     S.finish()
