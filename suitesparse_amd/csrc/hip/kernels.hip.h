@@ -864,13 +864,13 @@ __device__ __forceinline__ void tf_tiles (double *F, int ns, int c0, int pc, int
 #pragma unroll
     for (int s4 = 0 ; s4 < KS ; s4++)
     {
-        int k = 4 * s4 + lk ;
 #pragma unroll
         for (int g = 0 ; g < G ; g++)
         {
             int jr = j0 + 16 * g + lr ; jr = jr < ns ? jr : ns - 1 ;
+            // (k >= pc: the clamped column pc-1 is read again and meets af = 0; it is a column of
+            // the real product, so even a non-finite entry reaches nothing it does not reach anyway)
             double bv = F [koff [s4] + jr] ;
-            bv = (k < pc) ? bv : 0.0 ;
             acc [g] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, af [s4], acc [g], 0, 0, 0) ;
         }
     }
@@ -2077,6 +2077,21 @@ __global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
 #pragma unroll
         for (int u = 0 ; u < 48 ; u++) l3 [u] = (192 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
     }
+    // ... and so do the four 64 x 64 inverses (16 values per thread and sub-step): fetched
+    // inside the chain they cost one L2 / HBM latency per sub-step, four per launch
+    double w0 [16], w1 [16], w2 [16], w3 [16] ;
+    {
+        const double *Wm = Winv + (i64) T.inv * 8192 + r ;
+#pragma unroll
+        for (int u = 0 ; u < 16 ; u++)
+        {
+            const int o = (p + 4 * u) * 64 ;
+            w0 [u] = Wm [o] ;
+            w1 [u] = (nsub > 1) ? Wm [8192 + o] : 0.0 ;
+            w2 [u] = (nsub > 2) ? Wm [2 * 8192 + o] : 0.0 ;
+            w3 [u] = (nsub > 3) ? Wm [3 * 8192 + o] : 0.0 ;
+        }
+    }
     for (int rhs = 0 ; rhs < nrhs ; rhs++)
     {
         const double *x = X + (i64) rhs * ldx ;
@@ -2105,10 +2120,27 @@ __global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
             __syncthreads () ;
             if (tid < 64) t [tid] = xs [64 * k + tid] - ((part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid])) ;
             __syncthreads () ;
-            const double *Wm = Winv + (i64) (T.inv + k) * 8192 ;        // Wm [kk*64 + r] = W(r, kk)
-            double a = 0.0 ;
+            double a = 0.0 ;                                            // W(r, kk), kk == p (mod 4)
+            if (k == 0)
+            {
 #pragma unroll
-            for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (Wm [(p + 4 * u) * 64 + r], t [p + 4 * u], a) ;
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w0 [u], t [p + 4 * u], a) ;
+            }
+            else if (k == 1)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w1 [u], t [p + 4 * u], a) ;
+            }
+            else if (k == 2)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w2 [u], t [p + 4 * u], a) ;
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w3 [u], t [p + 4 * u], a) ;
+            }
             part [p][r] = a ;
             __syncthreads () ;
             if (tid < 64) xs [64 * k + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
@@ -2254,6 +2286,20 @@ __global__ void __launch_bounds__(256) k_solve_bwd_diag (const SolveBlk *tasks,
             for (int j = 0 ; j < 3 ; j++) m0 [3 * c + j] = (64 + 64 * j + lane < w) ? Lc0 [64 + 64 * j + lane] : 0.0 ;
         }
     }
+    // the transposed 64 x 64 inverses as well (see k_solve_fwd_diag)
+    double w0 [16], w1 [16], w2 [16], w3 [16] ;
+    {
+        const double *WmT = Winv + (i64) T.inv * 8192 + 4096 + r ;
+#pragma unroll
+        for (int u = 0 ; u < 16 ; u++)
+        {
+            const int o = (p + 4 * u) * 64 ;
+            w0 [u] = WmT [o] ;
+            w1 [u] = (nsub > 1) ? WmT [8192 + o] : 0.0 ;
+            w2 [u] = (nsub > 2) ? WmT [2 * 8192 + o] : 0.0 ;
+            w3 [u] = (nsub > 3) ? WmT [3 * 8192 + o] : 0.0 ;
+        }
+    }
     for (int rhs = 0 ; rhs < nrhs ; rhs++)
     {
         double *x = X + (i64) rhs * ldx ;
@@ -2296,10 +2342,27 @@ __global__ void __launch_bounds__(256) k_solve_bwd_diag (const SolveBlk *tasks,
             sum += __shfl_xor (sum, 32) ;
             if (seg == 0) t [16 * wave + c16] = xs [64 * k + 16 * wave + c16] - sum ;
             __syncthreads () ;
-            const double *WmT = Winv + (i64) (T.inv + k) * 8192 + 4096 ;     // WmT [kk*64 + c] = W(kk, c)
-            double a = 0.0 ;
+            double a = 0.0 ;                                            // W(kk, c), kk == p (mod 4)
+            if (k == 0)
+            {
 #pragma unroll
-            for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (WmT [(p + 4 * u) * 64 + r], t [p + 4 * u], a) ;
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w0 [u], t [p + 4 * u], a) ;
+            }
+            else if (k == 1)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w1 [u], t [p + 4 * u], a) ;
+            }
+            else if (k == 2)
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w2 [u], t [p + 4 * u], a) ;
+            }
+            else
+            {
+#pragma unroll
+                for (int u = 0 ; u < 16 ; u++) a = __builtin_fma (w3 [u], t [p + 4 * u], a) ;
+            }
             part [p][r] = a ;
             __syncthreads () ;
             if (tid < 64) xs [64 * k + tid] = (part [0][tid] + part [1][tid]) + (part [2][tid] + part [3][tid]) ;
