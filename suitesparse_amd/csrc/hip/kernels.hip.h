@@ -1476,6 +1476,21 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
         }
     } ;
 
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    // k_update2f's diagonal tile: the old values of the block are requested before the
+    // contraction starts -- after it they would put one HBM latency on the chain that
+    // leads into the elimination
+    double cv [TO_LDS ? TI : 1][TO_LDS ? TJ : 1][4] ;
+    if constexpr (TO_LDS)
+    {
+#pragma unroll
+        for (int a = 0 ; a < TI ; a++)
+#pragma unroll
+            for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                    cv [a][b][r] = C [wm * WM + a * 16 + (lane & 15) + (i64) (wn * WN + b * 16 + (lane >> 4) + 4 * r) * G.ldc] ;
+    }
     gload (0) ;
     if constexpr (DB)
     {
@@ -1503,20 +1518,11 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
             compute (0) ;
         }
     }
-    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
     if constexpr (TO_LDS)
     {
         // k_update2f, a full BM x BN tile on the diagonal: the updated block goes to LDS,
         // k-major (sm [j * BM + i], zero above the diagonal), for the elimination that follows
         static_assert (BM == BN && !DB, "diagonal tile") ;
-        double cv [TI][TJ][4] ;
-#pragma unroll
-        for (int a = 0 ; a < TI ; a++)
-#pragma unroll
-            for (int b = 0 ; b < TJ ; b++)
-#pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                    cv [a][b][r] = C [wm * WM + a * 16 + (lane & 15) + (i64) (wn * WN + b * 16 + (lane >> 4) + 4 * r) * G.ldc] ;
         __syncthreads () ;          // the operand slabs in sm are dead
 #pragma unroll
         for (int a = 0 ; a < TI ; a++)
