@@ -59,11 +59,29 @@ def main():
             Ax[Ap[int(O.Perm[kbad])]] = -3.0
         st_o = O.factorize(Ax)
         cb = make_allreduce()
-        S = ch.Session(rank=rank, world=world, allreduce=cb,
+        resident = os.environ.get("DIST_TEST_RESIDENT") == "1"
+        S = ch.Session(rank=rank, world=world, allreduce=cb, factor_on_device=resident,
                        hip_flags=int(os.environ.get("CHOLMOD_TEST_HIP_FLAGS", "0")))
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)
         ok = S.factorize(A, Lf)
+        if resident:
+            # factor left distributed on the devices: a second factorization clears only the
+            # slabs of Lx this rank holds; the gather (factor_to_host) then fills the rest, and
+            # the factorization after it must clear everything again
+            import ctypes as C
+            m0 = O.lower_mask()
+            errs = []
+            for _ in range(2):
+                assert S.refactorize_resident(Lf) == 1
+                assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
+                assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+                x = ch.FactorView(Lf).x
+                errs.append(float(np.linalg.norm((x - O.x)[m0]) / np.linalg.norm(O.x[m0])))
+            res["resident_errs"] = errs
+            assert S.refactorize_resident(Lf) == 1
+            assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
+            assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
         if os.environ.get("CHOLMOD_HIP_TEST_FAIL_LAUNCH"):
             # failure-injection case: every rank must come back with an error (no hang)
             res.update(ok=int(ok), status=int(S.cm.status))

@@ -198,6 +198,17 @@ def test_distributed_not_posdef_protocol():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_refactorizations_clear_only_their_slabs(world):
+    """Factor left on the devices: later factorizations clear only the parts of Lx a rank
+    holds; after a gather (the other ranks' columns are now in its Lx) everything again."""
+    res = _run_ranks(world, "gpu", "p3d_32", extra_env={"DIST_TEST_RESIDENT": "1"})
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+        assert all(e < 1e-12 for e in r["resident_errs"]), r
+
+
+@pytest.mark.gpu
 def test_distributed_with_memory_split_schedule():
     """Ranks + the memory-aware subtree sweep together (the 200^3 multi-GPU shape)."""
     res = _run_ranks(3, "gpu", "p3d_32", extra_env={"CHOLMOD_HIP_ARENA_BUDGET_MB": "20"})
