@@ -201,7 +201,9 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 // waves ever touch the same entry and no atomics are needed.  Reads of a child
 // CB column are contiguous (coalesced); the target rows follow the relative
 // map.  reference scatter: t_cholmod_super_numeric.c:756-772.
-#define EA_TW 16
+#ifndef EA_TW
+#define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
+#endif
 __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB)
 {
