@@ -1105,6 +1105,12 @@ static int build_host (cholmod_hip_plan *P)
             // columns of the assign fronts
             Launch Le {K_EA, 0, 0, S.eg.size (), 0, 0} ;
             blocks = 0 ;
+            // target columns per workgroup: 8, or 4 when the launch holds a big front (measured at
+            // 4 / 8 / 16 / 32: the nd24k stand-in and Poisson 100^3 like 4, the 2D problem 8)
+            int tw = EA_TW ;
+            for (int q = 0 ; q < nf ; q++)
+                if (P->fr [ids [q]].child_end != P->fr [ids [q]].child_begin && P->fr [ids [q]].nsrow >= 2048) tw = 4 ;
+            Le.aux = tw ;
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = P->fr [ids [q]] ;
@@ -1115,7 +1121,7 @@ static int build_host (cholmod_hip_plan *P)
                 if (phase == 1 && !asg) continue ;
                 if (hi <= lo) continue ;
                 S.eg.push_back (EaGroup {ids [q], blocks, lo, hi}) ;
-                blocks += (hi - lo + EA_TW - 1) / EA_TW ;
+                blocks += (hi - lo + tw - 1) / tw ;
                 if (phase == 0)
                     for (int c = f.child_begin ; c < f.child_end ; c++)
                     {
@@ -1382,7 +1388,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
         case K_EA:
             hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
-                P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb) ; break ;
+                P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb, L.aux > 0 ? L.aux : EA_TW) ; break ;
         case K_POTRF:
             hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 }
 
 // ---- extend-add: pull the children's contribution blocks into a front -------
-// One workgroup owns EA_TW consecutive target columns of the parent front and
+// One workgroup owns tw (EA_TW = 8, or 4) consecutive target columns of the parent front and
 // visits every child; wave w owns the target columns == w (mod 4), so no two
 // waves ever touch the same entry and no atomics are needed.  Reads of a child
 // CB column are contiguous (coalesced); the target rows follow the relative
@@ -205,12 +205,12 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 #define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
 #endif
 __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
-    const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB)
+    const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB, int tw)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &EaGroup::blk_start) ;
     const FrontD &P = fr [g [gi].front] ;
-    int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * EA_TW ;
-    int c1 = c0 + EA_TW < g [gi].c_hi ? c0 + EA_TW : g [gi].c_hi ;
+    int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * tw ;
+    int c1 = c0 + tw < g [gi].c_hi ? c0 + tw : g [gi].c_hi ;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
     i64 Ppsx = P.psx, Pcb = P.cb ;
     int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
