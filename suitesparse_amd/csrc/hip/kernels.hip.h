@@ -993,12 +993,16 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
         // -- a stride of NT entries crosses several short columns and costs a loop of
         // 25 - 60 instructions per entry.  Waves wholly past the end of a small block
         // (a leaf's 105 entries are 14 threads' worth) neither load nor decode.
-        const int e0 = c.base + NLD * tid ;
+        // (the last chunk of a block is dealt nq <= NLD entries per thread, so that all lanes
+        // share it: a leaf's 105 entries are two per thread, not eight for 14 threads)
+        int nq = (c.tot - c.base + NT - 1) / NT ; nq = nq < NLD ? nq : NLD ;
+        const int e0 = c.base + nq * tid ;
         if (__builtin_amdgcn_readfirstlane (e0) < c.tot)
         {
 #pragma unroll
             for (int q = 0 ; q < NLD ; q++)
             {
+                if (q >= nq) break ;
                 int e = e0 + q ;
                 v [q] = c.src [e < c.tot ? e : c.tot - 1] ;
             }
@@ -1015,7 +1019,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
             for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; if (e < c.m) rmc [e] = rmv [q] ; }
             tf_barrier<NW> () ;
         }
-        int e = c.base + NLD * tid, i, j ;
+        int nq = (c.tot - c.base + NT - 1) / NT ; nq = nq < NLD ? nq : NLD ;
+        int e = c.base + nq * tid, i, j ;
         if (__builtin_amdgcn_readfirstlane (e) >= c.tot) return ;
         const int m = c.m ;
         if (c.sq) { j = e / m ; i = e - j * m ; }
@@ -1023,6 +1028,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
 #pragma unroll
         for (int q = 0 ; q < NLD ; q++)
         {
+            if (q >= nq) break ;
             // (ds_add_f64: one LDS instruction instead of read / add / write; two entries of
             // one child never meet in the same entry, the barrier above separates children)
             if (e < c.tot && i >= j)
