@@ -268,6 +268,8 @@ struct cholmod_hip_plan {
     TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ; i32 *d_sm = nullptr ;
     std::vector<std::pair<i64, i64>> zslab ;   // multi-GPU: the parts of Lx this rank holds (offset, length), merged
     bool lx_clean_elsewhere = false ;           // ... and whether everything outside them is known to be zero
+    FrontD *d_smd = nullptr ; i64 *d_sp01 = nullptr ;   // thin launches: descriptor and range of S of every front, in block order (as d_sm)
+    ChildD *d_cdesc = nullptr ;      // per entry of the child lists: (cb, rel, ncb, cbp) of that child
     i32 *d_tu_cnt = nullptr ;       // k_trsm_upd: per group, workgroups that have read the rows workgroup 0 overwrites
     double cur_beta = 0 ;
     // resident input matrix
@@ -1149,7 +1151,7 @@ static void free_device (cholmod_hip_plan *P)
     }
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
-        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_gg, P->d_sm,
+        P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
         P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
@@ -1192,6 +1194,15 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_fr = dupload (P->fr, e) ; HIPCHK (e) ;
     P->d_supermap = dupload (P->supermap, e) ; HIPCHK (e) ;
     P->d_child = dupload (P->child, e) ; HIPCHK (e) ;
+    {
+        std::vector<ChildD> cdv (P->child.size ()) ;
+        for (size_t q = 0 ; q < P->child.size () ; q++)
+        {
+            const FrontD &cf = P->fr [P->child [q]] ;
+            cdv [q] = ChildD {cf.cb, cf.rel, cf.ncb, cf.cbp} ;
+        }
+        P->d_cdesc = dupload (cdv, e) ; HIPCHK (e) ;
+    }
     P->d_lvl_list = dupload (P->lvl_list, e) ; HIPCHK (e) ;
     P->d_zg = dupload (P->sch.zg, e) ; HIPCHK (e) ;
     P->d_eg = dupload (P->sch.eg, e) ; HIPCHK (e) ;
@@ -1200,6 +1211,12 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_tu_cnt, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32))) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
+    {
+        std::vector<FrontD> smd (P->sch.sm.size ()) ;
+        for (size_t q = 0 ; q < smd.size () ; q++) smd [q] = P->fr [P->sch.sm [q]] ;
+        P->d_smd = dupload (smd, e) ; HIPCHK (e) ;
+        HIPCHK (hipMalloc ((void **) &P->d_sp01, std::max<size_t> (2 * smd.size (), 1) * sizeof (i64))) ;
+    }
     P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
     double tu2 = pnow () ;
     HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
@@ -1284,7 +1301,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 long long *tim = P->d_thin_tim ? P->d_thin_tim + 10 * (size_t) (&L - P->sch.launches.data ()) : nullptr ;
 #define THIN_LAUNCH(NW_, TIMED_, MINW_) \
                 hipLaunchKernelGGL ((k_thin_front<NW_, TIMED_, MINW_>), dim3 (L.grid), dim3 (64 * NW_), thin_front_lds_bytes (L.aux), st, \
-                    P->d_sm + L.goff, P->d_fr, P->d_child, P->d_relmap, P->d_Ls, P->d_Sp, \
+                    P->d_sm + L.goff, P->d_smd + L.goff, P->d_sp01 + 2 * L.goff, P->d_cdesc, P->d_relmap, P->d_Ls, P->d_Sp, \
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta, \
                     P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim)
                 if (L.leaf_pw && P->cur_mapped && !P->s_unpacked && !tim)
@@ -1292,7 +1309,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     // leaf fronts two to a wave, once the assembly map of the resident S exists
 #define LEAF_LAUNCH(PW_, MINW_) \
                     hipLaunchKernelGGL ((k_leaf_pair<PW_, MINW_>), dim3 ((L.grid + 1) / 2), dim3 (64), (size_t) (2 * L.leaf_T + 128) * sizeof (double), st, \
-                        P->d_sm + L.goff, L.grid, P->d_fr, P->d_Sp, P->d_Sx, P->d_amap, P->cur_beta, P->d_Lx, P->d_cb, P->d_info, L.leaf_T)
+                        P->d_sm + L.goff, L.grid, P->d_smd + L.goff, P->d_sp01 + 2 * L.goff, P->d_Sx, P->d_amap, P->cur_beta, P->d_Lx, P->d_cb, P->d_info, L.leaf_T)
                     static const int lw = [] () { const char *e = getenv ("CHOLMOD_HIP_LEAF_MINW") ; int w = e ? atoi (e) : 4 ; return (w == 2 || w == 3 || w == 5 || w == 6) ? w : 4 ; } () ;
 #define LEAF_PW(MINW_) \
                     { if (L.leaf_pw <= 4) LEAF_LAUNCH (4, MINW_) ; else if (L.leaf_pw <= 8) LEAF_LAUNCH (8, MINW_) ; \
@@ -1882,6 +1899,18 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int
     if (Snz) HIPCHK (hipMemcpyAsync (P->d_Snz, Snz, n * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
     if (nz) HIPCHK (hipMemcpyAsync (P->d_Si, Si, nz * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
     if (nz) HIPCHK (hipMemcpyAsync (P->d_Sx, Sx, nz * sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
+    if (!P->sch.sm.empty ())
+    {
+        // the range of S every thin front's columns occupy, in the block order of its launch
+        std::vector<i64> sp01 (2 * P->sch.sm.size ()) ;
+        for (size_t q = 0 ; q < P->sch.sm.size () ; q++)
+        {
+            const FrontD &f = P->fr [P->sch.sm [q]] ;
+            sp01 [2 * q] = Sp [f.k1] ; sp01 [2 * q + 1] = Sp [f.k1 + f.nscol] ;
+        }
+        HIPCHK (hipMemcpyAsync (P->d_sp01, sp01.data (), sp01.size () * sizeof (i64), hipMemcpyHostToDevice, P->stream)) ;
+        HIPCHK (hipStreamSynchronize (P->stream)) ;     // (sp01 is a local)
+    }
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     P->s_unpacked = (Snz != nullptr) ;
     P->amap_valid = false ;         // a new pattern may have come with the new values

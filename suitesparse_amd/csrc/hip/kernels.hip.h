@@ -38,6 +38,9 @@ struct FrontD {
                     // full square with ld = ncb (written by the dense update kernel)
 };
 
+// what a parent needs of a child, in the order of the child lists: one load instead of the chain
+// child [ci] -> fr [child] -> (cb, rel, ncb, cbp)
+struct ChildD { i64 cb; i64 rel; i32 ncb; i32 cbp; };
 struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi; };   // extend-add into target columns [c_lo, c_hi)
 struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
 struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
@@ -919,7 +922,7 @@ __device__ __forceinline__ void tf_tile_row (double *F, int ns, int c0, int pc, 
 }
 template <int NW, bool TIMED = false, int MINW = (NW == 1 ? 6 : 2)>
 __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts,
-    const FrontD *fr, const i32 *child, const i32 *relmap, const i64 *Ls,
+    const FrontD *frl, const i64 *sp01, const ChildD *cd, const i32 *relmap, const i64 *Ls,
     const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
     double *Lx, double *CB, i32 *info, int ns_max, i64 *amap, int mapped, long long *tim = nullptr)
 {
@@ -936,25 +939,27 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     i32 *rm_l = rows_l + nsp ;                              // relative maps of two children (ping-pong)
     __shared__ int s_fail ;
     __shared__ __attribute__((aligned(16))) double s_bc [128 * NW] ;    // panel broadcast scratch
-    const i32 fid = fronts [blockIdx.x] ;
-    const FrontD &f = fr [fid] ;
+    // frl / sp01: the launch's fronts in block order -- descriptor and range of S of block b
+    // at index b, so that the first level of loads depends on blockIdx only (the chain
+    // front id -> descriptor -> column pointers -> data was four round trips deep)
+    const FrontD &f = frl [blockIdx.x] ;
     const int ns = f.nsrow, nc = f.nscol, ncb = f.ncb, k1 = f.k1 ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     const i64 psx = f.psx, cbo = f.cb ;
     const int T = ns * (ns + 1) / 2 ;
     const int cbeg = f.child_begin, cend = f.child_end ;
     // ---- (1) requests first: row list, column pointers of A, the first child
-    i64 rowv = (tid < ns) ? Ls [f.psi + tid] : 0 ;
     i64 p0 = 0, p1 = 0 ;
     // A of a packed S whose map is known (every factorization of a resident S after the
     // first): the entries of the front's columns are one contiguous range of S, lanes
     // stride it; amap [p] = -2 - (offset in the packed front), -1 = not in L
     const bool flat = mapped && !Snz && f.assemble ;
     const bool asm_col = !flat && f.assemble && tid < nc ;
+    const i64 rowv = (!flat && tid < ns) ? Ls [f.psi + tid] : 0 ;     // the row list: only the search path needs it
     i64 fq = -1 ; double fx = 0.0 ;
     if (flat)
     {
-        p0 = Sp [k1] + tid ; p1 = Sp [k1 + nc] ;
+        p0 = sp01 [2 * blockIdx.x] + tid ; p1 = sp01 [2 * blockIdx.x + 1] ;
         if (p0 < p1) { fq = amap [p0] ; fx = Sx [p0] ; }
     }
     if (asm_col)
@@ -964,13 +969,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     }
     // children stream: chunk = NLD * NT consecutive entries of one child's packed CB
     // (or NLD whole columns of a square one, see below); two register buffers
-    struct Cur { int ci, base, m, tot, sq ; const double *src ; } ;
+    struct Cur { int ci, base, m, tot, sq ; const double *src ; i64 rel ; } ;
     auto child_at = [&] (int ci, Cur &c)
     {
-        const FrontD &cf = fr [child [ci]] ;
+        const ChildD &cf = cd [ci] ;
         c.ci = ci ; c.base = 0 ; c.m = cf.ncb ; c.sq = !cf.cbp ;
         c.tot = cf.cbp ? cf.ncb * (cf.ncb + 1) / 2 : cf.ncb * cf.ncb ;
-        c.src = CB + cf.cb ;
+        c.src = CB + cf.cb ; c.rel = cf.rel ;
     } ;
     auto advance = [&] (Cur &c) -> bool                      // next chunk; false when the stream is over
     {
@@ -984,7 +989,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     {
         if (c.base == 0)
         {
-            const i32 *rm = relmap + fr [child [c.ci]].rel ;
+            const i32 *rm = relmap + c.rel ;
 #pragma unroll
             for (int q = 0 ; q < NRM ; q++) { int e = tid + NT * q ; rmv [q] = rm [e < c.m ? e : c.m - 1] ; }
         }
@@ -1047,7 +1052,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     if (haveA) { child_at (cbeg, cA) ; issue (cA, vA, rmA) ; }
     for (int e = tid ; e < T ; e += NT) F [e] = 0.0 ;
     if (tid == 0) s_fail = -1 ;
-    if (tid < ns) rows_l [tid] = (i32) rowv ;
+    if (!flat && tid < ns) rows_l [tid] = (i32) rowv ;
     tf_barrier<NW> () ;
     tick (0) ;
     // ---- A into the panel columns (ASSIGN semantics, entries outside the pattern dropped)
@@ -1152,7 +1157,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     }
     if (fail >= 0)
     {
-        if (tid == 0) info [fid] = fail + 1 ;
+        if (tid == 0) info [fronts [blockIdx.x]] = fail + 1 ;
         // the ancestors of a failed front compute values nobody keeps; give them zeros
         const int tot = ncb * (ncb + 1) / 2 ;
         for (int e = tid ; e < tot ; e += NT) CB [cbo + e] = 0.0 ;
@@ -1177,8 +1182,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
 // broadcast scratch -- 5 KB per wave for 26 x 12 leaves, so that the occupancy is set by
 // the registers (the kernel is latency-bound: four dependent loads in front of the work).
 template <int PW, int MINW>
-__global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int nfronts, const FrontD *fr,
-    const i64 *Sp, const double *Sx, const i64 *amap, double beta, double *Lx, double *CB, i32 *info, int LP_T)
+__global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int nfronts, const FrontD *frl,
+    const i64 *sp01, const double *Sx, const i64 *amap, double beta, double *Lx, double *CB, i32 *info, int LP_T)
 {
     extern __shared__ __attribute__((aligned(16))) double lp_lds [] ;
     double *Fs = lp_lds ;
@@ -1186,8 +1191,8 @@ __global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int 
     const int lane = threadIdx.x, h = lane >> 5, l = lane & 31 ;
     const int b = blockIdx.x ;
     const bool twin = 2 * b + 1 < nfronts ;
-    const i32 fida = fronts [2 * b], fidb = fronts [twin ? 2 * b + 1 : 2 * b] ;
-    const FrontD &fa = fr [fida], &fb = fr [fidb] ;
+    const int ia = 2 * b, ib = twin ? 2 * b + 1 : 2 * b ;
+    const FrontD &fa = frl [ia], &fb = frl [ib] ;
     const int nsA = fa.nsrow, ncA = fa.nscol, nsB = fb.nsrow, ncB = fb.nscol ;
     const bool live = h == 0 || twin ;
     const int ns = h ? nsB : nsA, nc = h ? ncB : ncA ;
@@ -1197,7 +1202,7 @@ __global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int 
     // ---- requests first: this half's range of S and its first entries
     i64 p0, p1 ;
     {
-        const i64 a0 = Sp [fa.k1], a1 = Sp [fa.k1 + ncA], b0 = Sp [fb.k1], b1 = Sp [fb.k1 + ncB] ;
+        const i64 a0 = sp01 [2 * ia], a1 = sp01 [2 * ia + 1], b0 = sp01 [2 * ib], b1 = sp01 [2 * ib + 1] ;
         p0 = (h ? b0 : a0) + l ; p1 = h ? b1 : a1 ;
     }
     if (!asmb) p1 = p0 ;
@@ -1308,7 +1313,7 @@ __global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int 
         double *Co = CB + f.cb ;
         if (fail_ >= 0)
         {
-            if (lane == 0) info [hh ? fidb : fida] = fail_ + 1 ;
+            if (lane == 0) info [fronts [hh ? ib : ia]] = fail_ + 1 ;
             const int tot = ncb_ * (ncb_ + 1) / 2 ;
             for (int e = lane ; e < tot ; e += 64) Co [e] = 0.0 ;
             continue ;
