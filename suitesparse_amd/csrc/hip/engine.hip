@@ -1198,6 +1198,7 @@ static int upload_plan (cholmod_hip_plan *P)
         std::vector<ChildD> cdv (P->child.size ()) ;
         for (size_t q = 0 ; q < P->child.size () ; q++)
         {
+            if (P->child [q] < 0 || (size_t) P->child [q] >= P->fr.size ()) { cdv [q] = ChildD {0, 0, 0, 1} ; continue ; }   // (padding entry of an empty list)
             const FrontD &cf = P->fr [P->child [q]] ;
             cdv [q] = ChildD {cf.cb, cf.rel, cf.ncb, cf.cbp} ;
         }
