@@ -97,6 +97,29 @@ def main():
                 r = (Af @ xx if cx else G.sym_matvec(n, Ap, Ai, Axx, -1, xx)) - bb
                 if not (np.linalg.norm(r) <= 1e-9 * np.linalg.norm(bb)):
                     msg.append(f"resid {np.linalg.norm(r) / np.linalg.norm(bb):.2e}")
+        if st == 0 and not cx:
+            # the same pattern with new values through cholmod_l_factorize again: the values-only
+            # path -- A through the assembly map of the resident S (thin fronts `mapped`, leaf
+            # fronts two to a wave), sometimes with a failing pivot
+            import ctypes as C
+            Ax2 = Axx * (1.0 + 0.25 * rng.random())
+            diag = Ai == np.repeat(np.arange(n), np.diff(Ap))
+            Ax2[diag] += rng.uniform(0.0, 1.0, int(diag.sum()))
+            if rng.random() < 0.2:
+                k = int(rng.integers(n))
+                Ax2[Ap[k]] = -abs(Ax2[Ap[k]])
+            ch._view(A.contents.x, len(Ax2), C.c_double, np.float64)[:] = Ax2
+            ok2 = S.factorize(A, Lf)
+            st2 = O.factorize(Ax2)
+            fv = ch.FactorView(Lf)
+            if ok2 != 1 or (S.cm.status != 0) != (st2 != 0):
+                msg.append(f"again: status gpu {S.cm.status} oracle {st2}")
+            if st2 != 0 and fv.minor != O.minor:
+                msg.append(f"again: minor {fv.minor} vs {O.minor}")
+            den = np.linalg.norm(O.x[mk])
+            err2 = np.linalg.norm((fv.x - O.x)[mk]) / (den if den > 0 else 1.0)
+            if not (err2 < 1e-11):
+                msg.append(f"again: L err {err2:.2e}")
         if msg:
             bad += 1
             print(f"FAIL case {it} kind {kind} n {n} order {omode} flags {flags} inject {inject} complex {cx} zomplex {zomplex}: "
