@@ -24,6 +24,12 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters) ;
  * from LDS every step), all-zero operands on request. */
 double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters, int zero_operands) ;
 
+/* The measured fp64 matrix-core ceiling (round 3): inline-assembly MFMA loop, nothing else in
+ * it.  flop/s; out3 = {shader cycles per MFMA per SIMD, sustained shader clock in GHz, flop/s
+ * that issue rate gives at 2.4 GHz}.  (cholmod_hip_bench_mfma_peak's loop carries VGPR <-> AGPR
+ * copies the compiler inserted and under-reports; it is kept for the round-1/2 records.) */
+double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, int zero_operands, double *out3) ;
+
 /* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;
 /* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */

@@ -44,7 +44,9 @@ static inline int outer_block (int maxrows, const ObThresholds &t)
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_ALLREDUCE, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_NKIND } ;
+// K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
+// the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -56,9 +58,8 @@ struct Launch {
     int stream = 0 ;    // 0 = main, 1 = look-ahead (panel) stream
     int wait_ev = -1 ;  // event this launch's stream waits for first
     int rec_ev = -1 ;   // event recorded on its stream right after it
-    i64 ar_off = 0, ar_cnt = 0 ;    // K_ALLREDUCE: slab of Lx summed over the ranks: starts at
-    int ar_ld = 0, ar_r0 = 0, ar_nc = 0 ;   // ar_off (column o0), ld ar_ld, rows >= ar_r0 of ar_nc columns
-    int ar_g0 = 0, ar_gn = 1 ;              // ... over the ranks [ar_g0, ar_g0+ar_gn)
+    XchgD xd = {0, 0, 0, 0, 0, 1, 0} ;     // K_XCHG_RS / K_XCHG_AG: the block column and its row chunks
+    int ar_g0 = 0, ar_gn = 1 ;              // ... exchanged over the ranks [ar_g0, ar_g0+ar_gn)
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
     int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
     int leaf_pw = 0 ;               // K_SMALL: every front is a leaf of <= 32 rows and <= leaf_pw (4/8/12/16) columns: two per wave (k_leaf_pair)
@@ -168,6 +169,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank) (ncclComm_t *, int, ncclUniqueId, int) = nullptr ;
     ncclResult_t (*CommSplit) (ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr ;
     ncclResult_t (*AllReduce) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr ;
+    ncclResult_t (*ReduceScatter) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr ;
+    ncclResult_t (*AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr ;
     ncclResult_t (*CommDestroy) (ncclComm_t) = nullptr ;
     const char *(*GetErrorString) (ncclResult_t) = nullptr ;
 } ;
@@ -177,17 +180,28 @@ static RcclApi *rccl_api ()
     static bool tried = false ;
     if (tried) return api.h ? &api : nullptr ;
     tried = true ;
+    // CHOLMOD_HIP_RCCL_LIBRARY names the collective library to bind instead of the system's RCCL
+    // (any library exporting the nccl* entry points below; tests/standin_rccl lets several ranks
+    // share one GPU, which RCCL itself refuses).  No fallback to RCCL when it is set and missing.
+    const char *over = getenv ("CHOLMOD_HIP_RCCL_LIBRARY") ;
     const char *names [] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr} ;
     void *h = nullptr ;
-    for (int q = 0 ; names [q] && !h ; q++) h = dlopen (names [q], RTLD_NOW | RTLD_LOCAL) ;
+    if (over && *over)
+    {
+        h = dlopen (over, RTLD_NOW | RTLD_LOCAL) ;
+        if (!h) fprintf (stderr, "cholmod_hip: CHOLMOD_HIP_RCCL_LIBRARY=%s: %s\n", over, dlerror ()) ;
+    }
+    else for (int q = 0 ; names [q] && !h ; q++) h = dlopen (names [q], RTLD_NOW | RTLD_LOCAL) ;
     if (!h) return nullptr ;
     api.GetUniqueId = (decltype (api.GetUniqueId)) dlsym (h, "ncclGetUniqueId") ;
     api.CommInitRank = (decltype (api.CommInitRank)) dlsym (h, "ncclCommInitRank") ;
     api.CommSplit = (decltype (api.CommSplit)) dlsym (h, "ncclCommSplit") ;
     api.AllReduce = (decltype (api.AllReduce)) dlsym (h, "ncclAllReduce") ;
+    api.ReduceScatter = (decltype (api.ReduceScatter)) dlsym (h, "ncclReduceScatter") ;
+    api.AllGather = (decltype (api.AllGather)) dlsym (h, "ncclAllGather") ;
     api.CommDestroy = (decltype (api.CommDestroy)) dlsym (h, "ncclCommDestroy") ;
     api.GetErrorString = (decltype (api.GetErrorString)) dlsym (h, "ncclGetErrorString") ;
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.AllReduce || !api.CommDestroy) return nullptr ;
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.AllReduce || !api.ReduceScatter || !api.AllGather || !api.CommDestroy) return nullptr ;
     api.h = h ;
     return &api ;
 }
@@ -225,7 +239,8 @@ struct cholmod_hip_plan {
     std::map<i64, ncclComm_t> nccl_group ;
     hipEvent_t ar_done = nullptr ;          // all-reduce on the second stream finished
     double *d_xchg = nullptr ;
-    double *d_stage = nullptr ;             // packed block-column slab for the all-reduce
+    double *d_stage = nullptr ;             // the g segments of a block column (reduce-scatter, in place)
+    double *d_ag = nullptr ;                // the g solved row chunks of a block column (all-gather, in place)
     // triangular solves: per level, the supernodes one workgroup handles whole
     // and the big ones walked in SOLVE_SB-column blocks by many workgroups (k_solve_*_blk)
     std::vector<SolveTask> sv_tasks ;       // [whole-supernode tasks by level | block tasks]
@@ -406,16 +421,34 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
-    auto emit_ar = [&] (int q, int c0, int c1, int wait_ev)
+    // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks
+    // (kernels.hip.h: XchgD).  This rank keeps the diagonal block and rows [own_lo, own_hi).
+    auto xchg_of = [&] (int q, int c0) -> XchgD
     {
         const FrontD &f = fr [ids [q]] ;
-        Launch La {K_ALLREDUCE, 0, 0, 0, 0, 0} ;
-        La.ar_off = f.psx + (i64) c0 * f.nsrow ;
-        La.ar_ld = f.nsrow ; La.ar_r0 = c0 ; La.ar_nc = c1 - c0 ;
-        La.ar_cnt = (i64) (c1 - c0) * (f.nsrow - c0) ;
-        La.bytes = 8.0 * La.ar_cnt ;
+        int c1 = std::min (c0 + MB, f.nscol) ;
+        int g = grpn [ids [q]], r = rank - grp0 [ids [q]] ;
+        if (world == 1) { g = 1 ; r = 0 ; }                 // (single-rank self test of the exchange path)
+        int mb = f.nsrow - c1 ;
+        int R = mb > 0 ? (((mb + g - 1) / g) + 15) / 16 * 16 : 0 ;
+        return XchgD {f.psx + c0 + (i64) c0 * f.nsrow, f.nsrow, c1 - c0, mb, R, g, r} ;
+    } ;
+    auto emit_rs = [&] (int q, int c0, int wait_ev)
+    {
+        Launch La {K_XCHG_RS, 0, 0, 0, 0, 0} ;
+        La.xd = xchg_of (q, c0) ;
+        La.bytes = 8.0 * ((double) La.xd.w * La.xd.w + (double) La.xd.R * La.xd.w) * La.xd.g ;
         La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
         La.wait_ev = wait_ev ;
+        S.launches.push_back (La) ;
+    } ;
+    auto emit_ag = [&] (int q, int c0)
+    {
+        Launch La {K_XCHG_AG, 0, 0, 0, 0, 0} ;
+        La.xd = xchg_of (q, c0) ;
+        if (La.xd.R == 0) return ;                          // nothing below the diagonal block
+        La.bytes = 8.0 * (double) La.xd.R * La.xd.w * La.xd.g ;
+        La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
         S.launches.push_back (La) ;
     } ;
     // One trailing-update step: for every listed front, columns [kc, kc+kk) update
@@ -450,6 +483,29 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             // dealt over the ranks of a shared front: the factor must exist on every rank)
             bool ff = fuse_potrf && !(x.wide && is_shared (ids [x.q])) && !x.cb && c0 == x.t0 && f.nscol - x.t0 >= NB && x.t1 - c0 >= NB ;
             if (ff) pf_done [x.q] = x.t0 ;
+            if (!x.wide && is_shared (ids [x.q]) && x.t1 > c0)
+            {
+                // a narrow update inside a block column of a shared front: its rows have been
+                // dealt to the ranks of the group (reduce-scatter by row chunks, emit_rs) -- the
+                // rows of the diagonal block (every rank) and this rank's chunk of the rows below
+                XchgD X = xchg_of (x.q, (x.kc / MB) * MB) ;
+                int b1 = (x.kc / MB) * MB + X.w ;
+                add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, b1 - c0, x.t1 - c0, false, false, ff) ;
+                int lo = b1 + X.r * X.R, hi = std::min (lo + X.R, f.nsrow) ;
+                if (hi > lo)
+                {
+                    GemmGroup G ;
+                    memset (&G, 0, sizeof (G)) ;
+                    G.a_off = f.psx + lo + (i64) x.kc * f.nsrow ;
+                    G.b_off = f.psx + c0 + (i64) x.kc * f.nsrow ;
+                    G.c_off = f.psx + lo + (i64) c0 * f.nsrow ;
+                    G.lda = f.nsrow ; G.ldc = f.nsrow ;
+                    G.m = hi - lo ; G.n = x.t1 - c0 ; G.k = x.kk ; G.tri = 0 ; G.front = ids [x.q] ;
+                    G.tile_mul = 1 ; G.tile_add = 0 ;
+                    small.push_back (G) ;
+                }
+                continue ;
+            }
             if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
             if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
         }
@@ -458,7 +514,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             for (const Upd &x : step)
             {
                 if (!x.wide || !is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
-                emit_ar (x.q, x.t0, std::min (x.t0 + MB, x.t1), ev_next) ;
+                emit_rs (x.q, x.t0, ev_next) ;
                 early [x.q] = x.t0 ;
             }
         step.clear () ;
@@ -476,7 +532,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             {
                 const FrontD &f = fr [ids [q]] ;
                 if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
-                emit_ar (q, i0, std::min (i0 + MB, f.nscol), -1) ;
+                emit_rs (q, i0, -1) ;
             }
         }
         // potrf of the diagonal blocks
@@ -534,18 +590,41 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= i0 || fused [q]) continue ;
             int nb = std::min (NB, f.nscol - i0) ;
-            int m = f.nsrow - (i0 + nb) ;
-            if (m <= 0) continue ;
-            TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
-                       f.psx + (i0 + nb) + (i64) i0 * f.nsrow, f.nsrow, m, nb,
-                       ids [q], i0, blocks} ;
-            blocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
-            S.tg.push_back (G) ;
-            Lt.flops += (double) m * nb * nb ;
-            Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
+            // rows to solve: everything below the diagonal block -- of a shared front, whose
+            // block column has been dealt to the ranks by row chunks: the rest of the 512-wide
+            // diagonal block (every rank of the group) and this rank's chunk below it
+            int lo [2] = {i0 + nb, 0}, hi [2] = {f.nsrow, 0} ;
+            if (is_shared (ids [q]))
+            {
+                XchgD X = xchg_of (q, (i0 / MB) * MB) ;
+                int b1 = (i0 / MB) * MB + X.w ;
+                hi [0] = b1 ;
+                lo [1] = b1 + X.r * X.R ; hi [1] = std::min (lo [1] + X.R, f.nsrow) ;
+            }
+            for (int part = 0 ; part < 2 ; part++)
+            {
+                int m = hi [part] - lo [part] ;
+                if (m <= 0) continue ;
+                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
+                           f.psx + lo [part] + (i64) i0 * f.nsrow, f.nsrow, m, nb,
+                           ids [q], i0, blocks} ;
+                blocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
+                S.tg.push_back (G) ;
+                Lt.flops += (double) m * nb * nb ;
+                Lt.aux = std::max (Lt.aux, (nb + 15) / 16 * 16) ;     // widest panel, in 16-column blocks
+            }
         }
         Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
         if (Lt.ng) S.launches.push_back (Lt) ;
+        // a block column of a shared front is complete on the rows of its owners: gather the
+        // solved row chunks on every rank of the group before anything uses it as an operand
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
+            int b0 = (i0 / MB) * MB ;
+            if (i0 + NB >= std::min (b0 + MB, f.nscol)) emit_ag (q, b0) ;
+        }
         // ---- trailing updates.  Inside an outer block column of the front (OB
         // columns, ob_of): recursive doubling -- with e 64-column blocks of it
         // factored and p the largest power of two dividing e, the last p blocks
@@ -1152,7 +1231,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1229,9 +1308,15 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
     {
-        i64 mx = 1 ;
-        for (const Launch &L : P->sch.launches) if (L.kind == K_ALLREDUCE && L.ar_r0 > 0) mx = std::max (mx, L.ar_cnt) ;
+        i64 mx = 1, mxg = 1 ;
+        for (const Launch &L : P->sch.launches)
+            if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG)
+            {
+                mx = std::max (mx, ((i64) L.xd.w * L.xd.w + (i64) L.xd.R * L.xd.w) * L.xd.g) ;
+                mxg = std::max (mxg, (i64) L.xd.R * L.xd.w * L.xd.g) ;
+            }
         HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_ag, (size_t) mxg * sizeof (double))) ;
     }
     double tu3 = pnow () ;
     if (getenv ("CHOLMOD_HIP_THIN_TIMING"))
@@ -1289,7 +1374,7 @@ static int thin_minw (int cls)
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
-    if (!serial && L.wait_ev >= 0 && L.kind != K_ALLREDUCE) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     switch (L.kind)
     {
         case K_JOIN: break ;
@@ -1336,68 +1421,73 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 #undef THIN_LAUNCH
             }
             break ;
-        case K_ALLREDUCE:
-            if (P->nccl_world)
+        case K_XCHG_RS:
+        case K_XCHG_AG:
             {
-                // native exchange: everything stream-ordered, the host never waits.  Ahead
-                // of time (wait_ev >= 0) the pack / all-reduce / unpack run on the second
-                // stream behind the event of the update that completed the slab, while the
-                // main stream goes on with the rest of the trailing update; the main stream
-                // then waits (on the device) for the sum before it touches the slab again.
-                RcclApi *R = rccl_api () ;
-                bool ahead = !serial && L.wait_ev >= 0 && P->stream2 ;
+                // Native exchange (cholmod_hip_rccl_attach): everything stream-ordered, the host
+                // never waits.  A reduce-scatter ahead of time (wait_ev >= 0) runs on the second
+                // stream behind the event of the update that completed the block column, while
+                // the main stream goes on with the rest of the trailing update; the main stream
+                // then waits (on the device) for the sum before it touches the block column.
+                // Host callback (gloo tests, --exchange callback): it only knows a sum
+                // all-reduce, so the reduce-scatter is an all-reduce of all segments and the
+                // all-gather a sum of buffers that are zero outside the sender's chunk.
+                const bool rs = L.kind == K_XCHG_RS ;
+                const XchgD &X = L.xd ;
+                RcclApi *R = P->nccl_world ? rccl_api () : nullptr ;
+                if (!R && !P->ar_fn) return CHOLMOD_HIP_INVALID ;
+                bool ahead = rs && !serial && L.wait_ev >= 0 && P->stream2 ;
                 hipStream_t cs = ahead ? P->stream2 : st ;
-                if (ahead) HIPCHK (hipStreamWaitEvent (cs, P->sync_ev [L.wait_ev], 0)) ;
+                if (ahead)
+                {
+                    if (R) HIPCHK (hipStreamWaitEvent (cs, P->sync_ev [L.wait_ev], 0)) ;
+                    else HIPCHK (hipEventSynchronize (P->sync_ev [L.wait_ev])) ;
+                }
                 ncclComm_t comm = P->nccl_world ;
-                if (L.ar_gn != P->world)
+                if (R && L.ar_gn != P->world)
                 {
                     auto it = P->nccl_group.find (((i64) L.ar_g0 << 16) | (i64) L.ar_gn) ;
                     if (it == P->nccl_group.end ()) return CHOLMOD_HIP_INVALID ;
                     comm = it->second ;
                 }
-                if (L.ar_r0 == 0)
-                    RCCLCHK (R->AllReduce (P->d_Lx + L.ar_off, P->d_Lx + L.ar_off, (size_t) L.ar_cnt, ncclDouble, ncclSum, comm, cs)) ;
+                const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w, chunk = (i64) X.R * X.w ;
+                auto move = [&] (int mode, i64 total)
+                {
+                    if (total <= 0) return ;
+                    unsigned grid = (unsigned) std::min<i64> ((total + 255) / 256, 8192) ;
+                    hipLaunchKernelGGL (k_xchg_move, dim3 (grid), dim3 (256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
+                } ;
+                if (rs)
+                {
+                    move (0, seg * X.g) ;
+                    if (R) RCCLCHK (R->ReduceScatter (P->d_stage, P->d_stage + (i64) X.r * seg, (size_t) seg, ncclDouble, ncclSum, comm, cs)) ;
+                    else
+                    {
+                        HIPCHK (hipStreamSynchronize (cs)) ;
+                        if (P->ar_fn (P->d_stage, seg * X.g, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                    }
+                    move (1, seg) ;
+                }
                 else
                 {
-                    size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
-                    double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
-                    HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
-                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
-                    RCCLCHK (R->AllReduce (P->d_stage, P->d_stage, (size_t) L.ar_cnt, ncclDouble, ncclSum, comm, cs)) ;
-                    HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
-                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
+                    if (!R) HIPCHK (hipMemsetAsync (P->d_ag, 0, (size_t) (chunk * X.g) * sizeof (double), cs)) ;
+                    move (2, chunk) ;
+                    if (R) RCCLCHK (R->AllGather (P->d_ag + (i64) X.r * chunk, P->d_ag, (size_t) chunk, ncclDouble, comm, cs)) ;
+                    else
+                    {
+                        HIPCHK (hipStreamSynchronize (cs)) ;
+                        if (P->ar_fn (P->d_ag, chunk * X.g, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                    }
+                    move (3, chunk * X.g) ;
                 }
                 if (ahead)
                 {
-                    HIPCHK (hipEventRecord (P->ar_done, cs)) ;
-                    HIPCHK (hipStreamWaitEvent (st, P->ar_done, 0)) ;
-                }
-                break ;
-            }
-            if (!P->ar_fn) return CHOLMOD_HIP_INVALID ;
-            {
-                // ahead of time (wait_ev >= 0): the slab is complete once the event
-                // has fired; the main stream keeps running the rest of the trailing
-                // update, staging goes through the second stream
-                bool ahead = !serial && L.wait_ev >= 0 && P->stream2 ;
-                hipStream_t cs = ahead ? P->stream2 : st ;
-                if (ahead) HIPCHK (hipEventSynchronize (P->sync_ev [L.wait_ev])) ;
-                if (L.ar_r0 == 0)
-                {
-                    HIPCHK (hipStreamSynchronize (cs)) ;
-                    if (P->ar_fn (P->d_Lx + L.ar_off, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-                }
-                else
-                {
-                    size_t w = (size_t) (L.ar_ld - L.ar_r0) * sizeof (double) ;
-                    double *slab = P->d_Lx + L.ar_off + L.ar_r0 ;
-                    HIPCHK (hipMemcpy2DAsync (P->d_stage, w, slab, (size_t) L.ar_ld * sizeof (double), w,
-                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
-                    HIPCHK (hipStreamSynchronize (cs)) ;
-                    if (P->ar_fn (P->d_stage, L.ar_cnt, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-                    HIPCHK (hipMemcpy2DAsync (slab, (size_t) L.ar_ld * sizeof (double), P->d_stage, w, w,
-                        (size_t) L.ar_nc, hipMemcpyDeviceToDevice, cs)) ;
-                    if (ahead) HIPCHK (hipStreamSynchronize (cs)) ;
+                    if (R)
+                    {
+                        HIPCHK (hipEventRecord (P->ar_done, cs)) ;
+                        HIPCHK (hipStreamWaitEvent (st, P->ar_done, 0)) ;
+                    }
+                    else HIPCHK (hipStreamSynchronize (cs)) ;
                 }
             }
             break ;
@@ -1509,7 +1599,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             // block in the collectives that follow: keep taking part in them (the data no
             // longer matters) and report the failure through the agreement exchange at
             // the end, so that every rank returns an error instead of hanging.
-            if (L.kind == K_ALLREDUCE) (void) run_launch (P, L, true) ;
+            if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) (void) run_launch (P, L, true) ;
             continue ;
         }
         int rl = run_launch (P, L, prof) ;
@@ -1572,7 +1662,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
         if (L.kind == K_TRSM_UPD) S [31] += 1 ;
-        if (L.kind == K_ALLREDUCE) { S [17] += 1 ; S [18] += L.bytes ; }
+        if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }

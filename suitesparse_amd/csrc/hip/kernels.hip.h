@@ -1799,6 +1799,70 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     }
 }
 
+// ---- multi-GPU: packing of a shared front's block column for the row-split exchange ----
+// A block column [b0, b0+w) of a front shared by g ranks holds per-rank partial sums in
+// its live rows (>= b0).  It is summed with ONE reduce-scatter whose segment q carries
+//     [ D : the w x w diagonal block (ld = w) | chunk q : R x w rows below it (ld = R) ]
+// (chunk q = rows b0 + w + q R ... of the front, zero-padded past nsrow): every rank
+// receives the summed diagonal block and the summed rows of ITS chunk, runs the panel
+// chain (dpotrf / dtrsm / K < 512 updates, reference t_cholmod_super_numeric.c:864-867,
+// :997-1002) on those rows only, and the solved chunks travel back with one all-gather
+// (XchgD::ag: g x R x w).  Same volume as the all-reduce it replaces; the dtrsm and the
+// narrow updates of the block column are no longer repeated by every rank of the group.
+struct XchgD {
+    i64 slab ;      // offset in Lx of entry (b0, b0) of the front
+    i32 lda ;       // nsrow
+    i32 w ;         // columns of the block column
+    i32 mb ;        // rows below the diagonal block (nsrow - b0 - w)
+    i32 R ;         // rows per chunk (g R >= mb)
+    i32 g, r ;      // group size, this rank's index in the group
+} ;
+// mode 0: Lx -> stage (all g segments: this rank's partial sums, D repeated per segment)
+// mode 1: segment r of stage -> Lx (summed D and own chunk)
+// mode 2: own chunk of Lx -> ag + r R w        mode 3: ag (all chunks but r) -> Lx
+__global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *Lx, double *stage, double *ag)
+{
+    const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w ;
+    const i64 total = (mode == 0) ? seg * X.g : (mode == 1) ? seg : (mode == 2) ? (i64) X.R * X.w : (i64) X.R * X.w * X.g ;
+    double *S = Lx + X.slab ;
+    for (i64 e = blockIdx.x * (i64) 256 + threadIdx.x ; e < total ; e += (i64) gridDim.x * 256)
+    {
+        if (mode <= 1)
+        {
+            int q = mode == 0 ? (int) (e / seg) : X.r ;
+            i64 t = mode == 0 ? e - (i64) q * seg : e ;
+            double *p = stage + (i64) q * seg + t ;
+            if (t < (i64) X.w * X.w)
+            {
+                int i = (int) (t % X.w), j = (int) (t / X.w) ;
+                double *d = S + i + (i64) j * X.lda ;
+                if (mode == 0) *p = (i >= j) ? *d : 0.0 ;
+                else if (i >= j) *d = *p ;
+            }
+            else
+            {
+                t -= (i64) X.w * X.w ;
+                int i = (int) (t % X.R), j = (int) (t / X.R) ;
+                i64 row = (i64) q * X.R + i ;
+                double *d = S + X.w + row + (i64) j * X.lda ;
+                if (mode == 0) *p = (row < X.mb) ? *d : 0.0 ;
+                else if (row < X.mb) *d = *p ;
+            }
+        }
+        else
+        {
+            int q = mode == 2 ? X.r : (int) (e / ((i64) X.R * X.w)) ;
+            i64 t = mode == 2 ? e : e - (i64) q * X.R * X.w ;
+            int i = (int) (t % X.R), j = (int) (t / X.R) ;
+            i64 row = (i64) q * X.R + i ;
+            double *d = S + X.w + row + (i64) j * X.lda ;
+            double *p = ag + (i64) q * X.R * X.w + t ;
+            if (mode == 2) *p = (row < X.mb) ? *d : 0.0 ;
+            else if (q != X.r && row < X.mb) *d = *p ;
+        }
+    }
+}
+
 // ---- first failing supernode (not-positive-definite protocol) ---------------------
 // out [0] = smallest supernode with info != 0 (nsuper if none), so that the host reads
 // 4 bytes per factorization instead of the whole info array (G3_circuit stand-in:

@@ -659,4 +659,49 @@ __global__ void __launch_bounds__(256) k_mfma_peak2 (double *out, int iters, dou
 }
 
 
+// ---- the fp64 matrix-core ceiling, third attempt (round 3) ---------------------------------
+// k_mfma_peak above is mis-built: hipcc keeps its accumulators in VGPRs across the loop edge and
+// in AGPRs inside it, i.e. 64 v_accvgpr_write + 64 v_accvgpr_read per 8 MFMAs (seen in the ISA);
+// it measures those copies (~104 cycles per MFMA), not the pipe.  Here the loop body is inline
+// assembly: NACC independent accumulators (>= 4: an accumulator is reused three MFMAs = 192
+// cycles later, no dependent-issue hazard), 4 x NACC MFMAs per iteration, operands from four
+// A / four B registers with distinct full-mantissa data, nothing else in the loop but the
+// scalar counter.  stamp [2b], [2b+1] = shader cycles (s_memtime) and 100 MHz wall ticks
+// (s_memrealtime) wave 0 of block b spent in the loop: cycles / ticks x 100 MHz = the clock
+// the chip sustained under this load, cycles / MFMAs issued by that wave's SIMD = issue rate.
+template <int NACC>
+__global__ void __launch_bounds__(256) k_mfma_ceiling (double *out, long long *stamp, int iters, double scale)
+{
+    static_assert (NACC >= 4 && NACC % 4 == 0, "independent accumulators") ;
+    d4 acc [NACC] ;
+    double a [4], b [4] ;
+#pragma unroll
+    for (int q = 0 ; q < 4 ; q++)
+    {
+        unsigned long long h = (threadIdx.x + 64 * q + 1) * 0x9E3779B97F4A7C15ull ;
+        a [q] = scale * (1.0 + (double) (h >> 12) * 0x1p-52) ;
+        h = (h ^ (h >> 29)) * 0xBF58476D1CE4E5B9ull ;
+        b [q] = scale * (1.0 - (double) (h >> 12) * 0x1p-53) ;
+    }
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) acc [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    __syncthreads () ;
+    long long c0 = __builtin_readcyclecounter (), w0 = wall_clock64 () ;
+    for (int it = 0 ; it < iters ; it++)
+    {
+#pragma unroll
+        for (int u = 0 ; u < 4 ; u++)
+#pragma unroll
+            for (int q = 0 ; q < NACC ; q++)
+                asm volatile ("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v" (acc [q]) : "v" (a [(q + u) & 3]), "v" (b [q & 3])) ;
+    }
+    long long c1 = __builtin_readcyclecounter (), w1 = wall_clock64 () ;
+    double sum = 0 ;
+#pragma unroll
+    for (int q = 0 ; q < NACC ; q++) sum += acc [q][0] + acc [q][1] + acc [q][2] + acc [q][3] ;
+    out [blockIdx.x * 256 + threadIdx.x] = sum ;
+    if (threadIdx.x == 0) { stamp [2 * blockIdx.x] = c1 - c0 ; stamp [2 * blockIdx.x + 1] = w1 - w0 ; }
+}
+
+
 } // namespace sship

@@ -322,5 +322,57 @@ double cholmod_hip_bench_mfma_peak (int waves_per_simd, int iters)
     return (double) blocks * 4.0 * iters * (acc16 ? 16.0 : 8.0) * 2048.0 / (ms * 1e-3) ;
 }
 
+/* The fp64 matrix-core ceiling: an inline-assembly v_mfma_f64_16x16x4_f64 loop (k_mfma_ceiling),
+ * `waves_per_simd` resident waves per SIMD on every CU, `nacc` (4 or 8) independent
+ * accumulators per wave.  Returns flop/s from HIP events; out3 [0] = shader cycles per MFMA
+ * per SIMD (64 = the pipe's issue rate), out3 [1] = the shader clock sustained inside the loop
+ * in GHz (s_memtime against the 100 MHz s_memrealtime), out3 [2] = flop/s that the issue rate
+ * would give at 2.4 GHz. */
+double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, int zero_operands, double *out3)
+{
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    if (waves_per_simd < 1) waves_per_simd = 1 ;
+    if (iters < 1) iters = 1 ;
+    if (nacc != 8) nacc = 4 ;
+    int blocks = 256 * waves_per_simd ;
+    double *d = nullptr ; long long *st = nullptr ;
+    if (hipMalloc ((void **) &d, (size_t) blocks * 256 * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    if (hipMalloc ((void **) &st, (size_t) blocks * 2 * sizeof (long long)) != hipSuccess) { (void) hipFree (d) ; return CHOLMOD_HIP_OUT_OF_MEMORY ; }
+    double scale = zero_operands ? 0.0 : 1.0 ;
+    auto launch = [&] (int it)
+    {
+        if (nacc == 8) hipLaunchKernelGGL ((k_mfma_ceiling<8>), dim3 (blocks), dim3 (256), 0, 0, d, st, it, scale) ;
+        else hipLaunchKernelGGL ((k_mfma_ceiling<4>), dim3 (blocks), dim3 (256), 0, 0, d, st, it, scale) ;
+    } ;
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    launch (64) ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    launch (iters) ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    hipError_t err = hipGetLastError () ;
+    std::vector<long long> h ((size_t) blocks * 2) ;
+    if (err == hipSuccess) err = hipMemcpy (h.data (), st, h.size () * sizeof (long long), hipMemcpyDeviceToHost) ;
+    (void) hipFree (d) ; (void) hipFree (st) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    if (out3)
+    {
+        double cyc = 0, ticks = 0 ;
+        for (int b = 0 ; b < blocks ; b++) { cyc += (double) h [2 * b] ; ticks += (double) h [2 * b + 1] ; }
+        double per_wave = 4.0 * nacc * (double) iters ;               // MFMAs one wave issued
+        // waves_per_simd waves share a SIMD's pipe while they are co-resident
+        out3 [0] = cyc / blocks / (per_wave * waves_per_simd) ;
+        out3 [1] = ticks > 0 ? cyc / ticks * 0.1 : 0.0 ;                // cycles per 10 ns tick -> GHz
+        out3 [2] = out3 [0] > 0 ? 256.0 * 4.0 * 2048.0 / out3 [0] * 2.4e9 : 0.0 ;
+    }
+    return (double) blocks * 4.0 * (4.0 * nacc * (double) iters) * 2048.0 / (ms * 1e-3) ;
+}
+
+
 
 } // extern "C"

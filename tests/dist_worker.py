@@ -58,12 +58,27 @@ def main():
             Ax = Ax.copy()
             Ax[Ap[int(O.Perm[kbad])]] = -3.0
         st_o = O.factorize(Ax)
-        cb = make_allreduce()
+        # exchange: the torch.distributed callback (gloo staging), or -- DIST_TEST_EXCHANGE=native --
+        # the engine's own path (cholmod_hip_rccl_attach: communicators, splits, stream-ordered
+        # reduce-scatter / all-gather / all-reduce) on the collective library named by
+        # CHOLMOD_HIP_RCCL_LIBRARY (tests/standin_rccl: ranks sharing one GPU)
+        native = os.environ.get("DIST_TEST_EXCHANGE") == "native"
+        cb = None if native else make_allreduce()
         resident = os.environ.get("DIST_TEST_RESIDENT") == "1"
         S = ch.Session(rank=rank, world=world, allreduce=cb, factor_on_device=resident,
                        hip_flags=int(os.environ.get("CHOLMOD_TEST_HIP_FLAGS", "0")))
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)
+        if native:
+            import ctypes as C
+            assert S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm)) == 1, S.cm.status
+            idb = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                assert S.L.cholmod_hip_rccl_unique_id(idb.ctypes.data) == 0
+            box = [idb.tobytes()]
+            dist.broadcast_object_list(box, src=0)
+            idb = np.frombuffer(box[0], dtype=np.uint8).copy()
+            assert S.L.cholmod_hip_rccl_attach(ch.FactorView(Lf).hip_plan, idb.ctypes.data) == 0
         ok = S.factorize(A, Lf)
         if resident:
             # factor left distributed on the devices: a second factorization clears only the
@@ -103,9 +118,15 @@ def main():
                    zero_pattern_equal=bool(np.array_equal(fv.x[m] != 0, O.x[m] != 0)),
                    nshared=int((owner < 0).sum()), nsuper=int(fv.nsuper),
                    owned=[int((owner == r).sum()) for r in range(world)],
-                   allreduce_calls=cb.stats["n"], allreduce_MB=cb.stats["bytes"] / 1e6,
-                   allreduce_group_sizes=sorted(cb.stats["by_size"]),
+                   allreduce_calls=cb.stats["n"] if cb else int(S.hip_stats(Lf)[17]),
+                   allreduce_MB=(cb.stats["bytes"] if cb else S.hip_stats(Lf)[18]) / 1e6,
+                   allreduce_group_sizes=sorted(cb.stats["by_size"]) if cb else [],
                    nsplit=int(S.hip_stats(Lf)[22]))
+        if native:
+            g0 = np.empty(fv.nsuper, dtype=np.int64)
+            gn = np.empty(fv.nsuper, dtype=np.int64)
+            assert S.L.cholmod_hip_get_groups(fv.hip_plan, g0.ctypes.data, gn.ctypes.data) == 0
+            res["allreduce_group_sizes"] = sorted({int(x) for x in gn[gn > 1]})
         if st_o == 0:
             b = G.demo_rhs(n)
             x = S.solve(Lf, b)
