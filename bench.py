@@ -50,33 +50,187 @@ def build_workload(name, m):
     raise ValueError(name)
 
 
+def _scipy_openblas():
+    """LP64 OpenBLAS shipped with scipy, in CHOLMOD_BLAS_LIBRARY syntax (path:symbol-prefix), or None."""
+    import glob
+    try:
+        import scipy
+        d = os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs")
+        c = sorted(glob.glob(os.path.join(d, "libscipy_openblas-*.so")))
+        return (c[0] + ":scipy_") if c else None
+    except Exception:
+        return None
+
+
+CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, os.environ["BENCH_ROOT"])
+from suitesparse_amd import cholmod as ch, generators as G
+import ctypes as C
+m = int(os.environ["BENCH_CPU_M"])
+n, Ap, Ai, Ax = G.poisson3d(m)
+perm = G.geometric_nd(m, m, m, 4)
+S = ch.Session(use_gpu=0)
+A = S.sparse(n, Ap, Ai, Ax, -1)
+Lf = S.analyze(A, perm)
+t0 = time.perf_counter()
+ok = S.factorize(A, Lf)
+dt = time.perf_counter() - t0
+assert ok == 1 and S.cm.status == 0
+S.L.ssamd_cpu_blas_name.restype = C.c_char_p
+print(json.dumps({"fl": S.cm.fl, "seconds": dt, "blas": S.L.ssamd_cpu_blas_name().decode(),
+                  "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count()}))
+"""
+
+
 def cpu_baseline(sample_m):
-    """Oracle (CPU restatement of the reference loop) timed on the host cores on a
-    bounded sample of the same workload family."""
-    from oracle.oracle import OracleFactor, bind_blas
+    """The build's own CPU supernodal path (Common->useGPU = 0: suitesparse_amd/csrc/host/cpu_numeric.c,
+    the reference's left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU
+    supernodal path") timed on the host cores on a bounded sample of the same workload family, in a
+    child process (the BLAS binding is per process).  Not the oracle: nothing under oracle/ is timed."""
+    import subprocess
+    env = dict(os.environ, BENCH_ROOT=ROOT, BENCH_CPU_M=str(sample_m))
+    if "CHOLMOD_BLAS_LIBRARY" not in env:
+        b = _scipy_openblas()
+        if b:
+            env["CHOLMOD_BLAS_LIBRARY"] = b
+    cores = os.cpu_count() or 1
+    # the loops around the BLAS are memory-bound and stop scaling at a few dozen threads
+    env.setdefault("OMP_NUM_THREADS", str(min(cores, 64)))
+    env.setdefault("OPENBLAS_NUM_THREADS", env["OMP_NUM_THREADS"])
+    try:
+        out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=600)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:      # report, never fail the bench line
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+    return {"value": r["fl"] / r["seconds"] / 1e9, "unit": "GFLOP/s", "cores": int(env["OMP_NUM_THREADS"]), "kind": "port",
+            "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
+            "sample": f"poisson3d {sample_m}^3 geometric ND, one factorization, fl={r['fl']:.3e}, "
+                      f"{r['seconds']:.2f} s, BLAS={r['blas']}, host cores {cores}"}
+
+
+PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r03_pmc_summary_poisson200_top48.json"}
+
+
+def roofline_of(S, Lf, wname, world):
+    """Roofline object of the dominant kernel of the workload: one extra, untimed factorization with
+    HIP events around every launch (on the engine's own stream).  The dense-update flops of a big
+    problem run in k_update3 (one wave per 64 x 64 tile, regions of >= 2048 tiles), the rest in
+    k_update2 (four waves per tile); whichever took more of this factorization is reported, the
+    other beside it."""
+    S.set_profiling(Lf, True)
+    assert S.refactorize_resident(Lf) == 1
+    ps = S.hip_stats(Lf)
+    S.set_profiling(Lf, False)
+    lp = S.launch_profile(Lf)
+    use_w = ps[32] > ps[6]
+    sec, nl, fl_, by_ = (ps[32], ps[33], ps[34], ps[35]) if use_w else (ps[6], ps[7], ps[8], ps[16])
+    if sec <= 0:
+        return None
+    kind = 12 if use_w else 5
+    kname = "k_update3<4> / <2> (one wave per 64x64 tile, no LDS)" if use_w else "k_update2<64,64,16,2,false>"
+    ach = fl_ / sec / 1e12
+    traffic, traffic_note, traffic_detail = None, None, None
+    # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc passes of the same
+    # workload (offline, profiles/README.md): FETCH_SIZE x 2 + WRITE_SIZE x 1, the calibration
+    # measured on known-byte kernels (DESIGN.md section 4)
+    upd = np.where(lp["kind"] == kind)[0]
+    pj = None
+    if wname in PMC_BY_WORKLOAD and world == 1:
+        pf = os.path.join(ROOT, "profiles", PMC_BY_WORKLOAD[wname])
+        pj = json.load(open(pf)) if os.path.exists(pf) else None
+    if pj is not None and pj.get("kernel_kind", 5) == kind and upd.size >= pj["launches_profiled"]:
+        k = pj["launches_profiled"]
+        top = upd[np.argsort(-lp["ms"][upd])[:k]]       # the same selection: the k longest launches
+        traffic = pj["traffic_bytes_per_launch"]
+        traffic_detail = {
+            "launches": int(k), "selection": pj["selection"],
+            "share_of_kernel_time": float(lp["ms"][top].sum() / lp["ms"][upd].sum()),
+            "ms_per_launch": float(lp["ms"][top].mean()),
+            "algorithmic_bytes_per_launch": float(lp["bytes"][top].mean()),
+            "algorithmic_flops_per_launch": float(lp["flops"][top].mean()),
+            "TFLOPs_on_these_launches": float(lp["flops"][top].sum() / (1e-3 * lp["ms"][top].sum()) / 1e12),
+            "fetch_bytes_per_launch": pj["fetch_bytes_per_launch"], "write_bytes_per_launch": pj["write_bytes_per_launch"],
+            "traffic_over_algorithmic": float(pj["traffic_bytes_per_launch"] / lp["bytes"][top].mean()),
+            "TBps_at_the_memory_side": float(pj["traffic_bytes_per_launch"] / (1e-3 * lp["ms"][top].mean()) / 1e12),
+            "source": "profiles/" + PMC_BY_WORKLOAD[wname]}
+        traffic_note = ("per launch over the %d longest launches (%.0f %% of this kernel's time): a counter pass over all "
+                        "launches of a 200^3 factorization does not finish" % (k, 100 * traffic_detail["share_of_kernel_time"]))
+    else:
+        traffic_note = "no PMC summary under profiles/ for this workload and kernel"
+    other = {"kernel": "k_update2<64,64,16,2,false>" if use_w else "k_update3", "seconds": ps[6] if use_w else ps[32],
+             "launches": int(ps[7] if use_w else ps[33]),
+             "TFLOPs": ((ps[8] / ps[6]) if use_w and ps[6] > 0 else (ps[34] / ps[32]) if (not use_w and ps[32] > 0) else 0.0) / 1e12}
+    return {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": traffic_note, "traffic_detail": traffic_detail,
+            "algorithmic_bytes_per_launch": by_ / max(nl, 1),
+            "algorithmic_flops_per_launch": fl_ / max(nl, 1),
+            "extend_add": {"algorithmic_GB": ps[10] / 1e9, "seconds_incl_zero": ps[9]},
+            "thin_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
+                                   "achieved_GBps": (ps[20] / ps[19] / 1e9) if ps[19] > 0 else None,
+                                   "hbm_peak_GBps": 8000.0},
+            "kernel": kname, "launches": int(nl),
+            "avg_launch_ms": 1e3 * sec / max(nl, 1),
+            "other_update_kernel": other,
+            "seconds_by_class": {"update_wave_tiles": ps[32], "update64": ps[6], "update64_K_below_512": ps[23],
+                                 "update64_plus_potrf_of_next_block": ps[27], "update128": ps[14], "extend_add+zero": ps[9],
+                                 "potrf": ps[11], "trsm": ps[12], "trsm_plus_K64_update_plus_potrf": ps[30], "assemble": ps[13],
+                                 "thin_fronts_fused": ps[19],
+                                 "total_profiled": ps[0]}}
+
+
+def secondary_line(workload, m, steps=3, warmup=1):
+    """One of the other single-GPU configurations of BASELINE.json (configs[1]: Poisson 100^3; SURVEY 8d's
+    stand-ins of nd24k and G3_circuit), same step as the headline: resident refactorizations, then
+    the profiled pass, the device solve, residual and factor invariants."""
+    from suitesparse_amd import cholmod as ch
     from suitesparse_amd import generators as G
-    blas = bind_blas()
-    n, Ap, Ai, Ax = G.poisson3d(sample_m)
-    perm = G.geometric_nd(sample_m, sample_m, sample_m, 4)
-    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    n, Ap, Ai, Ax, stype, perm, wname = build_workload(workload, m)
+    S = ch.Session(factor_on_device=True, ordering="default")
+    A = S.sparse(n, Ap, Ai, Ax, stype)
+    Lf = S.analyze(A, perm)
+    fl = S.cm.fl
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    for _ in range(warmup):
+        assert S.refactorize_resident(Lf) == 1
     t0 = time.perf_counter()
-    st = O.factorize(Ax)
-    dt = time.perf_counter() - t0
-    assert st == 0
-    cores = 1
-    if blas:
-        cores = os.cpu_count()
-        try:                                    # threads the dlopen'ed BLAS really uses
-            from threadpoolctl import threadpool_info
-            nt = [i["num_threads"] for i in threadpool_info() if "openblas" in (i.get("filepath") or "").lower()
-                  or i.get("internal_api") in ("openblas", "mkl", "blis")]
-            if nt:
-                cores = max(nt)
-        except Exception:
-            pass
-    return {"value": O.fl / dt / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"poisson3d {sample_m}^3 geometric ND, one factorization, fl={O.fl:.3e}, "
-                      f"{dt:.2f} s, BLAS={blas or 'built-in C kernels'}"}
+    for _ in range(steps):
+        assert S.refactorize_resident(Lf) == 1
+    dt = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+    dt_api = (time.perf_counter() - t0) / steps
+    stats = S.hip_stats(Lf)
+    roof = roofline_of(S, Lf, wname, 1)
+    b = G.demo_rhs(n)
+    x = S.solve(Lf, b)
+    r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
+    checks = S.factor_checks(Lf)
+    out = {"workload": wname, "n": int(n), "fl": fl, "executed_flops": stats[1], "value": fl / dt / 1e9, "unit": "GFLOP/s",
+           "ms_per_step": 1e3 * dt, "ms_per_step_api": 1e3 * dt_api, "steps": steps,
+           "pct_fp64_mfma_peak": 100.0 * fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+           "launches_per_step": int(stats[2]), "Lx_GB": 8e-9 * ch.FactorView(Lf).xsize,
+           "residual_2norm": float(np.linalg.norm(r) / np.linalg.norm(b)),
+           "upper_nonzeros": checks["upper_nonzeros"], "nonfinite": checks["nonfinite"],
+           "solve_device_ms": 1e3 * float(S.hip_stats(Lf)[24]), "roofline": roof}
+    if roof is not None:
+        tf = roof["thin_front_kernel"]
+        # the thin configuration is priced against HBM: algorithmic bytes of the whole factorization / time
+        if workload == "poisson2d":
+            algo = (roof["extend_add"]["algorithmic_GB"] + tf["algorithmic_GB"]) * 1e9 + 16.0 * stats[5]
+            out["hbm_roofline"] = {"bound": "hbm", "achieved": algo / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                   "frac": algo / dt / 8e12,
+                                   "algorithmic_bytes": "thin fronts (children in, panel + block out) + extend-add of the generic "
+                                                        "fronts + 16 B per entry of L for the generic panels"}
+    if workload in ("poisson3d", "poisson2d"):
+        ld = G.poisson_logdet(*([m] * (3 if workload == "poisson3d" else 2)))
+        out["logdet_rel_err"] = abs(2.0 * checks["half_logdet"] - ld) / abs(ld)
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
+    return out
 
 
 def main():
@@ -90,6 +244,9 @@ def main():
     ap.add_argument("--cpu-sample-m", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the other single-GPU configurations (Poisson 100^3, the nd24k and G3_circuit stand-ins) "
+                         "that follow the headline workload in the same JSON line")
     ap.add_argument("--check", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the solve / residual / factor invariants after the timed region")
@@ -269,62 +426,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_api = float(t.item())
 
-    # roofline of the dominant kernel (64x64-tile fp64-MFMA update): one extra,
-    # untimed factorization with HIP events around every launch
     roof = None
     if not args.no_profile_pass:
-        S.set_profiling(Lf, True)
-        assert S.refactorize_resident(Lf) == 1
-        ps = S.hip_stats(Lf)
-        S.set_profiling(Lf, False)
-        if ps[6] > 0:
-            ach = ps[8] / ps[6] / 1e12
-            traffic, traffic_note, traffic_detail = None, None, None
-            # HBM-side bytes per launch of this kernel from separate rocprofv3 --pmc passes of the
-            # same workload (offline, profiles/README.md): FETCH_SIZE x 2 + WRITE_SIZE x 1, the
-            # calibration measured on known-byte kernels
-            lp = S.launch_profile(Lf)
-            upd = np.where(lp["kind"] == 5)[0]
-            pmc_by_workload = {"poisson3d_200^3_geometricND_leaf4": "r02h_pmc_summary_poisson200_top48.json"}
-            pj = None
-            if wname in pmc_by_workload and world == 1:
-                pf = os.path.join(ROOT, "profiles", pmc_by_workload[wname])
-                pj = json.load(open(pf)) if os.path.exists(pf) else None
-            if pj is not None and upd.size >= pj["launches_profiled"]:
-                k = pj["launches_profiled"]
-                top = upd[np.argsort(-lp["ms"][upd])[:k]]       # the same selection: the k longest launches
-                traffic = pj["traffic_bytes_per_launch"]
-                traffic_detail = {
-                    "launches": int(k), "selection": pj["selection"],
-                    "share_of_kernel_time": float(lp["ms"][top].sum() / lp["ms"][upd].sum()),
-                    "ms_per_launch": float(lp["ms"][top].mean()),
-                    "algorithmic_bytes_per_launch": float(lp["bytes"][top].mean()),
-                    "algorithmic_flops_per_launch": float(lp["flops"][top].mean()),
-                    "TFLOPs_on_these_launches": float(lp["flops"][top].sum() / (1e-3 * lp["ms"][top].sum()) / 1e12),
-                    "fetch_bytes_per_launch": pj["fetch_bytes_per_launch"], "write_bytes_per_launch": pj["write_bytes_per_launch"],
-                    "traffic_over_algorithmic": float(pj["traffic_bytes_per_launch"] / lp["bytes"][top].mean()),
-                    "TBps_at_the_memory_side": float(pj["traffic_bytes_per_launch"] / (1e-3 * lp["ms"][top].mean()) / 1e12),
-                    "source": "profiles/" + pmc_by_workload[wname]}
-                traffic_note = ("per launch over the %d longest launches (%.0f %% of this kernel's time): a counter pass over all "
-                                "launches of a 200^3 factorization does not finish" % (k, 100 * traffic_detail["share_of_kernel_time"]))
-            else:
-                traffic_note = "no PMC summary under profiles/ for this workload"
-            roof = {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "traffic_note": traffic_note, "traffic_detail": traffic_detail,
-                    "algorithmic_bytes_per_launch": ps[16] / max(ps[7], 1),
-                    "algorithmic_flops_per_launch": ps[8] / max(ps[7], 1),
-                    "extend_add": {"algorithmic_GB": ps[10] / 1e9, "seconds_incl_zero": ps[9]},
-                    "thin_front_kernel": {"fronts": int(ps[21]), "algorithmic_GB": ps[20] / 1e9,
-                                           "achieved_GBps": (ps[20] / ps[19] / 1e9) if ps[19] > 0 else None,
-                                           "hbm_peak_GBps": 8000.0},
-                    "kernel": "k_update2<64,64,16,2,false>", "launches": int(ps[7]),
-                    "avg_launch_ms": 1e3 * ps[6] / max(ps[7], 1),
-                    "seconds_by_class": {"update64": ps[6], "update64_K_below_512": ps[23],
-                                         "update64_plus_potrf_of_next_block": ps[27], "update128": ps[14], "extend_add+zero": ps[9],
-                                         "potrf": ps[11], "trsm": ps[12], "trsm_plus_K64_update_plus_potrf": ps[30], "assemble": ps[13],
-                                         "thin_fronts_fused": ps[19],
-                                         "total_profiled": ps[0]}}
+        roof = roofline_of(S, Lf, wname, world)
 
     # correctness of what was just timed (outside the timed region): device solve ->
     # residual, and one pass over the resident factor for its invariants; for the
@@ -348,26 +452,44 @@ def main():
             checks["logdet_closed_form"] = ld
             checks["logdet_rel_err"] = abs(2.0 * checks["half_logdet"] - ld) / abs(ld)
 
+    # everything the line needs from the headline factor, then release its HBM (181.6 GB + arena at
+    # 200^3): the secondary workloads and the micro-benchmarks below need the room
+    nsuper, xsize = int(fv.nsuper), int(fv.xsize)
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.finish()
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.cpu_sample_m)
+        # the other single-GPU configurations of BASELINE.json, in the same record (a few seconds each)
+        secondary = []
+        if world == 1 and not args.no_secondary and not args.matrix and args.workload == "poisson3d" and m >= 160:
+            for wl, mm in (("poisson3d", 100), ("box3d", 42), ("poisson2d", 1259)):
+                try:
+                    secondary.append(secondary_line(wl, mm))
+                except Exception as e:          # never lose the headline line to a secondary workload
+                    secondary.append({"workload": f"{wl} {mm}", "error": repr(e)})
         pr = ch.probes()            # micro-benchmarks: lib/libcholmod_amd_probes.so, not the product library
-        mf = pr.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 0)
-        mf_big = pr.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 0)
-        # issue-bound v_mfma_f64_16x16x4 loops (no memory): waves per SIMD x accumulators per
-        # wave x operand data (full-mantissa / all-zero: the multipliers' switching power
-        # moves the clock); the ceiling printed is the best any of them -- or the real
-        # kernel at its large-K plateau -- reaches
+        mf = pr.cholmod_hip_bench_update_kernel(8192, 8192, 512, 3, 8192)
+        mf_big = pr.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 8192)
+        mf2_big = pr.cholmod_hip_bench_update_kernel(16384, 16384, 4096, 2, 0)
+        # The fp64 matrix-core ceiling, measured: an inline-assembly v_mfma_f64_16x16x4 loop with
+        # nothing else in it, ~0.25 s per point so that the clock settles (waves per SIMD x
+        # accumulators x operand data: full-mantissa operands cost power, i.e. clock).  Issue
+        # rate = 64 cycles per MFMA per SIMD exactly, so the ceiling is 78.6 TFLOP/s x clock / 2.4 GHz.
+        import ctypes as C2
         sweep = {}
         for zero in (0, 1):
-            for acc in (8, 16):
-                for w in (1, 2, 4, 8):
-                    code = (10000 if zero else 0) + (100 if acc == 16 else 0) + w
-                    r = pr.cholmod_hip_bench_mfma_peak(code, 20000 // w)
+            for nacc in (4, 8):
+                for w in (1, 2):
+                    o3 = (C2.c_double * 3)()
+                    r = pr.cholmod_hip_bench_mfma_ceiling(w, nacc, int(0.25 * 2.3e9 / (4 * nacc * 64 * w)), zero, o3)
                     if r > 0:
-                        sweep[f"{'zero' if zero else 'data'}_acc{acc}_waves{w}"] = r / 1e12
-        mpeak = max(list(sweep.values()) + [mf_big / 1e12 if mf_big > 0 else 0.0]) * 1e12
+                        sweep[f"{'zero' if zero else 'data'}_acc{nacc}_waves{w}"] = {
+                            "TFLOPs": r / 1e12, "clock_GHz": o3[1], "cycles_per_mfma_per_simd": o3[0] if w == 1 else None}
+        data_pts = [v["TFLOPs"] for k, v in sweep.items() if k.startswith("data")]
+        mpeak = max(data_pts) * 1e12 if data_pts else 0.0
         value = fl * args.steps / elapsed / 1e9        # one job, all ranks together
         line = {
             "metric": "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)",
@@ -376,8 +498,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "file" if args.matrix else "synthetic",
             "config": {"workload": wname, "n": int(n), "nnz_lower": int(Ap[-1]),
-                       "fl": fl, "executed_flops": exec_flops, "nsuper": fv.nsuper,
-                       "Lx_GB": 8e-9 * fv.xsize, "arena_GB": 1e-9 * stats[4],
+                       "fl": fl, "executed_flops": exec_flops, "nsuper": nsuper,
+                       "Lx_GB": 8e-9 * xsize, "arena_GB": 1e-9 * stats[4],
                        "levels": int(stats[3]), "launches_per_step": int(stats[2]),
                        "parallelism": "1 GPU" if world == 1 else
                        f"{world} GPUs: etree subtrees per rank + shared top fronts, "
@@ -388,8 +510,14 @@ def main():
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "measured_update_kernel_TFLOPs_8192x8192x512": mf / 1e12 if mf > 0 else None,
             "measured_update_kernel_TFLOPs_16384x16384x4096": mf_big / 1e12 if mf_big > 0 else None,
+            "measured_update_kernel_note": "k_update3 (one wave per 64x64 tile), the kernel of the big update regions; "
+                                           "k_update2 (four waves per tile, LDS-staged) on the large shape: %s TFLOP/s"
+                                           % (("%.1f" % (mf2_big / 1e12)) if mf2_big > 0 else "n/a"),
             "measured_fp64_mfma_ceiling_TFLOPs": mpeak / 1e12 if mpeak > 0 else None,
-            "mfma_issue_loop_sweep_TFLOPs": sweep,
+            "measured_fp64_mfma_ceiling_note": "best full-mantissa point of the inline-assembly MFMA loop (tools/mfma_ceiling.py): "
+                                               "the issue rate is 64 cycles per MFMA per SIMD = the 78.6 TFLOP/s spec at 2.4 GHz, "
+                                               "the figure is that rate at the clock the part sustains under the load",
+            "mfma_ceiling_sweep": sweep,
             "ms_per_step_resident": 1e3 * elapsed / args.steps,
             "ms_per_step_api": 1e3 * elapsed_api / api_steps,
             "api_step": "cholmod_l_factorize(A, L, Common) called again on a matrix with the same pattern (hash of p / i "
@@ -401,6 +529,8 @@ def main():
         if resid is not None:
             line["residual_2norm"] = resid
             line["factor_checks"] = checks
+        if secondary:
+            line["secondary"] = secondary
         if native:
             line["exchange"] = {"backend": "rccl (engine-native, stream-ordered)",
                                 "allreduce_calls_per_factorization": int(stats[17]),
@@ -414,9 +544,6 @@ def main():
                                 "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    S.free_factor(Lf)
-    S.free_sparse(A)
-    S.finish()
     if dist is not None:
         dist.destroy_process_group()
 

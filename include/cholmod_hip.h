@@ -221,16 +221,20 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [27] their seconds   [28] their flops   [29] their algorithmic bytes
  *  [30] seconds of the fused solve + K = 64 update + factorization launches (k_trsm_upd)
  *  [31] their number
+ *  [32] seconds in the one-wave-per-tile dense-update kernel (k_update3: the regions with
+ *       >= 2048 tiles)   [33] its launches   [34] its algorithmic flops   [35] its algorithmic bytes
+ *       (as [16]); the regions below that size stay with [6]-[8]
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
-#define CHOLMOD_HIP_NSTATS 32
+#define CHOLMOD_HIP_NSTATS 40
 int cholmod_hip_get_stats (cholmod_hip_plan *plan, double *stats) ;
 int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
 /* The launch list of the plan and, after a factorization with profiling on, the
  * device milliseconds of every launch (tuning; tools/launch_profile.py).
  * kind: 0 zero, 1 extend-add, 2 potrf, 3 trsm, 4 update(128), 5 update(64),
  * 7 all-reduce, 8 thin fronts, 9 update + factorization of the next diagonal block,
- * 10 solve + K = 64 update + factorization of the next diagonal block.  Fills at most cap entries of the arrays that are
+ * 10 solve + K = 64 update + factorization of the next diagonal block, 11 all-gather of a shared block column,
+ * 12 update (one wave per tile, k_update3).  Fills at most cap entries of the arrays that are
  * not NULL, returns the number of launches. */
 int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
     int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;

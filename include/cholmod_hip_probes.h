@@ -30,6 +30,10 @@ double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters,
  * copies the compiler inserted and under-reports; it is kept for the round-1/2 records.) */
 double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, int zero_operands, double *out3) ;
 
+/* Tuning probe: an update kernel selected by `flags` against k_update2 on the same operands;
+ * max |difference| / max |reference| (negative = a CHOLMOD_HIP_* code). */
+double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, int assign, int flags) ;
+
 /* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;
 /* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */

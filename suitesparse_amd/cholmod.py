@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CHOLMOD_AMD_LIB") or os.path.join(_HERE, "lib", "libc
 CSRC = os.path.join(_HERE, "csrc")
 
 CHOLMOD_MAXMETHODS = 9
-CHOLMOD_HIP_NSTATS = 32
+CHOLMOD_HIP_NSTATS = 40
 
 # constants (include/cholmod.h)
 PATTERN, REAL, COMPLEX, ZOMPLEX = 0, 1, 2, 3
@@ -148,7 +148,7 @@ PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
 PROBE_SYMBOLS = [
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
-    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling",
+    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_debug_update_diff",
 ]
 
 _lib = None
@@ -274,6 +274,7 @@ def probes():
             ("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mfma_ceiling", dbl, [C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+            ("cholmod_hip_debug_update_diff", dbl, [i64, i64, i64, C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_debug_potrf_cycles", C.c_int, [vp]),
             ("cholmod_hip_debug_panel_cycles", C.c_int, [vp]),
             ("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])):

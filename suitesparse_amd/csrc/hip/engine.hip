@@ -46,7 +46,7 @@ constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
 // the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -333,14 +333,33 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     } ;
     (void) maxrows ;
     std::vector<GemmGroup> pfv ;        // narrow updates whose first tile is factored on the spot (k_update2f)
+    std::vector<GemmGroup> wav ;        // regions big enough for one wave per 64 x 64 tile (k_update3)
+    // A region goes to k_update3 (one wave per tile: 75 TFLOP/s at K = 4096 against 64 for the
+    // four-wave k_update2, 58 against 49 at K = 512; measured, tools/upd3.py) when it has enough
+    // tiles to put two waves on every SIMD; below that the four waves per tile of k_update2
+    // fill the chip better.  CHOLMOD_HIP_UPD3_MIN_TILES overrides (0 = never).
+    static const i64 w_min_tiles = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; return e ? (i64) atoll (e) : (i64) 2048 ; } () ;
+    auto region_tiles = [] (const GemmGroup &G) -> i64
+    {
+        i64 mt = (G.m + SMALL - 1) / SMALL, nt = (G.n + SMALL - 1) / SMALL ;
+        return G.tri ? nt * (nt + 1) / 2 + (mt - nt) * nt : mt * nt ;
+    } ;
     auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
     {
-        for (int pass = 0 ; pass < 3 ; pass++)
+        if (w_min_tiles > 0 && !use_big)
         {
-            std::vector<GemmGroup> &v = pass == 2 ? pfv : pass ? small : big ;
+            // (a factored-first update of a big region: the diagonal block is factored by a
+            // separate launch instead -- 17 us next to milliseconds)
+            std::vector<GemmGroup> keep ;
+            for (auto &G : small) { if (region_tiles (G) >= w_min_tiles) wav.push_back (G) ; else keep.push_back (G) ; }
+            small.swap (keep) ;
+        }
+        for (int pass = 0 ; pass < 4 ; pass++)
+        {
+            std::vector<GemmGroup> &v = pass == 3 ? wav : pass == 2 ? pfv : pass ? small : big ;
             if (v.empty ()) continue ;
             int T = pass ? SMALL : BIG ;
-            Launch L {pass == 2 ? K_UPD_PF : pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
+            Launch L {pass == 3 ? K_UPD_W : pass == 2 ? K_UPD_PF : pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
             i64 tiles = 0 ;
             for (auto &G : v)
             {
@@ -401,6 +420,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         G.assign = (to_cb && kc == 0 && assign_cb && assign_cb [fid]) ? 1 : 0 ;
         if (split && is_shared (fid)) { G.tile_mul = grpn [fid] ; G.tile_add = rank - grp0 [fid] ; }
         if (factor_first) { G.pf_next = 1 ; G.pf_col0 = r0 ; pfv.push_back (G) ; return ; }
+
         bool isbig = use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
     } ;
@@ -482,6 +502,12 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             // (also the K >= 512 doubling updates inside an outer block, unless their tiles are
             // dealt over the ranks of a shared front: the factor must exist on every rank)
             bool ff = fuse_potrf && !(x.wide && is_shared (ids [x.q])) && !x.cb && c0 == x.t0 && f.nscol - x.t0 >= NB && x.t1 - c0 >= NB ;
+            if (ff && w_min_tiles > 0 && !use_big && !is_shared (ids [x.q]))
+            {
+                // a region big enough for k_update3 is not fused with the next dpotrf
+                i64 mt = (f.nsrow - c0 + SMALL - 1) / SMALL, nt = (x.t1 - c0 + SMALL - 1) / SMALL ;
+                if (nt * (nt + 1) / 2 + (mt - nt) * nt >= w_min_tiles) ff = false ;
+            }
             if (ff) pf_done [x.q] = x.t0 ;
             if (!x.wide && is_shared (ids [x.q]) && x.t1 > c0)
             {
@@ -1519,6 +1545,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
+        case K_UPD_W:
+            // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
+            if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            else hipLaunchKernelGGL ((k_update3<2>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            break ;
         case K_UPD_PF:
             hipLaunchKernelGGL (k_update2f, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
@@ -1660,6 +1691,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     {
         const Launch &L = P->sch.launches [q] ;
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
+        if (L.kind == K_UPD_W) { S [33] += 1 ; S [34] += L.flops ; S [35] += L.bytes ; }
         if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
         if (L.kind == K_TRSM_UPD) S [31] += 1 ;
         if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) { S [17] += 1 ; S [18] += L.bytes ; }
@@ -1684,6 +1716,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             {
                 case K_UPD_SMALL: S [6] += sec ; if (L.aux < MB) { S [23] += sec ; } break ;
                 case K_UPD_PF: S [27] += sec ; break ;
+                case K_UPD_W: S [32] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
                 case K_POTRF: S [11] += sec ; break ;

@@ -1580,6 +1580,182 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm) ;
 }
 
+// ---- dense update, third generation: one wave = one tile, no LDS, no barrier --------
+// Same contract as k_update2 (C -= A B' on a 64 x 64 tile of an update region, reference
+// dsyrk / dgemm t_cholmod_super_numeric.c:682-717).  k_update2's four waves share the
+// operand slabs through LDS and meet at two barriers per 16 columns of K; with five such
+// workgroups per CU the matrix pipe still idles 17 % of the time (rocprofv3
+// SQ_VALU_MFMA_BUSY_CYCLES) although neither LDS nor HBM is saturated: the waves of a
+// workgroup sit on four different SIMDs, progress at the pace of whatever shares those
+// SIMDs, and wait for the slowest at every barrier.  Here a wave owns the whole 64 x 64
+// tile (sixteen 16 x 16 accumulators = 128 registers) and streams its operands straight
+// from L1 / L2 into the MFMA operand layout:
+//   * lane (lr, lk) loads rows {2 lr, 2 lr + 1} (+ 32) of column k + lk of the A panel with
+//     ONE 16-byte load (rows of a packed panel are contiguous): the two doubles are the
+//     lane's entries of two different 16 x 4 operand fragments.  The tile's rows are
+//     thereby permuted over the fragments (fragment a, lane row t <-> tile row
+//     32 (a >> 1) + 2 t + (a & 1)); the epilogue applies the same permutation, which also
+//     turns the read-modify-write of C into 16-byte accesses;
+//   * 4 loads feed 16 MFMAs (1024 matrix-pipe cycles): operand traffic per flop as
+//     k_update2 (64 + 64 rows per 64 x 64 tile), no ds_write / ds_read / s_barrier at all;
+//   * DEPTH operand sets are in flight (3: the loads of a k-step are issued three steps,
+//     i.e. >= 3000 cycles, before their MFMAs), two waves per SIMD cover the rest.
+// Edge tiles (EDGE: a partial tile, or K not a multiple of 4) use 8-byte loads with
+// clamped rows and a masked last k-step.
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
+template <int DEPTH, bool EDGE>
+__device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB)
+{
+    const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4 ;
+    const int row0 = I * 64, col0 = J * 64 ;
+    const int mrem = G.m - row0, nrem = G.n - col0 ;
+    const i64 lda = G.lda ;
+    const int K = G.k ;
+    // operand pointers of this lane: element (row pair, column lk) of the A and B row blocks
+    const double *pa [2], *pb [2] ;
+    int ra [2][2], rb [2][2] ;          // (EDGE) clamped rows of the pair
+#pragma unroll
+    for (int q = 0 ; q < 2 ; q++)
+    {
+        ra [q][0] = 32 * q + 2 * lr ; ra [q][1] = ra [q][0] + 1 ;
+        rb [q][0] = 32 * q + 2 * lr ; rb [q][1] = rb [q][0] + 1 ;
+        if constexpr (EDGE)
+        {
+#pragma unroll
+            for (int h = 0 ; h < 2 ; h++)
+            {
+                if (ra [q][h] > mrem - 1) ra [q][h] = mrem - 1 ;
+                if (rb [q][h] > nrem - 1) rb [q][h] = nrem - 1 ;
+            }
+        }
+        pa [q] = Lx + G.a_off + row0 + (i64) lk * lda ;
+        pb [q] = Lx + G.b_off + col0 + (i64) lk * lda ;
+    }
+    struct Frag { double a [4], b [4] ; } ;     // a [2 q + h] = A (row pair q, member h), likewise b
+    auto load = [&] (Frag &F, int kk)
+    {
+        const i64 ko = (i64) kk * lda ;
+#pragma unroll
+        for (int q = 0 ; q < 2 ; q++)
+        {
+            if constexpr (EDGE)
+            {
+                // (the last step of a K that is no multiple of 4: columns past K read column K - 1 and count as zero)
+                const i64 kc = (kk + lk < K) ? ko : ko - (i64) (kk + lk - (K - 1)) * lda ;
+                const bool live = kk + lk < K ;
+                double a0 = pa [q][kc + ra [q][0]], a1 = pa [q][kc + ra [q][1]] ;
+                double b0 = pb [q][kc + rb [q][0]], b1 = pb [q][kc + rb [q][1]] ;
+                F.a [2 * q] = live ? a0 : 0.0 ; F.a [2 * q + 1] = live ? a1 : 0.0 ;
+                F.b [2 * q] = live ? b0 : 0.0 ; F.b [2 * q + 1] = live ? b1 : 0.0 ;
+            }
+            else
+            {
+                d2u va = *(const d2u *) (pa [q] + ko + ra [q][0]) ;
+                d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ;
+                F.a [2 * q] = va.x ; F.a [2 * q + 1] = va.y ;
+                F.b [2 * q] = vb.x ; F.b [2 * q + 1] = vb.y ;
+            }
+        }
+    } ;
+    d4 acc [4][4] ;
+#pragma unroll
+    for (int a = 0 ; a < 4 ; a++)
+#pragma unroll
+        for (int b = 0 ; b < 4 ; b++) acc [a][b] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    auto compute = [&] (const Frag &F)
+    {
+#pragma unroll
+        for (int a = 0 ; a < 4 ; a++)
+#pragma unroll
+            for (int b = 0 ; b < 4 ; b++)
+                acc [a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64 (F.b [b], F.a [a], acc [a][b], 0, 0, 0) ;
+    } ;
+    // Operand set d holds k-step s + d at the top of an iteration; the set consumed last is
+    // reloaded FIRST in the next iteration, every other set right after its MFMAs: the most
+    // recent load at the loop edge is one whole k-step (>= 1024 matrix-pipe cycles) old, so
+    // the conservative wait hipcc places at a loop header costs nothing.
+    const int nsteps = (K + 3) >> 2 ;
+    Frag f [DEPTH] ;
+#pragma unroll
+    for (int d = 0 ; d < DEPTH - 1 ; d++) if (d < nsteps) load (f [d], 4 * d) ;
+    // (nothing in flight at the loop header: hipcc merges the states of the two edges into
+    // it and would otherwise wait for all but one load at the top of EVERY iteration; with
+    // this the waits inside the loop are the exact counts)
+    __builtin_amdgcn_s_waitcnt (0x0F70) ;       // vmcnt(0)
+    int s = 0 ;
+    for ( ; s + 2 * DEPTH - 1 <= nsteps ; s += DEPTH)
+    {
+        load (f [DEPTH - 1], 4 * (s + DEPTH - 1)) ;
+#pragma unroll
+        for (int d = 0 ; d < DEPTH ; d++)
+        {
+            compute (f [d]) ;
+            if (d < DEPTH - 1) load (f [d], 4 * (s + DEPTH + d)) ;
+        }
+    }
+    for ( ; s < nsteps ; s += DEPTH)
+    {
+        if (s + DEPTH - 1 < nsteps) load (f [DEPTH - 1], 4 * (s + DEPTH - 1)) ;
+#pragma unroll
+        for (int d = 0 ; d < DEPTH ; d++)
+        {
+            if (s + d < nsteps) compute (f [d]) ;
+            if (d < DEPTH - 1 && s + DEPTH + d < nsteps) load (f [d], 4 * (s + DEPTH + d)) ;
+        }
+    }
+    // epilogue: acc [a][b][r] of lane (lr, lk) is C (row 32 (a >> 1) + 2 lr + (a & 1),
+    // column 32 (b >> 1) + 2 (lk + 4 r) + (b & 1))
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    const bool diag = G.tri && I == J ;
+#pragma unroll
+    for (int b = 0 ; b < 4 ; b++)
+#pragma unroll
+        for (int r = 0 ; r < 4 ; r++)
+        {
+            const int j = 32 * (b >> 1) + 2 * (lk + 4 * r) + (b & 1) ;
+            double *Cj = C + (i64) j * G.ldc ;
+#pragma unroll
+            for (int q = 0 ; q < 2 ; q++)
+            {
+                const int i = 32 * q + 2 * lr ;
+                if constexpr (EDGE)
+                {
+#pragma unroll
+                    for (int h = 0 ; h < 2 ; h++)
+                        if (i + h < mrem && j < nrem && (!diag || i + h >= j))
+                        {
+                            if (G.assign) Cj [i + h] = -acc [2 * q + h][b][r] ;
+                            else Cj [i + h] -= acc [2 * q + h][b][r] ;
+                        }
+                }
+                else if (!diag || i + 1 >= j)
+                {
+                    d2u v ;
+                    if (G.assign) { v.x = -acc [2 * q][b][r] ; v.y = -acc [2 * q + 1][b][r] ; }
+                    else
+                    {
+                        v = *(const d2u *) (Cj + i) ;
+                        v.x -= acc [2 * q][b][r] ; v.y -= acc [2 * q + 1][b][r] ;
+                    }
+                    if (diag && i < j) Cj [i + 1] = v.y ;           // (the pair straddles the diagonal)
+                    else *(d2u *) (Cj + i) = v ;
+                }
+            }
+        }
+}
+
+template <int DEPTH>
+__global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
+{
+    int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
+    GemmGroup G = g [gi] ;
+    int I, J ;
+    if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
+    if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
+    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64 && (G.k & 3) == 0) update_tile_w<DEPTH, false> (G, I, J, Lx, CB) ;
+    else update_tile_w<DEPTH, true> (G, I, J, Lx, CB) ;
+}
+
 // ---- trailing update that also factors the next diagonal block ------------------
 // The narrow (K < 512) updates of the panel chain are followed, on the same stream, by
 // the dpotrf of the block they have just finished updating: tile (0,0) of their region.

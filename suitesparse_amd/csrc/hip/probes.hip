@@ -71,7 +71,13 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
     auto launch = [&] ()
     {
-        if (flags & 1)      // the first-generation VALU kernel (cross-check)
+        if (flags & 8192)       // third generation: one wave per tile, no LDS (operand sets in flight: 3 / 2 / 4)
+            hipLaunchKernelGGL ((k_update3<3>), dim3 (grid), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else if (flags & 16384)
+            hipLaunchKernelGGL ((k_update3<2>), dim3 (grid), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else if (flags & 32768)
+            hipLaunchKernelGGL ((k_update3<4>), dim3 (grid), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else if (flags & 1)      // the first-generation VALU kernel (cross-check)
             hipLaunchKernelGGL ((k_update<SMALL, SMALL, BKK, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (small && (flags & 256))
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, 32, 2, false>), dim3 (grid), dim3 (256), 0, 0, dg, 1, d, d) ;
@@ -373,6 +379,60 @@ double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, 
     return (double) blocks * 4.0 * (4.0 * nacc * (double) iters) * 2048.0 / (ms * 1e-3) ;
 }
 
+
+/* Tuning probe: the update kernel selected by `flags` (as cholmod_hip_bench_update_kernel)
+ * against k_update2<64,64,16,2,false> on the same random operands, triangular region or not,
+ * assign mode or not: returns max |difference| / max |reference| over the target region
+ * (negative = a CHOLMOD_HIP_* code). */
+double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, int assign, int flags)
+{
+    if (m <= 0 || n <= 0 || k <= 0 || (tri && m < n)) return CHOLMOD_HIP_INVALID ;
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    i64 ld = std::max (m, n) + 3 ;
+    i64 a_off = 1, b_off = 1 + ld * k, c_off = 2 + 2 * ld * k ;      // (odd offsets: 8-byte alignment only)
+    i64 total = c_off + (m + 5) * n ;
+    std::vector<double> h (total), r0 (total), r1 (total) ;
+    unsigned long long sdd = 88172645463325252ull ;
+    for (i64 q = 0 ; q < total ; q++)
+    {
+        sdd ^= sdd << 13 ; sdd ^= sdd >> 7 ; sdd ^= sdd << 17 ;
+        h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
+    }
+    double *d = nullptr ; GemmGroup *dg = nullptr ;
+    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    HIPCHK (hipMalloc ((void **) &dg, sizeof (GemmGroup))) ;
+    GemmGroup G ;
+    memset (&G, 0, sizeof (G)) ;
+    G.a_off = a_off ; G.b_off = tri ? a_off : b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) (m + 5) ;
+    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = tri ? 1 : 0 ; G.assign = assign ? 1 : 0 ;
+    G.tile_mul = 1 ; G.tile_add = 0 ;
+    G.mt = (i32) ((m + 63) / 64) ; G.nt = (i32) ((n + 63) / 64) ;
+    G.ntiles = tri ? G.nt * (G.nt + 1) / 2 + (G.mt - G.nt) * G.nt : G.mt * G.nt ;
+    G.nblk = (G.ntiles + 63) / 64 * 64 ;
+    G.swz = G.nblk >= 1024 ;
+    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+    for (int pass = 0 ; pass < 2 ; pass++)
+    {
+        HIPCHK (hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice)) ;
+        if (pass == 0) hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (G.nblk), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if (flags & 16384) hipLaunchKernelGGL ((k_update3<2>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else if (flags & 32768) hipLaunchKernelGGL ((k_update3<4>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else hipLaunchKernelGGL ((k_update3<3>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
+        HIPCHK (hipDeviceSynchronize ()) ;
+        HIPCHK (hipMemcpy ((pass ? r1 : r0).data (), d, total * sizeof (double), hipMemcpyDeviceToHost)) ;
+    }
+    (void) hipFree (d) ; (void) hipFree (dg) ;
+    double mx = 0, df = 0 ;
+    bool touched = false ;
+    for (i64 q = 0 ; q < total ; q++)
+    {
+        mx = std::max (mx, fabs (r0 [q])) ;
+        df = std::max (df, fabs (r0 [q] - r1 [q])) ;
+        if (r0 [q] != h [q]) touched = true ;
+    }
+    if (!touched) return CHOLMOD_HIP_GPU_PROBLEM ;
+    return df / mx ;
+}
 
 
 } // extern "C"
