@@ -239,6 +239,7 @@ typedef struct cholmod_factor_struct
     uint64_t hip_apat_hash ;
     size_t hip_apat_nnz ;
     int hip_apat_valid ;
+    uint64_t hip_apat_hash2 ;   /* second, independent fingerprint of the same pattern */
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

@@ -102,7 +102,7 @@ class Factor(C.Structure):
                 ("dtype", C.c_int), ("useGPU", C.c_int),
                 ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
                 ("cx_twin", C.c_void_p), ("hip_apat_hash", C.c_uint64), ("hip_apat_nnz", C.c_size_t),
-                ("hip_apat_valid", C.c_int)]
+                ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare

@@ -338,7 +338,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // four-wave k_update2, 58 against 49 at K = 512; measured, tools/upd3.py) when it has enough
     // tiles to put two waves on every SIMD; below that the four waves per tile of k_update2
     // fill the chip better.  CHOLMOD_HIP_UPD3_MIN_TILES overrides (0 = never).
-    static const i64 w_min_tiles = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; return e ? (i64) atoll (e) : (i64) 2048 ; } () ;
+    // (read at every plan build: tests change it between plans)
+    const i64 w_min_tiles = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; return e ? (i64) atoll (e) : (i64) 2048 ; } () ;
     auto region_tiles = [] (const GemmGroup &G) -> i64
     {
         i64 mt = (G.m + SMALL - 1) / SMALL, nt = (G.n + SMALL - 1) / SMALL ;

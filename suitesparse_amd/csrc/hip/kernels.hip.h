@@ -141,6 +141,11 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
         while (lo < hi) { int mid = (lo + hi) >> 1 ; if (rows [mid] < i) lo = mid + 1 ; else hi = mid ; }
         if (lo < nsrow && rows [lo] == i)
         {
+            // (a valid cholmod_sparse holds no duplicate entries, Check/cholmod_check.c; if a
+            // sorted column carries some all the same, the LAST one wins here as in the
+            // reference's assignment loop, and only that one enters the map, so the mapped
+            // scatter of later factorizations -- one thread per entry -- has a single writer)
+            if (p + 1 < pend && Si [p + 1] == i) continue ;
             col [lo] = Sx [p] ;
             // remember where this entry of S lives in Lx: later factorizations of the same
             // resident S stream through the map instead of searching (k_assemble_mapped)
@@ -1600,8 +1605,8 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 //     k_update2 (64 + 64 rows per 64 x 64 tile), no ds_write / ds_read / s_barrier at all;
 //   * DEPTH operand sets are in flight (3: the loads of a k-step are issued three steps,
 //     i.e. >= 3000 cycles, before their MFMAs), two waves per SIMD cover the rest.
-// Edge tiles (EDGE: a partial tile, or K not a multiple of 4) use 8-byte loads with
-// clamped rows and a masked last k-step.
+// Partial tiles (EDGE) use 8-byte loads with clamped rows; a K that is no multiple of 4 ends
+// with one masked k-step in either path.
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
 template <int DEPTH, bool EDGE>
 __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB)
@@ -1632,6 +1637,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         pb [q] = Lx + G.b_off + col0 + (i64) lk * lda ;
     }
     struct Frag { double a [4], b [4] ; } ;     // a [2 q + h] = A (row pair q, member h), likewise b
+    // a full k-step (columns kk .. kk + 3 all below K)
     auto load = [&] (Frag &F, int kk)
     {
         const i64 ko = (i64) kk * lda ;
@@ -1640,13 +1646,8 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         {
             if constexpr (EDGE)
             {
-                // (the last step of a K that is no multiple of 4: columns past K read column K - 1 and count as zero)
-                const i64 kc = (kk + lk < K) ? ko : ko - (i64) (kk + lk - (K - 1)) * lda ;
-                const bool live = kk + lk < K ;
-                double a0 = pa [q][kc + ra [q][0]], a1 = pa [q][kc + ra [q][1]] ;
-                double b0 = pb [q][kc + rb [q][0]], b1 = pb [q][kc + rb [q][1]] ;
-                F.a [2 * q] = live ? a0 : 0.0 ; F.a [2 * q + 1] = live ? a1 : 0.0 ;
-                F.b [2 * q] = live ? b0 : 0.0 ; F.b [2 * q + 1] = live ? b1 : 0.0 ;
+                F.a [2 * q] = pa [q][ko + ra [q][0]] ; F.a [2 * q + 1] = pa [q][ko + ra [q][1]] ;
+                F.b [2 * q] = pb [q][ko + rb [q][0]] ; F.b [2 * q + 1] = pb [q][ko + rb [q][1]] ;
             }
             else
             {
@@ -1655,6 +1656,31 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
                 F.a [2 * q] = va.x ; F.a [2 * q + 1] = va.y ;
                 F.b [2 * q] = vb.x ; F.b [2 * q + 1] = vb.y ;
             }
+        }
+    } ;
+    // the last step of a K that is no multiple of 4: lanes whose column kk + lk lies past K read
+    // column K - 1 instead and contribute zero
+    auto load_tail = [&] (Frag &F, int kk)
+    {
+        const bool live = kk + lk < K ;
+        const i64 ko = (i64) kk * lda - (live ? 0 : (i64) (kk + lk - (K - 1)) * lda) ;
+#pragma unroll
+        for (int q = 0 ; q < 2 ; q++)
+        {
+            double a0, a1, b0, b1 ;
+            if constexpr (EDGE)
+            {
+                a0 = pa [q][ko + ra [q][0]] ; a1 = pa [q][ko + ra [q][1]] ;
+                b0 = pb [q][ko + rb [q][0]] ; b1 = pb [q][ko + rb [q][1]] ;
+            }
+            else
+            {
+                d2u va = *(const d2u *) (pa [q] + ko + ra [q][0]) ;
+                d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ;
+                a0 = va.x ; a1 = va.y ; b0 = vb.x ; b1 = vb.y ;
+            }
+            F.a [2 * q] = live ? a0 : 0.0 ; F.a [2 * q + 1] = live ? a1 : 0.0 ;
+            F.b [2 * q] = live ? b0 : 0.0 ; F.b [2 * q + 1] = live ? b1 : 0.0 ;
         }
     } ;
     d4 acc [4][4] ;
@@ -1674,16 +1700,17 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
     // reloaded FIRST in the next iteration, every other set right after its MFMAs: the most
     // recent load at the loop edge is one whole k-step (>= 1024 matrix-pipe cycles) old, so
     // the conservative wait hipcc places at a loop header costs nothing.
-    const int nsteps = (K + 3) >> 2 ;
+    const int nfull = K >> 2, nsteps = (K + 3) >> 2 ;      // (a partial last step: nsteps == nfull + 1)
+    auto load_any = [&] (Frag &F, int step) { if (step < nfull) load (F, 4 * step) ; else load_tail (F, 4 * step) ; } ;
     Frag f [DEPTH] ;
 #pragma unroll
-    for (int d = 0 ; d < DEPTH - 1 ; d++) if (d < nsteps) load (f [d], 4 * d) ;
+    for (int d = 0 ; d < DEPTH - 1 ; d++) if (d < nsteps) load_any (f [d], d) ;
     // (nothing in flight at the loop header: hipcc merges the states of the two edges into
     // it and would otherwise wait for all but one load at the top of EVERY iteration; with
     // this the waits inside the loop are the exact counts)
     __builtin_amdgcn_s_waitcnt (0x0F70) ;       // vmcnt(0)
     int s = 0 ;
-    for ( ; s + 2 * DEPTH - 1 <= nsteps ; s += DEPTH)
+    for ( ; s + 2 * DEPTH - 1 <= nfull ; s += DEPTH)
     {
         load (f [DEPTH - 1], 4 * (s + DEPTH - 1)) ;
 #pragma unroll
@@ -1695,12 +1722,12 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
     }
     for ( ; s < nsteps ; s += DEPTH)
     {
-        if (s + DEPTH - 1 < nsteps) load (f [DEPTH - 1], 4 * (s + DEPTH - 1)) ;
+        if (s + DEPTH - 1 < nsteps) load_any (f [DEPTH - 1], s + DEPTH - 1) ;
 #pragma unroll
         for (int d = 0 ; d < DEPTH ; d++)
         {
             if (s + d < nsteps) compute (f [d]) ;
-            if (d < DEPTH - 1 && s + DEPTH + d < nsteps) load (f [d], 4 * (s + DEPTH + d)) ;
+            if (d < DEPTH - 1 && s + DEPTH + d < nsteps) load_any (f [d], s + DEPTH + d) ;
         }
     }
     // epilogue: acc [a][b][r] of lane (lr, lk) is C (row 32 (a >> 1) + 2 lr + (a & 1),
@@ -1752,7 +1779,7 @@ __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, 
     int I, J ;
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
-    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64 && (G.k & 3) == 0) update_tile_w<DEPTH, false> (G, I, J, Lx, CB) ;
+    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false> (G, I, J, Lx, CB) ;
     else update_tile_w<DEPTH, true> (G, I, J, Lx, CB) ;
 }
 
@@ -1832,7 +1859,7 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     double *Ls = tu_lds ;                           // [64][64]  -L11 k-major; later the next diagonal block
     double *Wd = Ls + 64 * 64 ;                     // [4][16][16] inverses of the 16 x 16 diagonal blocks
     double *X0s = Wd + 4 * 256 ;                    // [64][TU_LDX]  -X_0 k-major
-    __shared__ int s_fail ;
+    __shared__ int s_fail, s_last ;
     __builtin_amdgcn_s_setprio (3) ;
     const int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
     const TrGroup G = g [gi] ;
@@ -1885,30 +1912,21 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     __syncthreads () ;
     auto tick = [] (int) {} ;
     trsm_diag_inverses (Ls, ldl, Wd, 4, lane, wave, tick) ;
-    // The solve is in place: workgroup 0 overwrites the rows of the next diagonal block
-    // that every other workgroup of the group reads (b0).  A write-after-read hazard,
-    // no data passes through memory: the others count themselves in once their loads
-    // have arrived, workgroup 0 stores only when all are in.  (Blocks are dispatched in
-    // order and only workgroup 0 ever waits, for workgroups right behind it: no
-    // deadlock; the wait is bounded all the same.)
+    // The solve is in place, and the rows of the next diagonal block (the first 64 rows below
+    // the panel, B0) are read by EVERY workgroup of the group (b0) before they are solved: a
+    // write-after-read hazard on those 64 rows, no data passes through memory.  Every
+    // workgroup computes the solved X_0 anyway, so the store of X_0 is left to whichever
+    // workgroup is the LAST to have its loads in: each counts itself in (one relaxed atomic)
+    // once its loads have arrived, and the one that draws nwg - 1 knows that nobody will read
+    // the old rows any more.  Nobody waits, nothing depends on the order in which the
+    // dispatcher starts workgroups (round 2 had workgroup 0 spin on the counter, bounded, and
+    // store regardless on time-out).
     const int nwg = (G.m + TRM_ROWS - 1) / TRM_ROWS ;
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
     __syncthreads () ;
-    if (tid == 0 && nwg > 1)
-    {
-        if (blk != 0) (void) __hip_atomic_fetch_add (cnt + gi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
-        else
-        {
-            for (int it = 0 ; it < (1 << 22) ; it++)
-            {
-                if (__hip_atomic_load (cnt + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg - 1) break ;
-                __builtin_amdgcn_s_sleep (4) ;
-            }
-        }
-    }
-    if (blk == 0) __syncthreads () ;
+    if (tid == 0) s_last = (nwg == 1 || __hip_atomic_fetch_add (cnt + gi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) ? 1 : 0 ;
     d4 xr [4], x0 [4] ;
-    trsm_solve_rows (bj, 4, Ls, ldl, Wd, lane, nvalid, rok, 64, B, lda, tick, xr) ;
+    trsm_solve_rows (bj, 4, Ls, ldl, Wd, lane, nvalid, rok && blk != 0, 64, B, lda, tick, xr) ;
     if (blk == 0)
     {
 #pragma unroll
@@ -1922,7 +1940,15 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
 #pragma unroll
         for (int r = 0 ; r < 4 ; r++)
             X0s [(16 * jj + lk + 4 * r) * TU_LDX + wave * 16 + lr] = -x0 [jj][r] ;
-    __syncthreads () ;                      // (also: every wave is done with Ls and Wd)
+    __syncthreads () ;                      // (also: every wave is done with Ls and Wd; s_last is visible)
+    if (s_last)
+    {
+        // the solved rows of the next diagonal block, by the last workgroup to have read the old ones
+#pragma unroll
+        for (int jj = 0 ; jj < 4 ; jj++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++) B0 [(i64) (16 * jj + lk + 4 * r) * lda] = x0 [jj][r] ;
+    }
     // C (row, 16 jt + lk + 4 r) -= sum_k X (row, k) X_0 (16 jt + .., k)
 #pragma unroll
     for (int i = 0 ; i < 4 ; i++)

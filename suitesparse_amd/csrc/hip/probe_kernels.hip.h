@@ -704,4 +704,15 @@ __global__ void __launch_bounds__(256) k_mfma_ceiling (double *out, long long *s
 }
 
 
+// full-mantissa pseudo-random fill in [-0.5, 0.5) (splitmix64 of the index)
+__global__ void __launch_bounds__(256) k_fill_random (double *x, i64 n)
+{
+    for (i64 e = blockIdx.x * (i64) 256 + threadIdx.x ; e < n ; e += (i64) gridDim.x * 256)
+    {
+        unsigned long long z = (unsigned long long) e * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull ;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull ; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull ; z ^= z >> 31 ;
+        x [e] = (double) (z >> 11) * 0x1p-53 - 0.5 ;
+    }
+}
+
 } // namespace sship

@@ -38,29 +38,39 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     if (m <= 0 || n <= 0 || k <= 0 || iters <= 0) return CHOLMOD_HIP_INVALID ;
     if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
     // A: m x k, B: n x k (both ld = max(m,n)), C: m x n, all in one "Lx" buffer
-    i64 ld = std::max (m, n) ;
-    i64 a_off = 0, b_off = ld * k, c_off = 2 * ld * k ;
-    i64 total = c_off + m * n ;
+    // flag 131072: the layout of a real front -- an odd leading dimension and operand offsets that are
+    // only 8-byte aligned (packed supernodes start anywhere, nsrow is any number)
+    const bool odd = (flags & 131072) != 0 ;
+    i64 ld = std::max (m, n) + (odd ? 1 + (std::max (m, n) & 1 ? 0 : 0) + ((std::max (m, n) + 1) % 2 == 0 ? 1 : 0) : 0) ;
+    i64 a_off = odd ? 1 : 0, b_off = a_off + ld * k + (odd ? 2 : 0), c_off = b_off + ld * k + (odd ? 1 : 0) ;
+    i64 total = c_off + (m + 3) * n ;
     double *d = nullptr ;
-    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    std::vector<double> h (total) ;
-    unsigned long long sdd = 88172645463325252ull ;
-    for (i64 q = 0 ; q < total ; q++)
-    {
-        sdd ^= sdd << 13 ; sdd ^= sdd >> 7 ; sdd ^= sdd << 17 ;
-        h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
-    }
-    (void) hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice) ;
+    // CHOLMOD_PROBE_OFFSET_GB=g: the operands sit g GB into ONE allocation of g GB + their own size (as the
+    // top fronts of a big factor sit deep inside the one Lx allocation): does the rate depend on it?
+    i64 skip = 0 ;
+    if (const char *e = getenv ("CHOLMOD_PROBE_OFFSET_GB")) skip = (i64) (atof (e) * 1e9 / 8.0) ;
+    if (hipMalloc ((void **) &d, (total + skip) * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    double *d_base = d ;
+    d += skip ;
+    // operands filled on the device (full-mantissa pseudo-random values in [-0.5, 0.5)): regions of
+    // the size of the factorization's top fronts (tens of GB) would take minutes through the host
+    hipLaunchKernelGGL (k_fill_random, dim3 (4096), dim3 (256), 0, 0, d, total) ;
+    if (hipDeviceSynchronize () != hipSuccess) { (void) hipFree (d_base) ; return CHOLMOD_HIP_GPU_PROBLEM ; }
     bool small = (flags & CHOLMOD_HIP_TILE128) == 0 ;
     int T = small ? SMALL : BIG ;
     GemmGroup G ;
     memset (&G, 0, sizeof (G)) ;
-    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) m ;
-    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
+    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) (m + (odd ? 3 : 0)) ;
+    G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = (flags & 65536) ? 1 : 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
+    if (G.tri) { G.b_off = a_off ; if (m < n) { (void) hipFree (d_base) ; return CHOLMOD_HIP_INVALID ; } }    // a syrk-shaped region: B = A, only tiles on / below the diagonal
     int TM = T, TN = T ;
     if (flags & 2048) { TM = 128 ; TN = 64 ; }      // experimental rectangular tiles (non-tri only)
     if (flags & 4096) { TM = 64 ; TN = 128 ; }
-    G.ntiles = (i32) (((m + TM - 1) / TM) * ((n + TN - 1) / TN)) ; G.nblk = (G.ntiles + 63) / 64 * 64 ;
+    {
+        i64 mt_ = (m + TM - 1) / TM, nt_ = (n + TN - 1) / TN ;
+        G.ntiles = (i32) (G.tri ? nt_ * (nt_ + 1) / 2 + (mt_ - nt_) * nt_ : mt_ * nt_) ;
+        G.nblk = (G.ntiles + 63) / 64 * 64 ;
+    }
     G.swz = (flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) ? 0 : 1 ;
     G.mt = (i32) ((m + TM - 1) / TM) ; G.nt = (i32) ((n + TN - 1) / TN) ;
     GemmGroup *dg = nullptr ;
@@ -103,10 +113,11 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     float ms = 0 ;
     (void) hipEventElapsedTime (&ms, e0, e1) ;
     hipError_t err = hipGetLastError () ;
-    (void) hipFree (d) ; (void) hipFree (dg) ;
+    (void) hipFree (d_base) ; (void) hipFree (dg) ;
     (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
     if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-    return 2.0 * (double) m * n * k * iters / (ms * 1e-3) ;
+    double entries = G.tri ? (double) n * (n + 1) / 2 + (double) (m - n) * n : (double) m * n ;
+    return 2.0 * entries * k * iters / (ms * 1e-3) ;
 }
 
 /* mixed MFMA+VALU issue test: returns seconds; flops are computed by the caller */

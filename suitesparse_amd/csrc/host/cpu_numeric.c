@@ -16,6 +16,7 @@
  * Product code: nothing here uses oracle/ (which is test infrastructure). */
 #include "host_internal.h"
 #include <dlfcn.h>
+#include <pthread.h>
 #include <time.h>
 
 /* ---- dense kernels --------------------------------------------------------------- */
@@ -52,15 +53,39 @@ static int try_blas (const char *path, const char *prefix)
     dtrsm_fn t = (dtrsm_fn) sym2 (h, prefix, "dtrsm_") ;
     dpotrf_fn p = (dpotrf_fn) sym2 (h, prefix, "dpotrf_") ;
     if (!g || !s || !t || !p) { dlclose (h) ; return 0 ; }
-    g_blas.handle = h ; g_blas.gemm = g ; g_blas.syrk = s ; g_blas.trsm = t ; g_blas.potrf = p ;
+    /* self-check before trusting it: the arguments below are 32-bit ints (LP64 interface); an
+     * ILP64 build found under the same soname would read garbage sizes.  3 x 3 dpotrf and a
+     * 3 x 2 dgemm with known answers. */
+    {
+        double M [9] = {4, 2, 2,  0, 5, 3,  0, 0, 6} ;          /* lower triangle, column-major */
+        int n3 = 3, info = -1 ;
+        p ("L", &n3, M, &n3, &info) ;
+        double Aa [6] = {1, 2, 3,  4, 5, 6}, Bb [4] = {1, 0,  0, 1}, Cc [6] = {0, 0, 0, 0, 0, 0} ;
+        int m3 = 3, n2 = 2, k2 = 2 ;
+        double one = 1.0, zero = 0.0 ;
+        g ("N", "N", &m3, &n2, &k2, &one, Aa, &m3, Bb, &k2, &zero, Cc, &m3) ;
+        int okp = (info == 0 && fabs (M [0] - 2.0) < 1e-14 && fabs (M [1] - 1.0) < 1e-14 && fabs (M [4] - 2.0) < 1e-14
+            && fabs (M [5] - 1.0) < 1e-14 && fabs (M [8] - 2.0) < 1e-14) ;
+        int okg = 1 ;
+        for (int q = 0 ; q < 6 ; q++) if (Cc [q] != Aa [q]) okg = 0 ;
+        if (!okp || !okg)
+        {
+            fprintf (stderr, "cholmod (CPU path): %s fails the LP64 self-check (an ILP64 build?): not used\n", path) ;
+            dlclose (h) ;
+            return 0 ;
+        }
+    }
+    g_blas.gemm = g ; g_blas.syrk = s ; g_blas.trsm = t ; g_blas.potrf = p ;
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;
+    g_blas.handle = h ;         /* (last: everything above is in place when a reader sees the handle) */
     return 1 ;
 }
 
 /* CHOLMOD_BLAS_LIBRARY = path[:symbol-prefix] ; "none" forces the built-in kernels */
-static void bind_blas_once (void)
+/* (bound exactly once per process, whatever the number of threads that enter the CPU path
+ * at the same time with their own Common: pthread_once publishes the finished binding) */
+static void bind_blas_impl (void)
 {
-    if (g_blas.tried) return ;
     g_blas.tried = 1 ;
     const char *e = getenv ("CHOLMOD_BLAS_LIBRARY") ;
     if (e && e [0])
@@ -81,6 +106,9 @@ static void bind_blas_once (void)
         if (try_blas (names [q], "")) return ;
     }
 }
+
+static pthread_once_t g_blas_once = PTHREAD_ONCE_INIT ;
+static void bind_blas_once (void) { (void) pthread_once (&g_blas_once, bind_blas_impl) ; }
 
 const char *ssamd_cpu_blas_name (void)
 {

@@ -58,5 +58,6 @@ cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common) ;
 int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common) ;
 void ssamd_cpu_super_solve (int which, const cholmod_factor *L, double *X, Int nrhs, Int ldx) ;
 const char *ssamd_cpu_blas_name (void) ;
+int ssamd_factor_has_cholesky_sizes (const cholmod_factor *L) ;
 
 #endif

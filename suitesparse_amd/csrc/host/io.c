@@ -241,14 +241,21 @@ double cholmod_l_norm_dense (cholmod_dense *X, int norm, cholmod_common *Common)
     RETURN_IF_NULL (X, EMPTY) ;
     if (norm < 0 || norm > 2 || (norm == 2 && X->ncol > 1)) { ERROR (CHOLMOD_INVALID, "invalid norm") ; return EMPTY ; }
     Common->status = CHOLMOD_OK ;
-    const double *x = X->x ;
+    /* |x| of an entry in each of the three numeric layouts (reference: abs_value,
+     * CHOLMOD/MatrixOps/cholmod_norm.c:34-60): real, complex (interleaved), zomplex (x and z) */
+    if (X->xtype < CHOLMOD_REAL || X->xtype > CHOLMOD_ZOMPLEX || !X->x || (X->xtype == CHOLMOD_ZOMPLEX && !X->z))
+    { ERROR (CHOLMOD_INVALID, "invalid xtype") ; return EMPTY ; }
+    const double *x = X->x, *z = X->z ;
+    const int xt = X->xtype ;
+#define ABS_AT(p_) (xt == CHOLMOD_REAL ? fabs (x [p_]) : xt == CHOLMOD_COMPLEX ? hypot (x [2 * (p_)], x [2 * (p_) + 1]) \
+    : hypot (x [p_], z [p_]))
     double res = 0 ;
     if (norm == 0)
     {
         for (size_t i = 0 ; i < X->nrow ; i++)
         {
             double s = 0 ;
-            for (size_t j = 0 ; j < X->ncol ; j++) s += fabs (x [i + j * X->d]) ;
+            for (size_t j = 0 ; j < X->ncol ; j++) s += ABS_AT (i + j * X->d) ;
             if (s > res || s != s) res = s ;
         }
     }
@@ -257,15 +264,22 @@ double cholmod_l_norm_dense (cholmod_dense *X, int norm, cholmod_common *Common)
         for (size_t j = 0 ; j < X->ncol ; j++)
         {
             double s = 0 ;
-            for (size_t i = 0 ; i < X->nrow ; i++) s += fabs (x [i + j * X->d]) ;
+            for (size_t i = 0 ; i < X->nrow ; i++) s += ABS_AT (i + j * X->d) ;
             if (s > res || s != s) res = s ;
         }
     }
     else
     {
-        for (size_t i = 0 ; i < X->nrow ; i++) res += x [i] * x [i] ;
+        /* (cholmod_norm.c:171-204: sum of x^2 (+ z^2) over the column, then the root) */
+        for (size_t i = 0 ; i < X->nrow ; i++)
+        {
+            if (xt == CHOLMOD_REAL) res += x [i] * x [i] ;
+            else if (xt == CHOLMOD_COMPLEX) res += x [2 * i] * x [2 * i] + x [2 * i + 1] * x [2 * i + 1] ;
+            else res += x [i] * x [i] + z [i] * z [i] ;
+        }
         res = sqrt (res) ;
     }
+#undef ABS_AT
     return res ;
 }
 

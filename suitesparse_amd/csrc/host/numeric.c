@@ -85,8 +85,21 @@ static int map_hip_status (int rc, cholmod_common *Common, const char *what)
     }
 }
 
+/* A factor analysed with CHOLMOD_ANALYZE_FOR_SPQR carries the row structure only:
+ * px [0] = 123456, the other px zero, xsize = 1 (cholmod_super_symbolic.c:662-663, :749-771).
+ * Nothing numeric may be built on it. */
+int ssamd_factor_has_cholesky_sizes (const cholmod_factor *L)
+{
+    if (!L || !L->is_super || !L->px || !L->super || !L->pi) return FALSE ;
+    const Int *px = L->px ;
+    if (L->nsuper > 0 && px [0] == 123456) return FALSE ;
+    return (size_t) px [L->nsuper] <= L->xsize ;
+}
+
 int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
 {
+    if (!ssamd_factor_has_cholesky_sizes (L))
+    { ERROR (CHOLMOD_INVALID, "L was analysed for SPQR (no Cholesky sizes)") ; return FALSE ; }
     if (L->hip_plan) return TRUE ;
     int st = 0 ;
     int world = Common->hip_world > 1 ? Common->hip_world : 1 ;
@@ -111,8 +124,8 @@ static void absorb_stats (cholmod_factor *L, cholmod_common *Common)
     Common->gpuKernelTime = s [0] ;
     Common->gpuFlops = (SuiteSparse_long) s [1] ;
     Common->gpuNumKernelLaunches = (int) s [2] ;
-    Common->cholmod_gpu_syrk_time = s [6] + s [14] + s [27] ;
-    Common->cholmod_gpu_syrk_calls = (size_t) (s [7] + s [26]) ;
+    Common->cholmod_gpu_syrk_time = s [6] + s [14] + s [27] + s [32] ;
+    Common->cholmod_gpu_syrk_calls = (size_t) (s [7] + s [26] + s [33]) ;
     Common->cholmod_gpu_gemm_time = 0 ; Common->cholmod_gpu_gemm_calls = 0 ;
     Common->cholmod_gpu_potrf_time = s [11] ;
     Common->cholmod_gpu_trsm_time = s [12] ;
@@ -173,6 +186,8 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
     if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "unsymmetric (A*F) case not built") ; return FALSE ; }
     if (A->nrow != A->ncol || A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
+    if (!ssamd_factor_has_cholesky_sizes (L))
+    { ERROR (CHOLMOD_INVALID, "L was analysed for SPQR (no Cholesky sizes): it cannot be factorized") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
     double b = beta ? beta [0] : 0.0 ;
     /* complex / zomplex A: the real factorization of the embedded matrix (complex.c) */
@@ -259,27 +274,44 @@ int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_
 
 /* 64-bit hash of a packed pattern (dimensions, stype, p, i): the key under which the
  * engine's value map of a matrix is remembered */
-static uint64_t pattern_hash (cholmod_sparse *A)
+/* Two independent 64-bit fingerprints of the pattern (p and i arrays): the values-only fast
+ * path of cholmod_l_factorize trusts them as proof that the resident S and its value map still
+ * fit A.  Each is a sum of position-keyed, avalanche-mixed words (order-independent, hence
+ * parallel and deterministic); the two use different keys, different mixers (the splitmix64
+ * and murmur3 finalisers) and are folded differently, so a pattern change must defeat 128
+ * bits, not 64 (round-2 review: one 64-bit sum folded by addition was thin). */
+static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
 {
     const Int *Ap = A->p, *Ai = A->i ;
     const Int ncol = (Int) A->ncol, nz = Ap [ncol] ;
     const int nth = ssamd_host_threads () ;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t) A->nrow * 0xff51afd7ed558ccdull) ^ ((uint64_t) (A->stype + 2) << 56) ;
-    uint64_t hp = 0, hi = 0 ;
-    /* position-dependent mixing, order-independent combination: parallel and deterministic */
-#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp)
+    uint64_t hp = 0, hi = 0, gp = 0, gi = 0 ;
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp,gp)
     for (Int j = 0 ; j <= ncol ; j++)
     {
         uint64_t x = (uint64_t) Ap [j] + 0x9E3779B97F4A7C15ull * (uint64_t) (j + 1) ;
         x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
         hp += x ;
+        uint64_t y = ((uint64_t) Ap [j] ^ 0xA24BAED4963EE407ull) * (2 * (uint64_t) j + 0x632BE59BD9B4E019ull) ;
+        y ^= y >> 33 ; y *= 0xff51afd7ed558ccdull ; y ^= y >> 33 ; y *= 0xc4ceb9fe1a85ec53ull ; y ^= y >> 33 ;
+        gp += y ;
     }
-#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hi)
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hi,gi)
     for (Int p = 0 ; p < nz ; p++)
     {
         uint64_t x = (uint64_t) Ai [p] + 0xD1B54A32D192ED03ull * (uint64_t) (p + 1) ;
         x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
         hi += x ;
+        uint64_t y = ((uint64_t) Ai [p] ^ 0x8EBC6AF09C88C6E3ull) * (2 * (uint64_t) p + 0x589965CC75374CC3ull) ;
+        y ^= y >> 33 ; y *= 0xff51afd7ed558ccdull ; y ^= y >> 33 ; y *= 0xc4ceb9fe1a85ec53ull ; y ^= y >> 33 ;
+        gi += y ;
+    }
+    if (second)
+    {
+        uint64_t g = gp ^ ((gi << 23) | (gi >> 41)) ^ ((uint64_t) nz * 0x9FB21C651E98DF25ull) ;
+        g ^= g >> 32 ; g *= 0xd6e8feb86659fd93ull ; g ^= g >> 32 ;
+        *second = g ^ ((uint64_t) ncol << 17) ;
     }
     return h ^ hp ^ (hi * 0x2545F4914F6CDD1Dull) ;
 }
@@ -305,9 +337,10 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
      * host-side permutation, the pattern upload and the assembly search are skipped. */
     const int vmap_ok = (A->xtype == CHOLMOD_REAL && A->packed && L->hip_plan && Common->hip_world <= 1
         && ssamd_resolve_use_gpu (Common) == 1) ;
-    uint64_t hash = vmap_ok ? pattern_hash (A) : 0 ;
+    uint64_t hash2 = 0 ;
+    uint64_t hash = vmap_ok ? pattern_hash (A, &hash2) : 0 ;
     size_t annz = vmap_ok ? (size_t) ((Int *) A->p) [A->ncol] : 0 ;
-    if (vmap_ok && L->hip_apat_valid && L->hip_apat_hash == hash && L->hip_apat_nnz == annz
+    if (vmap_ok && L->hip_apat_valid && L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2 && L->hip_apat_nnz == annz
         && (L->xtype == CHOLMOD_REAL || L->xtype == CHOLMOD_PATTERN))
     {
         int rc = cholmod_hip_refresh_values ((cholmod_hip_plan *) L->hip_plan, A->x, (int64_t) annz) ;
@@ -353,7 +386,8 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         if ((S == A ? id : src) && cholmod_hip_set_value_map ((cholmod_hip_plan *) L->hip_plan,
                 S == A ? id : src, (int64_t) snz, (int64_t) an) == CHOLMOD_HIP_OK)
         {
-            L->hip_apat_hash = vmap_ok ? hash : pattern_hash (A) ;
+            if (!vmap_ok) hash = pattern_hash (A, &hash2) ;
+            L->hip_apat_hash = hash ; L->hip_apat_hash2 = hash2 ;
             L->hip_apat_nnz = an ;
             L->hip_apat_valid = TRUE ;
         }

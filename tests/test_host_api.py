@@ -132,3 +132,42 @@ def test_etree_postorder_rowcolcounts_entry_points():
     S.free_sparse(U)
     S.free_sparse(A)
     S.finish()
+
+
+@pytest.mark.parametrize("zomplex", [False, True])
+def test_norm_dense_complex_and_zomplex(zomplex):
+    """cholmod_l_norm_dense on the complex layouts cholmod_l_solve now returns (round-2 advice):
+    |re + i im| per entry as CHOLMOD/MatrixOps/cholmod_norm.c:34-60, 2-norm of a column vector
+    as :171-204 -- the reference demo's residual check on the complex path."""
+    rng = np.random.default_rng(5)
+    S = ch.Session(use_gpu=0)
+    X = rng.standard_normal((3, 17)) + 1j * rng.standard_normal((3, 17))     # 3 columns of length 17
+    Xd = S.dense(X, zomplex=zomplex)
+    x1 = S.dense(X[0], zomplex=zomplex)
+    assert np.isclose(S.L.cholmod_l_norm_dense(Xd, 0, C.byref(S.cm)), np.abs(X).sum(axis=0).max(), rtol=1e-14)
+    assert np.isclose(S.L.cholmod_l_norm_dense(Xd, 1, C.byref(S.cm)), np.abs(X).sum(axis=1).max(), rtol=1e-14)
+    assert np.isclose(S.L.cholmod_l_norm_dense(x1, 2, C.byref(S.cm)), np.linalg.norm(X[0]), rtol=1e-14)
+    assert S.cm.status == ch.OK
+    S.free_dense(Xd)
+    S.free_dense(x1)
+    S.finish()
+
+
+def test_factorize_rejects_a_factor_analysed_for_spqr():
+    """CHOLMOD_ANALYZE_FOR_SPQR leaves px[0] = 123456 and xsize = 1 (cholmod_super_symbolic.c:
+    662-663, :749-771): cholmod_l_factorize on such a factor must return CHOLMOD_INVALID, not
+    write at Lx + 123456 (round-2 advice: reproduced heap overflow on the CPU path)."""
+    n, Ap, Ai, Ax = G.poisson3d(6)
+    perm = np.ascontiguousarray(G.geometric_nd(6, 6, 6, 3))
+    for use_gpu in (0, 1):
+        S = ch.Session(use_gpu=use_gpu)
+        S.cm.error_handler = ch.ERRFUNC(0)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.L.cholmod_l_analyze_p2(0, A, perm.ctypes.data, None, 0, C.byref(S.cm))
+        assert Lf and S.cm.status == ch.OK
+        assert S.L.cholmod_l_factorize(A, Lf, C.byref(S.cm)) == 0
+        assert S.cm.status == ch.INVALID
+        assert ch.FactorView(Lf).xsize == 1 and not Lf.contents.x
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()

@@ -7,7 +7,7 @@ import numpy as np
 from bench import build_workload
 from suitesparse_amd import cholmod as ch
 
-KIND = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "allreduce", 8: "thin", 9: "update+potrf", 10: "trsm+upd+potrf"}
+KIND = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "allreduce", 8: "thin", 9: "update+potrf", 10: "trsm+upd+potrf", 11: "allgather", 12: "update_w"}
 w, m = sys.argv[1], int(sys.argv[2])
 only = [int(v) for v in sys.argv[3:]]
 n, Ap, Ai, Ax, stype, perm, name = build_workload(w, m)
@@ -18,7 +18,7 @@ assert S.factorize(A, Lf) == 1
 S.refactorize_resident(Lf)
 S.set_profiling(Lf, True)
 best = None
-for _ in range(3):
+for _ in range(int(os.environ.get("REPEAT", "3"))):
     assert S.refactorize_resident(Lf) == 1
     p = S.launch_profile(Lf)
     best = p if best is None else dict(p, ms=np.minimum(best["ms"], p["ms"]))
