@@ -50,6 +50,9 @@ extern "C" {
                                          * front (no k_leaf_pair)                                */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
+#define CHOLMOD_HIP_CHAIN64      8192    /* tuning / tests: the panel chain of rounds 1-2 (64-column steps: k_potrf_mfma,
+                                         * k_trsm_mfma, k_trsm_upd, k_update2f) instead of the 256-column
+                                         * sub-block chain (k_diag, k_rowsolve)                            */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 
@@ -124,7 +127,13 @@ int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
 /* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it
  * (size 1 = private to owner[s]) */
 int cholmod_hip_get_groups (cholmod_hip_plan *plan, int64_t *first, int64_t *size) ;
-/* complete the factor on every rank (sums the ranks' private subtrees) */
+/* Several ranks: a rank allocates L only for the fronts it holds (its subtrees and the shared
+ * fronts of its groups, packed; cholmod_hip_get_stats [36] bytes against [5] for the whole
+ * factor).  This call builds the COMPLETE factor in the reference layout on every rank (a second,
+ * full-size array: each front written by the first rank of its group, one sum over all ranks);
+ * solves, downloads and checks of a multi-rank plan need it.  If the full array does not fit
+ * next to the rank's part, the contribution-block arena makes room and is allocated again by the
+ * next factorization.  The next factorization invalidates the gathered copy. */
 int cholmod_hip_gather_factor (cholmod_hip_plan *plan) ;
 
 /* Numeric factorization  L L' = S + beta*I  of the already permuted,
@@ -224,6 +233,7 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
  *  [32] seconds in the one-wave-per-tile dense-update kernel (k_update3: the regions with
  *       >= 2048 tiles)   [33] its launches   [34] its algorithmic flops   [35] its algorithmic bytes
  *       (as [16]); the regions below that size stay with [6]-[8]
+ *  [36] bytes of L this rank allocates: the fronts it holds, packed (= [5] with one rank)
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
 #define CHOLMOD_HIP_NSTATS 40

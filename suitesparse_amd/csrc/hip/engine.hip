@@ -46,7 +46,7 @@ constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
 
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
 // the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -143,6 +143,9 @@ struct Schedule {
     std::vector<PfGroup> pg ;
     std::vector<TrGroup> tg ;
     std::vector<GemmGroup> gg ;
+    std::vector<DgGroup> dg ;       // k_diag: diagonal sub-blocks (256-column panel chain)
+    std::vector<RsGroup> rg ;       // k_rowsolve: the rows below them
+    int max_dinv_slots = 0 ;        // most diagonal sub-blocks in one launch (size of the inverse buffer)
     std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
     int nevents = 0 ;
@@ -281,8 +284,18 @@ struct cholmod_hip_plan {
     double *d_Lx = nullptr, *d_cb = nullptr ;
     ZeroGroup *d_zg = nullptr ; EaGroup *d_eg = nullptr ; PfGroup *d_pg = nullptr ;
     TrGroup *d_tg = nullptr ; GemmGroup *d_gg = nullptr ; i32 *d_sm = nullptr ;
-    std::vector<std::pair<i64, i64>> zslab ;   // multi-GPU: the parts of Lx this rank holds (offset, length), merged
-    bool lx_clean_elsewhere = false ;           // ... and whether everything outside them is known to be zero
+    DgGroup *d_dg = nullptr ; RsGroup *d_rg = nullptr ; double *d_dinv = nullptr ;     // 256-column panel chain
+    // multi-GPU: a rank allocates L only for the fronts it holds (its own subtrees and the shared
+    // fronts of its groups), packed in supernode order: lpx [s] = offset of front s in the rank's
+    // d_Lx (-1: not held), lx_local = its length.  FrontD.psx is that LOCAL offset, so every kernel
+    // of the factorization works on the compact array unchanged.  The complete factor in the
+    // reference layout (L->px) exists on a rank only after cholmod_hip_gather_factor: d_Lx_full /
+    // d_fr_full (descriptors with the global offsets), what solves, downloads and checks use.
+    // One rank: lpx = px, the local array IS the factor.
+    std::vector<i64> lpx ;
+    i64 lx_local = 0 ;
+    double *d_Lx_full = nullptr ; FrontD *d_fr_full = nullptr ;
+    bool full_valid = false ;
     FrontD *d_smd = nullptr ; i64 *d_sp01 = nullptr ;   // thin launches: descriptor and range of S of every front, in block order (as d_sm)
     ChildD *d_cdesc = nullptr ;      // per entry of the child lists: (cb, rel, ncb, cbp) of that child
     i32 *d_tu_cnt = nullptr ;       // k_trsm_upd: per group, workgroups that have read the rows workgroup 0 overwrites
@@ -439,7 +452,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the chip busy.  early [q] = block column of front q already summed this way.
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
-    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
+    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && (flags & CHOLMOD_HIP_CHAIN64) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks
@@ -546,6 +559,96 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
         step.clear () ;
     } ;
+    // ---- the panel chain in 256-column sub-blocks (default; kernels.hip.h: k_diag / k_rowsolve).
+    // Per sub-block [i0, b1) of a front: one workgroup factors the diagonal sub-block, one launch
+    // solves every row below it, and -- recursive doubling over the sub-blocks of the outer block
+    // column, as before over 64-column steps -- with e sub-blocks done and p the largest power of
+    // two dividing e, the last p sub-blocks (K = 256 p) update the next p; the K = OB update
+    // closes the outer block column.  CHOLMOD_HIP_CHAIN64 restores the 64-column chain below.
+    const bool chain256 = !(flags & CHOLMOD_HIP_CHAIN64) ;
+    if (chain256)
+    {
+        const int SB = DG_W ;
+        for (int i0 = 0 ; i0 < maxnscol ; i0 += SB)
+        {
+            if (i0 % MB == 0)
+                for (int q = 0 ; q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
+                    emit_rs (q, i0, -1) ;
+                }
+            Launch Ld {K_DIAG, 0, 0, S.dg.size (), 0, 0} ;
+            Launch Lr {K_ROWSOLVE, 0, 0, S.rg.size (), 0, 0} ;
+            int rblocks = 0 ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0) continue ;
+                int OBq = ob_of (f) ;
+                int o0 = (i0 / OBq) * OBq ;
+                int o1 = std::min (o0 + OBq, f.nscol) ;
+                int b1 = std::min (i0 + SB, o1) ;
+                int w = b1 - i0 ;
+                int slot = (int) (S.dg.size () - Ld.goff) ;
+                S.dg.push_back (DgGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, slot, 0}) ;
+                Ld.flops += (double) w * w * w / 3.0 ;
+                // rows to solve: everything below the sub-block -- of a shared front the rest of the
+                // 512-wide diagonal block (every rank of the group) and this rank's chunk below it
+                int lo [2] = {b1, 0}, hi [2] = {f.nsrow, 0} ;
+                if (is_shared (ids [q]))
+                {
+                    XchgD X = xchg_of (q, (i0 / MB) * MB) ;
+                    int e1 = (i0 / MB) * MB + X.w ;
+                    hi [0] = e1 ;
+                    lo [1] = e1 + X.r * X.R ; hi [1] = std::min (lo [1] + X.R, f.nsrow) ;
+                }
+                for (int part = 0 ; part < 2 ; part++)
+                {
+                    int m = hi [part] - lo [part] ;
+                    if (m <= 0) continue ;
+                    S.rg.push_back (RsGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.psx + lo [part] + (i64) i0 * f.nsrow,
+                        f.nsrow, m, w, ids [q], i0, rblocks, slot, 0}) ;
+                    rblocks += (m + RS_ROWS - 1) / RS_ROWS ;
+                    Lr.flops += (double) m * w * w ;
+                    Lr.bytes += 16.0 * m * w ;
+                }
+            }
+            Ld.ng = Ld.grid = (int) (S.dg.size () - Ld.goff) ;
+            S.max_dinv_slots = std::max (S.max_dinv_slots, Ld.ng) ;
+            if (Ld.ng) S.launches.push_back (Ld) ;
+            Lr.ng = (int) (S.rg.size () - Lr.goff) ; Lr.grid = rblocks ;
+            if (Lr.ng) S.launches.push_back (Lr) ;
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
+                int b0 = (i0 / MB) * MB ;
+                if (i0 + SB >= std::min (b0 + MB, f.nscol)) emit_ag (q, b0) ;
+            }
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0) continue ;
+                int OBq = ob_of (f) ;
+                int o0 = (i0 / OBq) * OBq ;
+                int o1 = std::min (o0 + OBq, f.nscol) ;
+                if (i0 + SB >= o1)
+                {
+                    step.push_back (Upd {q, o0, o1 - o0, o1, f.nscol, true, true}) ;
+                    continue ;
+                }
+                int e = (i0 - o0) / SB + 1 ;
+                int p = e & -e ;
+                int t0 = o0 + e * SB ;
+                int t1 = std::min (o0 + (e + p) * SB, o1) ;
+                int kc = o0 + (e - p) * SB ;
+                step.push_back (Upd {q, kc, t0 - kc, t0, t1, false, p * SB >= MB}) ;
+            }
+            emit_step () ;
+        }
+        return ;
+    }
     for (int i0 = 0 ; i0 < maxnscol ; i0 += NB)
     {
         // ---- multi-GPU: a 512-column block column of a shared front holds per-rank
@@ -900,20 +1003,17 @@ static int build_host (cholmod_hip_plan *P)
         }
     }
     auto mine = [&] (i64 s) { return P->rank >= P->grp0 [s] && P->rank < P->grp0 [s] + P->grpn [s] ; } ;
-    // the parts of Lx this rank holds, merged into slabs (a subtree is mostly a contiguous
-    // supernode range; with too many pieces the full clear is cheaper than the launches)
-    P->zslab.clear () ;
-    if (P->world > 1)
+    // the rank's own L: the fronts it holds, packed in supernode order (see cholmod_hip_plan::lpx)
+    P->lpx.assign (std::max<i64> (nsuper, 1), -1) ;
+    P->lx_local = 0 ;
+    for (i64 s = 0 ; s < nsuper ; s++)
     {
-        for (i64 s = 0 ; s < nsuper ; s++)
-        {
-            if (!mine (s)) continue ;
-            i64 o = P->px [s], len = P->px [s+1] - P->px [s] ;
-            if (!P->zslab.empty () && P->zslab.back ().first + P->zslab.back ().second == o) P->zslab.back ().second += len ;
-            else P->zslab.push_back ({o, len}) ;
-        }
-        if (P->zslab.size () > 256) P->zslab.clear () ;
+        if (P->world > 1 && !mine (s)) { P->fr [s].psx = 0 ; continue ; }
+        P->lpx [s] = P->world > 1 ? P->lx_local : P->px [s] ;
+        P->fr [s].psx = P->lpx [s] ;
+        P->lx_local += P->px [s+1] - P->px [s] ;
     }
+    if (P->world == 1) P->lx_local = P->xsize ;
     // thin fronts (fused LDS-resident kernel): their contribution blocks are packed
     // lower triangles, the generic fronts' full squares
     for (i64 s = 0 ; s < nsuper ; s++)
@@ -1258,7 +1358,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1287,7 +1387,7 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipEventCreate (&P->ev1)) ;
     size_t freeb = 0, totalb = 0 ;
     HIPCHK (hipMemGetInfo (&freeb, &totalb)) ;
-    double need = 8.0 * P->xsize + 8.0 * P->arena + 8.0 * P->ssize + 4.0 * P->relsize
+    double need = 8.0 * P->lx_local + 8.0 * P->arena + 8.0 * P->ssize + 4.0 * P->relsize
         + sizeof (GemmGroup) * (double) P->sch.gg.size () + 64.0 * P->nsuper + (double) (64 << 20) ;
     if (need > (double) freeb)
     {
@@ -1317,6 +1417,9 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
     HIPCHK (hipMalloc ((void **) &P->d_tu_cnt, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32))) ;
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
+    P->d_dg = dupload (P->sch.dg, e) ; HIPCHK (e) ;
+    P->d_rg = dupload (P->sch.rg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P->d_dinv, (size_t) std::max (P->sch.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     {
         std::vector<FrontD> smd (P->sch.sm.size ()) ;
@@ -1331,7 +1434,7 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_first_fail, sizeof (int))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
     if (getenv ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
     {
@@ -1360,7 +1463,7 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipStreamSynchronize (P->stream)) ;
     }
     if (ptiming) fprintf (stderr, "cholmod_hip upload_plan: streams/events %.3f s, maps + schedule H2D %.3f s, hipMalloc (L %.1f GB, arena %.1f GB) %.3f s, relmap kernel %.3f s\n",
-        tu1 - tu0, tu2 - tu1, 8e-9 * P->xsize, 8e-9 * P->arena, tu3 - tu2, pnow () - tu3) ;
+        tu1 - tu0, tu2 - tu1, 8e-9 * P->lx_local, 8e-9 * P->arena, tu3 - tu2, pnow () - tu3) ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -1372,6 +1475,7 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_rowsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rowsolve_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
@@ -1546,6 +1650,14 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
+        case K_DIAG:
+            hipLaunchKernelGGL (k_diag, dim3 (L.grid), dim3 (256), 0, st, P->d_dg + L.goff, P->d_Lx, P->d_info, P->d_dinv) ;
+            break ;
+        case K_ROWSOLVE:
+            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+            hipLaunchKernelGGL (k_rowsolve, dim3 (L.grid), dim3 (256), rowsolve_lds_bytes (), st,
+                P->d_rg + L.goff, L.ng, P->d_Lx, P->d_info, P->d_dinv) ;
+            break ;
         case K_UPD_W:
             // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
             if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
@@ -1584,20 +1696,20 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     int poisoned = CHOLMOD_HIP_OK ;
     bool building_map = false ;
     if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
-    // Lx := 0.  Several ranks: a rank only ever writes the fronts it holds (its own subtrees and
-    // the shared fronts of its groups); once the rest of its Lx is known to be zero -- after one
-    // full clear, until cholmod_hip_gather_factor fills it with the other ranks' columns -- only
-    // those slabs are cleared (200^3 at 8 ranks: 28 ms of a 1.3 s rank step for the full 181 GB)
-    if (P->world > 1 && P->lx_clean_elsewhere && !P->zslab.empty ())
+    // Lx := 0 (several ranks: the rank's own fronts -- its d_Lx holds nothing else); the complete
+    // factor a gather may have left in d_Lx_full is stale from here on
+    P->full_valid = false ;
+    if (!P->d_cb)
     {
-        for (const auto &zs : P->zslab)
-            HIPCHK (hipMemsetAsync (P->d_Lx + zs.first, 0, (size_t) zs.second * sizeof (double), st)) ;
+        // (the arena made room for the gathered factor, see cholmod_hip_gather_factor)
+        if (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double)) != hipSuccess)
+        {
+            (void) hipGetLastError () ;
+            if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
+            HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
+        }
     }
-    else
-    {
-        HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->xsize, 1) * sizeof (double), st)) ;
-        P->lx_clean_elsewhere = P->world > 1 ;
-    }
+    HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
     if (P->n > 0 && P->amap_valid)
@@ -1688,6 +1800,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     S [3] = P->nlevels ;
     S [4] = 8.0 * P->arena ;
     S [5] = 8.0 * P->xsize ;
+    S [36] = 8.0 * P->lx_local ;
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
@@ -1720,7 +1833,8 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_UPD_W: S [32] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: S [9] += sec ; break ;
-                case K_POTRF: S [11] += sec ; break ;
+                case K_POTRF: case K_DIAG: S [11] += sec ; break ;
+                case K_ROWSOLVE: S [12] += sec ; break ;
                 case K_SMALL: S [19] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
                 case K_TRSM_UPD: S [30] += sec ; break ;
@@ -1756,15 +1870,24 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     if (sbad < 0) return CHOLMOD_HIP_OK ;
     const FrontD &f = P->fr [sbad] ;
     *minor = f.k1 + binfo - 1 ;
-    i64 zero_from = P->px [sbad + 1] ;
-    if (binfo == 1 || quick) zero_from = P->px [sbad] ;
-    if (zero_from < P->xsize)
-        HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->xsize - zero_from) * sizeof (double), st)) ;
+    // everything from supernode sbad + 1 on (from sbad itself when it has no valid column, or on
+    // a quick return) is zero: in the rank's own array, the fronts it holds with those indices
+    // (held fronts are packed in supernode order, so that is one tail of the array)
+    i64 first_zero = sbad + ((binfo == 1 || quick) ? 0 : 1) ;
+    i64 zero_from = P->lx_local ;
+    for (i64 q = first_zero ; q < P->nsuper ; q++) if (P->lpx [q] >= 0) { zero_from = P->lpx [q] ; break ; }
+    if (zero_from < P->lx_local)
+        HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->lx_local - zero_from) * sizeof (double), st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
     return CHOLMOD_HIP_NOT_POSDEF ;
 }
 
 } // namespace
+
+// The complete numeric factor in the reference layout and the descriptors that go with it: the
+// rank's own array when there is one rank, the gathered copy otherwise (nullptr before a gather).
+static double *whole_factor (cholmod_hip_plan *P) { return P->world == 1 ? P->d_Lx : (P->full_valid ? P->d_Lx_full : nullptr) ; }
+static const FrontD *whole_fronts (cholmod_hip_plan *P) { return P->world == 1 ? P->d_fr : P->d_fr_full ; }
 
 // ============================================================================
 // extern "C" shim
@@ -1880,44 +2003,65 @@ int cholmod_hip_get_partition (cholmod_hip_plan *P, int64_t *owner)
     return CHOLMOD_HIP_OK ;
 }
 
-/* After a distributed factorization every rank holds the shared fronts and its
- * own subtrees; the other ranks' subtrees are still zero in its Lx.  Summing
- * the solo ranges over the ranks completes the factor everywhere. */
+/* After a distributed factorization every rank holds, in its own packed array, the shared
+ * fronts of its groups and its own subtrees.  The gather builds the complete factor in the
+ * reference layout (L->px) on EVERY rank: each front is written into a zeroed full-size array by
+ * exactly one rank (the first of its group), and a sum over all ranks completes it everywhere.
+ * The full array needs 8 xsize bytes next to the rank's own part; if that does not fit, the
+ * contribution-block arena (dead between factorizations) makes room and is allocated again by
+ * the next factorization. */
 int cholmod_hip_gather_factor (cholmod_hip_plan *P)
 {
     if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
     if (P->world == 1) return CHOLMOD_HIP_OK ;
     if (!P->ar_fn && !P->nccl_world) return CHOLMOD_HIP_INVALID ;
     P->winv_valid = false ;
-    P->lx_clean_elsewhere = false ;         // the other ranks' columns arrive below
     HIPCHK (hipStreamSynchronize (P->stream)) ;
-    // Fronts shared by everybody are already complete everywhere.  Of every other
-    // front exactly one rank (the first of its group) keeps its copy, the rest
-    // zero theirs; the sum over all ranks then completes the factor everywhere.
-    const i64 chunk = (i64) 1 << 27 ;
-    auto everywhere = [&] (i64 q) { return P->grpn [q] == P->world ; } ;
+    if (!P->d_Lx_full)
+    {
+        if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) != hipSuccess)
+        {
+            (void) hipGetLastError () ;
+            P->d_Lx_full = nullptr ;
+            if (P->d_cb) { (void) hipFree (P->d_cb) ; P->d_cb = nullptr ; }
+            if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) != hipSuccess)
+            {
+                (void) hipGetLastError () ;
+                P->d_Lx_full = nullptr ;
+                fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on this rank\n", 8e-9 * P->xsize) ;
+                return CHOLMOD_HIP_OUT_OF_MEMORY ;
+            }
+        }
+    }
+    if (!P->d_fr_full)
+    {
+        std::vector<FrontD> ff (P->fr) ;
+        for (i64 q = 0 ; q < P->nsuper ; q++) ff [q].psx = P->px [q] ;
+        hipError_t e ;
+        P->d_fr_full = dupload (ff, e) ; HIPCHK (e) ;
+    }
+    HIPCHK (hipMemsetAsync (P->d_Lx_full, 0, std::max<i64> (P->xsize, 1) * sizeof (double), P->stream)) ;
     for (i64 q = 0 ; q < P->nsuper ; )
     {
-        if (everywhere (q)) { q++ ; continue ; }
+        // runs of consecutive fronts this rank contributes: contiguous in both arrays
+        if (!(P->lpx [q] >= 0 && P->rank == P->grp0 [q])) { q++ ; continue ; }
         i64 e = q ;
-        while (e < P->nsuper && !everywhere (e)) e++ ;
-        for (i64 t = q ; t < e ; t++)
-        {
-            bool held = P->rank >= P->grp0 [t] && P->rank < P->grp0 [t] + P->grpn [t] ;
-            if (held && P->rank != P->grp0 [t])
-                HIPCHK (hipMemsetAsync (P->d_Lx + P->px [t], 0, (size_t) (P->px [t+1] - P->px [t]) * sizeof (double), P->stream)) ;
-        }
-        HIPCHK (hipStreamSynchronize (P->stream)) ;
-        for (i64 off = P->px [q] ; off < P->px [e] ; off += chunk)
-        {
-            i64 cnt = std::min (chunk, P->px [e] - off) ;
-            if (P->nccl_world)
-                RCCLCHK (rccl_api ()->AllReduce (P->d_Lx + off, P->d_Lx + off, (size_t) cnt, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
-            else if (P->ar_fn (P->d_Lx + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-        }
+        while (e < P->nsuper && P->lpx [e] >= 0 && P->rank == P->grp0 [e] && P->lpx [e] - P->lpx [q] == P->px [e] - P->px [q]) e++ ;
+        HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], P->d_Lx + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
+            hipMemcpyDeviceToDevice, P->stream)) ;
         q = e ;
     }
     HIPCHK (hipStreamSynchronize (P->stream)) ;
+    const i64 chunk = (i64) 1 << 27 ;
+    for (i64 off = 0 ; off < P->xsize ; off += chunk)
+    {
+        i64 cnt = std::min (chunk, P->xsize - off) ;
+        if (P->nccl_world)
+            RCCLCHK (rccl_api ()->AllReduce (P->d_Lx_full + off, P->d_Lx_full + off, (size_t) cnt, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
+        else if (P->ar_fn (P->d_Lx_full + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    }
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    P->full_valid = true ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -2082,16 +2226,32 @@ int cholmod_hip_factorize_resident (cholmod_hip_plan *P, double beta,
 int cholmod_hip_download_factor (cholmod_hip_plan *P, double *Lx_host)
 {
     if (!P || P->host_only || !Lx_host) return CHOLMOD_HIP_INVALID ;
-    HIPCHK (hipMemcpy (Lx_host, P->d_Lx, P->xsize * sizeof (double), hipMemcpyDeviceToHost)) ;
+    const double *Lw = whole_factor (P) ;
+    if (!Lw) return CHOLMOD_HIP_INVALID ;           // several ranks: cholmod_hip_gather_factor first
+    HIPCHK (hipMemcpy (Lx_host, Lw, P->xsize * sizeof (double), hipMemcpyDeviceToHost)) ;
     return CHOLMOD_HIP_OK ;
 }
 
 int cholmod_hip_upload_factor (cholmod_hip_plan *P, const double *Lx_host)
 {
     if (!P || P->host_only || !Lx_host) return CHOLMOD_HIP_INVALID ;
-    HIPCHK (hipMemcpy (P->d_Lx, Lx_host, P->xsize * sizeof (double), hipMemcpyHostToDevice)) ;
+    double *Lw = P->d_Lx ;
+    if (P->world > 1)
+    {
+        // several ranks: the complete factor lives beside the rank's own part
+        if (!P->d_Lx_full) HIPCHK (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double))) ;
+        if (!P->d_fr_full)
+        {
+            std::vector<FrontD> ff (P->fr) ;
+            for (i64 q = 0 ; q < P->nsuper ; q++) ff [q].psx = P->px [q] ;
+            hipError_t e ;
+            P->d_fr_full = dupload (ff, e) ; HIPCHK (e) ;
+        }
+        Lw = P->d_Lx_full ;
+    }
+    HIPCHK (hipMemcpy (Lw, Lx_host, P->xsize * sizeof (double), hipMemcpyHostToDevice)) ;
     P->winv_valid = false ;
-    P->lx_clean_elsewhere = false ;
+    P->full_valid = P->world > 1 ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -2115,6 +2275,9 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
 {
     if (!P || P->host_only || !X || nrhs < 0 || ldx < P->n) return CHOLMOD_HIP_INVALID ;
     if (nrhs == 0 || P->n == 0) return CHOLMOD_HIP_OK ;
+    const double *Lw = whole_factor (P) ;
+    const FrontD *frw = whole_fronts (P) ;
+    if (!Lw || !frw) return CHOLMOD_HIP_INVALID ;  // several ranks: cholmod_hip_gather_factor first
     i64 need = ldx * nrhs ;
     if (need > P->x_cap)
     {
@@ -2156,7 +2319,7 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         if (!P->winv_valid)
         {
             hipLaunchKernelGGL (k_diag_inv64, dim3 ((unsigned) P->inv_tasks.size ()), dim3 (64), 0, st,
-                P->d_inv_tasks, P->d_fr, P->d_Lx, P->d_winv) ;
+                P->d_inv_tasks, frw, Lw, P->d_winv) ;
             P->winv_valid = true ;
         }
     }
@@ -2168,19 +2331,19 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         {
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
             if (nf) hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
-                P->d_sv + P->sv_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                P->d_sv + P->sv_ptr [l], frw, P->d_Ls, Lw, P->d_X, (i64) ldx, (int) nrhs) ;
             for (int q = P->sb_lvl_ptr [l] ; q < P->sb_lvl_ptr [l+1] ; q++)
             {
                 const auto &B = P->sb_launch [q] ;
                 hipLaunchKernelGGL (k_solve_fwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
-                    P->d_sb_tasks + B.first, P->d_fr, P->d_Lx, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
+                    P->d_sb_tasks + B.first, frw, Lw, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
                 if (B.grid > 0) hipLaunchKernelGGL (k_solve_fwd_apply, dim3 (B.grid), dim3 (256), 0, st,
-                    P->d_sb_tasks + B.first, (int) B.ntasks, P->d_fr, P->d_Ls, P->d_Lx,
+                    P->d_sb_tasks + B.first, (int) B.ntasks, frw, P->d_Ls, Lw,
                     P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
             }
             const auto &Cm = P->sb_commit_launch [l] ;
             if (Cm.ntasks) hipLaunchKernelGGL (k_solve_commit, dim3 (Cm.grid), dim3 (256), 0, st,
-                P->d_sb_commit + Cm.first, (int) Cm.ntasks, P->d_fr, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
+                P->d_sb_commit + Cm.first, (int) Cm.ntasks, frw, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
         }
     }
     if (which == 0 || which == 2)
@@ -2191,14 +2354,14 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
             {
                 const auto &B = P->sb_launch [q] ;
                 if (B.grid > 0) hipLaunchKernelGGL (k_solve_bwd_apply, dim3 (B.grid), dim3 (256), 0, st,
-                    P->d_sb_tasks + B.first, (int) B.ntasks, P->d_fr, P->d_Ls, P->d_Lx,
+                    P->d_sb_tasks + B.first, (int) B.ntasks, frw, P->d_Ls, Lw,
                     P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
                 hipLaunchKernelGGL (k_solve_bwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
-                    P->d_sb_tasks + B.first, P->d_fr, P->d_Lx, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
+                    P->d_sb_tasks + B.first, frw, Lw, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
             }
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
             if (nf) hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
-                P->d_sv + P->sv_ptr [l], P->d_fr, P->d_Ls, P->d_Lx, P->d_X, (i64) ldx, (int) nrhs) ;
+                P->d_sv + P->sv_ptr [l], frw, P->d_Ls, Lw, P->d_X, (i64) ldx, (int) nrhs) ;
         }
     }
     HIPCHK (hipGetLastError ()) ;
@@ -2221,8 +2384,10 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
     { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }
     HIPCHK (hipMemsetAsync (P->d_chk_out, 0, 5 * sizeof (double), P->stream)) ;
+    // (several ranks before a gather: the rank's own fronts only -- the others read as absent)
+    const bool whole = whole_factor (P) != nullptr ;
     hipLaunchKernelGGL (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
-        P->d_chk, P->d_fr, P->d_Lx, P->d_chk_out) ;
+        P->d_chk, whole ? whole_fronts (P) : P->d_fr, whole ? whole_factor (P) : P->d_Lx, P->d_chk_out) ;
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
@@ -2250,8 +2415,9 @@ int cholmod_hip_download_even_columns (cholmod_hip_plan *P, double *out_host)
     double *tmp = nullptr ;
     const size_t bytes = (size_t) (P->xsize / 2) * sizeof (double) ;
     if (hipMalloc ((void **) &tmp, bytes) != hipSuccess) { (void) hipGetLastError () ; return CHOLMOD_HIP_OUT_OF_MEMORY ; }
+    if (!whole_factor (P)) { (void) hipFree (tmp) ; return CHOLMOD_HIP_INVALID ; }
     hipLaunchKernelGGL (k_even_columns, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
-        P->d_chk, P->d_fr, P->d_Lx, tmp) ;
+        P->d_chk, whole_fronts (P), whole_factor (P), tmp) ;
     hipError_t e = hipGetLastError () ;
     if (e == hipSuccess) e = hipMemcpyAsync (out_host, tmp, bytes, hipMemcpyDeviceToHost, P->stream) ;
     if (e == hipSuccess) e = hipStreamSynchronize (P->stream) ;
@@ -2286,6 +2452,7 @@ int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
     P->stats [3] = P->nlevels ;
     P->stats [4] = 8.0 * P->arena ;
     P->stats [5] = 8.0 * P->xsize ;
+    P->stats [36] = 8.0 * P->lx_local ;
     P->stats [22] = P->nsplit ;
     P->stats [24] = P->solve_seconds ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
@@ -2359,6 +2526,9 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     HIPCHK (hipMalloc ((void **) &P.d_tu_cnt, std::max<size_t> (S.tg.size (), 1) * sizeof (i32))) ;
     HIPCHK (hipMemset (P.d_tu_cnt, 0, std::max<size_t> (S.tg.size (), 1) * sizeof (i32))) ;
     P.d_gg = dupload (S.gg, e) ; HIPCHK (e) ;
+    P.d_dg = dupload (S.dg, e) ; HIPCHK (e) ;
+    P.d_rg = dupload (S.rg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P.d_dinv, (size_t) std::max (S.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
     HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
     if (ncb > 0)
         HIPCHK (hipMemcpy2D (P.d_cb, ncb * sizeof (double), F + nscol + nscol * nsrow,
@@ -2379,6 +2549,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
     P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ; P.d_tu_cnt = nullptr ;
+    P.d_dg = nullptr ; P.d_rg = nullptr ; P.d_dinv = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef long long i64;
 typedef int i32;
@@ -46,6 +47,10 @@ struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
 struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
 struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
                  i32 col0; i32 blk_start; };
+// the 256-column panel chain (k_diag / k_rowsolve): a diagonal sub-block of a front and the
+// rows below it
+struct DgGroup { i64 off; i32 lda; i32 w; i32 front; i32 col0; i32 slot; i32 pad; };
+struct RsGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 w; i32 front; i32 col0; i32 blk_start; i32 slot; i32 pad; };
 struct GemmGroup {
     i64 a_off, b_off, c_off;    // a/b index Lx; c indexes Lx or the CB arena
     i32 lda, ldc;
@@ -2063,6 +2068,259 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
             else if (q != X.r && row < X.mb) *d = *p ;
         }
     }
+}
+
+// ---- the panel chain in 256-column sub-blocks -------------------------------------------
+// Rounds 1-2 walked a front's outer block column in 64-column steps: dpotrf of the diagonal
+// block, dtrsm of ALL rows below, the K = 64 ... 256 doubling updates -- about fifteen dependent
+// launches of 15-30 us per 512 columns whose arithmetic is microseconds (the nd24k stand-in
+// spent 16 of its 30 ms there, Poisson 100^3 43 of 150).  Here the chain advances 256 columns
+// per pair of launches (reference steps: dpotrf t_cholmod_super_numeric.c:864-867, dtrsm
+// :997-1002, applied to a 256-column sub-block):
+//   k_diag      ONE workgroup per front factors the w x w (w <= 256) diagonal sub-block, left-
+//               looking over 64-column panels: the panel's 64 x 64 diagonal block is updated with
+//               the sub-block's earlier columns on the matrix cores (operands straight from L2
+//               in MFMA layout), eliminated in LDS (pf_eliminate), its rows inside the sub-block
+//               solved as k_trsm_mfma does; the sixteen 16 x 16 diagonal-block inverses it needs
+//               for that are published (dinv) for
+//   k_rowsolve  every 64 rows below the sub-block, one workgroup: X = B inv(L)' for all w columns
+//               at once -- per 64-column panel the rows of L it multiplies with are staged
+//               k-major in LDS (negated), the solved 16 x 16 blocks of X stay in registers in
+//               the A-operand layout (16 x d4 per wave) and feed the later panels' products; the
+//               K < 256 "narrow updates" of the old chain do not exist any more, they are the
+//               left-looking products inside these two kernels.
+// Not-positive-definite protocol as before: the first pivot <= 0 goes to info [front] (1-based,
+// relative to the front), every later column of the front is written as zero.
+#define DG_W 256
+template <typename Tick>
+__device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A, i64 lda, int rowc, int c0, int w, int lr, int lk, Tick)
+{
+    // acc [jb] -= L (rowc, 0 : c0) L (c0 + 16 jb + lr', 0 : c0)'   (rows of the wave in lanes lr, columns lk + 4 r)
+    const double *pa = A + rowc + (i64) lk * lda ;
+    const double *pb [4] ;
+#pragma unroll
+    for (int jb = 0 ; jb < 4 ; jb++)
+    {
+        int rb = c0 + 16 * jb + lr ; if (rb > w - 1) rb = w - 1 ;
+        pb [jb] = A + rb + (i64) lk * lda ;
+    }
+    for (int k0 = 0 ; k0 < c0 ; k0 += 8)
+    {
+        double af [2], bf [2][4] ;
+#pragma unroll
+        for (int u = 0 ; u < 2 ; u++)
+        {
+            af [u] = pa [(i64) (k0 + 4 * u) * lda] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++) bf [u][jb] = pb [jb][(i64) (k0 + 4 * u) * lda] ;
+        }
+#pragma unroll
+        for (int u = 0 ; u < 2 ; u++)
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+                acc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bf [u][jb], af [u], acc [jb], 0, 0, 0) ;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32 *info, double *dinv)
+{
+    __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;     // the panel's 64 x 64 diagonal block, k-major
+    __shared__ __attribute__((aligned(16))) double Ls [64 * 64] ;           // -L11 k-major (diagonal positive), identity-padded
+    __shared__ __attribute__((aligned(16))) double Wd [4 * 256] ;           // inverses of its four 16 x 16 diagonal blocks
+    __shared__ int s_fail ;
+    __builtin_amdgcn_s_setprio (3) ;
+    const DgGroup G = g [blockIdx.x] ;
+    double *A = Lx + G.off ;
+    const i64 lda = G.lda ;
+    const int w = G.w ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4 ;
+    double *DI = dinv + (i64) G.slot * 4096 ;
+    auto tick = [] (int) {} ;
+    bool dead = info [G.front] != 0 ;        // an earlier pivot of this front failed
+    for (int c0 = 0 ; c0 < w ; c0 += 64)
+    {
+        const int pw = (w - c0 < 64) ? w - c0 : 64 ;
+        if (dead)
+        {
+            // the front's remaining columns are zero (:889-895, :926-931); identity "inverses" so
+            // that nothing non-finite reaches k_rowsolve's (masked) products
+            for (int k = wave ; k < pw ; k += 4)
+                for (int i = c0 + k + lane ; i < w ; i += 64) A [i + (i64) (c0 + k) * lda] = 0.0 ;
+            for (int e = tid ; e < 1024 ; e += 256) DI [(c0 >> 6) * 1024 + e] = ((e & 255) >> 4) == (e & 15) ? 1.0 : 0.0 ;
+            continue ;
+        }
+        // ---- the panel's diagonal block: this wave's 16 rows, left-looking update, into T
+        {
+            const int rowg = c0 + 16 * wave + lr ;
+            const int rowc = rowg < w ? rowg : w - 1 ;
+            d4 acc [4] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int col = c0 + 16 * jb + lk + 4 * r ; if (col > w - 1) col = w - 1 ;
+                    acc [jb][r] = A [rowc + (i64) col * lda] ;
+                }
+            dg_left_looking (acc, A, lda, rowc, c0, w, lr, lk, tick) ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    const int i = 16 * wave + lr, j = 16 * jb + lk + 4 * r ;
+                    T [j * PF2_LD + i] = (i < pw && j < pw) ? (i >= j ? acc [jb][r] : 0.0) : (i == j ? 1.0 : 0.0) ;
+                }
+        }
+        if (tid == 0) s_fail = -1 ;
+        __syncthreads () ;
+        pf_eliminate (T, (pw + 15) >> 4, &s_fail, tid, tick) ;
+        const int fail = s_fail ;
+        const int nvalid = fail >= 0 ? fail : pw ;
+        if (fail >= 0 && tid == 0) info [G.front] = G.col0 + c0 + fail + 1 ;
+        // the factored block to Lx (columns at / beyond a failed pivot: zero), and -L11 k-major for the row solves
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            const int k = wave + 4 * q, i = lane ;
+            if (k < pw && i >= k && i < pw) A [(c0 + i) + (i64) (c0 + k) * lda] = (k < nvalid) ? T [k * PF2_LD + i] : 0.0 ;
+            double v = (i == k) ? 1.0 : 0.0 ;
+            if (i < nvalid && k < i) v = -T [k * PF2_LD + i] ;
+            if (i < nvalid && k == i) v = T [k * PF2_LD + k] ;
+            Ls [k * 64 + i] = v ;
+        }
+        __syncthreads () ;
+        trsm_diag_inverses (Ls, 64, Wd, 4, lane, wave, tick) ;
+        __syncthreads () ;
+        for (int e = tid ; e < 1024 ; e += 256) DI [(c0 >> 6) * 1024 + e] = Wd [e] ;
+        // ---- the rows of the sub-block below this panel (only behind a full panel)
+        for (int rr = c0 + 64 ; rr < w ; rr += 64)
+        {
+            const int row = rr + 16 * wave + lr ;
+            const bool rok = row < w ;
+            const int rowc = rok ? row : w - 1 ;
+            d4 bj [4], xr [4] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++) bj [jb][r] = A [rowc + (i64) (c0 + 16 * jb + lk + 4 * r) * lda] ;
+            dg_left_looking (bj, A, lda, rowc, c0, w, lr, lk, tick) ;
+            trsm_solve_rows (bj, 4, Ls, 64, Wd, lane, nvalid, rok, 64, A + rowc + (i64) c0 * lda, lda, tick, xr) ;
+        }
+        if (fail >= 0) dead = true ;
+        __syncthreads () ;          // this panel's columns are in Lx for the next panel's products (workgroup scope)
+    }
+}
+
+#define RS_ROWS 64
+__host__ __device__ inline size_t rowsolve_lds_bytes () { return (size_t) (DG_W * 64 + 4 * 256) * sizeof (double) ; }
+__global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, double *Lx, const i32 *info, const double *dinv)
+{
+    extern __shared__ __attribute__((aligned(16))) double rs_lds [] ;
+    double *Lst = rs_lds ;                  // [k][c]: -L (c0 + c, k) for k < c0 + c (k-major, 64 columns wide), identity-padded
+    double *Wd = Lst + DG_W * 64 ;          // the panel's four 16 x 16 diagonal-block inverses (from k_diag)
+    const int gi = find_group (g, ng, (int) blockIdx.x, &RsGroup::blk_start) ;
+    const RsGroup G = g [gi] ;
+    const i64 lda = G.lda ;
+    const int w = G.w ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4 ;
+    const int row = ((int) blockIdx.x - G.blk_start) * RS_ROWS + wave * 16 + lr ;
+    const bool rok = row < G.m ;
+    double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;       // this lane's row, first column of the sub-block
+    const double *L = Lx + G.l_off ;                          // L (0, 0) of the sub-block
+    const double *DI = dinv + (i64) G.slot * 4096 ;
+    const int inf = info [G.front] ;
+    int nvt = w ;                                             // valid columns of the sub-block
+    if (inf != 0) { nvt = inf - 1 - G.col0 ; if (nvt < 0) nvt = 0 ; if (nvt > w) nvt = w ; }
+    d4 X [16] ;
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++) X [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    // one 64-column panel; j is a compile-time constant so that X [] stays in registers
+    auto panel = [&] (auto jc)
+    {
+        constexpr int j = decltype (jc)::value ;
+        constexpr int c0 = 64 * j ;
+        if (c0 < w)
+        {
+            const int pw = (w - c0 < 64) ? w - c0 : 64 ;
+            int nvj = nvt - c0 ; if (nvj < 0) nvj = 0 ; if (nvj > pw) nvj = pw ;
+            d4 bj [4] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int c = 16 * jb + lk + 4 * r ; if (c > pw - 1) c = pw - 1 ;
+                    bj [jb][r] = B [(i64) (c0 + c) * lda] ;
+                }
+            __syncthreads () ;              // the previous panel's readers are done with Lst / Wd
+            {
+                // stage the rows c0 .. c0 + 63 of L, columns 0 .. c0 + 63, sixteen loads in flight per thread
+                const int c = lane ;
+                const int rowL = (c0 + c < w) ? c0 + c : w - 1 ;
+                const int nk = c0 + 64 ;
+                for (int kb = 0 ; kb < nk ; kb += 64)
+                {
+                    double tmp [16] ;
+#pragma unroll
+                    for (int q = 0 ; q < 16 ; q++)
+                    {
+                        int k = kb + wave + 4 * q ; if (k > w - 1) k = w - 1 ;
+                        tmp [q] = L [rowL + (i64) k * lda] ;
+                    }
+#pragma unroll
+                    for (int q = 0 ; q < 16 ; q++)
+                    {
+                        const int k = kb + wave + 4 * q ;
+                        double v = (k == c0 + c) ? 1.0 : 0.0 ;
+                        if (c < nvj && k < c0 + c) v = -tmp [q] ;
+                        if (c < nvj && k == c0 + c) v = tmp [q] ;
+                        Lst [k * 64 + c] = v ;
+                    }
+                }
+                for (int e = tid ; e < 1024 ; e += 256) Wd [e] = DI [j * 1024 + e] ;
+            }
+            __syncthreads () ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+            {
+                d4 acc = bj [jb] ;
+#pragma unroll
+                for (int kb = 0 ; kb < 16 ; kb++)
+                {
+                    if (kb < 4 * j + jb)
+                    {
+#pragma unroll
+                        for (int s4 = 0 ; s4 < 4 ; s4++)
+                        {
+                            double b = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, X [kb][s4], acc, 0, 0, 0) ;
+                        }
+                    }
+                }
+                d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
+#pragma unroll
+                for (int s4 = 0 ; s4 < 4 ; s4++)
+                {
+                    double b = Wd [jb * 256 + (4 * s4 + lk) * 16 + lr] ;
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, acc [s4], x, 0, 0, 0) ;
+                }
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    const int c = 16 * jb + lk + 4 * r ;
+                    const double v = (c < nvj) ? x [r] : 0.0 ;
+                    x [r] = v ;
+                    if (rok && c < pw) B [(i64) (c0 + c) * lda] = v ;
+                }
+                X [4 * j + jb] = x ;
+            }
+        }
+    } ;
+    panel (std::integral_constant<int, 0> {}) ;
+    panel (std::integral_constant<int, 1> {}) ;
+    panel (std::integral_constant<int, 2> {}) ;
+    panel (std::integral_constant<int, 3> {}) ;
 }
 
 // ---- first failing supernode (not-positive-definite protocol) ---------------------
