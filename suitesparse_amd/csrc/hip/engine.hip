@@ -452,7 +452,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the chip busy.  early [q] = block column of front q already summed this way.
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
-    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && (flags & CHOLMOD_HIP_CHAIN64) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
+    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !(flags & CHOLMOD_HIP_CHAIN256) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks
@@ -559,13 +559,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
         step.clear () ;
     } ;
-    // ---- the panel chain in 256-column sub-blocks (default; kernels.hip.h: k_diag / k_rowsolve).
+    // ---- the panel chain in 256-column sub-blocks (kernels.hip.h: k_diag / k_rowsolve).
     // Per sub-block [i0, b1) of a front: one workgroup factors the diagonal sub-block, one launch
     // solves every row below it, and -- recursive doubling over the sub-blocks of the outer block
     // column, as before over 64-column steps -- with e sub-blocks done and p the largest power of
     // two dividing e, the last p sub-blocks (K = 256 p) update the next p; the K = OB update
-    // closes the outer block column.  CHOLMOD_HIP_CHAIN64 restores the 64-column chain below.
-    const bool chain256 = !(flags & CHOLMOD_HIP_CHAIN64) ;
+    // closes the outer block column.  Opt-in (CHOLMOD_HIP_CHAIN256): measured no faster than the 64-column chain below, see DESIGN.md section 4.
+    const bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 ;
     if (chain256)
     {
         const int SB = DG_W ;

@@ -2070,13 +2070,12 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
     }
 }
 
-// ---- the panel chain in 256-column sub-blocks -------------------------------------------
-// Rounds 1-2 walked a front's outer block column in 64-column steps: dpotrf of the diagonal
-// block, dtrsm of ALL rows below, the K = 64 ... 256 doubling updates -- about fifteen dependent
-// launches of 15-30 us per 512 columns whose arithmetic is microseconds (the nd24k stand-in
-// spent 16 of its 30 ms there, Poisson 100^3 43 of 150).  Here the chain advances 256 columns
-// per pair of launches (reference steps: dpotrf t_cholmod_super_numeric.c:864-867, dtrsm
-// :997-1002, applied to a 256-column sub-block):
+// ---- the panel chain in 256-column sub-blocks (opt-in: CHOLMOD_HIP_CHAIN256) ---------------
+// The default chain walks a front's outer block column in 64-column steps: dpotrf of the
+// diagonal block, dtrsm of ALL rows below, the K = 64 ... 256 doubling updates -- about fifteen
+// dependent launches of 15-30 us per 512 columns.  This variant advances 256 columns per pair of
+// launches (reference steps: dpotrf t_cholmod_super_numeric.c:864-867, dtrsm :997-1002, applied
+// to a 256-column sub-block):
 //   k_diag      ONE workgroup per front factors the w x w (w <= 256) diagonal sub-block, left-
 //               looking over 64-column panels: the panel's 64 x 64 diagonal block is updated with
 //               the sub-block's earlier columns on the matrix cores (operands straight from L2
@@ -2087,10 +2086,18 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
 //               at once -- per 64-column panel the rows of L it multiplies with are staged
 //               k-major in LDS (negated), the solved 16 x 16 blocks of X stay in registers in
 //               the A-operand layout (16 x d4 per wave) and feed the later panels' products; the
-//               K < 256 "narrow updates" of the old chain do not exist any more, they are the
+//               K < 256 "narrow updates" of the 64-column chain do not exist here, they are the
 //               left-looking products inside these two kernels.
-// Not-positive-definite protocol as before: the first pivot <= 0 goes to info [front] (1-based,
-// relative to the front), every later column of the front is written as zero.
+// Measured (round 3, MI355X): 2.3x fewer launches (nd24k stand-in 617 -> 273), same parity, but
+// k_diag takes 126 us per full sub-block (four 64-column eliminations at ~11 us, whose column
+// chain of ~250 cycles per column is what any variant waits for, plus the in-block solves) and
+// k_rowsolve 39 us (544 MFMAs per wave, serial on its SIMD): 190 us per 256 columns against
+// ~220 us for the 64-column chain's sixteen launches -- and slower where many fronts share a
+// launch.  Poisson 100^3 156 against 150 ms, nd24k stand-in 32.9 against 29.4, 2D 1259^2 7.7
+// against 5.3.  Kept as an option: a one-workgroup diagonal kernel is what a look-ahead on a
+// CU-masked stream would need.
+// Not-positive-definite protocol as everywhere: the first pivot <= 0 goes to info [front]
+// (1-based, relative to the front), every later column of the front is written as zero.
 #define DG_W 256
 template <typename Tick>
 __device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A, i64 lda, int rowc, int c0, int w, int lr, int lk, Tick)
@@ -2104,18 +2111,19 @@ __device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A,
         int rb = c0 + 16 * jb + lr ; if (rb > w - 1) rb = w - 1 ;
         pb [jb] = A + rb + (i64) lk * lda ;
     }
-    for (int k0 = 0 ; k0 < c0 ; k0 += 8)
+    // (c0 is a multiple of 64: batches of 32 columns, all forty loads of a batch in flight before its MFMAs)
+    for (int k0 = 0 ; k0 < c0 ; k0 += 32)
     {
-        double af [2], bf [2][4] ;
+        double af [8], bf [8][4] ;
 #pragma unroll
-        for (int u = 0 ; u < 2 ; u++)
+        for (int u = 0 ; u < 8 ; u++)
         {
             af [u] = pa [(i64) (k0 + 4 * u) * lda] ;
 #pragma unroll
             for (int jb = 0 ; jb < 4 ; jb++) bf [u][jb] = pb [jb][(i64) (k0 + 4 * u) * lda] ;
         }
 #pragma unroll
-        for (int u = 0 ; u < 2 ; u++)
+        for (int u = 0 ; u < 8 ; u++)
 #pragma unroll
             for (int jb = 0 ; jb < 4 ; jb++)
                 acc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bf [u][jb], af [u], acc [jb], 0, 0, 0) ;
@@ -2284,20 +2292,23 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 #pragma unroll
             for (int jb = 0 ; jb < 4 ; jb++)
             {
-                d4 acc = bj [jb] ;
+                // (four partial sums: a dependent fp64 MFMA costs ~190 cycles, an independent one 64)
+                d4 acc = bj [jb], a1 = (d4) {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1 ;
 #pragma unroll
                 for (int kb = 0 ; kb < 16 ; kb++)
                 {
                     if (kb < 4 * j + jb)
                     {
+                        double b [4] ;
 #pragma unroll
-                        for (int s4 = 0 ; s4 < 4 ; s4++)
-                        {
-                            double b = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, X [kb][s4], acc, 0, 0, 0) ;
-                        }
+                        for (int s4 = 0 ; s4 < 4 ; s4++) b [s4] = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [0], X [kb][0], acc, 0, 0, 0) ;
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [1], X [kb][1], a1, 0, 0, 0) ;
+                        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [2], X [kb][2], a2, 0, 0, 0) ;
+                        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [3], X [kb][3], a3, 0, 0, 0) ;
                     }
                 }
+                acc = (acc + a1) + (a2 + a3) ;
                 d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
 #pragma unroll
                 for (int s4 = 0 ; s4 < 4 ; s4++)

@@ -398,3 +398,41 @@ def test_bench_matrix_file_reader_path():
     d = json.loads(lines[0])
     assert d["data"] == "file" and d["config"]["n"] == 66 and d["value"] > 0
     assert d["residual_2norm"] < 1e-11
+
+
+# ---- the 256-column panel chain (opt-in) ----------------------------------------------------
+
+@pytest.mark.parametrize("name", ["box42_r3_nd", "p3d_64_nd", "p2d_1259_nd"])
+def test_chain256_matches_oracle(name):
+    """CHOLMOD_HIP_CHAIN256 (flag 8192): k_diag factors a front's diagonal blocks 256 columns at a time in
+    one workgroup, k_rowsolve solves every row below them in one launch -- against the oracle."""
+    _compare(name, session_kwargs={"hip_flags": 8192})
+
+
+def test_chain256_dense_front_and_not_posdef():
+    """The same chain on a dense front with ragged sizes against LAPACK, and a failing pivot in the
+    middle of a sub-block (LAPACK's info, zeros behind it)."""
+    import scipy.linalg as sl
+    L = ch.lib()
+    nsrow, nscol = 1900, 777
+    rng = np.random.default_rng(1900)
+    W = rng.standard_normal((nsrow, 48))
+    Fm = W @ W.T
+    Fm[np.diag_indices(nsrow)] += 30.0 + np.arange(nsrow) * 1e-3
+    F = np.asfortranarray(Fm.copy())
+    info = C.c_int64(-1)
+    assert L.cholmod_hip_dense_partial_factor(F.ctypes.data, nsrow, nscol, 8192, C.byref(info)) == 0 and info.value == 0
+    ref = np.linalg.cholesky(Fm[:nscol, :nscol])
+    assert np.linalg.norm(np.tril(F[:nscol, :nscol]) - ref) / np.linalg.norm(ref) < 1e-13
+    L21 = sl.solve_triangular(ref, Fm[nscol:, :nscol].T, lower=True).T
+    assert np.linalg.norm(F[nscol:, :nscol] - L21) / np.linalg.norm(L21) < 1e-12
+    Sc = np.tril(Fm[nscol:, nscol:] - L21 @ L21.T)
+    assert np.linalg.norm(np.tril(F[nscol:, nscol:]) - Sc) / np.linalg.norm(Sc) < 1e-12
+    bad = 333                                    # inside the second sub-block, second panel
+    Fb = Fm.copy()
+    Fb[bad, bad] = -1.0
+    F = np.asfortranarray(Fb.copy())
+    assert L.cholmod_hip_dense_partial_factor(F.ctypes.data, nsrow, nscol, 8192, C.byref(info)) == 0
+    assert info.value == bad + 1
+    assert np.linalg.norm(np.tril(F[:bad, :bad]) - ref[:bad, :bad]) / np.linalg.norm(ref[:bad, :bad]) < 1e-13
+    assert np.all(F[bad:, bad:nscol][np.tril_indices(nsrow - bad, 0, nscol - bad)] == 0)
