@@ -219,7 +219,7 @@ def secondary_line(workload, m, steps=3, warmup=1):
         tf = roof["thin_front_kernel"]
         # the thin configuration is priced against HBM: algorithmic bytes of the whole factorization / time
         if workload == "poisson2d":
-            algo = (roof["extend_add"]["algorithmic_GB"] + tf["algorithmic_GB"]) * 1e9 + 16.0 * stats[5]
+            algo = (roof["extend_add"]["algorithmic_GB"] + tf["algorithmic_GB"]) * 1e9 + 2.0 * stats[5]   # stats[5] = 8 B x entries of L
             out["hbm_roofline"] = {"bound": "hbm", "achieved": algo / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                                    "frac": algo / dt / 8e12,
                                    "algorithmic_bytes": "thin fronts (children in, panel + block out) + extend-add of the generic "

@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""k_update3 (one wave per tile, no LDS) against k_update2: agreement on ragged / triangular /
-assign regions, then TFLOP/s on the shapes of the factorization's update launches."""
+"""k_update3 (one wave per 64 x 64 tile, no LDS) against k_update2, one mode per question asked in round 3:
+  standalone  agreement on ragged / triangular / assign regions, TFLOP/s on the shapes of the update launches
+  big         regions of the size of Poisson 200^3's top fronts (triangular 49 152^2, K = 4096), XCD walk on / off,
+              a real front's odd layout, the MFMA ceiling over 3 s
+  tail        contraction lengths that are no multiple of 4: agreement and rate
+  sustain     the same launch for 0.3 / 1.6 / 4.8 s (is the rate inside a long factorization a power effect?)
+  offset      the operands 0 / 60 / 150 / 240 GB into one allocation (does it matter where a front lives?)
+usage: python tools/upd3.py [mode]      prints one JSON line"""
+import ctypes as C
 import json
 import os
 import sys
@@ -9,12 +16,49 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from suitesparse_amd import cholmod as ch
 
 pr = ch.probes()
-out = {"diff": {}, "TFLOPs": {}}
-for fl in (8192, 16384, 32768):
-    for (m, n, k, tri, asg) in ((64, 64, 64, 0, 0), (200, 130, 67, 0, 0), (333, 333, 129, 1, 0), (1000, 700, 512, 1, 1),
-                                (129, 65, 4, 0, 1), (2049, 2049, 1030, 1, 0), (4096, 4096, 256, 0, 0)):
-        out["diff"][f"f{fl}_{m}x{n}x{k}_tri{tri}_asg{asg}"] = pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, fl)
-for (m, n, k, it) in ((16384, 16384, 4096, 2), (16384, 16384, 1024, 4), (8192, 8192, 512, 8), (8192, 8192, 128, 16), (4096, 4096, 64, 32)):
-    for name, fl in (("update2_64", 0), ("update3_d3", 8192), ("update3_d2", 16384), ("update3_d4", 32768)):
-        out["TFLOPs"][f"{name}_{m}x{n}x{k}"] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
+TRI, NOSWZ, ODD, D2, D3, D4 = 65536, 32, 131072, 16384, 8192, 32768
+mode = sys.argv[1] if len(sys.argv) > 1 else "standalone"
+out = {}
+if mode == "standalone":
+    out = {"diff": {}, "TFLOPs": {}}
+    for fl in (D3, D2, D4):
+        for (m, n, k, tri, asg) in ((64, 64, 64, 0, 0), (200, 130, 67, 0, 0), (333, 333, 129, 1, 0), (1000, 700, 512, 1, 1),
+                                    (129, 65, 4, 0, 1), (2049, 2049, 1030, 1, 0), (4096, 4096, 256, 0, 0)):
+            out["diff"][f"f{fl}_{m}x{n}x{k}_tri{tri}_asg{asg}"] = pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, fl)
+    for (m, n, k, it) in ((16384, 16384, 4096, 2), (16384, 16384, 1024, 4), (8192, 8192, 512, 8), (8192, 8192, 128, 16), (4096, 4096, 64, 32)):
+        for name, fl in (("update2_64", 0), ("update3_d3", D3), ("update3_d2", D2), ("update3_d4", D4)):
+            out["TFLOPs"][f"{name}_{m}x{n}x{k}"] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
+elif mode == "big":
+    for name, (m, n, k, it, fl) in {
+            "u2_sq16k_K4096": (16384, 16384, 4096, 2, 0), "u3_sq16k_K4096": (16384, 16384, 4096, 2, D4),
+            "u2_tri48k_K4096": (49152, 49152, 4096, 1, TRI), "u3_tri48k_K4096": (49152, 49152, 4096, 1, TRI | D4),
+            "u3_tri48k_K4096_noswz": (49152, 49152, 4096, 1, TRI | D4 | NOSWZ),
+            "u3_tri48k_K1024": (49152, 49152, 1024, 2, TRI | D4), "u3_tri48k_K512": (49152, 49152, 512, 2, TRI | D2),
+            "u3_tri24k_K4096": (24576, 24576, 4096, 2, TRI | D4),
+            "u3_tri48k_K4096_oddlayout": (49153, 49153, 4096, 1, TRI | D4 | ODD), "u2_tri48k_K4096_oddlayout": (49153, 49153, 4096, 1, TRI | ODD),
+            "u3_tri48k_K512_oddlayout": (49153, 49153, 512, 2, TRI | D2 | ODD),
+            "u3_tri12k_K4096": (12288, 12288, 4096, 4, TRI | D4), "u3_tri6k_K2048": (6144, 6144, 2048, 8, TRI | D4),
+            "u2_tri6k_K2048": (6144, 6144, 2048, 8, TRI)}.items():
+        out[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
+    o3 = (C.c_double * 3)()
+    r = pr.cholmod_hip_bench_mfma_ceiling(1, 8, int(3.0 * 2.3e9 / (4 * 8 * 64)), 0, o3)
+    out["ceiling_3s_data_acc8_waves1"] = {"TFLOPs": r / 1e12, "clock_GHz": o3[1]}
+elif mode == "tail":
+    out = {"diff": {}, "TFLOPs": {}}
+    for fl in (D2, D4):
+        for (m, n, k, tri, asg) in ((64, 64, 1, 0, 0), (200, 130, 67, 0, 0), (333, 333, 129, 1, 0), (1000, 700, 513, 1, 1), (129, 65, 3, 0, 1),
+                                    (2049, 2049, 1030, 1, 0), (512, 512, 7, 0, 0), (640, 640, 9, 1, 0), (640, 640, 10, 1, 0), (640, 640, 11, 1, 0),
+                                    (640, 640, 17, 0, 0), (640, 640, 23, 0, 0)):
+            out["diff"][f"f{fl}_{m}x{n}x{k}_tri{tri}_asg{asg}"] = pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, fl)
+    for k in (3432, 3433, 1349, 1348):
+        out["TFLOPs"][f"u3_tri24k_K{k}"] = pr.cholmod_hip_bench_update_kernel(24576, 24576, k, 2, TRI | D4) / 1e12
+elif mode == "sustain":
+    for it in (2, 12, 36):
+        out[f"u3_tri48k_K4096_iters{it}"] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, it, TRI | D4) / 1e12
+elif mode == "offset":
+    for gb in ("0", "60", "150", "240"):
+        os.environ["CHOLMOD_PROBE_OFFSET_GB"] = gb
+        out["offset_%sGB" % gb] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, 3, TRI | D4) / 1e12
+else:
+    raise SystemExit(__doc__)
 print(json.dumps(out))
