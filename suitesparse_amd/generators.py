@@ -245,3 +245,26 @@ def sym_matvec(n, Ap, Ai, Ax, stype, x):
     if stype != 0:
         np.add.at(y, cols[off], Ax[off] * x[Ai[off]])
     return y
+
+
+def hermitian_phases(n, Ap, Ai, Ax, seed=0, scale=0.9):
+    """A Hermitian positive definite matrix on the pattern of a real, diagonally dominant SPD one
+    (lower-stored CSC): every off-diagonal entry is turned by a random phase and shrunk, the
+    diagonal keeps dominating.  Returns the complex value array (same Ap, Ai)."""
+    rng = np.random.default_rng(seed)
+    vals = np.asarray(Ax, dtype=np.complex128).copy()
+    cols = np.repeat(np.arange(n), np.diff(Ap))
+    off = np.asarray(Ai) != cols
+    vals[off] *= scale * np.exp(1j * rng.uniform(0, 2 * np.pi, int(off.sum())))
+    return vals
+
+
+def herm_matvec(n, Ap, Ai, Ax, x):
+    """y = A x for a Hermitian matrix given by its lower triangle (CSC)."""
+    cols = np.repeat(np.arange(n), np.diff(Ap))
+    rows = np.asarray(Ai)
+    y = np.zeros(n, dtype=np.complex128)
+    np.add.at(y, rows, Ax * x[cols])
+    off = rows != cols
+    np.add.at(y, cols[off], np.conj(Ax[off]) * x[rows[off]])
+    return y

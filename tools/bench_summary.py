@@ -17,6 +17,11 @@ def show(d, tag=""):
         print("   mfma ceiling %.1f TF, update kernel 16384^2 x 4096: %s" % (d["measured_fp64_mfma_ceiling_TFLOPs"],
               d.get("measured_update_kernel_TFLOPs_16384x16384x4096")))
     for s in d.get("secondary", []):
+        if "complex" in s:
+            print("   secondary", s["workload"][:40], "| real %.2f ms, complex %.2f ms (x%.2f), residuals %.1e / %.1e" % (
+                s["real"]["ms_per_step"], s["complex"]["ms_per_step"], s["complex_over_real_time"],
+                s["real"]["residual_2norm"], s["complex"]["residual_2norm"]))
+            continue
         rr = s.get("roofline") or {}
         print("   secondary", s.get("workload", "?")[:28], "| GF/s %.0f (%.1f %%) ms %.3f api %.3f resid %.1e" % (
             s.get("value", 0), s.get("pct_fp64_mfma_peak", 0), s.get("ms_per_step", 0), s.get("ms_per_step_api", 0),
