@@ -2384,10 +2384,10 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
     { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }
     HIPCHK (hipMemsetAsync (P->d_chk_out, 0, 5 * sizeof (double), P->stream)) ;
-    // (several ranks before a gather: the rank's own fronts only -- the others read as absent)
-    const bool whole = whole_factor (P) != nullptr ;
+    // (several ranks: the complete factor exists only after cholmod_hip_gather_factor)
+    if (!whole_factor (P) || !whole_fronts (P)) return CHOLMOD_HIP_INVALID ;
     hipLaunchKernelGGL (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
-        P->d_chk, whole ? whole_fronts (P) : P->d_fr, whole ? whole_factor (P) : P->d_Lx, P->d_chk_out) ;
+        P->d_chk, whole_fronts (P), whole_factor (P), P->d_chk_out) ;
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;

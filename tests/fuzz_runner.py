@@ -46,7 +46,7 @@ def main():
             n = int(rng.integers(2, 3000)); Ap, Ai, Ax = rand_spd(rng, n, rng.uniform(1.0, 8.0) / n, bool(rng.integers(2)))
         omode = ("natural", "nesdis", "random")[int(rng.integers(3))]
         perm = rng.permutation(n).astype(np.int64) if omode == "random" else None
-        flags = int(rng.choice([0, 0, 0, 64, 128, 16, 2048, 512]))
+        flags = int(rng.choice([0, 0, 0, 64, 128, 16, 2048, 512, 8192, 8192 | 128]))      # (8192: the 256-column panel chain)
         cx = (it % 4 == 3)
         zomplex = cx and bool(rng.integers(2))
         if cx:

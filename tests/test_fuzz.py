@@ -18,6 +18,16 @@ def test_randomised_parity(seed):
     assert "40 cases, 0 failures" in out.stdout, out.stdout[-2000:]
 
 
+@pytest.mark.gpu
+def test_randomised_parity_wave_tile_kernel_everywhere():
+    """The same run with every dense update through k_update3 (CHOLMOD_HIP_UPD3_MIN_TILES=1): ragged tiles,
+    every contraction length, assign-mode blocks."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_runner.py"), "40", "7"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CHOLMOD_HIP_UPD3_MIN_TILES="1"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "40 cases, 0 failures" in out.stdout, out.stdout[-2000:]
+
+
 def test_randomised_parity_cpu_path():
     """The same run through the product's CPU path (Common->useGPU = 0), complex cases included."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_runner.py"), "16", "5"],
