@@ -346,6 +346,19 @@ def test_native_exchange_both_orders_and_subgroups(flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,native", [(3, True), (4, True), (2, False)])
+def test_distributed_with_wave_tile_kernel_on_dealt_tiles(world, native):
+    """The update kernel an 8-GPU run of the headline spends its time in (k_update3, one wave per tile) on
+    the tiles of shared fronts that are DEALT over the ranks of a group (GemmGroup.tile_mul / tile_add):
+    the small test problems never reach its 2048-tile threshold, so CHOLMOD_HIP_UPD3_MIN_TILES=1 sends
+    every region through it."""
+    env = dict(NATIVE if native else {}, CHOLMOD_HIP_UPD3_MIN_TILES="1")
+    res = _run_ranks(world, "gpu", "p3d_48" if world < 4 else "p3d_32", extra_env=env)
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+
+
+@pytest.mark.gpu
 def test_native_exchange_not_posdef_agreement():
     res = _run_ranks(3, "gpu", "p3d_16_notposdef", extra_env=NATIVE)
     for r in res:
