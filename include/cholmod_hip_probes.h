@@ -34,6 +34,10 @@ double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, 
  * max |difference| / max |reference| (negative = a CHOLMOD_HIP_* code). */
 double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, int assign, int flags) ;
 
+/* Tuning probe: per-phase shader cycles of one k_diag workgroup on a w x w sub-block ([0..7]), the launch in ns [8],
+ * k_rowsolve over m rows below it in ns [9]. */
+int cholmod_hip_debug_diag_cycles (long long *out10, int w, int m) ;
+
 /* Tuning probe: per-phase shader cycles of one 64x64 k_potrf launch. */
 int cholmod_hip_debug_potrf_cycles (long long *out8) ;
 /* Same for the matrix-core panel kernels: [0..7] k_potrf_mfma, [8..15] k_trsm_mfma. */

@@ -148,7 +148,7 @@ PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
 PROBE_SYMBOLS = [
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
-    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_debug_update_diff",
+    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
 ]
 
 _lib = None
@@ -275,6 +275,7 @@ def probes():
             ("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mfma_ceiling", dbl, [C.c_int, C.c_int, C.c_int, C.c_int, vp]),
             ("cholmod_hip_debug_update_diff", dbl, [i64, i64, i64, C.c_int, C.c_int, C.c_int]),
+            ("cholmod_hip_debug_diag_cycles", C.c_int, [vp, C.c_int, C.c_int]),
             ("cholmod_hip_debug_potrf_cycles", C.c_int, [vp]),
             ("cholmod_hip_debug_panel_cycles", C.c_int, [vp]),
             ("cholmod_hip_debug_latency", C.c_int, [vp, C.c_int])):

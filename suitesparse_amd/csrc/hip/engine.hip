@@ -1651,7 +1651,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_DIAG:
-            hipLaunchKernelGGL (k_diag, dim3 (L.grid), dim3 (256), 0, st, P->d_dg + L.goff, P->d_Lx, P->d_info, P->d_dinv) ;
+            hipLaunchKernelGGL (k_diag<false>, dim3 (L.grid), dim3 (256), 0, st, P->d_dg + L.goff, P->d_Lx, P->d_info, P->d_dinv, (long long *) nullptr) ;
             break ;
         case K_ROWSOLVE:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }

@@ -2111,7 +2111,8 @@ __device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A,
         int rb = c0 + 16 * jb + lr ; if (rb > w - 1) rb = w - 1 ;
         pb [jb] = A + rb + (i64) lk * lda ;
     }
-    // (c0 is a multiple of 64: batches of 32 columns, all forty loads of a batch in flight before its MFMAs)
+    // (c0 is a multiple of 64: batches of 32 columns, all forty loads of a batch in flight before its MFMAs.
+    // Fetching the next batch under this batch's MFMAs was tried: 160 more registers, spills, 130 -> 219 us.)
     for (int k0 = 0 ; k0 < c0 ; k0 += 32)
     {
         double af [8], bf [8][4] ;
@@ -2130,8 +2131,12 @@ __device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A,
     }
 }
 
-__global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32 *info, double *dinv)
+template <bool TIMED>
+__global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32 *info, double *dinv, long long *tim)
 {
+    long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
+    auto stamp = [&] (int slot) { if constexpr (TIMED) { long long t = __builtin_readcyclecounter () ; tc [slot] += t - t_prev ; t_prev = t ; } } ;
+    if constexpr (TIMED) t_prev = __builtin_readcyclecounter () ;
     __shared__ __attribute__((aligned(16))) double T [PF_NB * PF2_LD] ;     // the panel's 64 x 64 diagonal block, k-major
     __shared__ __attribute__((aligned(16))) double Ls [64 * 64] ;           // -L11 k-major (diagonal positive), identity-padded
     __shared__ __attribute__((aligned(16))) double Wd [4 * 256] ;           // inverses of its four 16 x 16 diagonal blocks
@@ -2171,6 +2176,7 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
                     acc [jb][r] = A [rowc + (i64) col * lda] ;
                 }
             dg_left_looking (acc, A, lda, rowc, c0, w, lr, lk, tick) ;
+            stamp (0) ;
 #pragma unroll
             for (int jb = 0 ; jb < 4 ; jb++)
 #pragma unroll
@@ -2182,7 +2188,9 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
         }
         if (tid == 0) s_fail = -1 ;
         __syncthreads () ;
+        stamp (1) ;
         pf_eliminate (T, (pw + 15) >> 4, &s_fail, tid, tick) ;
+        stamp (2) ;
         const int fail = s_fail ;
         const int nvalid = fail >= 0 ? fail : pw ;
         if (fail >= 0 && tid == 0) info [G.front] = G.col0 + c0 + fail + 1 ;
@@ -2198,9 +2206,11 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
             Ls [k * 64 + i] = v ;
         }
         __syncthreads () ;
+        stamp (3) ;
         trsm_diag_inverses (Ls, 64, Wd, 4, lane, wave, tick) ;
         __syncthreads () ;
         for (int e = tid ; e < 1024 ; e += 256) DI [(c0 >> 6) * 1024 + e] = Wd [e] ;
+        stamp (4) ;
         // ---- the rows of the sub-block below this panel (only behind a full panel)
         for (int rr = c0 + 64 ; rr < w ; rr += 64)
         {
@@ -2213,11 +2223,15 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
 #pragma unroll
                 for (int r = 0 ; r < 4 ; r++) bj [jb][r] = A [rowc + (i64) (c0 + 16 * jb + lk + 4 * r) * lda] ;
             dg_left_looking (bj, A, lda, rowc, c0, w, lr, lk, tick) ;
+            stamp (5) ;
             trsm_solve_rows (bj, 4, Ls, 64, Wd, lane, nvalid, rok, 64, A + rowc + (i64) c0 * lda, lda, tick, xr) ;
+            stamp (6) ;
         }
         if (fail >= 0) dead = true ;
         __syncthreads () ;          // this panel's columns are in Lx for the next panel's products (workgroup scope)
+        stamp (7) ;
     }
+    if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
 #define RS_ROWS 64

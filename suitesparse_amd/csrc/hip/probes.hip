@@ -445,5 +445,58 @@ double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, 
     return df / mx ;
 }
 
+/* Tuning probe: per-phase shader cycles (wave 0) of one k_diag workgroup on a w x w diagonal sub-block:
+ * [0] loads + left-looking update of the panel's diagonal block, [1] into LDS + barrier, [2] the 64 x 64
+ * elimination, [3] store + negated copy + barrier, [4] 16 x 16 inverses + barrier + publish, [5] loads +
+ * left-looking update of the row chunks, [6] their solves, [7] closing barrier; out [8] = whole launch in ns
+ * (HIP events), out [9] = k_rowsolve over `m` rows below the same block in ns. */
+int cholmod_hip_debug_diag_cycles (long long *out10, int w, int m)
+{
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    if (w < 1 || w > DG_W || m < 0) return CHOLMOD_HIP_INVALID ;
+    const int n = w + m ;
+    std::vector<double> A ((size_t) n * w) ;
+    for (int j = 0 ; j < w ; j++) for (int i = 0 ; i < n ; i++) A [i + (size_t) j * n] = (i == j) ? w + 1.0 : 1.0 / (1.0 + abs (i - j) % 61) ;
+    double *d = nullptr, *dinv = nullptr ; i32 *dinfo = nullptr ; long long *dt = nullptr ; DgGroup *dg = nullptr ; RsGroup *rg = nullptr ;
+    HIPCHK (hipMalloc ((void **) &d, A.size () * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &dinv, 4096 * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &dinfo, sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &dt, 8 * sizeof (long long))) ;
+    HIPCHK (hipMalloc ((void **) &dg, sizeof (DgGroup))) ;
+    HIPCHK (hipMalloc ((void **) &rg, sizeof (RsGroup))) ;
+    DgGroup G {0, n, w, 0, 0, 0, 0} ;
+    RsGroup R {0, (i64) w, n, m, w, 0, 0, 0, 0, 0} ;
+    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+    HIPCHK (hipMemcpy (rg, &R, sizeof (R), hipMemcpyHostToDevice)) ;
+    HIPCHK (hipMemset (dinfo, 0, sizeof (i32))) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_rowsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rowsolve_lds_bytes ())) ;
+    hipEvent_t e0, e1, e2 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ; (void) hipEventCreate (&e2) ;
+    float best_d = 1e30f, best_r = 1e30f ;
+    for (int rep = 0 ; rep < 4 ; rep++)
+    {
+        HIPCHK (hipMemcpy (d, A.data (), A.size () * sizeof (double), hipMemcpyHostToDevice)) ;
+        HIPCHK (hipEventRecord (e0, 0)) ;
+        if (rep == 0) hipLaunchKernelGGL (k_diag<true>, dim3 (1), dim3 (256), 0, 0, dg, d, dinfo, dinv, dt) ;
+        else hipLaunchKernelGGL (k_diag<false>, dim3 (1), dim3 (256), 0, 0, dg, d, dinfo, dinv, (long long *) nullptr) ;
+        HIPCHK (hipEventRecord (e1, 0)) ;
+        if (m > 0) hipLaunchKernelGGL (k_rowsolve, dim3 ((m + RS_ROWS - 1) / RS_ROWS), dim3 (256), rowsolve_lds_bytes (), 0, rg, 1, d, dinfo, dinv) ;
+        HIPCHK (hipEventRecord (e2, 0)) ;
+        HIPCHK (hipDeviceSynchronize ()) ;
+        float a = 0, b = 0 ;
+        HIPCHK (hipEventElapsedTime (&a, e0, e1)) ;
+        HIPCHK (hipEventElapsedTime (&b, e1, e2)) ;
+        if (rep > 0) { best_d = std::min (best_d, a) ; best_r = std::min (best_r, b) ; }
+    }
+    HIPCHK (hipMemcpy (out10, dt, 8 * sizeof (long long), hipMemcpyDeviceToHost)) ;
+    out10 [8] = (long long) (best_d * 1e6) ;
+    out10 [9] = (long long) (best_r * 1e6) ;
+    i32 inf = 0 ;
+    HIPCHK (hipMemcpy (&inf, dinfo, sizeof (i32), hipMemcpyDeviceToHost)) ;
+    (void) hipFree (d) ; (void) hipFree (dinv) ; (void) hipFree (dinfo) ; (void) hipFree (dt) ; (void) hipFree (dg) ; (void) hipFree (rg) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ; (void) hipEventDestroy (e2) ;
+    return inf == 0 ? CHOLMOD_HIP_OK : CHOLMOD_HIP_NOT_POSDEF ;
+}
+
 
 } // extern "C"
