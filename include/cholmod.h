@@ -240,6 +240,7 @@ typedef struct cholmod_factor_struct
     size_t hip_apat_nnz ;
     int hip_apat_valid ;
     uint64_t hip_apat_hash2 ;   /* second, independent fingerprint of the same pattern */
+    int hip_is_twin ;           /* this factor IS the real twin of a complex factor (its owner's cx_twin) */
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

@@ -54,6 +54,13 @@ extern "C" {
                                          * factors a diagonal sub-block; k_rowsolve: all rows below it in one launch)
                                          * instead of the 64-column chain (k_potrf_mfma, k_trsm_mfma, k_trsm_upd,
                                          * k_update2f): 2.3x fewer launches, measured 4-12 % slower */
+#define CHOLMOD_HIP_PHI_TWIN    16384    /* the structure is the real twin of a complex factor (every supernode, row and
+                                         * column doubled, host/complex.c; checked at plan creation): the update kernels
+                                         * contract over the even panel columns only and rebuild the 2 x 2 blocks of the
+                                         * embedding in the lanes -- a complex multiply-add as 4 real ones, not 8
+                                         * (reference zherk / zgemm, t_cholmod_super_numeric.c:41-83, :682-717).  Set by
+                                         * cholmod_l_super_numeric for complex / zomplex A; CHOLMOD_HIP_TWIN_FULL_K=1
+                                         * in the environment keeps the plain embedding (A/B timing, tests) */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 

@@ -28,6 +28,9 @@ NATURAL, GIVEN, POSTORDERED = 0, 1, 6
 SIMPLICIAL, AUTO, SUPERNODAL = 0, 1, 2
 SYS_A, SYS_LDLt, SYS_LD, SYS_DLt, SYS_L, SYS_Lt, SYS_D, SYS_P, SYS_Pt = range(9)
 HIP_PLAN_HOST_ONLY = 2
+# plan flags (include/cholmod_hip.h)
+HIP_WIDE_OB, HIP_NO_FUSED_POTRF, HIP_NO_FUSED_TRSM, HIP_PHI_TWIN = 128, 512, 1024, 16384
+HIP_INVALID = -4
 
 
 class Method(C.Structure):
@@ -102,7 +105,7 @@ class Factor(C.Structure):
                 ("dtype", C.c_int), ("useGPU", C.c_int),
                 ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
                 ("cx_twin", C.c_void_p), ("hip_apat_hash", C.c_uint64), ("hip_apat_nnz", C.c_size_t),
-                ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64)]
+                ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64), ("hip_is_twin", C.c_int)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare

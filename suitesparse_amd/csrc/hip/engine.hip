@@ -329,7 +329,20 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
     const char *assign_cb = nullptr)
 {
-    bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 ;
+    // The real twin of a complex factor (phi embedding, host/complex.c): every row / column pair
+    // (2i, 2i+1) is (re, im) of one complex row, the odd columns of a panel are the rotations of the
+    // even ones.  The update kernels then contract over the EVEN columns only -- column stride
+    // 2 nsrow, K / 2 -- and rebuild the 2 x 2 blocks from the four real products in the lanes
+    // (kernels.hip.h: update_tile / update_tile_w, TW): half the flops of the embedding.
+    const bool twin = (flags & CHOLMOD_HIP_PHI_TWIN) != 0 ;
+    bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 && !twin ;
+    auto twin_operands = [] (GemmGroup &G, int origin, int kc)
+    {
+        // (everything is even in a doubled structure; a plan that claims to be a twin and is not
+        // would silently drop a column)
+        if ((origin | kc | G.k | G.m | G.n | G.lda | G.ldc) & 1) { fprintf (stderr, "cholmod_hip: twin plan with an odd region\n") ; abort () ; }
+        G.lda *= 2 ; G.k /= 2 ;
+    } ;
     int maxnscol = 0, maxrows = 0 ;
     for (int q = 0 ; q < nf ; q++)
     {
@@ -429,6 +442,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
         else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
+        if (twin) twin_operands (G, r0, kc) ;
         G.tile_mul = 1 ; G.tile_add = 0 ;
         // first update of a contribution block nobody zeroed: C = -A*B'
         G.assign = (to_cb && kc == 0 && assign_cb && assign_cb [fid]) ? 1 : 0 ;
@@ -542,6 +556,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     G.lda = f.nsrow ; G.ldc = f.nsrow ;
                     G.m = hi - lo ; G.n = x.t1 - c0 ; G.k = x.kk ; G.tri = 0 ; G.front = ids [x.q] ;
                     G.tile_mul = 1 ; G.tile_add = 0 ;
+                    if (twin) twin_operands (G, (lo | c0), x.kc) ;
                     small.push_back (G) ;
                 }
                 continue ;
@@ -1505,6 +1520,7 @@ static int thin_minw (int cls)
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
+    const bool twin = (P->flags & CHOLMOD_HIP_PHI_TWIN) != 0 ;      // update kernels contract over the even columns
     if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     switch (L.kind)
     {
@@ -1647,7 +1663,9 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_SMALL:
-            hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
+            if (twin) hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false, true>), dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            else hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_DIAG:
@@ -1660,11 +1678,18 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_UPD_W:
             // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
-            if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            if (twin)
+            {
+                if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4, true>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+                else hipLaunchKernelGGL ((k_update3<2, true>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            }
+            else if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             else hipLaunchKernelGGL ((k_update3<2>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_PF:
-            hipLaunchKernelGGL (k_update2f, dim3 (L.grid), dim3 (256), 0, st,
+            if (twin) hipLaunchKernelGGL (k_update2f<true>, dim3 (L.grid), dim3 (256), 0, st,
+                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
+            else hipLaunchKernelGGL (k_update2f<false>, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
             break ;
     }
@@ -1937,6 +1962,14 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
     if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
     const double tpc = std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ;
+    if (flags & CHOLMOD_HIP_PHI_TWIN)
+    {
+        // a twin has every supernode boundary and row in (2i, 2i+1) pairs
+        bool ok = (n % 2 == 0) ;
+        for (i64 q = 0 ; ok && q <= nsuper ; q++) ok = (super [q] % 2 == 0) && (pi [q] % 2 == 0) ;
+        for (i64 q = 0 ; ok && q + 1 < pi [nsuper] ; q += 2) ok = (s [q] % 2 == 0) && (s [q + 1] == s [q] + 1) ;
+        if (!ok) { if (status) *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
+    }
     P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
     P->rank = rank ; P->world = world ;
     P->super.assign (super, super + nsuper + 1) ;

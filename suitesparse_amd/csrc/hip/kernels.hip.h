@@ -77,6 +77,7 @@ struct GemmGroup {
 __host__ __device__ __forceinline__ int tri_col (int j, int m) { return j * m - ((j * (j + 1)) >> 1) ; }
 
 typedef double d4 __attribute__((ext_vector_type(4))) ;
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
 
 __device__ __forceinline__ int lower_bound_i32 (const i32 *a, int n, int v)
 {
@@ -1410,10 +1411,21 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
 //  * DB = true double-buffers the LDS slabs (one barrier per slab).
 // One BM x BN tile of an update region (tile row I, tile column J): the whole
 // contraction and the read-modify-write (or assignment) of the target.
-template <int BM, int BN, int BK, bool DB, bool TO_LDS = false>
+//
+// TW ("twin"): the operands are the EVEN columns of a phi-embedded complex panel (rows 2i, 2i+1 =
+// re, im of complex row i; the odd columns are their rotations and are not read: the scheduler
+// hands over lda = 2 nsrow and k = K / 2).  With P = A_even B_even' the full-K update of the
+// embedding is U (2i, 2j) = U (2i+1, 2j+1) = P (2i, 2j) + P (2i+1, 2j+1) and
+// U (2i+1, 2j) = -U (2i, 2j+1) = P (2i+1, 2j) - P (2i, 2j+1) -- a complex multiply-add as four
+// real ones instead of the embedding's eight.  The slab rows are dealt so that fragment a of a
+// wave holds the rows of parity a (position 32 w + 16 a + t <-> row 32 w + 2 t + a, likewise
+// the columns): the four products of one complex entry then sit in the same lane and slot of
+// acc [0..1][0..1] and are combined there; the epilogue stores row pairs.
+template <int BM, int BN, int BK, bool DB, bool TO_LDS = false, bool TW = false>
 __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     double *Lx, double *CB, double *sm)
 {
+    static_assert (!TW || (BM == 64 && BN == 64), "twin tiles are 64 x 64") ;
     constexpr int LDT = BM + 16 ;
     constexpr int LDU = BN + 16 ;
     constexpr int WM = BM / 2, WN = BN / 2 ;
@@ -1431,8 +1443,14 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     // same for every q when BM divides 256, the k offset advances by 256/BM
     const double *pa, *pb ;
     {
-        int i = tid % BM ; if (i > mrem - 1) i = mrem - 1 ;
-        int j = tid % BN ; if (j > nrem - 1) j = nrem - 1 ;
+        int i = tid % BM, j = tid % BN ;
+        if constexpr (TW)
+        {
+            i = (i & 32) + 2 * (i & 15) + ((i >> 4) & 1) ;
+            j = (j & 32) + 2 * (j & 15) + ((j >> 4) & 1) ;
+        }
+        if (i > mrem - 1) i = mrem - 1 ;
+        if (j > nrem - 1) j = nrem - 1 ;
         pa = Lx + G.a_off + row0 + i + (i64) (tid / BM) * lda ;
         pb = Lx + G.b_off + col0 + j + (i64) (tid / BN) * lda ;
     }
@@ -1512,7 +1530,11 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
             for (int b = 0 ; b < TJ ; b++)
 #pragma unroll
                 for (int r = 0 ; r < 4 ; r++)
-                    cv [a][b][r] = C [wm * WM + a * 16 + (lane & 15) + (i64) (wn * WN + b * 16 + (lane >> 4) + 4 * r) * G.ldc] ;
+                {
+                    int i = wm * WM + a * 16 + (lane & 15), j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
+                    if constexpr (TW) { i = wm * WM + 2 * (lane & 15) + a ; j = wn * WN + 2 * ((lane >> 4) + 4 * r) + b ; }
+                    cv [a][b][r] = C [i + (i64) j * G.ldc] ;
+                }
     }
     gload (0) ;
     if constexpr (DB)
@@ -1541,6 +1563,16 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
             compute (0) ;
         }
     }
+    if constexpr (TW)
+    {
+        static_assert (!TW || (TI == 2 && TJ == 2), "one fragment per parity") ;
+#pragma unroll
+        for (int r = 0 ; r < 4 ; r++)
+        {
+            const double ee = acc [0][0][r] + acc [TI - 1][TJ - 1][r], oe = acc [TI - 1][0][r] - acc [0][TJ - 1][r] ;
+            acc [0][0][r] = ee ; acc [TI - 1][TJ - 1][r] = ee ; acc [TI - 1][0][r] = oe ; acc [0][TJ - 1][r] = -oe ;
+        }
+    }
     if constexpr (TO_LDS)
     {
         // k_update2f, a full BM x BN tile on the diagonal: the updated block goes to LDS,
@@ -1556,8 +1588,38 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
                 {
                     int i = wm * WM + a * 16 + (lane & 15) ;
                     int j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
+                    if constexpr (TW) { i = wm * WM + 2 * (lane & 15) + a ; j = wn * WN + 2 * ((lane >> 4) + 4 * r) + b ; }
                     sm [j * BM + i] = (i >= j) ? cv [a][b][r] - acc [a][b][r] : 0.0 ;
                 }
+        return ;
+    }
+    if constexpr (TW)
+    {
+        // row pairs (2 t, 2 t + 1) of a column: one 16-byte read-modify-write (m, n and the
+        // region's origin are even: a pair lies inside the region or outside it)
+#pragma unroll
+        for (int b = 0 ; b < TJ ; b++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                const int i = wm * WM + 2 * (lane & 15) ;
+                const int j = wn * WN + 2 * ((lane >> 4) + 4 * r) + b ;
+                if (i >= mrem || j >= nrem) continue ;
+                const bool both = !G.tri || row0 + i >= col0 + j ;
+                const bool second = G.tri && row0 + i + 1 == col0 + j ;
+                double *Cj = C + i + (i64) j * G.ldc ;
+                if (both)
+                {
+                    d2u v ;
+                    if (G.assign) { v.x = -acc [0][b][r] ; v.y = -acc [1][b][r] ; }
+                    else { v = *(const d2u *) Cj ; v.x -= acc [0][b][r] ; v.y -= acc [1][b][r] ; }
+                    *(d2u *) Cj = v ;
+                }
+                else if (second)
+                {
+                    if (G.assign) Cj [1] = -acc [1][b][r] ; else Cj [1] -= acc [1][b][r] ;
+                }
+            }
         return ;
     }
 #pragma unroll
@@ -1577,7 +1639,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
             }
 }
 
-template <int BM, int BN, int BK, int MINW, bool DB>
+template <int BM, int BN, int BK, int MINW, bool DB, bool TW = false>
 __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int ng,
     double *Lx, double *CB)
 {
@@ -1587,7 +1649,7 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
     int I, J ;
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
-    update_tile<BM, BN, BK, DB> (G, I, J, Lx, CB, sm) ;
+    update_tile<BM, BN, BK, DB, false, TW> (G, I, J, Lx, CB, sm) ;
 }
 
 // ---- dense update, third generation: one wave = one tile, no LDS, no barrier --------
@@ -1612,8 +1674,10 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 //     i.e. >= 3000 cycles, before their MFMAs), two waves per SIMD cover the rest.
 // Partial tiles (EDGE) use 8-byte loads with clamped rows; a K that is no multiple of 4 ends
 // with one masked k-step in either path.
-typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
-template <int DEPTH, bool EDGE>
+// TW: the even columns of a phi-embedded complex panel (see update_tile): the row / column pairs a
+// lane loads ARE the (re, im) pairs, fragment parity = row parity, so the four real products of a
+// complex entry are acc [2 q + {0,1}][2 p + {0,1}][r] of one lane and are combined in place.
+template <int DEPTH, bool EDGE, bool TW = false>
 __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4 ;
@@ -1735,6 +1799,21 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
             if (d < DEPTH - 1 && s + DEPTH + d < nsteps) load_any (f [d], s + DEPTH + d) ;
         }
     }
+    if constexpr (TW)
+    {
+#pragma unroll
+        for (int q = 0 ; q < 2 ; q++)
+#pragma unroll
+            for (int p = 0 ; p < 2 ; p++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    const double ee = acc [2 * q][2 * p][r] + acc [2 * q + 1][2 * p + 1][r] ;
+                    const double oe = acc [2 * q + 1][2 * p][r] - acc [2 * q][2 * p + 1][r] ;
+                    acc [2 * q][2 * p][r] = ee ; acc [2 * q + 1][2 * p + 1][r] = ee ;
+                    acc [2 * q + 1][2 * p][r] = oe ; acc [2 * q][2 * p + 1][r] = -oe ;
+                }
+    }
     // epilogue: acc [a][b][r] of lane (lr, lk) is C (row 32 (a >> 1) + 2 lr + (a & 1),
     // column 32 (b >> 1) + 2 (lk + 4 r) + (b & 1))
     double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
@@ -1776,7 +1855,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         }
 }
 
-template <int DEPTH>
+template <int DEPTH, bool TW = false>
 __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
@@ -1784,8 +1863,8 @@ __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, 
     int I, J ;
     if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
-    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false> (G, I, J, Lx, CB) ;
-    else update_tile_w<DEPTH, true> (G, I, J, Lx, CB) ;
+    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
+    else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
 }
 
 // ---- trailing update that also factors the next diagonal block ------------------
@@ -1796,6 +1875,7 @@ __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, 
 // tiles -- one launch of ~17 us less per 64 columns of the chain (potrf -> trsm -> update,
 // ~43 us per step, is half the time of a mid-size factorization).  Everything else in
 // the launch is k_update2<64,64,16,2,false>.
+template <bool TW>
 __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng,
     double *Lx, double *CB, i32 *info)
 {
@@ -1809,11 +1889,11 @@ __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng
     if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
     if (!(G.pf_next && I == 0 && J == 0))
     {
-        update_tile<64, 64, 16, false> (G, I, J, Lx, CB, sm) ;
+        update_tile<64, 64, 16, false, false, TW> (G, I, J, Lx, CB, sm) ;
         return ;
     }
     __builtin_amdgcn_s_setprio (3) ;
-    update_tile<64, 64, 16, false, true> (G, 0, 0, Lx, CB, sm) ;
+    update_tile<64, 64, 16, false, true, TW> (G, 0, 0, Lx, CB, sm) ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
     if (tid == 0) s_fail = -1 ;
     __syncthreads () ;

@@ -70,6 +70,7 @@ cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common)
         Tpx [s] = (Lpx [0] == 123456) ? Lpx [s] : 4 * Lpx [s] ;
     }
     for (size_t p = 0 ; p < L->ssize ; p++) { Ts [2*p] = 2 * Ls [p] ; Ts [2*p+1] = 2 * Ls [p] + 1 ; }
+    T->hip_is_twin = TRUE ;
     L->cx_twin = T ;
     return T ;
 }

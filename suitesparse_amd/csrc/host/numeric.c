@@ -103,8 +103,17 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
     if (L->hip_plan) return TRUE ;
     int st = 0 ;
     int world = Common->hip_world > 1 ? Common->hip_world : 1 ;
+    int flags = Common->hip_flags ;
+    /* the real twin of a complex factor (complex.c): the update kernels contract over the even
+     * panel columns only -- the complex multiply-add as four real ones (zherk / zgemm,
+     * t_cholmod_super_numeric.c:41-83) instead of the eight of the plain embedding */
+    if (L->hip_is_twin)
+    {
+        const char *e = getenv ("CHOLMOD_HIP_TWIN_FULL_K") ;
+        if (!(e && atoi (e) != 0)) flags |= CHOLMOD_HIP_PHI_TWIN ;
+    }
     cholmod_hip_plan *P = cholmod_hip_plan_create_dist ((int64_t) L->n, (int64_t) L->nsuper,
-        L->super, L->pi, L->px, L->s, Common->hip_flags, world > 1 ? Common->hip_rank : 0, world, &st) ;
+        L->super, L->pi, L->px, L->s, flags, world > 1 ? Common->hip_rank : 0, world, &st) ;
     if (!P) return map_hip_status (st ? st : CHOLMOD_HIP_GPU_PROBLEM, Common, "HIP plan creation failed") ;
     /* (several ranks need an exchange: the Common->hip_allreduce callback, or the
      * native RCCL path attached to L->hip_plan with cholmod_hip_rccl_attach after

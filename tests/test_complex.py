@@ -296,3 +296,81 @@ def test_complex_gpu_not_posdef_protocol(quick):
 @pytest.mark.gpu
 def test_real_factor_complex_rhs_gpu():
     _check_real_factor_complex_rhs(1)
+
+
+# ---- the twin's update kernels: even-column contraction (CHOLMOD_HIP_PHI_TWIN) ------------------
+# A complex multiply-add as four real ones (zherk / zgemm, t_cholmod_super_numeric.c:41-83,
+# :682-717): the update kernels read the even columns of the embedded panels only and rebuild
+# the 2 x 2 blocks in the lanes.  Every kernel that carries the variant, against the oracle's
+# complex template, and the plain embedding (CHOLMOD_HIP_TWIN_FULL_K) beside it.
+
+def test_twin_flag_is_checked_at_plan_creation():
+    """A plan that claims the doubled structure of a twin and does not have it is refused
+    (host-only plan: no device needed)."""
+    lib = ch.lib()
+    n, Ap, Ai, Ax = G.poisson3d(5)
+    O = OracleFactor(n, Ap, Ai, -1, perm=None, postorder=True)
+    sup, pi, px, s = (np.ascontiguousarray(getattr(O, k), dtype=np.int64) for k in ("super", "pi", "px", "s"))
+    st = C.c_int(0)
+    args = (n, len(sup) - 1, sup.ctypes.data_as(C.c_void_p), pi.ctypes.data_as(C.c_void_p),
+            px.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+    P = lib.cholmod_hip_plan_create(*args, ch.HIP_PLAN_HOST_ONLY | ch.HIP_PHI_TWIN, C.byref(st))
+    assert not P and st.value == ch.HIP_INVALID
+    # the doubled structure passes
+    sup2, pi2, px2 = 2 * sup, 2 * pi, 4 * px
+    s2 = np.empty(2 * len(s), dtype=np.int64)
+    s2[0::2] = 2 * s
+    s2[1::2] = 2 * s + 1
+    args2 = (2 * n, len(sup) - 1, sup2.ctypes.data_as(C.c_void_p), pi2.ctypes.data_as(C.c_void_p),
+             px2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p))
+    P = lib.cholmod_hip_plan_create(*args2, ch.HIP_PLAN_HOST_ONLY | ch.HIP_PHI_TWIN, C.byref(st))
+    assert P and st.value == 0
+    lib.cholmod_hip_plan_destroy(P)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["full_k", "wave_tiles_everywhere", "four_wave_tiles_only", "no_fused_potrf", "wide_ob"])
+@pytest.mark.parametrize("name", ["p3d_24_nd", "box16r2_nd"])
+def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, variant):
+    assert ch.lib().cholmod_hip_probe() == 1, "no HIP device visible"
+    kw = {}
+    if variant == "full_k":
+        monkeypatch.setenv("CHOLMOD_HIP_TWIN_FULL_K", "1")
+    elif variant == "wave_tiles_everywhere":
+        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "1")       # k_update3<.., TW> incl. partial tiles
+    elif variant == "four_wave_tiles_only":
+        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "0")       # k_update2<.., TW> / k_update2f<TW> only
+    elif variant == "no_fused_potrf":
+        kw["hip_flags"] = ch.HIP_NO_FUSED_POTRF
+    elif variant == "wide_ob":
+        kw["hip_flags"] = ch.HIP_WIDE_OB
+    _check(name, golden_dir, use_gpu=1, dense_check=False, session_kwargs=kw)
+
+
+@pytest.mark.gpu
+def test_complex_gpu_big_fronts_even_column_updates(monkeypatch):
+    """A complex problem whose top fronts reach the one-wave-per-tile update kernel by themselves
+    (twin root of 2 x 1600 columns), by residual, factor invariants and against the plain embedding."""
+    m = 40
+    n, Ap, Ai, Ax = G.poisson3d(m)
+    perm = G.geometric_nd(m, m, m, 4)
+    cAp, cAi, cAx = hermitian_from(n, Ap, Ai, Ax)
+    Af = full_hermitian(n, cAp, cAi, cAx)
+    b = np.exp(1j * np.arange(n))
+    xs = {}
+    for full_k in (False, True):
+        if full_k:
+            monkeypatch.setenv("CHOLMOD_HIP_TWIN_FULL_K", "1")
+        S = ch.Session(use_gpu=1)
+        A = S.sparse(n, cAp, cAi, cAx, -1)
+        Lf = S.analyze(A, perm)
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        assert S.L.cholmod_l_check_factor(Lf, C.byref(S.cm)) == 1
+        fv = ch.FactorView(Lf)
+        xs[full_k] = fv.x.copy()
+        x = S.solve(Lf, b)
+        assert np.linalg.norm(Af @ x - b) / np.linalg.norm(b) < TOL_RES
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+    assert np.linalg.norm(xs[False] - xs[True]) / np.linalg.norm(xs[True]) < TOL_L
