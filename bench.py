@@ -235,19 +235,23 @@ def secondary_line(workload, m, steps=3, warmup=1):
 
 def complex_line(m=64, steps=3):
     """Complex (Hermitian positive definite) input through the same calls: Poisson m^3's pattern with random
-    phases on the off-diagonals.  The engine factors the real twin [re -im; im re] of the doubled structure
-    (DESIGN 7e); its update kernels contract over the even panel columns only (a complex multiply-add as four
-    real ones, plan flag CHOLMOD_HIP_PHI_TWIN).  Beside it the plain embedding (all columns: eight real
-    multiply-adds, CHOLMOD_HIP_TWIN_FULL_K=1) and the real factorization of the same pattern."""
+    phases on the off-diagonals.  The engine computes on the index space of the real twin [re -im; im re]
+     and keeps the factor in complex storage (the even twin columns only = the interleaved complex
+    factor, 2 xsize doubles; CHOLMOD_HIP_CX_STORAGE); its update kernels contract over the even panel columns
+    (a complex multiply-add as four real ones).  Beside it the full twin with the same update kernels
+    (CHOLMOD_HIP_CX_TWIN=1, 4 xsize doubles), the plain embedding (eight real multiply-adds,
+    CHOLMOD_HIP_TWIN_FULL_K=1) and the real factorization of the same pattern."""
     from suitesparse_amd import cholmod as ch
     from suitesparse_amd import generators as G
     n, Ap, Ai, Ax = G.poisson3d(m)
     perm = G.geometric_nd(m, m, m, 4)
     Az = G.hermitian_phases(n, Ap, Ai, Ax, seed=m)
     out = {"workload": f"hermitian_poisson3d_{m}^3_geometricND_leaf4 (complex input)", "n": int(n)}
-    for tag, vals in (("real", Ax), ("complex", Az), ("complex_plain_embedding", Az)):
+    for tag, vals in (("real", Ax), ("complex", Az), ("complex_full_twin", Az), ("complex_plain_embedding", Az)):
         if tag == "complex_plain_embedding":
             os.environ["CHOLMOD_HIP_TWIN_FULL_K"] = "1"
+        if tag == "complex_full_twin":
+            os.environ["CHOLMOD_HIP_CX_TWIN"] = "1"
         try:
             S = ch.Session(factor_on_device=True, ordering="default")
             A = S.sparse(n, Ap, Ai, vals, -1)
@@ -268,15 +272,23 @@ def complex_line(m=64, steps=3):
             if cx:
                 # a complex multiply-add = 4 real ones = 8 flop: the complex factorization is 4 fl
                 out[tag]["TFLOPs_on_4fl"] = 4.0 * fl / dt / 1e12
+                T = C.cast(Lf.contents.cx_twin, C.POINTER(ch.Factor))
+                st = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+                S.L.cholmod_hip_get_stats(T.contents.hip_plan, st.ctypes.data)
+                out[tag]["factor_GB_in_HBM"] = st[5] / 1e9
+                out[tag]["arena_GB"] = st[4] / 1e9
             S.free_factor(Lf)
             S.free_sparse(A)
             S.finish()
         finally:
             os.environ.pop("CHOLMOD_HIP_TWIN_FULL_K", None)
+            os.environ.pop("CHOLMOD_HIP_CX_TWIN", None)
     out["complex_over_real_time"] = out["complex"]["ms_per_step"] / out["real"]["ms_per_step"]
-    out["even_columns_over_plain_embedding_time"] = out["complex"]["ms_per_step"] / out["complex_plain_embedding"]["ms_per_step"]
+    out["complex_storage_over_plain_embedding_time"] = out["complex"]["ms_per_step"] / out["complex_plain_embedding"]["ms_per_step"]
+    out["full_twin_over_plain_embedding_time"] = out["complex_full_twin"]["ms_per_step"] / out["complex_plain_embedding"]["ms_per_step"]
     out["note"] = ("a complex multiply-add is 4 real ones: zherk / zgemm cost 4x the real update flops of the same pattern (what the "
-                   "even-column update kernels execute), the plain embedding 8x; panel chain, extend-add and storage are those of the twin")
+                   "even-column update kernels execute), the plain embedding 8x; complex storage = the reference's interleaved L->x in "
+                   "HBM (half the twin's bytes in L, contribution blocks and extend-add); the panel chain runs on the twin's index space")
     return out
 
 

@@ -240,7 +240,9 @@ typedef struct cholmod_factor_struct
     size_t hip_apat_nnz ;
     int hip_apat_valid ;
     uint64_t hip_apat_hash2 ;   /* second, independent fingerprint of the same pattern */
-    int hip_is_twin ;           /* this factor IS the real twin of a complex factor (its owner's cx_twin) */
+    int hip_is_twin ;           /* this factor IS the real twin of a complex factor (its owner's cx_twin): 1 = the
+                                 * full twin (x: 4 xsize doubles), 2 = engine-only, complex storage (px = 2 x the
+                                 * complex px; CHOLMOD_HIP_CX_STORAGE) */
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

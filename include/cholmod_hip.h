@@ -61,6 +61,15 @@ extern "C" {
                                          * (reference zherk / zgemm, t_cholmod_super_numeric.c:41-83, :682-717).  Set by
                                          * cholmod_l_super_numeric for complex / zomplex A; CHOLMOD_HIP_TWIN_FULL_K=1
                                          * in the environment keeps the plain embedding (A/B timing, tests) */
+#define CHOLMOD_HIP_CX_STORAGE   32768    /* a complex factor in its own storage: super / pi / s are those of the twin (as
+                                         * CHOLMOD_HIP_PHI_TWIN, implied), px [s] = 2 x the complex factor's px [s]: of
+                                         * every front only the even twin columns exist -- nsrow_twin x nscol_twin / 2
+                                         * doubles, i.e. the interleaved complex panel of the reference's L->x
+                                         * (t_cholmod_super_numeric.c:41-83, L_ENTRY 2): 2 xsize doubles of HBM instead of
+                                         * the twin's 4 xsize, contribution blocks likewise.  Kernels rebuild the odd
+                                         * columns (rotations of the even ones) on the way into LDS / registers.  One
+                                         * rank, generic kernels only (no thin-front kernels).  cholmod_hip_download_factor
+                                         * then returns the complex factor itself */
 #define CHOLMOD_HIP_PLAN_HOST_ONLY 2    /* build the schedule only, touch no device
                                            (CPU-side tests of the host logic)       */
 
@@ -262,6 +271,9 @@ int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int
  * [2] children, [3] panel chain, [4] publish + row solves, [5] store + barrier,
  * [6] trailing update / contribution block. */
 int cholmod_hip_debug_thin_cycles (cholmod_hip_plan *plan, int64_t launch, long long *out10) ;
+/* tuning: the update regions of one update launch, 12 numbers each (m, n, k, tri, c_in_cb, lda,
+ * ldc, ntiles, nblk, front, assign, swz); returns the number of regions (tools/launch_profile.py) */
+int64_t cholmod_hip_debug_launch_regions (cholmod_hip_plan *plan, int64_t launch, int64_t cap, int64_t *out) ;
 
 /* Test hook: run the engine's dense partial factorization on ONE dense front
  * given on the host (column-major nsrow-by-nsrow, lower; the first nscol

@@ -142,7 +142,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     
     
-    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles",
+    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles", "cholmod_hip_debug_launch_regions",
     "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach", "cholmod_hip_rccl_detach",
     "cholmod_hip_version",
 ]
@@ -253,6 +253,7 @@ def lib():
     sig("cholmod_hip_factor_checks", C.c_int, [vp, vp])
     sig("cholmod_hip_get_launch_profile", i64, [vp, i64, vp, vp, vp, vp, vp, vp])
     sig("cholmod_hip_debug_thin_cycles", C.c_int, [vp, i64, vp])
+    sig("cholmod_hip_debug_launch_regions", i64, [vp, i64, i64, vp])
     sig("cholmod_hip_rccl_unique_id", C.c_int, [vp])
     sig("cholmod_hip_rccl_attach", C.c_int, [vp, vp])
     sig("cholmod_hip_rccl_detach", C.c_int, [vp])

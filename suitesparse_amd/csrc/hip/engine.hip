@@ -209,6 +209,9 @@ static RcclApi *rccl_api ()
     return &api ;
 }
 }
+#define COMMA ,
+// (solves, checks) K<true> for a complex factor in its own storage; needs `cxs` in scope
+#define CXS_LAUNCH(K, ...) do { if (cxs) hipLaunchKernelGGL (K<true>, __VA_ARGS__) ; else hipLaunchKernelGGL (K<false>, __VA_ARGS__) ; } while (0)
 #define RCCLCHK(call) do { ncclResult_t r_ = (call) ; if (r_ != ncclSuccess) { \
     fprintf (stderr, "cholmod_hip: %s failed: %s (%s:%d)\n", #call, \
         (rccl_api () && rccl_api ()->GetErrorString) ? rccl_api ()->GetErrorString (r_) : "?", __FILE__, __LINE__) ; \
@@ -334,14 +337,21 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // even ones.  The update kernels then contract over the EVEN columns only -- column stride
     // 2 nsrow, K / 2 -- and rebuild the 2 x 2 blocks from the four real products in the lanes
     // (kernels.hip.h: update_tile / update_tile_w, TW): half the flops of the embedding.
-    const bool twin = (flags & CHOLMOD_HIP_PHI_TWIN) != 0 ;
+    // A complex factor in its own storage (CHOLMOD_HIP_CX_STORAGE; kernels.hip.h: ldcx / stcx): the
+    // index space is still the twin's, but only its even columns exist -- column c of a front or
+    // of a contribution block lives at (c >> 1) ld, the panels ARE their even columns (operand
+    // stride ld, K / 2 contraction steps).
+    const bool cx = (flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
+    const bool twin = (flags & CHOLMOD_HIP_PHI_TWIN) != 0 || cx ;
     bool use_big = (flags & CHOLMOD_HIP_TILE128) != 0 && !twin ;
-    auto twin_operands = [] (GemmGroup &G, int origin, int kc)
+    auto co = [cx] (int c, i64 ld) -> i64 { return cx ? (i64) (c >> 1) * ld : (i64) c * ld ; } ;
+    auto twin_operands = [cx] (GemmGroup &G, int origin, int kc)
     {
         // (everything is even in a doubled structure; a plan that claims to be a twin and is not
         // would silently drop a column)
         if ((origin | kc | G.k | G.m | G.n | G.lda | G.ldc) & 1) { fprintf (stderr, "cholmod_hip: twin plan with an odd region\n") ; abort () ; }
-        G.lda *= 2 ; G.k /= 2 ;
+        if (!cx) G.lda *= 2 ;
+        G.k /= 2 ;
     } ;
     int maxnscol = 0, maxrows = 0 ;
     for (int q = 0 ; q < nf ; q++)
@@ -388,8 +398,20 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             int T = pass ? SMALL : BIG ;
             Launch L {pass == 3 ? K_UPD_W : pass == 2 ? K_UPD_PF : pass ? K_UPD_SMALL : K_UPD_BIG, 0, (int) v.size (), S.gg.size (), 0, 0} ;
             i64 tiles = 0 ;
+            // tuning (CHOLMOD_HIP_UPDW_ONE_REGION=1): every region of a k_update3 launch as a launch of
+            // its own, so that tools/launch_profile.py times the regions one by one
+            static const bool one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
+            auto close_launch = [&] ()
+            {
+                L.ng = (int) (S.gg.size () - L.goff) ;
+                L.grid = (int) tiles ;
+                if (L.ng) S.launches.push_back (L) ;
+                L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
+                tiles = 0 ;
+            } ;
             for (auto &G : v)
             {
+                if (one_region && pass == 3 && S.gg.size () > L.goff) close_launch () ;
                 G.mt = (G.m + T - 1) / T ; G.nt = (G.n + T - 1) / T ;
                 i64 cnt = G.tri ? (i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt
                                 : (i64) G.mt * G.nt ;
@@ -419,9 +441,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 L.bytes += ((G.assign ? 8.0 : 16.0) * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
                 S.gg.push_back (G) ;
             }
-            L.ng = (int) (S.gg.size () - L.goff) ;
-            L.grid = (int) tiles ;
-            if (L.ng) S.launches.push_back (L) ;
+            close_launch () ;
             v.clear () ;
         }
     } ;
@@ -436,11 +456,11 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (m <= 0 || ncols <= 0 || kk <= 0) return ;
         GemmGroup G ;
         memset (&G, 0, sizeof (G)) ;
-        G.a_off = f.psx + r0 + (i64) kc * f.nsrow ;
+        G.a_off = f.psx + r0 + co (kc, f.nsrow) ;
         G.b_off = G.a_off ;
         G.lda = f.nsrow ;
         if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
-        else { G.c_off = f.psx + r0 + (i64) r0 * f.nsrow ; G.ldc = f.nsrow ; }
+        else { G.c_off = f.psx + r0 + co (r0, f.nsrow) ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
         if (twin) twin_operands (G, r0, kc) ;
         G.tile_mul = 1 ; G.tile_add = 0 ;
@@ -466,7 +486,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the chip busy.  early [q] = block column of front q already summed this way.
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
-    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !(flags & CHOLMOD_HIP_CHAIN256) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
+    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !((flags & CHOLMOD_HIP_CHAIN256) && !cx) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks
@@ -550,9 +570,9 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 {
                     GemmGroup G ;
                     memset (&G, 0, sizeof (G)) ;
-                    G.a_off = f.psx + lo + (i64) x.kc * f.nsrow ;
-                    G.b_off = f.psx + c0 + (i64) x.kc * f.nsrow ;
-                    G.c_off = f.psx + lo + (i64) c0 * f.nsrow ;
+                    G.a_off = f.psx + lo + co (x.kc, f.nsrow) ;
+                    G.b_off = f.psx + c0 + co (x.kc, f.nsrow) ;
+                    G.c_off = f.psx + lo + co (c0, f.nsrow) ;
                     G.lda = f.nsrow ; G.ldc = f.nsrow ;
                     G.m = hi - lo ; G.n = x.t1 - c0 ; G.k = x.kk ; G.tri = 0 ; G.front = ids [x.q] ;
                     G.tile_mul = 1 ; G.tile_add = 0 ;
@@ -580,7 +600,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // column, as before over 64-column steps -- with e sub-blocks done and p the largest power of
     // two dividing e, the last p sub-blocks (K = 256 p) update the next p; the K = OB update
     // closes the outer block column.  Opt-in (CHOLMOD_HIP_CHAIN256): measured no faster than the 64-column chain below, see DESIGN.md section 4.
-    const bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 ;
+    const bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 && !cx ;
     if (chain256)
     {
         const int SB = DG_W ;
@@ -688,7 +708,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             if (f.nscol <= i0) continue ;
             if (pf_done [q] == i0) continue ;       // factored by the update that preceded it
             int nb = std::min (NB, f.nscol - i0) ;
-            PfGroup G {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, nb, ids [q], i0} ;
+            PfGroup G {f.psx + i0 + co (i0, f.nsrow), f.nsrow, nb, ids [q], i0} ;
             S.pg.push_back (G) ;
             Lp.flops += (double) nb * nb * nb / 3.0 ;
         }
@@ -714,8 +734,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 int e = (i0 - o0) / NB + 1 ;
                 if ((e & -e) != 1) continue ;               // p = 1 steps only
                 int m = f.nsrow - (i0 + NB) ;
-                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
-                           f.psx + (i0 + NB) + (i64) i0 * f.nsrow, f.nsrow, m, NB,
+                TrGroup G {f.psx + i0 + co (i0, f.nsrow),
+                           f.psx + (i0 + NB) + co (i0, f.nsrow), f.nsrow, m, NB,
                            ids [q], i0, fblocks} ;
                 fblocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
                 S.tg.push_back (G) ;
@@ -750,8 +770,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             {
                 int m = hi [part] - lo [part] ;
                 if (m <= 0) continue ;
-                TrGroup G {f.psx + i0 + (i64) i0 * f.nsrow,
-                           f.psx + lo [part] + (i64) i0 * f.nsrow, f.nsrow, m, nb,
+                TrGroup G {f.psx + i0 + co (i0, f.nsrow),
+                           f.psx + lo [part] + co (i0, f.nsrow), f.nsrow, m, nb,
                            ids [q], i0, blocks} ;
                 blocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
                 S.tg.push_back (G) ;
@@ -1036,9 +1056,11 @@ static int build_host (cholmod_hip_plan *P)
         FrontD &f = P->fr [s] ;
         f.cbp = (!(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX && !(P->owner [s] < 0)) ? 1 : 0 ;
     }
+    const bool cx_storage = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
     auto cb_len = [&] (const FrontD &f) -> i64
     {
-        return f.cbp ? (i64) f.ncb * (f.ncb + 1) / 2 : (i64) f.ncb * f.ncb ;
+        // (a complex front in its own storage: the even columns of the twin's square)
+        return f.cbp ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
     } ;
     // this rank's view of the child lists: a shared parent pulls only the
     // contribution blocks this rank computed (its own subtrees and its partial
@@ -1315,8 +1337,8 @@ static int build_host (cholmod_hip_plan *P)
         {
             const FrontD &f = P->fr [ids [q]] ;
             if (f.ncb == 0 || P->assign_cb [ids [q]]) continue ;
-            S.zg.push_back (ZeroGroup {f.cb, (i64) f.ncb, blocks, 0}) ;
-            blocks += (f.ncb + ZERO_COLS - 1) / ZERO_COLS ;
+            S.zg.push_back (ZeroGroup {f.cb, (i64) f.ncb, blocks, (P->flags & CHOLMOD_HIP_CX_STORAGE) ? 1 : 0}) ;
+            blocks += (((P->flags & CHOLMOD_HIP_CX_STORAGE) ? f.ncb / 2 : f.ncb) + ZERO_COLS - 1) / ZERO_COLS ;
             Lz.bytes += 4.0 * (double) f.ncb * f.ncb ;
         }
         Lz.ng = (int) (S.zg.size () - Lz.goff) ; Lz.grid = blocks ;
@@ -1487,9 +1509,11 @@ static int raise_lds_limits ()
 {
     static bool done = false ;
     if (done) return CHOLMOD_HIP_OK ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_rowsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rowsolve_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
@@ -1520,7 +1544,13 @@ static int thin_minw (int cls)
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
-    const bool twin = (P->flags & CHOLMOD_HIP_PHI_TWIN) != 0 ;      // update kernels contract over the even columns
+    const bool cx = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;      // a complex factor in its own storage (kernels.hip.h: ldcx / stcx)
+    const bool twin = !cx && (P->flags & CHOLMOD_HIP_PHI_TWIN) != 0 ;      // update kernels contract over the even columns
+// K<true> for a complex factor in its own storage, K<false> otherwise
+#define CX_LAUNCH(K, ...) do { if (cx) hipLaunchKernelGGL (K<true>, __VA_ARGS__) ; else hipLaunchKernelGGL (K<false>, __VA_ARGS__) ; } while (0)
+// the update kernels: 0 real, 1 twin (even-column contraction), 2 complex storage
+#define TW_LAUNCH(KA, KB, ...) do { if (cx) hipLaunchKernelGGL ((KA 2 KB), __VA_ARGS__) ; else if (twin) hipLaunchKernelGGL ((KA 1 KB), __VA_ARGS__) ; \
+                                    else hipLaunchKernelGGL ((KA 0 KB), __VA_ARGS__) ; } while (0)
     if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     switch (L.kind)
     {
@@ -1642,20 +1672,24 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
         case K_EA:
-            hipLaunchKernelGGL (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
+            CX_LAUNCH (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb, L.aux > 0 ? L.aux : EA_TW) ; break ;
         case K_POTRF:
-            hipLaunchKernelGGL (k_potrf_mfma<false>, dim3 (L.grid), dim3 (256), 0, st,
+            if (cx) hipLaunchKernelGGL ((k_potrf_mfma<false, true>), dim3 (L.grid), dim3 (256), 0, st,
+                P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
+            else hipLaunchKernelGGL ((k_potrf_mfma<false, false>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;
             break ;
         case K_TRSM:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            hipLaunchKernelGGL (k_trsm_mfma<false>, dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
+            if (cx) hipLaunchKernelGGL ((k_trsm_mfma<false, true>), dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
+                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
+            else hipLaunchKernelGGL ((k_trsm_mfma<false, false>), dim3 (L.grid), dim3 (256), trsm_mfma_lds_bytes (L.aux), st,
                 P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, L.aux, (long long *) nullptr) ;
             break ;
         case K_TRSM_UPD:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            hipLaunchKernelGGL (k_trsm_upd, dim3 (L.grid), dim3 (256), trsm_upd_lds_bytes (), st,
+            CX_LAUNCH (k_trsm_upd, dim3 (L.grid), dim3 (256), trsm_upd_lds_bytes (), st,
                 P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, P->d_tu_cnt + L.goff) ;
             break ;
         case K_UPD_BIG:
@@ -1663,9 +1697,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_SMALL:
-            if (twin) hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false, true>), dim3 (L.grid), dim3 (256), 0, st,
-                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
-            else hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (L.grid), dim3 (256), 0, st,
+            TW_LAUNCH (k_update2<SMALL COMMA SMALL COMMA BKK COMMA 2 COMMA false COMMA, >, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_DIAG:
@@ -1678,18 +1710,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_UPD_W:
             // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
-            if (twin)
-            {
-                if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4, true>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
-                else hipLaunchKernelGGL ((k_update3<2, true>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
-            }
-            else if (L.aux >= 1024) hipLaunchKernelGGL ((k_update3<4>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
-            else hipLaunchKernelGGL ((k_update3<2>), dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            else TW_LAUNCH (k_update3<2 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_PF:
-            if (twin) hipLaunchKernelGGL (k_update2f<true>, dim3 (L.grid), dim3 (256), 0, st,
-                P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
-            else hipLaunchKernelGGL (k_update2f<false>, dim3 (L.grid), dim3 (256), 0, st,
+            TW_LAUNCH (k_update2f<, >, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb, P->d_info) ;
             break ;
     }
@@ -1744,13 +1769,20 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             hipLaunchKernelGGL (k_assemble_mapped, dim3 ((unsigned) ((P->s_nz + 255) / 256)), dim3 (256), 0, st,
                 P->s_nz, P->d_amap, P->d_Sx, P->d_Lx) ;
         if (beta != 0.0)
-            hipLaunchKernelGGL (k_add_beta, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+        {
+            if (P->flags & CHOLMOD_HIP_CX_STORAGE) hipLaunchKernelGGL (k_add_beta<true>, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
                 P->n, P->d_supermap, P->d_fr, P->d_Lx, beta) ;
+            else hipLaunchKernelGGL (k_add_beta<false>, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+                P->n, P->d_supermap, P->d_fr, P->d_Lx, beta) ;
+        }
     }
     else if (P->n > 0)
     {
         HIPCHK (hipMemsetAsync (P->d_amap, 0xFF, std::max<i64> (P->s_nz, 1) * sizeof (i64), st)) ;     // -1: not in L
-        hipLaunchKernelGGL (k_assemble, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+        if (P->flags & CHOLMOD_HIP_CX_STORAGE) hipLaunchKernelGGL (k_assemble<true>, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+            P->n, P->d_Sp, P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx,
+            P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta, P->d_amap) ;
+        else hipLaunchKernelGGL (k_assemble<false>, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
             P->n, P->d_Sp, P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx,
             P->d_supermap, P->d_fr, P->d_Ls, P->d_Lx, beta, P->d_amap) ;
         building_map = true ;       // (the thin-front kernels record their part; valid once every launch has run)
@@ -1962,6 +1994,14 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
     if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
     const double tpc = std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ;
+    if (flags & CHOLMOD_HIP_CX_STORAGE)
+    {
+        // complex storage: the twin's index space, the generic kernels only (the LDS-resident thin-front
+        // kernels and the 256-column chain have no complex-storage form), one rank
+        if (world > 1) { if (status) *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
+        flags |= CHOLMOD_HIP_PHI_TWIN | CHOLMOD_HIP_NO_SMALL_FRONTS ;
+        flags &= ~(CHOLMOD_HIP_CHAIN256 | CHOLMOD_HIP_TILE128) ;
+    }
     if (flags & CHOLMOD_HIP_PHI_TWIN)
     {
         // a twin has every supernode boundary and row in (2i, 2i+1) pairs
@@ -2311,6 +2351,7 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
     const double *Lw = whole_factor (P) ;
     const FrontD *frw = whole_fronts (P) ;
     if (!Lw || !frw) return CHOLMOD_HIP_INVALID ;  // several ranks: cholmod_hip_gather_factor first
+    const bool cxs = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
     i64 need = ldx * nrhs ;
     if (need > P->x_cap)
     {
@@ -2351,7 +2392,7 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         }
         if (!P->winv_valid)
         {
-            hipLaunchKernelGGL (k_diag_inv64, dim3 ((unsigned) P->inv_tasks.size ()), dim3 (64), 0, st,
+            CXS_LAUNCH (k_diag_inv64, dim3 ((unsigned) P->inv_tasks.size ()), dim3 (64), 0, st,
                 P->d_inv_tasks, frw, Lw, P->d_winv) ;
             P->winv_valid = true ;
         }
@@ -2363,14 +2404,14 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
         for (int l = 0 ; l < P->nlevels ; l++)
         {
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
-            if (nf) hipLaunchKernelGGL (k_lsolve, dim3 (nf), dim3 (256), 0, st,
+            if (nf) CXS_LAUNCH (k_lsolve, dim3 (nf), dim3 (256), 0, st,
                 P->d_sv + P->sv_ptr [l], frw, P->d_Ls, Lw, P->d_X, (i64) ldx, (int) nrhs) ;
             for (int q = P->sb_lvl_ptr [l] ; q < P->sb_lvl_ptr [l+1] ; q++)
             {
                 const auto &B = P->sb_launch [q] ;
-                hipLaunchKernelGGL (k_solve_fwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
+                CXS_LAUNCH (k_solve_fwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
                     P->d_sb_tasks + B.first, frw, Lw, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
-                if (B.grid > 0) hipLaunchKernelGGL (k_solve_fwd_apply, dim3 (B.grid), dim3 (256), 0, st,
+                if (B.grid > 0) CXS_LAUNCH (k_solve_fwd_apply, dim3 (B.grid), dim3 (256), 0, st,
                     P->d_sb_tasks + B.first, (int) B.ntasks, frw, P->d_Ls, Lw,
                     P->d_X, (i64) ldx, (int) nrhs, P->d_solved) ;
             }
@@ -2386,14 +2427,14 @@ int cholmod_hip_solve (cholmod_hip_plan *P, int which, double *X, int64_t nrhs, 
             for (int q = P->sb_lvl_ptr [l+1] - 1 ; q >= P->sb_lvl_ptr [l] ; q--)
             {
                 const auto &B = P->sb_launch [q] ;
-                if (B.grid > 0) hipLaunchKernelGGL (k_solve_bwd_apply, dim3 (B.grid), dim3 (256), 0, st,
+                if (B.grid > 0) CXS_LAUNCH (k_solve_bwd_apply, dim3 (B.grid), dim3 (256), 0, st,
                     P->d_sb_tasks + B.first, (int) B.ntasks, frw, P->d_Ls, Lw,
                     P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
-                hipLaunchKernelGGL (k_solve_bwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
+                CXS_LAUNCH (k_solve_bwd_diag, dim3 (B.ntasks), dim3 (256), 0, st,
                     P->d_sb_tasks + B.first, frw, Lw, P->d_winv, P->d_X, (i64) ldx, (int) nrhs, P->d_sv_acc) ;
             }
             int nf = P->sv_ptr [l+1] - P->sv_ptr [l] ;
-            if (nf) hipLaunchKernelGGL (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
+            if (nf) CXS_LAUNCH (k_ltsolve, dim3 (nf), dim3 (256), 0, st,
                 P->d_sv + P->sv_ptr [l], frw, P->d_Ls, Lw, P->d_X, (i64) ldx, (int) nrhs) ;
         }
     }
@@ -2419,7 +2460,8 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     HIPCHK (hipMemsetAsync (P->d_chk_out, 0, 5 * sizeof (double), P->stream)) ;
     // (several ranks: the complete factor exists only after cholmod_hip_gather_factor)
     if (!whole_factor (P) || !whole_fronts (P)) return CHOLMOD_HIP_INVALID ;
-    hipLaunchKernelGGL (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
+    const bool cxs = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
+    CXS_LAUNCH (k_factor_checks, dim3 ((unsigned) P->nchk), dim3 (256), 0, P->stream,
         P->d_chk, whole_fronts (P), whole_factor (P), P->d_chk_out) ;
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
@@ -2444,6 +2486,13 @@ int cholmod_hip_download_even_columns (cholmod_hip_plan *P, double *out_host)
 {
     if (!P || P->host_only || !out_host) return CHOLMOD_HIP_INVALID ;
     if (P->nsuper == 0 || P->xsize == 0) return CHOLMOD_HIP_OK ;
+    if (P->flags & CHOLMOD_HIP_CX_STORAGE)
+    {
+        // the factor is stored as its even columns: it IS the interleaved complex factor
+        if (!whole_factor (P)) return CHOLMOD_HIP_INVALID ;
+        HIPCHK (hipMemcpy (out_host, whole_factor (P), (size_t) P->xsize * sizeof (double), hipMemcpyDeviceToHost)) ;
+        return CHOLMOD_HIP_OK ;
+    }
     { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }
     double *tmp = nullptr ;
     const size_t bytes = (size_t) (P->xsize / 2) * sizeof (double) ;
@@ -2515,6 +2564,22 @@ int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *P, int64_t cap, int32_
         if (bytes) bytes [q] = L.bytes ;
     }
     return nl ;
+}
+
+// tuning: the update regions of launch `launch` (an update launch of any kind), 12 numbers per
+// region: m, n, k, tri, c_in_cb, lda, ldc, ntiles, nblk, front, assign, swz
+int64_t cholmod_hip_debug_launch_regions (cholmod_hip_plan *P, int64_t launch, int64_t cap, int64_t *out)
+{
+    if (!P || launch < 0 || launch >= (i64) P->sch.launches.size ()) return CHOLMOD_HIP_INVALID ;
+    const Launch &L = P->sch.launches [launch] ;
+    if (L.kind != K_UPD_W && L.kind != K_UPD_SMALL && L.kind != K_UPD_BIG && L.kind != K_UPD_PF) return 0 ;
+    for (i64 q = 0 ; q < L.ng && q < cap ; q++)
+    {
+        const GemmGroup &G = P->sch.gg [L.goff + q] ;
+        const i64 v [12] = {G.m, G.n, G.k, G.tri, G.c_in_cb, G.lda, G.ldc, G.ntiles, G.nblk, G.front, G.assign, G.swz} ;
+        for (int t = 0 ; t < 12 ; t++) out [12 * q + t] = v [t] ;
+    }
+    return L.ng ;
 }
 
 int cholmod_hip_set_profiling (cholmod_hip_plan *P, int on)

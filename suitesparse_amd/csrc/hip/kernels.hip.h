@@ -79,6 +79,35 @@ __host__ __device__ __forceinline__ int tri_col (int j, int m) { return j * m - 
 typedef double d4 __attribute__((ext_vector_type(4))) ;
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
 
+// ---- complex factors in their own storage (CX) -----------------------------------------
+// A complex factor is computed on the index space of its real twin (phi embedding: rows /
+// columns 2i, 2i+1 = re, im of i; host/complex.c) but STORED as the reference stores it
+// (t_cholmod_super_numeric.c:41-83: L complex, interleaved): of every front only the even twin
+// columns exist -- column c of the twin lives at (c >> 1) * ld, ld = the twin's row count =
+// twice the complex one -- i.e. the panel IS the interleaved complex panel (2 xsize doubles
+// instead of the twin's 4 xsize).  The odd columns are the rotations of the even ones,
+//     twin (2i, 2j+1) = -twin (2i+1, 2j)      twin (2i+1, 2j+1) = twin (2i, 2j),
+// and are rebuilt on the way into LDS / registers by ldcx; stcx keeps the even columns only.
+// `base` must address an element with an even row and an even column of the twin.
+template <bool CX>
+__device__ __forceinline__ double ldcx (const double *base, int r, int c, i64 ld)
+{
+    if constexpr (!CX) return base [r + (i64) c * ld] ;
+    else
+    {
+        const double v = base [(r ^ (c & 1)) + (i64) (c >> 1) * ld] ;
+        return ((c & 1) && !(r & 1)) ? -v : v ;
+    }
+}
+template <bool CX>
+__device__ __forceinline__ void stcx (double *base, int r, int c, i64 ld, double v)
+{
+    if constexpr (!CX) base [r + (i64) c * ld] = v ;
+    else if (!(c & 1)) base [r + (i64) (c >> 1) * ld] = v ;
+}
+// offset of twin column c of a panel with leading dimension ld
+template <bool CX> __host__ __device__ __forceinline__ i64 colx (int c, i64 ld) { return CX ? (i64) (c >> 1) * ld : (i64) c * ld ; }
+
 __device__ __forceinline__ int lower_bound_i32 (const i32 *a, int n, int v)
 {
     int lo = 0, hi = n ;
@@ -126,6 +155,7 @@ __global__ void __launch_bounds__(256) k_relmap (int nsuper, const FrontD *fr,
 // ---- assemble A into the panels ---------------------------------------------
 // reference: t_cholmod_super_numeric.c:353-431 (ASSIGN semantics, entries not
 // in the symbolic pattern are dropped, beta added to the diagonal).
+template <bool CX>
 __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     const i64 *Snz, const i64 *Si, const double *Sx, const i32 *supermap,
     const FrontD *fr, const i64 *Ls, double *Lx, double beta, i64 *amap)
@@ -137,8 +167,13 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     i64 psx = f.psx, psi = f.psi ;
     int nsrow = f.nsrow, k1 = f.k1 ;
     const i64 *rows = Ls + psi ;
-    double *col = Lx + psx + (i64) (k - k1) * nsrow ;
     i64 p = Sp [k], pend = Snz ? p + Snz [k] : Sp [k+1] ;
+    if constexpr (CX)
+    {
+        // (the odd columns of the embedded matrix are not stored)
+        if (k & 1) { for (i64 q = p ; q < pend ; q++) amap [q] = -1 ; return ; }
+    }
+    double *col = Lx + psx + colx<CX> ((int) (k - k1), nsrow) ;
     for ( ; p < pend ; p++)
     {
         i64 i = Si [p] ;
@@ -180,13 +215,15 @@ __global__ void __launch_bounds__(256) k_gather_values (i64 nz, const i64 *src, 
 }
 
 // Lx(k,k) += beta for the columns this rank's k_assemble owns (after k_assemble_mapped)
+template <bool CX>
 __global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, const FrontD *fr, double *Lx, double beta)
 {
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
     const FrontD &f = fr [supermap [k]] ;
     if (f.assemble != 1) return ;
-    Lx [f.psx + (i64) (k - f.k1) * (f.nsrow + 1)] += beta ;
+    if (CX && (k & 1)) return ;
+    Lx [f.psx + colx<CX> ((int) (k - f.k1), f.nsrow) + (k - f.k1)] += beta ;
 }
 
 // ---- zero the contribution blocks of a level --------------------------------
@@ -199,13 +236,16 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
     int gi = find_group (g, ng, (int) blockIdx.x, &ZeroGroup::blk_start) ;
     ZeroGroup G = g [gi] ;
     int ncb = (int) G.len ;                 // len holds ncb (square side)
+    // (G.pad = 1: a complex front in its own storage, ncb / 2 stored columns, stored column j
+    // = twin column 2 j whose live rows start at 2 j)
+    int ncol = G.pad ? ncb >> 1 : ncb, cs = G.pad ? 2 : 1 ;
     int j0 = ((int) blockIdx.x - G.blk_start) * ZERO_COLS ;
-    int j1 = j0 + ZERO_COLS < ncb ? j0 + ZERO_COLS : ncb ;
+    int j1 = j0 + ZERO_COLS < ncol ? j0 + ZERO_COLS : ncol ;
     double *dst = CB + G.off ;
     for (int j = j0 ; j < j1 ; j++)
     {
         double *col = dst + (i64) j * ncb ;
-        for (int i = j0 + threadIdx.x ; i < ncb ; i += 256) col [i] = 0.0 ;
+        for (int i = cs * j0 + threadIdx.x ; i < ncb ; i += 256) col [i] = 0.0 ;
     }
 }
 
@@ -218,6 +258,7 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 #ifndef EA_TW
 #define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
 #endif
+template <bool CX>
 __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB, int tw)
 {
@@ -240,12 +281,13 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
         for (int j = j0 ; j < j1 ; j++)
         {
             int tc = rm [j] ;
-            if ((tc & 3) != wave) continue ;
+            if constexpr (CX) { if ((j & 1) || ((tc >> 1) & 3) != wave) continue ; }      // (an even child column lands on an even column)
+            else if ((tc & 3) != wave) continue ;
             double *dst ;
             int roff ;
-            if (tc < Pnscol) { dst = Lx + Ppsx + (i64) tc * Pnsrow ; roff = 0 ; }
-            else { dst = CB + Pcb + (i64) (tc - Pnscol) * Pncb ; roff = Pnscol ; }
-            const double *sc = Cc.cbp ? src + tri_col (j, nc) : src + (i64) j * nc ;
+            if (tc < Pnscol) { dst = Lx + Ppsx + colx<CX> (tc, Pnsrow) ; roff = 0 ; }
+            else { dst = CB + Pcb + colx<CX> (tc - Pnscol, Pncb) ; roff = Pnscol ; }
+            const double *sc = (!CX && Cc.cbp) ? src + tri_col (j, nc) : src + colx<CX> (j, nc) ;
             // eight, then four independent gather / read-modify-write chains in flight per wave
             int i = j + lane ;
             for ( ; i + 448 < nc ; i += 512)
@@ -427,7 +469,27 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
     }
 }
 
-template <bool TIMED>
+// The factored 64 x 64 block of pf_eliminate back to the front: the lower triangle, zero at /
+// beyond a failed pivot.  CX: the even columns only, and entry (2j+1, 2j) -- the imaginary part
+// of a diagonal entry, a rounding residue of the embedded elimination -- as the exact zero
+// zpotrf leaves there (the rotation then rebuilds an exactly zero (2j, 2j+1)).
+template <bool CX>
+__device__ __forceinline__ void pf_store (double *A, i64 lda, const double *T, int nb, int fail, int lane, int wave)
+{
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++)
+    {
+        int k = wave + 4 * q, i = lane ;
+        if (k < nb && i >= k && i < nb)
+        {
+            double v = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
+            if (CX && i == k + 1) v = 0.0 ;
+            stcx<CX> (A, i, k, lda, v) ;
+        }
+    }
+}
+
+template <bool TIMED, bool CX = false>
 __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *Lx, i32 *info, long long *tim)
 {
     long long tc [8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0 ;
@@ -443,7 +505,7 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
     if (info [G.front] != 0)
     {
         for (int k = wave ; k < nb ; k += 4)
-            if (lane >= k && lane < nb) A [lane + (i64) k * lda] = 0.0 ;
+            if (lane >= k && lane < nb) stcx<CX> (A, lane, k, lda, 0.0) ;
         return ;
     }
     int nbp = (nb + 15) / 16 * 16 ;
@@ -457,7 +519,7 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
         for (int q = 0 ; q < 16 ; q++)
         {
             int k = wave + 4 * q ;
-            tmp [q] = A [ic + (i64) (k < nb ? k : nb - 1) * lda] ;
+            tmp [q] = ldcx<CX> (A, ic, k < nb ? k : nb - 1, lda) ;
         }
 #pragma unroll
         for (int q = 0 ; q < 16 ; q++)
@@ -473,13 +535,7 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
     int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + fail + 1 ;
     // write-back of the lower triangle (columns at / beyond a failed pivot: zero)
-#pragma unroll
-    for (int q = 0 ; q < 16 ; q++)
-    {
-        int k = wave + 4 * q, i = lane ;
-        if (k < nb && i >= k && i < nb)
-            A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
-    }
+    pf_store<CX> (A, lda, T, nb, fail, lane, wave) ;
     tick (6) ;
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
@@ -554,9 +610,10 @@ __device__ __forceinline__ void trsm_diag_inverses (const double *Ls, int ldl, d
 // bj [jj][r] = B(row lr of the wave's 16 rows, column 16 jj + lk + 4 r) in the
 // accumulator layout; solves X = B inv(L11)' block column by block column and stores it.
 // xr [j] receives the solved block j, again in the accumulator (= A-operand) layout.
-template <typename Tick>
+// (B: base of the row block, an even row / even column of the twin when CX; brow: this lane's row in it)
+template <bool CX, typename Tick>
 __device__ __forceinline__ void trsm_solve_rows (const d4 (&bj) [4], int nblk, const double *Ls, int ldl,
-    const double *Wd, int lane, int nvalid, bool rok, int nb, double *B, i64 lda, Tick tick, d4 (&xr) [4])
+    const double *Wd, int lane, int nvalid, bool rok, int nb, double *B, int brow, i64 lda, Tick tick, d4 (&xr) [4])
 {
     const int lr = lane & 15, lk = lane >> 4 ;
 #pragma unroll
@@ -592,7 +649,7 @@ __device__ __forceinline__ void trsm_solve_rows (const d4 (&bj) [4], int nblk, c
                 int c = 16 * j + lk + 4 * r ;
                 double v = (c < nvalid) ? x [r] : 0.0 ;
                 x [r] = v ;
-                if (rok && c < nb) B [(i64) c * lda] = v ;
+                if (rok && c < nb) stcx<CX> (B, brow, c, lda, v) ;
             }
             xr [j] = x ;
             tick (5) ;
@@ -600,7 +657,7 @@ __device__ __forceinline__ void trsm_solve_rows (const d4 (&bj) [4], int nblk, c
     }
 }
 
-template <bool TIMED>
+template <bool TIMED, bool CX = false>
 __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     double *Lx, const i32 *info, int ldl, long long *tim)
 {
@@ -630,7 +687,8 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     int row0 = ((int) blockIdx.x - G.blk_start) * TRM_ROWS + wave * 16 ;
     int row = row0 + lr ;
     bool rok = row < G.m ;
-    double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;
+    double *B = Lx + G.b_off ;
+    const int brow = rok ? row : G.m - 1 ;
     // stage L11 (thread = row j of L11, columns 4 apart); the loads of this
     // wave's 16 rows of B are issued right behind and only waited for when the
     // first block needs them
@@ -643,7 +701,7 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
         for (int q = 0 ; q < 16 ; q++)
         {
             int k = (tid >> 6) + 4 * q ;
-            tmp [q] = L11 [jc + (i64) (k < nb ? k : nb - 1) * lda] ;
+            tmp [q] = ldcx<CX> (L11, jc, k < nb ? k : nb - 1, lda) ;
         }
         // B straight into the accumulator layout: lane holds B(row lr, col 16 j + lk + 4 r)
 #pragma unroll
@@ -652,7 +710,7 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
             for (int r = 0 ; r < 4 ; r++)
             {
                 int c = 16 * jj + lk + 4 * r ;
-                bj [jj][r] = B [(i64) (c < nb ? c : nb - 1) * lda] ;
+                bj [jj][r] = ldcx<CX> (B, brow, c < nb ? c : nb - 1, lda) ;
             }
 #pragma unroll
         for (int q = 0 ; q < 16 ; q++)
@@ -677,7 +735,7 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
     // lk): a solved block X_i and the intermediate B_j - sum feed the next MFMAs
     // straight from registers, no LDS round trip, no barrier.
     d4 xr [4] ;
-    trsm_solve_rows (bj, nblk, Ls, ldl, Wd, lane, nvalid, rok, nb, B, lda, tick, xr) ;
+    trsm_solve_rows<CX> (bj, nblk, Ls, ldl, Wd, lane, nvalid, rok, nb, B, brow, lda, tick, xr) ;
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
@@ -1421,7 +1479,10 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
 // wave holds the rows of parity a (position 32 w + 16 a + t <-> row 32 w + 2 t + a, likewise
 // the columns): the four products of one complex entry then sit in the same lane and slot of
 // acc [0..1][0..1] and are combined there; the epilogue stores row pairs.
-template <int BM, int BN, int BK, bool DB, bool TO_LDS = false, bool TW = false>
+// TW = 2 (CX): the same contraction on a front in complex storage (ldcx / stcx above): the panel IS
+// its even twin columns (lda = ld of the front, k = complex columns), and of the target only the
+// even twin columns exist, column j at (j >> 1) ldc.
+template <int BM, int BN, int BK, bool DB, bool TO_LDS = false, int TW = 0>
 __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
     double *Lx, double *CB, double *sm)
 {
@@ -1517,7 +1578,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
         }
     } ;
 
-    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + colx<TW == 2> (col0, G.ldc) ;
     // k_update2f's diagonal tile: the old values of the block are requested before the
     // contraction starts -- after it they would put one HBM latency on the chain that
     // leads into the elimination
@@ -1533,7 +1594,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
                 {
                     int i = wm * WM + a * 16 + (lane & 15), j = wn * WN + b * 16 + (lane >> 4) + 4 * r ;
                     if constexpr (TW) { i = wm * WM + 2 * (lane & 15) + a ; j = wn * WN + 2 * ((lane >> 4) + 4 * r) + b ; }
-                    cv [a][b][r] = C [i + (i64) j * G.ldc] ;
+                    cv [a][b][r] = ldcx<TW == 2> (C, i, j, G.ldc) ;
                 }
     }
     gload (0) ;
@@ -1598,7 +1659,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
         // row pairs (2 t, 2 t + 1) of a column: one 16-byte read-modify-write (m, n and the
         // region's origin are even: a pair lies inside the region or outside it)
 #pragma unroll
-        for (int b = 0 ; b < TJ ; b++)
+        for (int b = 0 ; b < (TW == 2 ? 1 : TJ) ; b++)
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++)
             {
@@ -1607,7 +1668,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
                 if (i >= mrem || j >= nrem) continue ;
                 const bool both = !G.tri || row0 + i >= col0 + j ;
                 const bool second = G.tri && row0 + i + 1 == col0 + j ;
-                double *Cj = C + i + (i64) j * G.ldc ;
+                double *Cj = C + i + colx<TW == 2> (j, G.ldc) ;
                 if (both)
                 {
                     d2u v ;
@@ -1639,7 +1700,7 @@ __device__ __forceinline__ void update_tile (const GemmGroup &G, int I, int J,
             }
 }
 
-template <int BM, int BN, int BK, int MINW, bool DB, bool TW = false>
+template <int BM, int BN, int BK, int MINW, bool DB, int TW = 0>
 __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int ng,
     double *Lx, double *CB)
 {
@@ -1677,7 +1738,7 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 // TW: the even columns of a phi-embedded complex panel (see update_tile): the row / column pairs a
 // lane loads ARE the (re, im) pairs, fragment parity = row parity, so the four real products of a
 // complex entry are acc [2 q + {0,1}][2 p + {0,1}][r] of one lane and are combined in place.
-template <int DEPTH, bool EDGE, bool TW = false>
+template <int DEPTH, bool EDGE, int TW = 0>
 __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4 ;
@@ -1816,15 +1877,16 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
     }
     // epilogue: acc [a][b][r] of lane (lr, lk) is C (row 32 (a >> 1) + 2 lr + (a & 1),
     // column 32 (b >> 1) + 2 (lk + 4 r) + (b & 1))
-    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + (i64) col0 * G.ldc ;
+    double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + colx<TW == 2> (col0, G.ldc) ;
     const bool diag = G.tri && I == J ;
 #pragma unroll
     for (int b = 0 ; b < 4 ; b++)
 #pragma unroll
         for (int r = 0 ; r < 4 ; r++)
         {
+            if (TW == 2 && (b & 1)) continue ;          // (complex storage: the even twin columns only)
             const int j = 32 * (b >> 1) + 2 * (lk + 4 * r) + (b & 1) ;
-            double *Cj = C + (i64) j * G.ldc ;
+            double *Cj = C + colx<TW == 2> (j, G.ldc) ;
 #pragma unroll
             for (int q = 0 ; q < 2 ; q++)
             {
@@ -1855,7 +1917,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         }
 }
 
-template <int DEPTH, bool TW = false>
+template <int DEPTH, int TW = 0>
 __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
@@ -1875,7 +1937,7 @@ __global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, 
 // tiles -- one launch of ~17 us less per 64 columns of the chain (potrf -> trsm -> update,
 // ~43 us per step, is half the time of a mid-size factorization).  Everything else in
 // the launch is k_update2<64,64,16,2,false>.
-template <bool TW>
+template <int TW>
 __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng,
     double *Lx, double *CB, i32 *info)
 {
@@ -1903,19 +1965,14 @@ __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng
     {
         // an earlier pivot of this front failed: its remaining columns are zero
         for (int k = wave ; k < PF_NB ; k += 4)
-            if (lane >= k) A [lane + (i64) k * lda] = 0.0 ;
+            if (lane >= k) stcx<TW == 2> (A, lane, k, lda, 0.0) ;
         return ;
     }
     auto tick = [] (int) {} ;
     pf_eliminate (sm, PF_NB / 16, &s_fail, tid, tick) ;
     const int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.pf_col0 + fail + 1 ;
-#pragma unroll
-    for (int q = 0 ; q < 16 ; q++)
-    {
-        const int k = wave + 4 * q, i = lane ;
-        if (i >= k) A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : sm [k * PF2_LD + i] ;
-    }
+    pf_store<TW == 2> (A, lda, sm, PF_NB, fail, lane, wave) ;
 }
 
 // ---- panel solve + the K = 64 update of the next block column + its dpotrf ---------
@@ -1938,6 +1995,7 @@ __host__ __device__ inline size_t trsm_upd_lds_bytes ()
 {
     return (size_t) (64 * 64 + 4 * 256 + 64 * TU_LDX) * sizeof (double) ;
 }
+template <bool CX>
 __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, double *Lx, i32 *info, i32 *cnt)
 {
     extern __shared__ __attribute__((aligned(16))) double tu_lds [] ;
@@ -1964,24 +2022,25 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     const int blk = (int) blockIdx.x - G.blk_start ;
     const int row = blk * TRM_ROWS + wave * 16 + lr ;
     const bool rok = row < G.m ;
-    double *B = Lx + G.b_off + (rok ? row : G.m - 1) ;          // this lane's row of the rows below
-    double *B0 = Lx + G.b_off + wave * 16 + lr ;                // its row of the next diagonal block's rows
-    double *Cr = B + 64 * lda ;                                 // the same row, 64 columns to the right
+    double *B = Lx + G.b_off ;                                  // the rows below the panel
+    const int brow = rok ? row : G.m - 1 ;                      // this lane's row of them
+    const int b0row = wave * 16 + lr ;                          // its row of the next diagonal block's rows
+    double *Cr = B + colx<CX> (64, lda) ;                       // the same rows, 64 columns to the right
     d4 bj [4], b0 [4], cj [4] ;
     {
         const int j = tid & 63 ;
         double tmp [16] ;
 #pragma unroll
-        for (int q = 0 ; q < 16 ; q++) tmp [q] = L11 [j + (i64) ((tid >> 6) + 4 * q) * lda] ;
+        for (int q = 0 ; q < 16 ; q++) tmp [q] = ldcx<CX> (L11, j, (tid >> 6) + 4 * q, lda) ;
 #pragma unroll
         for (int jj = 0 ; jj < 4 ; jj++)
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++)
             {
-                const i64 co = (i64) (16 * jj + lk + 4 * r) * lda ;
-                bj [jj][r] = B [co] ;
-                b0 [jj][r] = B0 [co] ;
-                cj [jj][r] = Cr [co] ;
+                const int c = 16 * jj + lk + 4 * r ;
+                bj [jj][r] = ldcx<CX> (B, brow, c, lda) ;
+                b0 [jj][r] = ldcx<CX> (B, b0row, c, lda) ;
+                cj [jj][r] = ldcx<CX> (Cr, brow, c, lda) ;
             }
 #pragma unroll
         for (int q = 0 ; q < 16 ; q++)
@@ -2011,13 +2070,13 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     __syncthreads () ;
     if (tid == 0) s_last = (nwg == 1 || __hip_atomic_fetch_add (cnt + gi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) ? 1 : 0 ;
     d4 xr [4], x0 [4] ;
-    trsm_solve_rows (bj, 4, Ls, ldl, Wd, lane, nvalid, rok && blk != 0, 64, B, lda, tick, xr) ;
+    trsm_solve_rows<CX> (bj, 4, Ls, ldl, Wd, lane, nvalid, rok && blk != 0, 64, B, brow, lda, tick, xr) ;
     if (blk == 0)
     {
 #pragma unroll
         for (int j = 0 ; j < 4 ; j++) x0 [j] = xr [j] ;
     }
-    else trsm_solve_rows (b0, 4, Ls, ldl, Wd, lane, nvalid, false, 64, B0, lda, tick, x0) ;
+    else trsm_solve_rows<CX> (b0, 4, Ls, ldl, Wd, lane, nvalid, false, 64, B, b0row, lda, tick, x0) ;
     // -X_0 k-major: X0s [k][j] = -X_0 (j, k); block jj, element r of the accumulator layout is
     // (row lr of the wave's 16 rows, column 16 jj + lk + 4 r)
 #pragma unroll
@@ -2032,7 +2091,7 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
 #pragma unroll
         for (int jj = 0 ; jj < 4 ; jj++)
 #pragma unroll
-            for (int r = 0 ; r < 4 ; r++) B0 [(i64) (16 * jj + lk + 4 * r) * lda] = x0 [jj][r] ;
+            for (int r = 0 ; r < 4 ; r++) stcx<CX> (B, b0row, 16 * jj + lk + 4 * r, lda, x0 [jj][r]) ;
     }
     // C (row, 16 jt + lk + 4 r) -= sum_k X (row, k) X_0 (16 jt + .., k)
 #pragma unroll
@@ -2052,17 +2111,17 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
 #pragma unroll
             for (int jt = 0 ; jt < 4 ; jt++)
 #pragma unroll
-                for (int r = 0 ; r < 4 ; r++) Cr [(i64) (16 * jt + lk + 4 * r) * lda] = cj [jt][r] ;
+                for (int r = 0 ; r < 4 ; r++) stcx<CX> (Cr, brow, 16 * jt + lk + 4 * r, lda, cj [jt][r]) ;
         }
         return ;
     }
     // workgroup 0: the updated tile is the next diagonal block
-    double *A = Lx + G.b_off + 64 * lda ;
+    double *A = Cr ;
     if (inf != 0)
     {
         // an earlier pivot of this front failed: its remaining columns are zero
         for (int k = wave ; k < PF_NB ; k += 4)
-            if (lane >= k) A [lane + (i64) k * lda] = 0.0 ;
+            if (lane >= k) stcx<CX> (A, lane, k, lda, 0.0) ;
         return ;
     }
     double *T = Ls ;                                // T [k * PF2_LD + i] = A (i, k), zero above the diagonal
@@ -2078,12 +2137,7 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     pf_eliminate (T, PF_NB / 16, &s_fail, tid, tick) ;
     const int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + 64 + fail + 1 ;
-#pragma unroll
-    for (int q = 0 ; q < 16 ; q++)
-    {
-        const int k = wave + 4 * q, i = lane ;
-        if (i >= k) A [i + (i64) k * lda] = (fail >= 0 && k >= fail) ? 0.0 : T [k * PF2_LD + i] ;
-    }
+    pf_store<CX> (A, lda, T, PF_NB, fail, lane, wave) ;
 }
 
 // ---- multi-GPU: packing of a shared front's block column for the row-split exchange ----
@@ -2304,7 +2358,7 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
                 for (int r = 0 ; r < 4 ; r++) bj [jb][r] = A [rowc + (i64) (c0 + 16 * jb + lk + 4 * r) * lda] ;
             dg_left_looking (bj, A, lda, rowc, c0, w, lr, lk, tick) ;
             stamp (5) ;
-            trsm_solve_rows (bj, 4, Ls, 64, Wd, lane, nvalid, rok, 64, A + rowc + (i64) c0 * lda, lda, tick, xr) ;
+            trsm_solve_rows<false> (bj, 4, Ls, 64, Wd, lane, nvalid, rok, 64, A + (i64) c0 * lda, rowc, lda, tick, xr) ;
             stamp (6) ;
         }
         if (fail >= 0) dead = true ;
@@ -2446,6 +2500,7 @@ __global__ void __launch_bounds__(256) k_first_fail (i64 nsuper, const i32 *info
 // L2' * X[Ls2]) needs no atomics.
 struct SolveTask { i32 front ; i32 c0, c1 ; i32 below ; } ;   // columns [c0,c1) of a supernode
 
+template <bool CX>
 __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
 {
@@ -2469,7 +2524,7 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
             for (int e = tid ; e < 64 * 64 ; e += 256)
             {
                 int i = e & 63, j = e >> 6 ;
-                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? L [(jb + i) + (i64) (jb + j) * nsrow] : (i == j ? 1.0 : 0.0) ;
+                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? ldcx<CX> (L, jb + i, jb + j, nsrow) : (i == j ? 1.0 : 0.0) ;
             }
             __syncthreads () ;
             if (wave == 0)
@@ -2492,15 +2547,14 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
             for (int i = jb + nb + tid ; i < c1 ; i += 256)
             {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
-                const double *Li = L + i + (i64) jb * nsrow ;
                 int j = 0 ;
                 for ( ; j + 4 <= nb ; j += 4)
                 {
-                    double l0 = Li [(i64) j * nsrow], l1 = Li [(i64) (j + 1) * nsrow] ;
-                    double l2 = Li [(i64) (j + 2) * nsrow], l3 = Li [(i64) (j + 3) * nsrow] ;
+                    double l0 = ldcx<CX> (L, i, jb + j, nsrow), l1 = ldcx<CX> (L, i, jb + j + 1, nsrow) ;
+                    double l2 = ldcx<CX> (L, i, jb + j + 2, nsrow), l3 = ldcx<CX> (L, i, jb + j + 3, nsrow) ;
                     a0 += l0 * xb [j] ; a1 += l1 * xb [j + 1] ; a2 += l2 * xb [j + 2] ; a3 += l3 * xb [j + 3] ;
                 }
-                for ( ; j < nb ; j++) a0 += Li [(i64) j * nsrow] * xb [j] ;
+                for ( ; j < nb ; j++) a0 += ldcx<CX> (L, i, jb + j, nsrow) * xb [j] ;
                 x [k1 + i] -= (a0 + a1) + (a2 + a3) ;
             }
             __syncthreads () ;
@@ -2511,16 +2565,15 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
             for (int i = nscol + tid ; i < nsrow ; i += 256)
             {
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
-                const double *Li = L + i ;
                 int j = 0 ;
                 for ( ; j + 4 <= nscol ; j += 4)
                 {
-                    double l0 = Li [(i64) j * nsrow], l1 = Li [(i64) (j + 1) * nsrow] ;
-                    double l2 = Li [(i64) (j + 2) * nsrow], l3 = Li [(i64) (j + 3) * nsrow] ;
+                    double l0 = ldcx<CX> (L, i, j, nsrow), l1 = ldcx<CX> (L, i, j + 1, nsrow) ;
+                    double l2 = ldcx<CX> (L, i, j + 2, nsrow), l3 = ldcx<CX> (L, i, j + 3, nsrow) ;
                     a0 += l0 * x [k1 + j] ; a1 += l1 * x [k1 + j + 1] ;
                     a2 += l2 * x [k1 + j + 2] ; a3 += l3 * x [k1 + j + 3] ;
                 }
-                for ( ; j < nscol ; j++) a0 += Li [(i64) j * nsrow] * x [k1 + j] ;
+                for ( ; j < nscol ; j++) a0 += ldcx<CX> (L, i, j, nsrow) * x [k1 + j] ;
                 atomicAdd (&x [rows [i]], -((a0 + a1) + (a2 + a3))) ;
             }
         }
@@ -2533,6 +2586,7 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
 #define SOLVE_SB 256         /* column block of the big-front walk: four inverse blocks */
 #define SOLVE_BIG_COLS 256   /* fronts wider than this (or > 512 KB) take the multi-workgroup walk */
 
+template <bool CX>
 __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs)
 {
@@ -2561,10 +2615,9 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
                 __syncthreads () ;
                 for (int j = wave ; j < nscol ; j += 4)
                 {
-                    const double *Lc = L + i0 + (i64) j * nsrow ;
                     double v [8] ;
 #pragma unroll
-                    for (int u = 0 ; u < 8 ; u++) { int q = lane + 64 * u ; v [u] = (q < nr) ? Lc [q] : 0.0 ; }
+                    for (int u = 0 ; u < 8 ; u++) { int q = lane + 64 * u ; v [u] = (q < nr) ? ldcx<CX> (L, i0 + q, j, nsrow) : 0.0 ; }
                     double acc = 0.0 ;
 #pragma unroll
                     for (int u = 0 ; u < 8 ; u++) acc += v [u] * ych [lane + 64 * u] ;
@@ -2582,21 +2635,20 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
             for (int e = tid ; e < 64 * 64 ; e += 256)
             {
                 int i = e & 63, j = e >> 6 ;
-                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? L [(jb + i) + (i64) (jb + j) * nsrow] : (i == j ? 1.0 : 0.0) ;
+                Dl [i * 65 + j] = (i < nb && j < nb && j <= i) ? ldcx<CX> (L, jb + i, jb + j, nsrow) : (i == j ? 1.0 : 0.0) ;
             }
             for (int jj = wave ; jj < nb ; jj += 4)
             {
                 int j = jb + jj ;
-                const double *Lc = L + (i64) j * nsrow ;
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0 ;
                 int i = jb + nb + lane ;
                 for ( ; i + 192 < c1 ; i += 256)
                 {
-                    double l0 = Lc [i], l1 = Lc [i + 64], l2 = Lc [i + 128], l3 = Lc [i + 192] ;
+                    double l0 = ldcx<CX> (L, i, j, nsrow), l1 = ldcx<CX> (L, i + 64, j, nsrow), l2 = ldcx<CX> (L, i + 128, j, nsrow), l3 = ldcx<CX> (L, i + 192, j, nsrow) ;
                     a0 += l0 * x [k1 + i] ; a1 += l1 * x [k1 + i + 64] ;
                     a2 += l2 * x [k1 + i + 128] ; a3 += l3 * x [k1 + i + 192] ;
                 }
-                for ( ; i < c1 ; i += 64) a0 += Lc [i] * x [k1 + i] ;
+                for ( ; i < c1 ; i += 64) a0 += ldcx<CX> (L, i, j, nsrow) * x [k1 + i] ;
                 double acc = (a0 + a1) + (a2 + a3) ;
                 for (int o = 32 ; o > 0 ; o >>= 1) acc += __shfl_down (acc, o) ;
                 if (lane == 0) xb [jj] = x [k1 + j] - acc ;
@@ -2639,6 +2691,7 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
 // identity-padded past the supernode's last column.
 struct InvTask { i32 front ; i32 jb ; i64 w_off ; } ;
 
+template <bool CX>
 __global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const FrontD *fr,
     const double *Lx, double *Winv)
 {
@@ -2649,9 +2702,9 @@ __global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const 
     const FrontD &f = fr [T.front] ;
     int nsrow = f.nsrow, q = threadIdx.x ;
     int nb = f.nscol - T.jb < 64 ? f.nscol - T.jb : 64 ;
-    const double *L = Lx + f.psx + T.jb + (i64) T.jb * nsrow ;
+    const double *L = Lx + f.psx + T.jb + colx<CX> (T.jb, nsrow) ;
     for (int e = 0 ; e < 64 ; e++)
-        Lm [e * 64 + q] = (q < nb && e < nb && e <= q) ? L [q + (i64) e * nsrow] : (q == e ? 1.0 : 0.0) ;
+        Lm [e * 64 + q] = (q < nb && e < nb && e <= q) ? ldcx<CX> (L, q, e, nsrow) : (q == e ? 1.0 : 0.0) ;
     __syncthreads () ;
     rdl [q] = 1.0 / Lm [q * 64 + q] ;
     __syncthreads () ;
@@ -2699,6 +2752,7 @@ __device__ __forceinline__ int find_solve_task (const SolveBlk *t, int nt, int b
 // forward, step 1 (one workgroup per task): x_b = inv(L_bb) x_b by 64-column
 // sub-blocks -- explicit inverses on the diagonal, matrix-vector products below it.
 // The solved x_b goes to the side vector Y (k_solve_commit copies it back per level).
+template <bool CX>
 __global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
     const FrontD *fr, const double *Lx, const double *Winv, const double *X, i64 ldx, int nrhs, double *Y)
 {
@@ -2715,15 +2769,12 @@ __global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
     // only waits for LDS and for the 64 x 64 inverses (L2)
     double l1 [16], l2 [32], l3 [48] ;
     {
-        const double *Lr = L + (jb + 64 + r) + (i64) jb * nsrow ;
 #pragma unroll
-        for (int u = 0 ; u < 16 ; u++) l1 [u] = (64 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
-        Lr += 64 ;
+        for (int u = 0 ; u < 16 ; u++) l1 [u] = (64 + r < w) ? ldcx<CX> (L, jb + 64 + r, jb + p + 4 * u, nsrow) : 0.0 ;
 #pragma unroll
-        for (int u = 0 ; u < 32 ; u++) l2 [u] = (128 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
-        Lr += 64 ;
+        for (int u = 0 ; u < 32 ; u++) l2 [u] = (128 + r < w) ? ldcx<CX> (L, jb + 128 + r, jb + p + 4 * u, nsrow) : 0.0 ;
 #pragma unroll
-        for (int u = 0 ; u < 48 ; u++) l3 [u] = (192 + r < w) ? Lr [(i64) (p + 4 * u) * nsrow] : 0.0 ;
+        for (int u = 0 ; u < 48 ; u++) l3 [u] = (192 + r < w) ? ldcx<CX> (L, jb + 192 + r, jb + p + 4 * u, nsrow) : 0.0 ;
     }
     // ... and so do the four 64 x 64 inverses (16 values per thread and sub-step): fetched
     // inside the chain they cost one L2 / HBM latency per sub-step, four per launch
@@ -2801,6 +2852,7 @@ __global__ void __launch_bounds__(256) k_solve_fwd_diag (const SolveBlk *tasks,
 
 // forward, step 2: X[rows below] -= L[rows, b] x_b ; workgroup = (256-row chunk) x
 // (64-column sub-block), so that a single supernode fills the chip
+template <bool CX>
 __global__ void __launch_bounds__(256) k_solve_fwd_apply (const SolveBlk *tasks, int ntasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, double *X, i64 ldx, int nrhs, const double *Y)
 {
@@ -2822,18 +2874,17 @@ __global__ void __launch_bounds__(256) k_solve_fwd_apply (const SolveBlk *tasks,
         __syncthreads () ;
         if (i < nsrow)
         {
-            const double *Li = L + i + (i64) (jb + c0) * nsrow ;
             double acc [4] = {0.0, 0.0, 0.0, 0.0} ;
             int c = 0 ;
             for ( ; c + 16 <= cw ; c += 16)
             {
                 double l [16] ;
 #pragma unroll
-                for (int u = 0 ; u < 16 ; u++) l [u] = Li [(i64) (c + u) * nsrow] ;
+                for (int u = 0 ; u < 16 ; u++) l [u] = ldcx<CX> (L, i, jb + c0 + c + u, nsrow) ;
 #pragma unroll
                 for (int u = 0 ; u < 16 ; u++) acc [u & 3] = __builtin_fma (l [u], xs [c + u], acc [u & 3]) ;
             }
-            for ( ; c < cw ; c++) acc [0] = __builtin_fma (Li [(i64) c * nsrow], xs [c], acc [0]) ;
+            for ( ; c < cw ; c++) acc [0] = __builtin_fma (ldcx<CX> (L, i, jb + c0 + c, nsrow), xs [c], acc [0]) ;
             double sm = (acc [0] + acc [1]) + (acc [2] + acc [3]) ;
             // (several column sub-blocks, and siblings of the level, add into the same row)
             atomicAdd (i < nscol ? &x [k1 + i] : &x [rows [i]], -sm) ;
@@ -2856,6 +2907,7 @@ __global__ void __launch_bounds__(256) k_solve_commit (const SolveBlk *tasks, in
 // backward, step 1: acc (task) += L[rows, b]' x[rows] ; workgroup = (256-row chunk) x
 // (64-column sub-block); thread = row, the column sums of a wave go through an LDS
 // transpose, one atomic add per column and wave
+template <bool CX>
 __global__ void __launch_bounds__(256) k_solve_bwd_apply (const SolveBlk *tasks, int ntasks,
     const FrontD *fr, const i64 *Ls, const double *Lx, const double *X, i64 ldx, int nrhs, double *accbuf)
 {
@@ -2882,10 +2934,9 @@ __global__ void __launch_bounds__(256) k_solve_bwd_apply (const SolveBlk *tasks,
         double y = ok ? ((i < nscol) ? x [k1 + i] : x [rows [i]]) : 0.0 ;
         for (int q = 4 * qsub ; q < 4 * qsub + 4 ; q++)
         {
-            const double *Li = L + (ok ? i : r0) + (i64) (jb + 16 * q) * nsrow ;
             double l [16] ;
 #pragma unroll
-            for (int c = 0 ; c < 16 ; c++) l [c] = Li [(i64) (16 * q + c < w ? c : 0) * nsrow] ;
+            for (int c = 0 ; c < 16 ; c++) l [c] = ldcx<CX> (L, ok ? i : r0, jb + 16 * q + (16 * q + c < w ? c : 0), nsrow) ;
 #pragma unroll
             for (int c = 0 ; c < 16 ; c++) Tw [wave][lane * 17 + c] = (16 * q + c < w) ? l [c] * y : 0.0 ;
             __builtin_amdgcn_s_waitcnt (0xc07f) ;      // lgkmcnt(0): own wave's LDS writes landed
@@ -2903,6 +2954,7 @@ __global__ void __launch_bounds__(256) k_solve_bwd_apply (const SolveBlk *tasks,
 
 // backward, step 2 (one workgroup per task): x_b = inv(L_bb)' (x_b - acc) by
 // sub-blocks from the bottom; the accumulator is cleared for the next step
+template <bool CX>
 __global__ void __launch_bounds__(256) k_solve_bwd_diag (const SolveBlk *tasks,
     const FrontD *fr, const double *Lx, const double *Winv, double *X, i64 ldx, int nrhs, double *accbuf)
 {
@@ -2924,14 +2976,11 @@ __global__ void __launch_bounds__(256) k_solve_bwd_diag (const SolveBlk *tasks,
 #pragma unroll
         for (int c = 0 ; c < 16 ; c++)
         {
-            const double *Lc2 = L + jb + (i64) (jb + 128 + 16 * wave + c) * nsrow ;
-            m2 [c] = (192 + lane < w) ? Lc2 [192 + lane] : 0.0 ;
-            const double *Lc1 = L + jb + (i64) (jb + 64 + 16 * wave + c) * nsrow ;
+            m2 [c] = (192 + lane < w) ? ldcx<CX> (L, jb + 192 + lane, jb + 128 + 16 * wave + c, nsrow) : 0.0 ;
 #pragma unroll
-            for (int j = 0 ; j < 2 ; j++) m1 [2 * c + j] = (128 + 64 * j + lane < w) ? Lc1 [128 + 64 * j + lane] : 0.0 ;
-            const double *Lc0 = L + jb + (i64) (jb + 16 * wave + c) * nsrow ;
+            for (int j = 0 ; j < 2 ; j++) m1 [2 * c + j] = (128 + 64 * j + lane < w) ? ldcx<CX> (L, jb + 128 + 64 * j + lane, jb + 64 + 16 * wave + c, nsrow) : 0.0 ;
 #pragma unroll
-            for (int j = 0 ; j < 3 ; j++) m0 [3 * c + j] = (64 + 64 * j + lane < w) ? Lc0 [64 + 64 * j + lane] : 0.0 ;
+            for (int j = 0 ; j < 3 ; j++) m0 [3 * c + j] = (64 + 64 * j + lane < w) ? ldcx<CX> (L, jb + 64 + 64 * j + lane, jb + 16 * wave + c, nsrow) : 0.0 ;
         }
     }
     // the transposed 64 x 64 inverses as well (see k_solve_fwd_diag)
@@ -3061,6 +3110,8 @@ __global__ void __launch_bounds__(256) k_even_columns (const CheckTask *tasks, c
             O [(i64) (c >> 1) * nsrow + i] = (i == c + 1) ? 0.0 : L [(i64) c * nsrow + i] ;
 }
 
+// (CX: the checks run on the twin the storage stands for -- ldx rebuilds the odd columns)
+template <bool CX>
 __global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, const FrontD *fr,
     const double *Lx, double *out)
 {
@@ -3074,10 +3125,9 @@ __global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, 
     int c1 = T.c0 + CHK_COLS < nscol ? T.c0 + CHK_COLS : nscol ;
     for (int j = T.c0 + wave ; j < c1 ; j += 4)
     {
-        const double *col = L + (i64) j * nsrow ;
         for (int i = lane ; i < nsrow ; i += 64)
         {
-            double v = col [i] ;
+            double v = ldcx<CX> (L, i, j, nsrow) ;
             if (i < j) { if (v != 0.0) nup += 1.0 ; }
             else
             {

@@ -33,15 +33,36 @@
  * zherk/zgemm tile kernel; see DESIGN.md section 7e. */
 #include "host_internal.h"
 
+/* Which form the twin takes on the engine: 2 = complex storage (the engine keeps only the even
+ * columns of every front, i.e. the interleaved complex factor itself, 2 xsize doubles:
+ * CHOLMOD_HIP_CX_STORAGE), 1 = the full twin (4 xsize doubles).  The CPU path and several ranks
+ * use the full twin; CHOLMOD_HIP_CX_TWIN=1 (or CHOLMOD_HIP_TWIN_FULL_K=1) asks for it on one GPU. */
+static int twin_kind_wanted (cholmod_common *Common)
+{
+    /* (a silent degradation to the CPU path, if asked for, needs the full twin as well) */
+    if (ssamd_resolve_use_gpu (Common) != 1 || Common->hip_world > 1 || Common->hip_cpu_fallback) return 1 ;
+    const char *e = getenv ("CHOLMOD_HIP_CX_TWIN"), *f = getenv ("CHOLMOD_HIP_TWIN_FULL_K") ;
+    if ((e && atoi (e) != 0) || (f && atoi (f) != 0)) return 1 ;
+    return 2 ;
+}
+
 /* the twin of a complex factor: real supernodal symbolic factor of the doubled structure */
 cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common)
 {
-    if (L->cx_twin) return (cholmod_factor *) L->cx_twin ;
+    const int kind = twin_kind_wanted (Common) ;
+    if (L->cx_twin)
+    {
+        cholmod_factor *T0 = (cholmod_factor *) L->cx_twin ;
+        /* a twin that already lives on the engine keeps its form; one without a plan (symbolic, or
+         * CPU values only) is rebuilt when the other form is wanted */
+        if (T0->hip_is_twin == kind || T0->hip_plan) return T0 ;
+        cholmod_l_free_factor ((cholmod_factor **) &L->cx_twin, Common) ;
+    }
     size_t n = L->n, nsuper = L->nsuper ;
     cholmod_factor *T = cholmod_l_calloc (1, sizeof (cholmod_factor), Common) ;
     if (!T) return NULL ;
     T->n = 2 * n ; T->minor = 2 * n ;
-    T->nsuper = nsuper ; T->ssize = 2 * L->ssize ; T->xsize = 4 * L->xsize ;
+    T->nsuper = nsuper ; T->ssize = 2 * L->ssize ; T->xsize = (kind == 2 ? 2 : 4) * L->xsize ;
     T->maxcsize = 4 * L->maxcsize ; T->maxesize = 2 * L->maxesize ;
     T->ordering = CHOLMOD_NATURAL ; T->is_ll = TRUE ; T->is_super = TRUE ; T->is_monotonic = TRUE ;
     T->itype = CHOLMOD_LONG ; T->xtype = CHOLMOD_PATTERN ; T->dtype = CHOLMOD_DOUBLE ;
@@ -67,10 +88,10 @@ cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common)
     for (size_t s = 0 ; s <= nsuper ; s++)
     {
         Tsuper [s] = 2 * Super [s] ; Tpi [s] = 2 * Lpi [s] ;
-        Tpx [s] = (Lpx [0] == 123456) ? Lpx [s] : 4 * Lpx [s] ;
+        Tpx [s] = (Lpx [0] == 123456) ? Lpx [s] : (kind == 2 ? 2 : 4) * Lpx [s] ;
     }
     for (size_t p = 0 ; p < L->ssize ; p++) { Ts [2*p] = 2 * Ls [p] ; Ts [2*p+1] = 2 * Ls [p] + 1 ; }
-    T->hip_is_twin = TRUE ;
+    T->hip_is_twin = kind ;
     L->cx_twin = T ;
     return T ;
 }
@@ -174,6 +195,7 @@ int ssamd_complex_sync_host (cholmod_factor *L, cholmod_common *Common)
             return TRUE ;
         }
     }
+    if (T->hip_is_twin == 2) { ERROR (CHOLMOD_GPU_PROBLEM, "complex factor: download from the engine failed") ; return FALSE ; }
     if (!cholmod_l_factor_to_host (T, Common)) return FALSE ;
     if (!gather_even_columns (L, T, Common)) return FALSE ;
     L->hip_host_valid = TRUE ;

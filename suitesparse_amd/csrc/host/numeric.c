@@ -107,7 +107,8 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
     /* the real twin of a complex factor (complex.c): the update kernels contract over the even
      * panel columns only -- the complex multiply-add as four real ones (zherk / zgemm,
      * t_cholmod_super_numeric.c:41-83) instead of the eight of the plain embedding */
-    if (L->hip_is_twin)
+    if (L->hip_is_twin == 2) flags |= CHOLMOD_HIP_CX_STORAGE ;      /* the complex factor in its own storage */
+    else if (L->hip_is_twin)
     {
         const char *e = getenv ("CHOLMOD_HIP_TWIN_FULL_K") ;
         if (!(e && atoi (e) != 0)) flags |= CHOLMOD_HIP_PHI_TWIN ;
@@ -236,6 +237,7 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
         L->useGPU = 0 ;
     }
     /* ---- CPU path */
+    if (L->hip_is_twin == 2) { ERROR (CHOLMOD_GPU_PROBLEM, "a complex factor in engine storage has no CPU form") ; return FALSE ; }
     int was_symbolic = (L->x == NULL) ;
     if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
     if (!L->x) return FALSE ;           /* out of memory: L is returned symbolic (cholmod_super_numeric.c:235-248) */

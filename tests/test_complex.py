@@ -329,28 +329,64 @@ def test_twin_flag_is_checked_at_plan_creation():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["full_k", "wave_tiles_everywhere", "four_wave_tiles_only", "no_fused_potrf", "wide_ob"])
+@pytest.mark.parametrize("variant", ["default", "wave_tiles_everywhere", "four_wave_tiles_only", "no_fused_potrf", "no_fused_trsm", "wide_ob"])
+@pytest.mark.parametrize("storage", ["complex_storage", "twin_even_columns", "plain_embedding"])
 @pytest.mark.parametrize("name", ["p3d_24_nd", "box16r2_nd"])
-def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, variant):
+def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, storage, variant):
+    """The three forms the engine has for a complex factor -- its own storage (default on one GPU:
+    CHOLMOD_HIP_CX_STORAGE, 2 xsize doubles, odd twin columns rebuilt in the kernels), the full twin with
+    even-column updates, the plain embedding -- through every update / panel kernel variant."""
     assert ch.lib().cholmod_hip_probe() == 1, "no HIP device visible"
+    if storage == "plain_embedding" and variant not in ("default", "wave_tiles_everywhere"):
+        pytest.skip("the plain embedding runs the real kernels, covered by the real parity tests")
     kw = {}
-    if variant == "full_k":
+    if storage == "twin_even_columns":
+        monkeypatch.setenv("CHOLMOD_HIP_CX_TWIN", "1")
+    elif storage == "plain_embedding":
         monkeypatch.setenv("CHOLMOD_HIP_TWIN_FULL_K", "1")
-    elif variant == "wave_tiles_everywhere":
-        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "1")       # k_update3<.., TW> incl. partial tiles
+    if variant == "wave_tiles_everywhere":
+        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "1")       # k_update3 incl. partial tiles
     elif variant == "four_wave_tiles_only":
-        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "0")       # k_update2<.., TW> / k_update2f<TW> only
+        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "0")       # k_update2 / k_update2f only
     elif variant == "no_fused_potrf":
         kw["hip_flags"] = ch.HIP_NO_FUSED_POTRF
+    elif variant == "no_fused_trsm":
+        kw["hip_flags"] = ch.HIP_NO_FUSED_TRSM
     elif variant == "wide_ob":
         kw["hip_flags"] = ch.HIP_WIDE_OB
     _check(name, golden_dir, use_gpu=1, dense_check=False, session_kwargs=kw)
 
 
 @pytest.mark.gpu
+def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
+    """The engine's factor of a complex matrix occupies 2 xsize doubles in its own storage, 4 xsize as a twin
+    (cholmod_hip_get_stats [5] = bytes of L on the device)."""
+    n, Ap, Ai, Ax, perm = _case("p3d_24_nd", golden_dir)
+    sizes = {}
+    for twin in (False, True):
+        if twin:
+            monkeypatch.setenv("CHOLMOD_HIP_CX_TWIN", "1")
+        S = ch.Session(use_gpu=1, factor_on_device=True)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.analyze(A, perm)
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        T = C.cast(Lf.contents.cx_twin, C.POINTER(ch.Factor))
+        st = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+        S.L.cholmod_hip_get_stats(T.contents.hip_plan, st.ctypes.data)
+        sizes[twin] = (st[5], int(Lf.contents.xsize), int(T.contents.hip_is_twin))
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+    assert sizes[False][2] == 2 and sizes[True][2] == 1
+    assert sizes[False][0] == 8.0 * 2 * sizes[False][1]
+    assert sizes[True][0] == 8.0 * 4 * sizes[True][1]
+
+
+@pytest.mark.gpu
 def test_complex_gpu_big_fronts_even_column_updates(monkeypatch):
     """A complex problem whose top fronts reach the one-wave-per-tile update kernel by themselves
-    (twin root of 2 x 1600 columns), by residual, factor invariants and against the plain embedding."""
+    (twin root of 2 x 1600 columns), by residual, factor invariants and against the plain embedding,
+    in the engine's three forms."""
     m = 40
     n, Ap, Ai, Ax = G.poisson3d(m)
     perm = G.geometric_nd(m, m, m, 4)
@@ -358,19 +394,23 @@ def test_complex_gpu_big_fronts_even_column_updates(monkeypatch):
     Af = full_hermitian(n, cAp, cAi, cAx)
     b = np.exp(1j * np.arange(n))
     xs = {}
-    for full_k in (False, True):
-        if full_k:
-            monkeypatch.setenv("CHOLMOD_HIP_TWIN_FULL_K", "1")
+    for form, env in (("complex_storage", None), ("twin_even_columns", "CHOLMOD_HIP_CX_TWIN"), ("plain_embedding", "CHOLMOD_HIP_TWIN_FULL_K")):
+        monkeypatch.delenv("CHOLMOD_HIP_CX_TWIN", raising=False)
+        monkeypatch.delenv("CHOLMOD_HIP_TWIN_FULL_K", raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
         S = ch.Session(use_gpu=1)
         A = S.sparse(n, cAp, cAi, cAx, -1)
         Lf = S.analyze(A, perm)
         assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
         assert S.L.cholmod_l_check_factor(Lf, C.byref(S.cm)) == 1
         fv = ch.FactorView(Lf)
-        xs[full_k] = fv.x.copy()
+        xs[form] = fv.x.copy()
         x = S.solve(Lf, b)
         assert np.linalg.norm(Af @ x - b) / np.linalg.norm(b) < TOL_RES
         S.free_factor(Lf)
         S.free_sparse(A)
         S.finish()
-    assert np.linalg.norm(xs[False] - xs[True]) / np.linalg.norm(xs[True]) < TOL_L
+    ref = xs["plain_embedding"]
+    for form in ("complex_storage", "twin_even_columns"):
+        assert np.linalg.norm(xs[form] - ref) / np.linalg.norm(ref) < TOL_L, form

@@ -39,3 +39,8 @@ for i in range(len(p["ms"])):
         S.L.cholmod_hip_debug_thin_cycles(Lf.contents.hip_plan, i, t.ctypes.data)
         print("      cycles: req+zero %d, A %d, children %d, panels %d, store+barrier %d, trailing %d" % tuple(t[:6]))
     print("%5d %-10s grid=%7d aux=%5d ms=%8.4f MB=%9.2f GB/s=%8.1f TF/s=%6.2f" % (i, KIND.get(p["kind"][i], p["kind"][i]), p["grid"][i], p["aux"][i], p["ms"][i], p["bytes"][i] / 1e6, gbps, tf))
+    if os.environ.get("REGIONS") and p["kind"][i] in (4, 5, 9, 12):
+        out = np.zeros(12 * 16, dtype=np.int64)
+        ng = S.L.cholmod_hip_debug_launch_regions(Lf.contents.hip_plan, i, 16, out.ctypes.data)
+        for r in range(min(ng, 16)):
+            print("          region m %d n %d k %d tri %d cb %d lda %d ldc %d tiles %d front %d assign %d swz %d" % tuple(out[12 * r + t] for t in (0, 1, 2, 3, 4, 5, 6, 7, 9, 10, 11)))

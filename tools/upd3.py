@@ -6,6 +6,7 @@
   tail        contraction lengths that are no multiple of 4: agreement and rate
   sustain     the same launch for 0.3 / 1.6 / 4.8 s (is the rate inside a long factorization a power effect?)
   offset      the operands 0 / 60 / 150 / 240 GB into one allocation (does it matter where a front lives?)
+  rounds      triangular regions of 6k .. 48k rows at K = 4096 / 1024: rate against the number of rounds of 2048 tiles
 usage: python tools/upd3.py [mode]      prints one JSON line"""
 import ctypes as C
 import json
@@ -59,6 +60,14 @@ elif mode == "offset":
     for gb in ("0", "60", "150", "240"):
         os.environ["CHOLMOD_PROBE_OFFSET_GB"] = gb
         out["offset_%sGB" % gb] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, 3, TRI | D4) / 1e12
+elif mode == "rounds":
+    for k in (4096, 1024):
+        for nrows in (6144, 8192, 12288, 16384, 20480, 24576, 28672, 32768, 40960, 49152):
+            nt = nrows // 64
+            tiles = nt * (nt + 1) // 2
+            tf = pr.cholmod_hip_bench_update_kernel(nrows, nrows, k, 2, TRI | D4) / 1e12
+            out[f"tri{nrows}_K{k}"] = {"tiles": tiles, "rounds": tiles / 2048.0, "TFLOPs": tf,
+                                       "ms_per_launch": 2.0 * (nrows * (nrows + 1) / 2) * k / tf / 1e9}
 else:
     raise SystemExit(__doc__)
 print(json.dumps(out))
