@@ -29,6 +29,12 @@ double cholmod_hip_bench_mfma_peak2 (int variant, int waves_per_simd, int iters,
  * that issue rate gives at 2.4 GHz}.  (cholmod_hip_bench_mfma_peak's loop carries VGPR <-> AGPR
  * copies the compiler inserted and under-reports; it is kept for the round-1/2 records.) */
 double cholmod_hip_bench_mfma_ceiling (int waves_per_simd, int nacc, int iters, int zero_operands, double *out3) ;
+/* CU masks (tools/cumask.py): where the workgroups of a stream created with hipExtStreamCreateWithCUMask run
+ * (out [b] = (XCC_ID << 32) | HW_ID), and the one-wave-per-tile update beside a chain of small dependent
+ * launches on two masked streams */
+double cholmod_hip_probe_cu_mask (const uint32_t *mask, int nwords, int blocks, int spin_us, long long *out) ;
+int cholmod_hip_probe_overlap (const uint32_t *mask_a, const uint32_t *mask_b, int nwords, int64_t m, int64_t k,
+    int nchain, int chain_blocks, int chain_us, double *out4) ;
 
 /* Tuning probe: an update kernel selected by `flags` against k_update2 on the same operands;
  * max |difference| / max |reference| (negative = a CHOLMOD_HIP_* code). */

@@ -151,7 +151,7 @@ PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
 PROBE_SYMBOLS = [
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
-    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
+    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_probe_cu_mask", "cholmod_hip_probe_overlap", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
 ]
 
 _lib = None
@@ -278,6 +278,8 @@ def probes():
             ("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mfma_ceiling", dbl, [C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+            ("cholmod_hip_probe_cu_mask", dbl, [vp, C.c_int, C.c_int, C.c_int, vp]),
+            ("cholmod_hip_probe_overlap", C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, C.c_int, C.c_int, vp]),
             ("cholmod_hip_debug_update_diff", dbl, [i64, i64, i64, C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_debug_diag_cycles", C.c_int, [vp, C.c_int, C.c_int]),
             ("cholmod_hip_debug_potrf_cycles", C.c_int, [vp]),

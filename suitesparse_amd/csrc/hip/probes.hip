@@ -499,4 +499,93 @@ int cholmod_hip_debug_diag_cycles (long long *out10, int w, int m)
 }
 
 
+/* ---- CU masks: which compute units a masked stream's workgroups land on ------------------
+ * (tuning: can the panel chain of the next outer block run on CUs of its own beside the trailing
+ * update?)  Launches `blocks` one-wave workgroups that each spin for `spin_us` on a stream created
+ * with hipExtStreamCreateWithCUMask (nwords 32-bit words; nwords == 0: an ordinary stream) and
+ * records (XCC_ID, HW_ID) of each: out [b] = (xcc << 32) | hw_id.  Returns the launch's
+ * milliseconds or a negative status. */
+__global__ void k_where_am_i (long long *out, long long spin_ticks)
+{
+    if (threadIdx.x == 0)
+    {
+        unsigned hw = __builtin_amdgcn_s_getreg ((31 << 11) | 4) ;      // HW_REG_HW_ID, 32 bits
+        unsigned xcc = __builtin_amdgcn_s_getreg ((31 << 11) | 20) ;    // HW_REG_XCC_ID
+        out [blockIdx.x] = ((long long) xcc << 32) | hw ;
+    }
+    long long t0 = __builtin_amdgcn_s_memrealtime () ;
+    while (__builtin_amdgcn_s_memrealtime () - t0 < spin_ticks) __builtin_amdgcn_s_sleep (8) ;
+}
+
+double cholmod_hip_probe_cu_mask (const uint32_t *mask, int nwords, int blocks, int spin_us, long long *out)
+{
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    hipStream_t st = nullptr ;
+    hipError_t e = nwords > 0 ? hipExtStreamCreateWithCUMask (&st, (uint32_t) nwords, mask) : hipStreamCreate (&st) ;
+    if (e != hipSuccess) { (void) hipGetLastError () ; return CHOLMOD_HIP_INVALID ; }
+    long long *d = nullptr ;
+    if (hipMalloc ((void **) &d, (size_t) blocks * sizeof (long long)) != hipSuccess) { (void) hipStreamDestroy (st) ; return CHOLMOD_HIP_OUT_OF_MEMORY ; }
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    (void) hipEventRecord (e0, st) ;
+    hipLaunchKernelGGL (k_where_am_i, dim3 (blocks), dim3 (64), 0, st, d, (long long) spin_us * 100) ;
+    (void) hipEventRecord (e1, st) ;
+    e = hipStreamSynchronize (st) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    if (e == hipSuccess) e = hipMemcpy (out, d, (size_t) blocks * sizeof (long long), hipMemcpyDeviceToHost) ;
+    (void) hipFree (d) ; (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ; (void) hipStreamDestroy (st) ;
+    return e == hipSuccess ? (double) ms : (double) CHOLMOD_HIP_GPU_PROBLEM ;
+}
+
+/* Two kernels side by side on two masked streams: the one-wave-per-tile update on a triangular
+ * region (m rows, contraction k) on stream A (mask_a), and `nchain` dependent launches of a small
+ * kernel that spins chain_us each on stream B (mask_b).  out4: [0] update alone ms, [1] chain
+ * alone ms, [2] both started together: update ms, [3] chain ms. */
+int cholmod_hip_probe_overlap (const uint32_t *mask_a, const uint32_t *mask_b, int nwords, int64_t m, int64_t k,
+    int nchain, int chain_blocks, int chain_us, double *out4)
+{
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    hipStream_t sa = nullptr, sb = nullptr ;
+    if (nwords > 0)
+    {
+        HIPCHK (hipExtStreamCreateWithCUMask (&sa, (uint32_t) nwords, mask_a)) ;
+        HIPCHK (hipExtStreamCreateWithCUMask (&sb, (uint32_t) nwords, mask_b)) ;
+    }
+    else { HIPCHK (hipStreamCreate (&sa)) ; HIPCHK (hipStreamCreate (&sb)) ; }
+    const i64 lda = m ;
+    double *d = nullptr ; long long *w = nullptr ; GemmGroup *dg = nullptr ;
+    HIPCHK (hipMalloc ((void **) &d, (size_t) (lda * (k + m)) * sizeof (double))) ;
+    HIPCHK (hipMemset (d, 0, (size_t) (lda * (k + m)) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &w, (size_t) chain_blocks * sizeof (long long))) ;
+    GemmGroup G ;
+    memset (&G, 0, sizeof (G)) ;
+    G.a_off = 0 ; G.b_off = 0 ; G.c_off = lda * k ; G.lda = (i32) lda ; G.ldc = (i32) lda ;
+    G.m = (i32) m ; G.n = (i32) m ; G.k = (i32) k ; G.tri = 1 ; G.tile_mul = 1 ;
+    G.mt = G.nt = (i32) ((m + 63) / 64) ;
+    G.ntiles = (i32) ((i64) G.nt * (G.nt + 1) / 2) ;
+    G.nblk = (G.ntiles + 63) / 64 * 64 ; G.swz = G.nblk >= 1024 ;
+    HIPCHK (hipMalloc ((void **) &dg, sizeof (G))) ;
+    HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+    hipEvent_t a0, a1, b0, b1 ;
+    (void) hipEventCreate (&a0) ; (void) hipEventCreate (&a1) ; (void) hipEventCreate (&b0) ; (void) hipEventCreate (&b1) ;
+    auto upd = [&] () { hipLaunchKernelGGL ((k_update3<4>), dim3 (G.nblk), dim3 (64), 0, sa, dg, 1, d, d) ; } ;
+    auto chain = [&] () { for (int q = 0 ; q < nchain ; q++) hipLaunchKernelGGL (k_where_am_i, dim3 (chain_blocks), dim3 (64), 0, sb, w, (long long) chain_us * 100) ; } ;
+    float t = 0 ;
+    upd () ; HIPCHK (hipDeviceSynchronize ()) ;
+    (void) hipEventRecord (a0, sa) ; upd () ; (void) hipEventRecord (a1, sa) ; HIPCHK (hipDeviceSynchronize ()) ;
+    (void) hipEventElapsedTime (&t, a0, a1) ; out4 [0] = t ;
+    (void) hipEventRecord (b0, sb) ; chain () ; (void) hipEventRecord (b1, sb) ; HIPCHK (hipDeviceSynchronize ()) ;
+    (void) hipEventElapsedTime (&t, b0, b1) ; out4 [1] = t ;
+    (void) hipEventRecord (a0, sa) ; upd () ; (void) hipEventRecord (a1, sa) ;
+    (void) hipEventRecord (b0, sb) ; chain () ; (void) hipEventRecord (b1, sb) ;
+    HIPCHK (hipDeviceSynchronize ()) ;
+    (void) hipEventElapsedTime (&t, a0, a1) ; out4 [2] = t ;
+    (void) hipEventElapsedTime (&t, b0, b1) ; out4 [3] = t ;
+    (void) hipFree (d) ; (void) hipFree (w) ; (void) hipFree (dg) ;
+    (void) hipEventDestroy (a0) ; (void) hipEventDestroy (a1) ; (void) hipEventDestroy (b0) ; (void) hipEventDestroy (b1) ;
+    (void) hipStreamDestroy (sa) ; (void) hipStreamDestroy (sb) ;
+    return CHOLMOD_HIP_OK ;
+}
+
 } // extern "C"
