@@ -1412,7 +1412,18 @@ static int upload_plan (cholmod_hip_plan *P)
     const bool ptiming = getenv ("CHOLMOD_HIP_PLAN_TIMING") != nullptr ;
     auto pnow = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
     double tu0 = pnow () ;
-    HIPCHK (hipStreamCreate (&P->stream)) ;
+    // tuning (CHOLMOD_HIP_CU_MASK_32THS = k, 1 .. 31): the main stream on k / 32 of the CUs of every XCD
+    // (mask bit b <-> CU b / 8 of XCD b % 8 on this part, tools/cumask.py): what the kernels of a
+    // factorization cost on a share of the chip (look-ahead arithmetic)
+    if (const char *e = getenv ("CHOLMOD_HIP_CU_MASK_32THS"))
+    {
+        int k = atoi (e) ;
+        if (k < 1 || k > 31) return CHOLMOD_HIP_INVALID ;
+        uint32_t m [8] ;
+        for (int w = 0 ; w < 8 ; w++) m [w] = (4 * w + 4 <= k) ? 0xFFFFFFFFu : (4 * w >= k) ? 0u : (uint32_t) ((1ull << (8 * (k - 4 * w))) - 1) ;
+        HIPCHK (hipExtStreamCreateWithCUMask (&P->stream, 8, m)) ;
+    }
+    else HIPCHK (hipStreamCreate (&P->stream)) ;
     HIPCHK (hipStreamCreate (&P->stream2)) ;
     for (int q = 0 ; q < P->sch.nevents ; q++)
     {
