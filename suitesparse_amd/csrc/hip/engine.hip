@@ -426,6 +426,14 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     i64 mych = nch > G.tile_add ? (nch - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
                     mine = mych * 64 ;
                     G.swz = !(flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) && mine >= 1024 ;
+                    // one wave per tile: an XCD runs 256 tiles at a time -- big unshared regions walk 16 x 16
+                    // super-tiles (32 operand panels per 256 tiles; measured against 8 x 8 on a triangular
+                    // 49 152^2 region, K = 4096: 74.6 against 74.4 TFLOP/s, 200 against 220 GB fetched)
+                    if (G.swz && pass == 3 && G.tile_mul == 1 && cnt >= 8192 && !getenv ("CHOLMOD_HIP_NO_SWZ16"))
+                    {
+                        G.swz = 2 ;
+                        mine = (cnt + 255) / 256 * 256 ;
+                    }
                     if (G.swz) tiles = (tiles + 7) / 8 * 8 ;     // keep block % 8 == XCD aligned
                     else if (G.tile_mul == 1) mine = cnt ;
                 }

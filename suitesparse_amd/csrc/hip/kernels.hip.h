@@ -1422,37 +1422,41 @@ __global__ void __launch_bounds__(64, MINW) k_leaf_pair (const i32 *fronts, int 
 // Returns false for a padding block (past the end of the rank's last chunk).
 __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, int &J)
 {
+    // strips of W tile columns: W = 8 (64 consecutive tiles = an 8 x 8 super-tile), or 16 with
+    // G.swz == 2 (256 consecutive tiles = a 16 x 16 super-tile = the tiles ONE XCD runs at a time
+    // with one wave per tile: 32 operand panels for 256 tiles)
+    const int W = G.swz == 2 ? 16 : 8, LW = G.swz == 2 ? 8 : 6 ;
     int t ;
     if (G.tile_mul == 1 && !G.swz) t = u ;
     else
     {
         int cl, within ;
-        if (G.swz && u < (G.nblk / 512) * 512) { int q = u >> 3 ; cl = (q >> 6) * 8 + (u & 7) ; within = q & 63 ; }
-        else { cl = u >> 6 ; within = u & 63 ; }
-        t = ((cl * G.tile_mul + G.tile_add) << 6) + within ;
+        if (G.swz && u < (G.nblk >> (LW + 3)) << (LW + 3)) { int q = u >> 3 ; cl = (q >> LW) * 8 + (u & 7) ; within = q & ((1 << LW) - 1) ; }
+        else { cl = u >> LW ; within = u & ((1 << LW) - 1) ; }
+        t = ((cl * G.tile_mul + G.tile_add) << LW) + within ;
     }
     if (t >= G.ntiles) return false ;
     int S = 0, w, mt = G.mt, nt = G.nt ;
     for ( ; ; S++)
     {
-        w = nt - 8 * S ; if (w > 8) w = 8 ;
-        int rows = G.tri ? mt - 8 * S : mt ;
+        w = nt - W * S ; if (w > W) w = W ;
+        int rows = G.tri ? mt - W * S : mt ;
         int c = G.tri ? w * (w + 1) / 2 + (rows - w) * w : rows * w ;
         if (t < c) break ;
         t -= c ;
     }
-    if (!G.tri) { I = t / w ; J = 8 * S + t % w ; return true ; }
+    if (!G.tri) { I = t / w ; J = W * S + t % w ; return true ; }
     int tri = w * (w + 1) / 2 ;
     if (t < tri)
     {
         int r = 0 ;
         while ((r + 1) * (r + 2) / 2 <= t) r++ ;
-        I = 8 * S + r ; J = 8 * S + t - r * (r + 1) / 2 ;
+        I = W * S + r ; J = W * S + t - r * (r + 1) / 2 ;
     }
     else
     {
         int t2 = t - tri ;
-        I = 8 * S + w + t2 / w ; J = 8 * S + t2 % w ;
+        I = W * S + w + t2 / w ; J = W * S + t2 % w ;
     }
     return true ;
 }

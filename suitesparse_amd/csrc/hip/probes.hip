@@ -72,6 +72,8 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
         G.nblk = (G.ntiles + 63) / 64 * 64 ;
     }
     G.swz = (flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) ? 0 : 1 ;
+    // flag 262144: 16-wide strips, an XCD walks 16 x 16 super-tiles (256 tiles = what it runs at a time)
+    if ((flags & 262144) && G.swz) { G.swz = 2 ; G.nblk = (G.ntiles + 255) / 256 * 256 ; }
     G.mt = (i32) ((m + TM - 1) / TM) ; G.nt = (i32) ((n + TN - 1) / TN) ;
     GemmGroup *dg = nullptr ;
     (void) hipMalloc ((void **) &dg, sizeof (G)) ;
@@ -425,6 +427,12 @@ double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, 
     for (int pass = 0 ; pass < 2 ; pass++)
     {
         HIPCHK (hipMemcpy (d, h.data (), total * sizeof (double), hipMemcpyHostToDevice)) ;
+        if (pass == 1 && (flags & 262144))
+        {
+            // the one-wave-per-tile kernel walking 16 x 16 super-tiles (swz = 2), against k_update2's 8 x 8 walk
+            G.swz = 2 ; G.nblk = (G.ntiles + 255) / 256 * 256 ;
+            HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
+        }
         if (pass == 0) hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (G.nblk), dim3 (256), 0, 0, dg, 1, d, d) ;
         else if (flags & 16384) hipLaunchKernelGGL ((k_update3<2>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
         else if (flags & 32768) hipLaunchKernelGGL ((k_update3<4>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;

@@ -328,6 +328,17 @@ def test_update_kernel_microbench_runs(L):
     assert not hasattr(L, "cholmod_hip_bench_mfma_peak")      # ... and not in the product
 
 
+def test_wave_tile_kernel_16x16_super_tile_walk_is_bit_identical():
+    """k_update3 walking 16 x 16 super-tiles (GemmGroup.swz == 2: what an XCD runs at a time with one wave per
+    tile; the engine uses it for unshared regions of >= 8192 tiles) covers every tile exactly once: bitwise the
+    result of k_update2's 8 x 8 walk, on ragged / triangular / assign regions of up to 61 x 79 tiles."""
+    Pr = ch.probes()
+    D4, SWZ16 = 32768, 262144
+    for (m, n, k, tri, asg) in ((2049, 2049, 34, 1, 0), (4096, 4096, 16, 0, 0), (5000, 3000, 19, 1, 1), (3900, 3333, 9, 1, 0),
+                                (64, 64, 8, 0, 0), (1100, 900, 12, 0, 1), (5056, 3900, 5, 0, 0)):
+        assert Pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, D4 | SWZ16) == 0.0, (m, n, k, tri, asg)
+
+
 def test_shim_level_factorize_with_host_copy(L, golden_dir):
     """The plain-pointer ABI exactly as INTEGRATION.md binds it: plan from the index
     maps, cholmod_hip_factorize with an Lx_host buffer, solve on the device."""

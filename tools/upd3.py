@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from suitesparse_amd import cholmod as ch
 
 pr = ch.probes()
-TRI, NOSWZ, ODD, D2, D3, D4 = 65536, 32, 131072, 16384, 8192, 32768
+TRI, NOSWZ, ODD, D2, D3, D4, SWZ16 = 65536, 32, 131072, 16384, 8192, 32768, 262144
 mode = sys.argv[1] if len(sys.argv) > 1 else "standalone"
 out = {}
 if mode == "standalone":
@@ -60,6 +60,23 @@ elif mode == "offset":
     for gb in ("0", "60", "150", "240"):
         os.environ["CHOLMOD_PROBE_OFFSET_GB"] = gb
         out["offset_%sGB" % gb] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, 3, TRI | D4) / 1e12
+elif mode == "swz16diff":
+    out = {f"{m}x{n}x{k}_tri{tri}_asg{asg}": pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, D4 | SWZ16)
+           for (m, n, k, tri, asg) in ((2049, 2049, 130, 1, 0), (4096, 4096, 64, 0, 0), (5000, 3000, 67, 1, 1), (3333, 3333, 129, 1, 0), (64, 64, 8, 0, 0), (1100, 900, 40, 0, 1))}
+elif mode == "swz16":
+    # 16 x 16 super-tiles per XCD against 8 x 8 (speed; the fetch side: rocprofv3 --pmc FETCH_SIZE over this mode)
+    for name, (m, n, k, it, fl) in {
+            "u3_tri48k_K4096_8x8": (49152, 49152, 4096, 1, TRI | D4), "u3_tri48k_K4096_16x16": (49152, 49152, 4096, 1, TRI | D4 | SWZ16),
+            "u3_tri24k_K4096_8x8": (24576, 24576, 4096, 2, TRI | D4), "u3_tri24k_K4096_16x16": (24576, 24576, 4096, 2, TRI | D4 | SWZ16),
+            "u3_tri24k_K1024_8x8": (24576, 24576, 1024, 4, TRI | D4), "u3_tri24k_K1024_16x16": (24576, 24576, 1024, 4, TRI | D4 | SWZ16),
+            "u3_sq16k_K4096_8x8": (16384, 16384, 4096, 2, D4), "u3_sq16k_K4096_16x16": (16384, 16384, 4096, 2, D4 | SWZ16)}.items():
+        out[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
+elif mode == "fetch":
+    # under rocprofv3 --pmc FETCH_SIZE: dispatches of k_update3<4> in order = [8x8 warm-up, 8x8, 16x16 warm-up, 16x16] x shapes
+    for name, (m, n, k, it, fl) in {
+            "u3_tri48k_K4096_8x8": (49152, 49152, 4096, 1, TRI | D4), "u3_tri48k_K4096_16x16": (49152, 49152, 4096, 1, TRI | D4 | SWZ16),
+            "u3_tri24k_K1024_8x8": (24576, 24576, 1024, 1, TRI | D4), "u3_tri24k_K1024_16x16": (24576, 24576, 1024, 1, TRI | D4 | SWZ16)}.items():
+        out[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
 elif mode == "rounds":
     for k in (4096, 1024):
         for nrows in (6144, 8192, 12288, 16384, 20480, 24576, 28672, 32768, 40960, 49152):
