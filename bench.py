@@ -109,7 +109,7 @@ def cpu_baseline(sample_m):
                       f"{r['seconds']:.2f} s, BLAS={r['blas']}, host cores {cores}"}
 
 
-PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r03_pmc_summary_poisson200_top48.json"}
+PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r03j_pmc_summary_poisson200_top48.json"}
 
 
 def roofline_of(S, Lf, wname, world):
@@ -493,10 +493,43 @@ def main():
     # residual, and one pass over the resident factor for its invariants; for the
     # Poisson grids log det(A) is known in closed form (a checksum of the whole factor)
     resid, checks = None, None
-    if not args.no_check:
+    check_note = None
+    do_check = not args.no_check
+    dist_checks = None
+    if not args.no_check and world > 1:
+        # invariants of the factor as it lies distributed over the ranks (every front checked by the first rank
+        # of its group, the five sums all-reduced): no gathered copy, so this works where the gather does not fit
+        import torch
         from suitesparse_amd import generators as G
-        if world > 1:
-            assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
+        loc = torch.from_numpy(S.factor_checks_local(Lf)).cuda()
+        dist.all_reduce(loc)
+        v = loc.cpu().numpy()
+        dist_checks = dict(half_logdet=float(v[0]), upper_nonzeros=int(v[1]), nonfinite=int(v[2]), fro2=float(v[3]), nonpositive_diag=int(v[4]))
+        if not args.matrix and args.workload in ("poisson3d", "poisson2d"):
+            ld = G.poisson_logdet(*([m] * (3 if args.workload == "poisson3d" else 2)))
+            dist_checks["logdet_closed_form"] = ld
+            dist_checks["logdet_rel_err"] = abs(2.0 * dist_checks["half_logdet"] - ld) / abs(ld)
+            # ||L||_F^2 = trace (A) = 2 d n for the d-dimensional Dirichlet Laplacian
+            tr = 2.0 * (3 if args.workload == "poisson3d" else 2) * n
+            dist_checks["trace_rel_err"] = abs(dist_checks["fro2"] - tr) / tr
+    if do_check and world > 1:
+        # the complete factor on every rank, next to the rank's own part: 181.6 GB + 117 GB at two ranks do
+        # not fit in 288 GB -- the line is then printed without the solve / factor checks rather than lost
+        # (every rank must take the same decision)
+        import torch
+        eh = S.cm.error_handler
+        S.cm.error_handler = ch.ERRFUNC(0)
+        got = S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
+        S.cm.error_handler = eh
+        flag = torch.tensor([0.0 if got else 1.0], device="cuda")
+        dist.all_reduce(flag)
+        if flag.item() > 0:
+            do_check = False
+            check_note = ("skipped: the gathered factor does not fit next to the rank's own part of L on every rank "
+                          f"(status {S.cm.status} on rank {rank})")
+            S.cm.status = ch.OK
+    if do_check:
+        from suitesparse_amd import generators as G
         t0 = time.perf_counter()
         b = G.demo_rhs(n)
         x = S.solve(Lf, b)
@@ -592,6 +625,10 @@ def main():
         if resid is not None:
             line["residual_2norm"] = resid
             line["factor_checks"] = checks
+        if check_note:
+            line["residual_2norm_note"] = check_note
+        if dist_checks is not None:
+            line["factor_checks_distributed"] = dist_checks
         if secondary:
             line["secondary"] = secondary
         if native:

@@ -220,6 +220,10 @@ int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
  * entries of the lower trapezoids;  out5[3] = ||L||_F^2 over the lower
  * trapezoids;  out5[4] = diagonal entries <= 0. */
 int cholmod_hip_factor_checks (cholmod_hip_plan *plan, double *out5) ;
+/* The same five numbers over the fronts this rank answers for (the first rank of a front's group),
+ * from the rank's own part of a distributed factor: their sums over the ranks are the invariants
+ * of the complete factor, no gathered copy needed. */
+int cholmod_hip_factor_checks_local (cholmod_hip_plan *plan, double *out5) ;
 
 /* Statistics of the last factorization / of the plan (doubles):
  *  [0] device seconds, whole factorization (HIP events on the engine stream)

@@ -142,7 +142,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_get_maps", "cholmod_hip_get_stats", "cholmod_hip_set_profiling",
     
     
-    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles", "cholmod_hip_debug_launch_regions",
+    "cholmod_hip_dense_partial_factor", "cholmod_hip_factor_checks", "cholmod_hip_factor_checks_local", "cholmod_hip_get_launch_profile", "cholmod_hip_debug_thin_cycles", "cholmod_hip_debug_launch_regions",
     "cholmod_hip_rccl_unique_id", "cholmod_hip_rccl_attach", "cholmod_hip_rccl_detach",
     "cholmod_hip_version",
 ]
@@ -251,6 +251,7 @@ def lib():
     sig("cholmod_hip_set_profiling", C.c_int, [vp, C.c_int])
     sig("cholmod_hip_dense_partial_factor", C.c_int, [vp, i64, i64, C.c_int, C.POINTER(i64)])
     sig("cholmod_hip_factor_checks", C.c_int, [vp, vp])
+    sig("cholmod_hip_factor_checks_local", C.c_int, [vp, vp])
     sig("cholmod_hip_get_launch_profile", i64, [vp, i64, vp, vp, vp, vp, vp, vp])
     sig("cholmod_hip_debug_thin_cycles", C.c_int, [vp, i64, vp])
     sig("cholmod_hip_debug_launch_regions", i64, [vp, i64, i64, vp])
@@ -442,6 +443,17 @@ class Session:
             raise RuntimeError(f"cholmod_hip_factor_checks failed: {rc}")
         return dict(half_logdet=out[0], upper_nonzeros=int(out[1]), nonfinite=int(out[2]),
                     fro2=out[3], nonpositive_diag=int(out[4]))
+
+    def factor_checks_local(self, Lf):
+        """This rank's share of the invariants of a distributed factor (cholmod_hip_factor_checks_local):
+        the five numbers as an array; their sums over the ranks are those of the complete factor."""
+        out = np.zeros(5)
+        f = Lf.contents
+        plan = C.cast(f.cx_twin, C.POINTER(Factor)).contents.hip_plan if f.cx_twin else f.hip_plan
+        rc = self.L.cholmod_hip_factor_checks_local(plan, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"cholmod_hip_factor_checks_local failed: {rc}")
+        return out
 
     def launch_profile(self, Lf):
         """Per-launch (kind, grid, aux, ms, flops, bytes) of the last profiled factorization."""

@@ -426,10 +426,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     i64 mych = nch > G.tile_add ? (nch - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
                     mine = mych * 64 ;
                     G.swz = !(flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) && mine >= 1024 ;
-                    // one wave per tile: an XCD runs 256 tiles at a time -- big unshared regions walk 16 x 16
-                    // super-tiles (32 operand panels per 256 tiles; measured against 8 x 8 on a triangular
-                    // 49 152^2 region, K = 4096: 74.6 against 74.4 TFLOP/s, 200 against 220 GB fetched)
-                    if (G.swz && pass == 3 && G.tile_mul == 1 && cnt >= 8192 && !getenv ("CHOLMOD_HIP_NO_SWZ16"))
+                    // one wave per tile: an XCD runs 256 tiles at a time, so a 16 x 16 super-tile (32 operand
+                    // panels per 256 tiles) is one XCD's load.  Opt-in (CHOLMOD_HIP_SWZ16=1): standalone on a
+                    // triangular 49 152^2 region, K = 4096, it is 74.6 against 74.4 TFLOP/s and 200 against
+                    // 220 GB fetched, inside the 200^3 factorization 105.4 against 105.1 ms per launch and
+                    // 478 against 462 GB (same box, top-48 launches): the tiles of an XCD drift apart in k
+                    // either way, and the wider strip only widens what they drift over.
+                    if (G.swz && pass == 3 && G.tile_mul == 1 && cnt >= 8192 && getenv ("CHOLMOD_HIP_SWZ16"))
                     {
                         G.swz = 2 ;
                         mine = (cnt + 255) / 256 * 256 ;
@@ -2109,7 +2112,11 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     if (!P->ar_fn && !P->nccl_world) return CHOLMOD_HIP_INVALID ;
     P->winv_valid = false ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
-    if (!P->d_Lx_full)
+    // test hook CHOLMOD_HIP_TEST_FAIL_GATHER=r: rank r finds no room for the complete factor
+    const char *tfg = getenv ("CHOLMOD_HIP_TEST_FAIL_GATHER") ;
+    const bool fail_here = tfg && atoi (tfg) == P->rank ;
+    if (fail_here && P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
+    if (!P->d_Lx_full && !fail_here)
     {
         if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) != hipSuccess)
         {
@@ -2120,9 +2127,27 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
             {
                 (void) hipGetLastError () ;
                 P->d_Lx_full = nullptr ;
-                fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on this rank\n", 8e-9 * P->xsize) ;
-                return CHOLMOD_HIP_OUT_OF_MEMORY ;
+                fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on rank %d\n", 8e-9 * P->xsize, P->rank) ;
             }
+        }
+    }
+    {
+        // every rank must enter the sums below or none: a rank without room tells the others first
+        // (a rank that returned on its own would leave them waiting in the collective)
+        double mine = P->d_Lx_full ? 0.0 : 1.0, any = 0.0 ;
+        HIPCHK (hipMemcpy (P->d_xchg, &mine, sizeof (double), hipMemcpyHostToDevice)) ;
+        if (P->nccl_world)
+        {
+            RCCLCHK (rccl_api ()->AllReduce (P->d_xchg, P->d_xchg, 1, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
+            HIPCHK (hipStreamSynchronize (P->stream)) ;
+        }
+        else if (P->ar_fn (P->d_xchg, 1, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        HIPCHK (hipMemcpy (&any, P->d_xchg, sizeof (double), hipMemcpyDeviceToHost)) ;
+        if (any != 0.0)
+        {
+            if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
+            P->full_valid = false ;
+            return CHOLMOD_HIP_OUT_OF_MEMORY ;
         }
     }
     if (!P->d_fr_full)
@@ -2486,6 +2511,34 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     return CHOLMOD_HIP_OK ;
+}
+
+/* The same invariants over the fronts THIS rank answers for in a distributed factor (every front
+ * belongs to the first rank of its group), read from the rank's own part of L -- no gathered copy
+ * needed: the sums of out5 over all ranks are the invariants of the complete factor.  (One rank:
+ * the same numbers as cholmod_hip_factor_checks.) */
+int cholmod_hip_factor_checks_local (cholmod_hip_plan *P, double *out5)
+{
+    if (!P || P->host_only || !out5) return CHOLMOD_HIP_INVALID ;
+    for (int q = 0 ; q < 5 ; q++) out5 [q] = 0 ;
+    if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
+    std::vector<CheckTask> t ;
+    for (i64 s = 0 ; s < P->nsuper ; s++)
+        if (P->lpx [s] >= 0 && P->rank == P->grp0 [s])
+            for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS) t.push_back (CheckTask {(i32) s, c0}) ;
+    if (t.empty ()) return CHOLMOD_HIP_OK ;
+    hipError_t e ;
+    CheckTask *dt = dupload (t, e) ; HIPCHK (e) ;
+    double *dout = nullptr ;
+    if (hipMalloc ((void **) &dout, 5 * sizeof (double)) != hipSuccess) { (void) hipGetLastError () ; (void) hipFree (dt) ; return CHOLMOD_HIP_OUT_OF_MEMORY ; }
+    (void) hipMemsetAsync (dout, 0, 5 * sizeof (double), P->stream) ;
+    const bool cxs = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
+    CXS_LAUNCH (k_factor_checks, dim3 ((unsigned) t.size ()), dim3 (256), 0, P->stream, dt, P->d_fr, P->d_Lx, dout) ;
+    e = hipGetLastError () ;
+    if (e == hipSuccess) e = hipMemcpyAsync (out5, dout, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream) ;
+    if (e == hipSuccess) e = hipStreamSynchronize (P->stream) ;
+    (void) hipFree (dt) ; (void) hipFree (dout) ;
+    return e == hipSuccess ? CHOLMOD_HIP_OK : CHOLMOD_HIP_GPU_PROBLEM ;
 }
 
 static int ensure_check_tasks (cholmod_hip_plan *P)

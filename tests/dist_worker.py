@@ -65,7 +65,7 @@ def main():
         native = os.environ.get("DIST_TEST_EXCHANGE") == "native"
         cb = None if native else make_allreduce()
         resident = os.environ.get("DIST_TEST_RESIDENT") == "1"
-        S = ch.Session(rank=rank, world=world, allreduce=cb, factor_on_device=resident,
+        S = ch.Session(rank=rank, world=world, allreduce=cb, factor_on_device=resident or os.environ.get("DIST_TEST_RESIDENT_PLAIN") == "1",
                        hip_flags=int(os.environ.get("CHOLMOD_TEST_HIP_FLAGS", "0")))
         A = S.sparse(n, Ap, Ai, Ax, -1)
         Lf = S.analyze(A, perm)
@@ -97,6 +97,31 @@ def main():
             assert S.refactorize_resident(Lf) == 1
             assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
             assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+        if os.environ.get("CHOLMOD_HIP_TEST_FAIL_GATHER"):
+            # one rank has no room for the complete factor: EVERY rank's gather must come back with
+            # CHOLMOD_OUT_OF_MEMORY (nobody left waiting in the collective); the distributed factor survives:
+            # without the hook the next gather succeeds and the factor matches the oracle
+            import ctypes as C
+            assert ok == 1
+            S.cm.error_handler = ch.ERRFUNC(0)
+            g1 = S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm))
+            st1 = int(S.cm.status)
+            del os.environ["CHOLMOD_HIP_TEST_FAIL_GATHER"]
+            S.cm.status = ch.OK
+            g2 = S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm))
+            assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+            m0 = O.lower_mask()
+            x = ch.FactorView(Lf).x
+            res.update(gather_failed=int(g1), gather_failed_status=st1, gather_again=int(g2),
+                       err=float(np.linalg.norm((x - O.x)[m0]) / np.linalg.norm(O.x[m0])))
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            with open(f"{out}.{rank}", "w") as f:
+                json.dump(res, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         if os.environ.get("CHOLMOD_HIP_TEST_FAIL_LAUNCH"):
             # failure-injection case: every rank must come back with an error (no hang)
             res.update(ok=int(ok), status=int(S.cm.status))

@@ -384,6 +384,20 @@ def test_native_exchange_local_failure_does_not_hang_the_other_ranks():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("native", [True, False])
+def test_a_rank_without_room_for_the_gathered_factor_does_not_hang_the_others(native):
+    """cholmod_hip_gather_factor builds the complete factor on every rank (181.6 GB at the headline size, next to
+    the rank's own 117 GB at two ranks: more than one MI355X holds).  A rank that finds no room (test hook) tells
+    the others before anybody enters the sums: every rank returns CHOLMOD_OUT_OF_MEMORY, and the factor -- still
+    distributed -- gathers fine once there is room."""
+    res = _run_ranks(3, "gpu", "p3d_20", timeout=300, extra_env=dict(NATIVE if native else {}, CHOLMOD_HIP_TEST_FAIL_GATHER="1",
+                                                                      DIST_TEST_RESIDENT_PLAIN="1"))
+    for r in res:
+        assert r["gather_failed"] == 0 and r["gather_failed_status"] == ch.OUT_OF_MEMORY, r
+        assert r["gather_again"] == 1 and r["err"] < 1e-12, r
+
+
+@pytest.mark.gpu
 def test_local_failure_does_not_hang_the_other_ranks():
     """A launch of rank 1 fails in the middle of the factorization (test hook): rank 1
     keeps taking part in the remaining collectives and the failure travels through
