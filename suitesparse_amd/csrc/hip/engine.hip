@@ -247,6 +247,7 @@ struct cholmod_hip_plan {
     double *d_xchg = nullptr ;
     double *d_stage = nullptr ;             // the g segments of a block column (reduce-scatter, in place)
     double *d_ag = nullptr ;                // the g solved row chunks of a block column (all-gather, in place)
+    i64 stage_len = 0, ag_len = 0 ;
     // triangular solves: per level, the supernodes one workgroup handles whole
     // and the big ones walked in SOLVE_SB-column blocks by many workgroups (k_solve_*_blk)
     std::vector<SolveTask> sv_tasks ;       // [whole-supernode tasks by level | block tasks]
@@ -1506,6 +1507,7 @@ static int upload_plan (cholmod_hip_plan *P)
             }
         HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
         HIPCHK (hipMalloc ((void **) &P->d_ag, (size_t) mxg * sizeof (double))) ;
+        P->stage_len = mx ; P->ag_len = mxg ;
     }
     double tu3 = pnow () ;
     if (getenv ("CHOLMOD_HIP_THIN_TIMING"))
@@ -1780,6 +1782,16 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
             HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
         }
+    }
+    // test hook CHOLMOD_HIP_TEST_POISON_ARENA=1: the contribution-block arena (and the exchange staging) start every
+    // factorization as NaNs -- an entry somebody reads before anybody has written it then shows in the factor,
+    // whatever a fresh allocation happens to hold (tests/test_gpu_parity.py, tests/test_dist.py)
+    const bool poison = getenv ("CHOLMOD_HIP_TEST_POISON_ARENA") != nullptr ;
+    if (poison)
+    {
+        HIPCHK (hipMemsetAsync (P->d_cb, 0xFF, std::max<i64> (P->arena, 1) * sizeof (double), st)) ;
+        if (P->d_stage) HIPCHK (hipMemsetAsync (P->d_stage, 0xFF, (size_t) P->stage_len * sizeof (double), st)) ;
+        if (P->d_ag) HIPCHK (hipMemsetAsync (P->d_ag, 0xFF, (size_t) P->ag_len * sizeof (double), st)) ;
     }
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;

@@ -827,6 +827,13 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
             if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
         }
     }
+    // Every wave holds its own copy of the PW diagonal rows, and wave 0 writes the FINISHED diagonal
+    // rows back into F at the end of its elimination: nobody may be that far before everybody has
+    // its copy.  Without this barrier a wave that the scheduler held back between two of the loads
+    // above read rows that wave 0 had already scaled (seen in world-4 runs with four processes on
+    // one GPU: the last columns of one wave's rows off by the factor of a wrong pivot, one run in
+    // three; never in a single process -- round 3, tests/test_dist.py, tools/flaky_dist.sh).
+    if constexpr (NW > 1) tf_barrier<NW> () ;
     double dv = 1.0 ;                                       // lane c keeps the pivot of column c
 #pragma unroll
     for (int c = 0 ; c < PW ; c++)

@@ -147,6 +147,12 @@ def main():
                    allreduce_MB=(cb.stats["bytes"] if cb else S.hip_stats(Lf)[18]) / 1e6,
                    allreduce_group_sizes=sorted(cb.stats["by_size"]) if cb else [],
                    nsplit=int(S.hip_stats(Lf)[22]))
+        if st_o == 0:
+            # the rank's share of the factor invariants (its own part of L, no gathered copy) and the invariants
+            # of the gathered factor: the shares must add up to them
+            res["checks_local"] = S.factor_checks_local(Lf).tolist()
+            fc = S.factor_checks(Lf)
+            res["checks_full"] = [fc["half_logdet"], fc["upper_nonzeros"], fc["nonfinite"], fc["fro2"], fc["nonpositive_diag"]]
         if native:
             g0 = np.empty(fv.nsuper, dtype=np.int64)
             gn = np.empty(fv.nsuper, dtype=np.int64)

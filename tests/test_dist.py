@@ -327,6 +327,12 @@ def test_native_exchange_between_ranks_matches_oracle(world, case):
         assert r["nshared"] > 0 and r["nshared"] + sum(r["owned"]) == r["nsuper"], r
         assert r["allreduce_calls"] > 0
     assert len({json.dumps(r["owned"]) for r in res}) == 1
+    # cholmod_hip_factor_checks_local: the ranks' shares of the invariants (log det / 2, dead-triangle entries,
+    # non-finite entries, ||L||_F^2, non-positive pivots) add up to those of the gathered factor
+    tot = np.sum([r["checks_local"] for r in res], axis=0)
+    full = np.array(res[0]["checks_full"])
+    assert abs(tot[0] - full[0]) <= 1e-11 * abs(full[0]) and abs(tot[3] - full[3]) <= 1e-11 * full[3], (tot, full)
+    assert tot[1] == full[1] == 0 and tot[2] == full[2] == 0 and tot[4] == full[4] == 0, (tot, full)
 
 
 @pytest.mark.gpu
@@ -356,6 +362,19 @@ def test_distributed_with_wave_tile_kernel_on_dealt_tiles(world, native):
     res = _run_ranks(world, "gpu", "p3d_48" if world < 4 else "p3d_32", extra_env=env)
     for r in res:
         assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+
+
+@pytest.mark.gpu
+def test_world4_on_one_gpu_repeatedly():
+    """Four processes time-slicing one GPU, five factorizations in a row, every dense update through the
+    one-wave-per-tile kernel: the run that exposed the diagonal-row race of k_thin_front<4> in round 3 (a wave held
+    back between two of its loads read diagonal rows wave 0 had already finished: the last columns of that wave's
+    rows off by a wrong pivot, one run in three; tf_panel now waits until every wave has its copy)."""
+    env = dict(NATIVE, CHOLMOD_HIP_UPD3_MIN_TILES="1", CHOLMOD_HIP_TEST_POISON_ARENA="1")
+    for _ in range(5):
+        res = _run_ranks(4, "gpu", "p3d_32", extra_env=env)
+        for r in res:
+            assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
 
 
 @pytest.mark.gpu

@@ -328,6 +328,28 @@ def test_update_kernel_microbench_runs(L):
     assert not hasattr(L, "cholmod_hip_bench_mfma_peak")      # ... and not in the product
 
 
+def test_nothing_reads_the_arena_before_it_is_written(golden_dir, monkeypatch):
+    """Contribution blocks are not zero-filled (the first trailing update of a front assigns them): with the arena
+    poisoned with NaNs before every factorization (test hook), nothing of it may reach the factor -- whatever a
+    fresh allocation happens to hold.  First factorization (search path) and one through the assembly map."""
+    monkeypatch.setenv("CHOLMOD_HIP_TEST_POISON_ARENA", "1")
+    for name in ("p3d_12_nd", "p2d_40_nat"):
+        n, Ap, Ai, Ax, stype, perm = _case(name, golden_dir)
+        O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
+        assert O.factorize(Ax) == 0
+        S = ch.Session()
+        A = S.sparse(n, Ap, Ai, Ax, stype)
+        Lf = S.analyze(A, perm)
+        m = O.lower_mask()
+        for _ in range(2):
+            assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+            x = ch.FactorView(Lf).x
+            assert np.all(np.isfinite(x)) and np.linalg.norm((x - O.x)[m]) / np.linalg.norm(O.x[m]) < 1e-12
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+
+
 def test_wave_tile_kernel_16x16_super_tile_walk_is_bit_identical():
     """k_update3 walking 16 x 16 super-tiles (GemmGroup.swz == 2: what an XCD runs at a time with one wave per
     tile; the engine uses it for unshared regions of >= 8192 tiles) covers every tile exactly once: bitwise the
