@@ -333,7 +333,7 @@ def test_nothing_reads_the_arena_before_it_is_written(golden_dir, monkeypatch):
     poisoned with NaNs before every factorization (test hook), nothing of it may reach the factor -- whatever a
     fresh allocation happens to hold.  First factorization (search path) and one through the assembly map."""
     monkeypatch.setenv("CHOLMOD_HIP_TEST_POISON_ARENA", "1")
-    for name in ("p3d_12_nd", "p2d_40_nat"):
+    for name in ("p3d_12_nd", "p2d_60_nd", "box9r2_nd"):
         n, Ap, Ai, Ax, stype, perm = _case(name, golden_dir)
         O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
         assert O.factorize(Ax) == 0
