@@ -57,3 +57,30 @@ def test_bench_two_ranks_over_gloo():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
     assert d["exchange"]["allreduce_calls_per_factorization"] > 0
     assert d["residual_2norm"] < 1e-11
+    # the invariants of the factor as it lies distributed over the ranks (no gathered copy)
+    fc = d["factor_checks_distributed"]
+    assert fc["logdet_rel_err"] < 1e-11 and fc["trace_rel_err"] < 1e-11, fc
+    assert fc["upper_nonzeros"] == 0 and fc["nonfinite"] == 0 and fc["nonpositive_diag"] == 0, fc
+
+
+@pytest.mark.gpu
+def test_bench_keeps_its_line_when_the_gathered_factor_does_not_fit():
+    """Two ranks at the headline size cannot hold the gathered factor next to their own part (181.6 + 117 GB): the
+    line must still be printed -- without the residual, with the note and the distributed invariants.  Here rank 1
+    is told that it has no room (test hook)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "24", "--steps", "1", "--warmup", "1",
+                          "--dist-backend", "gloo", "--check"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CHOLMOD_HIP_TEST_FAIL_GATHER="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "residual_2norm" not in d and "skipped" in d["residual_2norm_note"]
+    assert d["factor_checks_distributed"]["logdet_rel_err"] < 1e-11
