@@ -357,6 +357,50 @@ def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, storage
     _check(name, golden_dir, use_gpu=1, dense_check=False, session_kwargs=kw)
 
 
+def _tiny_cases():
+    """1 x 1, a dense 3 x 3 and a 70 x 70 arrow (one 70-row front wider than a tile) Hermitian positive definite matrices."""
+    out = [(1, np.array([0, 1], dtype=np.int64), np.array([0], dtype=np.int64), np.array([2.5 + 0j]))]
+    rng = np.random.default_rng(3)
+    for n in (3, 70):
+        M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        A = M @ M.conj().T + n * np.eye(n)
+        if n == 70:                     # arrow: dense last rows, diagonal elsewhere
+            mask = np.zeros((n, n), dtype=bool)
+            mask[np.diag_indices(n)] = True
+            mask[-6:, :] = True
+            A = np.where(mask | mask.T, A, 0)
+            A[np.diag_indices(n)] = np.abs(A).sum(axis=1) + 1.0
+        L = sp.tril(sp.csc_matrix(A)).tocsc()
+        L.sort_indices()
+        out.append((n, L.indptr.astype(np.int64), L.indices.astype(np.int64), L.data.astype(np.complex128)))
+    return out
+
+
+@pytest.mark.parametrize("use_gpu", [0, pytest.param(1, marks=pytest.mark.gpu)])
+def test_complex_tiny_matrices(use_gpu, monkeypatch):
+    for storage in (("cx",) if use_gpu == 0 else ("cx", "twin")):
+        if storage == "twin":
+            monkeypatch.setenv("CHOLMOD_HIP_CX_TWIN", "1")
+        for (n, Ap, Ai, Ax) in _tiny_cases():
+            S = ch.Session(use_gpu=use_gpu)
+            A = S.sparse(n, Ap, Ai, Ax, -1)
+            Lf = S.analyze(A)
+            assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+            fv = ch.FactorView(Lf)
+            Ld = dense_L(fv, fv.x)
+            Af = full_hermitian(n, Ap, Ai, Ax).toarray()
+            P = fv.Perm
+            assert np.linalg.norm(Ld @ Ld.conj().T - Af[np.ix_(P, P)]) / np.linalg.norm(Af) < 1e-13
+            assert np.all(np.diag(Ld).imag == 0)
+            b = np.exp(1j * np.arange(n))
+            x = S.solve(Lf, b)
+            assert np.linalg.norm(Af @ x - b) / np.linalg.norm(b) < TOL_RES
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            assert S.cm.malloc_count == 0
+            S.finish()
+
+
 @pytest.mark.gpu
 def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
     """The engine's factor of a complex matrix occupies 2 xsize doubles in its own storage, 4 xsize as a twin
