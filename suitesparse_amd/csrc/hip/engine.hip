@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
 #include <queue>
 #include <vector>
 #include <chrono>
@@ -1773,6 +1775,12 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     // Lx := 0 (several ranks: the rank's own fronts -- its d_Lx holds nothing else); the complete
     // factor a gather may have left in d_Lx_full is stale from here on
     P->full_valid = false ;
+    if (!P->d_Lx)
+    {
+        // (the gather went through the host and released the rank's own array: cholmod_hip_gather_factor)
+        if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
+        HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double))) ;
+    }
     if (!P->d_cb)
     {
         // (the arena made room for the gathered factor, see cholmod_hip_gather_factor)
@@ -2124,23 +2132,69 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     if (!P->ar_fn && !P->nccl_world) return CHOLMOD_HIP_INVALID ;
     P->winv_valid = false ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
-    // test hook CHOLMOD_HIP_TEST_FAIL_GATHER=r: rank r finds no room for the complete factor
-    const char *tfg = getenv ("CHOLMOD_HIP_TEST_FAIL_GATHER") ;
-    const bool fail_here = tfg && atoi (tfg) == P->rank ;
-    if (fail_here && P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
-    if (!P->d_Lx_full && !fail_here)
+    // test hooks: CHOLMOD_HIP_TEST_FAIL_GATHER=r: rank r finds no room for the complete factor at all;
+    // CHOLMOD_HIP_TEST_GATHER_STAGED=r: rank r finds none next to its own part (the host-staged way below)
+    const char *tfg = getenv ("CHOLMOD_HIP_TEST_FAIL_GATHER"), *tgs = getenv ("CHOLMOD_HIP_TEST_GATHER_STAGED") ;
+    const bool fail_here = tfg && atoi (tfg) == P->rank, staged_here = tgs && atoi (tgs) == P->rank ;
+    // (nothing newer than the gathered copy: the same on every rank -- full_valid is set by a complete gather
+    // and cleared by a factorization, collectively both)
+    if (P->full_valid && P->d_Lx_full && !fail_here && !staged_here) return CHOLMOD_HIP_OK ;
+    if ((fail_here || staged_here) && P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
+    std::unique_ptr<double []> own_host ;   // the rank's own part of L on the host (staged way only)
+    bool staged = false ;
+    auto restore_own = [&] () -> bool       // the rank's own array back from the host copy
     {
-        if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) != hipSuccess)
+        if (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double)) == hipSuccess
+            && hipMemcpy (P->d_Lx, own_host.get (), (size_t) P->lx_local * sizeof (double), hipMemcpyHostToDevice) == hipSuccess) return true ;
+        (void) hipGetLastError () ;
+        fprintf (stderr, "cholmod_hip_gather_factor: rank %d lost its part of the factor\n", P->rank) ;
+        if (P->d_Lx) { (void) hipFree (P->d_Lx) ; P->d_Lx = nullptr ; }
+        return false ;
+    } ;
+    auto try_full = [&] () -> bool
+    {
+        if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) == hipSuccess) return true ;
+        (void) hipGetLastError () ;
+        P->d_Lx_full = nullptr ;
+        return false ;
+    } ;
+    if (!P->d_Lx_full && !fail_here && P->d_Lx)
+    {
+        bool got = !staged_here && try_full () ;
+        if (!got && !staged_here)
         {
-            (void) hipGetLastError () ;
-            P->d_Lx_full = nullptr ;
+            // the contribution-block arena is dead between factorizations: it makes room
             if (P->d_cb) { (void) hipFree (P->d_cb) ; P->d_cb = nullptr ; }
-            if (hipMalloc ((void **) &P->d_Lx_full, std::max<i64> (P->xsize, 1) * sizeof (double)) != hipSuccess)
+            got = try_full () ;
+        }
+        if (!got)
+        {
+            // Still no room next to the rank's own part (two ranks at Poisson 200^3: 117 GB + 181.6 GB): the own
+            // part takes a detour through host memory -- download, release it (and the arena), reserve the complete
+            // array, upload the fronts this rank contributes straight into their places.  The next factorization
+            // reserves the rank's own array again (run_factorize).
+            // (only with plenty of host memory to spare -- the other ranks of the node may be doing the same, and an
+            // over-committed allocation fails when it is touched, not here: 40 % of what /proc/meminfo calls available)
+            double avail = 0 ;
+            if (FILE *mf = fopen ("/proc/meminfo", "r"))
             {
-                (void) hipGetLastError () ;
-                P->d_Lx_full = nullptr ;
-                fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on rank %d\n", 8e-9 * P->xsize, P->rank) ;
+                char line [256] ;
+                while (fgets (line, sizeof (line), mf))
+                    if (strncmp (line, "MemAvailable:", 13) == 0) { avail = 1024.0 * atof (line + 13) ; break ; }
+                fclose (mf) ;
             }
+            if (8.0 * (double) P->lx_local <= 0.4 * avail)
+                own_host.reset (new (std::nothrow) double [(size_t) std::max<i64> (P->lx_local, 1)]) ;
+            if (own_host && hipMemcpy (own_host.get (), P->d_Lx, (size_t) P->lx_local * sizeof (double), hipMemcpyDeviceToHost) == hipSuccess)
+            {
+                if (P->d_cb) { (void) hipFree (P->d_cb) ; P->d_cb = nullptr ; }
+                (void) hipFree (P->d_Lx) ; P->d_Lx = nullptr ;
+                if (try_full ()) staged = true ;
+                else (void) restore_own () ;        // (not even alone: the rank's part goes back where it was)
+            }
+            else (void) hipGetLastError () ;
+            if (!P->d_Lx_full)
+                fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on rank %d\n", 8e-9 * P->xsize, P->rank) ;
         }
     }
     {
@@ -2159,6 +2213,7 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
         {
             if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
             P->full_valid = false ;
+            if (staged && !restore_own ()) return CHOLMOD_HIP_GPU_PROBLEM ;     // (another rank had no room: this one keeps its part)
             return CHOLMOD_HIP_OUT_OF_MEMORY ;
         }
     }
@@ -2176,7 +2231,9 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
         if (!(P->lpx [q] >= 0 && P->rank == P->grp0 [q])) { q++ ; continue ; }
         i64 e = q ;
         while (e < P->nsuper && P->lpx [e] >= 0 && P->rank == P->grp0 [e] && P->lpx [e] - P->lpx [q] == P->px [e] - P->px [q]) e++ ;
-        HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], P->d_Lx + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
+        if (staged) HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], own_host.get () + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
+            hipMemcpyHostToDevice, P->stream)) ;
+        else HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], P->d_Lx + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
             hipMemcpyDeviceToDevice, P->stream)) ;
         q = e ;
     }
@@ -2534,6 +2591,7 @@ int cholmod_hip_factor_checks_local (cholmod_hip_plan *P, double *out5)
     if (!P || P->host_only || !out5) return CHOLMOD_HIP_INVALID ;
     for (int q = 0 ; q < 5 ; q++) out5 [q] = 0 ;
     if (P->nsuper == 0) return CHOLMOD_HIP_OK ;
+    if (!P->d_Lx) return CHOLMOD_HIP_INVALID ;          // (released by a host-staged gather: the gathered factor is what there is)
     std::vector<CheckTask> t ;
     for (i64 s = 0 ; s < P->nsuper ; s++)
         if (P->lpx [s] >= 0 && P->rank == P->grp0 [s])

@@ -97,6 +97,33 @@ def main():
             assert S.refactorize_resident(Lf) == 1
             assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1
             assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+        if os.environ.get("CHOLMOD_HIP_TEST_GATHER_STAGED"):
+            # one rank has no room for the complete factor NEXT TO its own part (two ranks at the headline size): its
+            # part takes the detour through host memory; the gathered factor must be right, and so must the next
+            # factorization (which reserves the rank's own array again) and its gather
+            import ctypes as C
+            assert ok == 1
+            m0 = O.lower_mask()
+            errs = []
+            for it in range(2):
+                assert S.L.cholmod_l_gather_factor(Lf, C.byref(S.cm)) == 1, S.cm.status
+                assert S.L.cholmod_l_factor_to_host(Lf, C.byref(S.cm)) == 1
+                x = ch.FactorView(Lf).x
+                errs.append(float(np.linalg.norm((x - O.x)[m0]) / np.linalg.norm(O.x[m0])))
+                b = G.demo_rhs(n)
+                xs = S.solve(Lf, b)
+                errs.append(float(np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, -1, xs) - b) / np.linalg.norm(b)))
+                if it == 0:
+                    assert S.refactorize_resident(Lf) == 1
+            res.update(staged_errs=errs)
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            with open(f"{out}.{rank}", "w") as f:
+                json.dump(res, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         if os.environ.get("CHOLMOD_HIP_TEST_FAIL_GATHER"):
             # one rank has no room for the complete factor: EVERY rank's gather must come back with
             # CHOLMOD_OUT_OF_MEMORY (nobody left waiting in the collective); the distributed factor survives:

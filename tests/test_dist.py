@@ -417,6 +417,19 @@ def test_a_rank_without_room_for_the_gathered_factor_does_not_hang_the_others(na
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("native", [True, False])
+def test_gather_through_host_memory_when_the_factor_does_not_fit_next_to_the_own_part(native):
+    """Rank 1 (test hook) finds no room for the complete factor next to its own part: it downloads its part, releases
+    it, reserves the complete array and uploads its fronts into place -- the others gather directly.  The gathered factor
+    and a solve are right; so are the next factorization (the rank reserves its own array again) and its gather."""
+    res = _run_ranks(3, "gpu", "p3d_20", timeout=300, extra_env=dict(NATIVE if native else {}, CHOLMOD_HIP_TEST_GATHER_STAGED="1",
+                                                                      DIST_TEST_RESIDENT_PLAIN="1"))
+    for r in res:
+        e = r["staged_errs"]
+        assert e[0] < 1e-12 and e[2] < 1e-12 and e[1] < 1e-11 and e[3] < 1e-11, r
+
+
+@pytest.mark.gpu
 def test_local_failure_does_not_hang_the_other_ranks():
     """A launch of rank 1 fails in the middle of the factorization (test hook): rank 1
     keeps taking part in the remaining collectives and the failure travels through
