@@ -513,9 +513,9 @@ def main():
             tr = 2.0 * (3 if args.workload == "poisson3d" else 2) * n
             dist_checks["trace_rel_err"] = abs(dist_checks["fro2"] - tr) / tr
     if do_check and world > 1:
-        # the complete factor on every rank, next to the rank's own part: 181.6 GB + 117 GB at two ranks do
-        # not fit in 288 GB -- the line is then printed without the solve / factor checks rather than lost
-        # (every rank must take the same decision)
+        # the complete factor on every rank, next to the rank's own part: 181.6 GB + 117 GB at two ranks leave 8 GB of
+        # one MI355X; the engine makes room (arena, then the rank's part through host memory) and its ranks agree on
+        # the outcome -- if there is no room, the line is printed without the solve / factor checks rather than lost
         import torch
         eh = S.cm.error_handler
         S.cm.error_handler = ch.ERRFUNC(0)

@@ -65,8 +65,8 @@ def test_bench_two_ranks_over_gloo():
 
 @pytest.mark.gpu
 def test_bench_keeps_its_line_when_the_gathered_factor_does_not_fit():
-    """Two ranks at the headline size cannot hold the gathered factor next to their own part (181.6 + 117 GB): the
-    line must still be printed -- without the residual, with the note and the distributed invariants.  Here rank 1
+    """A rank that has no room for the gathered factor (two ranks at the headline size hold 181.6 + 117 GB with 8 GB to
+    spare): the line must still be printed -- without the residual, with the note and the distributed invariants.  Here rank 1
     is told that it has no room (test hook)."""
     import socket
     s = socket.socket()
