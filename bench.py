@@ -501,10 +501,15 @@ def main():
         # of its group, the five sums all-reduced): no gathered copy, so this works where the gather does not fit
         import torch
         from suitesparse_amd import generators as G
-        loc = torch.from_numpy(S.factor_checks_local(Lf)).cuda()
+        try:
+            mine = np.concatenate([S.factor_checks_local(Lf), [0.0]])
+        except Exception:               # (a rank that cannot check still takes part in the sum, and says so)
+            mine = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0])
+        loc = torch.from_numpy(mine).cuda()
         dist.all_reduce(loc)
         v = loc.cpu().numpy()
-        dist_checks = dict(half_logdet=float(v[0]), upper_nonzeros=int(v[1]), nonfinite=int(v[2]), fro2=float(v[3]), nonpositive_diag=int(v[4]))
+        dist_checks = dict(half_logdet=float(v[0]), upper_nonzeros=int(v[1]), nonfinite=int(v[2]), fro2=float(v[3]), nonpositive_diag=int(v[4]),
+                           ranks_that_could_not_check=int(v[5]))
         if not args.matrix and args.workload in ("poisson3d", "poisson2d"):
             ld = G.poisson_logdet(*([m] * (3 if args.workload == "poisson3d" else 2)))
             dist_checks["logdet_closed_form"] = ld
