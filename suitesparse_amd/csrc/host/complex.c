@@ -53,10 +53,11 @@ cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common)
     if (L->cx_twin)
     {
         cholmod_factor *T0 = (cholmod_factor *) L->cx_twin ;
-        /* a twin that already lives on the engine keeps its form; one without a plan (symbolic, or
-         * CPU values only) is rebuilt when the other form is wanted */
-        if (T0->hip_is_twin == kind || T0->hip_plan) return T0 ;
+        /* the other form is wanted (the caller switched between the engine and the CPU path, or between
+         * one rank and several): the twin is rebuilt -- its values are about to be recomputed anyway */
+        if (T0->hip_is_twin == kind) return T0 ;
         cholmod_l_free_factor ((cholmod_factor **) &L->cx_twin, Common) ;
+        L->hip_on_device = FALSE ;
     }
     size_t n = L->n, nsuper = L->nsuper ;
     cholmod_factor *T = cholmod_l_calloc (1, sizeof (cholmod_factor), Common) ;

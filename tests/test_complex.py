@@ -402,6 +402,34 @@ def test_complex_tiny_matrices(use_gpu, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_complex_factor_moves_between_the_engine_and_the_cpu_path(golden_dir):
+    """The same complex L factorized on the engine (complex storage), then with Common->useGPU = 0 (the CPU path
+    needs the full twin: the engine-side twin is rebuilt), then on the engine again: the oracle's factor every time."""
+    n, Ap, Ai, Ax, perm = _case("p3d_9_nd", golden_dir)
+    O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+    assert O.factorize_complex(Ax) == 0
+    mask = O.lower_mask()
+    S = ch.Session(use_gpu=1)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    b = np.exp(1j * np.arange(n))
+    Af = full_hermitian(n, Ap, Ai, Ax)
+    for use_gpu, kind in ((1, 2), (0, 1), (1, 2)):
+        S.cm.useGPU = use_gpu
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        T = C.cast(Lf.contents.cx_twin, C.POINTER(ch.Factor))
+        assert T.contents.hip_is_twin == kind
+        fv = ch.FactorView(Lf)
+        assert np.linalg.norm((fv.x - O.xc)[mask]) / np.linalg.norm(O.xc[mask]) < TOL_L
+        x = S.solve(Lf, b)
+        assert np.linalg.norm(Af @ x - b) / np.linalg.norm(b) < TOL_RES
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
+
+
+@pytest.mark.gpu
 def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
     """The engine's factor of a complex matrix occupies 2 xsize doubles in its own storage, 4 xsize as a twin
     (cholmod_hip_get_stats [5] = bytes of L on the device)."""
