@@ -434,7 +434,7 @@ def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
     """The engine's factor of a complex matrix occupies 2 xsize doubles in its own storage, 4 xsize as a twin
     (cholmod_hip_get_stats [5] = bytes of L on the device)."""
     n, Ap, Ai, Ax, perm = _case("p3d_24_nd", golden_dir)
-    sizes = {}
+    sizes, checks = {}, {}
     for twin in (False, True):
         if twin:
             monkeypatch.setenv("CHOLMOD_HIP_CX_TWIN", "1")
@@ -446,10 +446,16 @@ def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
         st = np.zeros(ch.CHOLMOD_HIP_NSTATS)
         S.L.cholmod_hip_get_stats(T.contents.hip_plan, st.ctypes.data)
         sizes[twin] = (st[5], int(Lf.contents.xsize), int(T.contents.hip_is_twin))
+        # the factor invariants are those of the twin the storage stands for (k_factor_checks rebuilds the odd columns)
+        out = np.zeros(5)
+        assert S.L.cholmod_hip_factor_checks(T.contents.hip_plan, out.ctypes.data) == 0
+        checks[twin] = out.copy()
         S.free_factor(Lf)
         S.free_sparse(A)
         S.finish()
     assert sizes[False][2] == 2 and sizes[True][2] == 1
+    a, b = checks[False], checks[True]
+    assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and abs(a[3] - b[3]) < 1e-11 * b[3] and a[1] == b[1] == 0 and a[2] == b[2] == 0 and a[4] == b[4] == 0, (a, b)
     assert sizes[False][0] == 8.0 * 2 * sizes[False][1]
     assert sizes[True][0] == 8.0 * 4 * sizes[True][1]
 
