@@ -390,8 +390,19 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         {
             // (a factored-first update of a big region: the diagonal block is factored by a
             // separate launch instead -- 17 us next to milliseconds)
+            // ... and what fills the chip is the LAUNCH, not the region: the regions of many mid-size fronts of one
+            // level (a few hundred tiles each, K >= 256) together are tens of thousands of tiles -- they go with the
+            // big ones when their sum reaches the threshold (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only).  Below
+            // K = 256 the update is bound by the read-modify-write of C and the two kernels are on par.
+            static const bool by_launch = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; return !(e && atoi (e) == 0) ; } () ;
+            i64 pooled = 0 ;
+            if (by_launch) for (auto &G : small) if (G.k >= 256 || region_tiles (G) >= w_min_tiles) pooled += region_tiles (G) ;
             std::vector<GemmGroup> keep ;
-            for (auto &G : small) { if (region_tiles (G) >= w_min_tiles) wav.push_back (G) ; else keep.push_back (G) ; }
+            for (auto &G : small)
+            {
+                const bool w = region_tiles (G) >= w_min_tiles || (by_launch && pooled >= w_min_tiles && G.k >= 256) ;
+                if (w) wav.push_back (G) ; else keep.push_back (G) ;
+            }
             small.swap (keep) ;
         }
         for (int pass = 0 ; pass < 4 ; pass++)
