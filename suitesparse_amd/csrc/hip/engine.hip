@@ -564,6 +564,22 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
         int ev_next = -1 ;
         if (any_next) { flush_updates (big, small) ; ev_next = record_last () ; }
+        // The fused "update + dpotrf of the next diagonal block" (k_update2f) saves a 17 us launch and runs the
+        // update in the four-wave kernel.  Where the K >= 512 chain updates of the fronts of this step are a
+        // matrix-core-sized piece of work together (4096 tiles: the mid-size fronts of one level, each below
+        // the per-region threshold), the update goes to k_update3 and the diagonal blocks to a dpotrf launch
+        // of their own -- as a single big region does (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only).
+        static const bool ff_by_launch = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; return !(e && atoi (e) == 0) ; } () ;
+        i64 ff_pooled = 0 ;
+        if (ff_by_launch && fuse_potrf && w_min_tiles > 0 && !use_big)
+            for (const Upd &x : step)
+            {
+                const FrontD &f = fr [ids [x.q]] ;
+                if (is_shared (ids [x.q]) || x.cb || x.kk < 512 || f.nscol - x.t0 < NB || x.t1 - x.t0 < NB) continue ;
+                i64 mt = (f.nsrow - x.t0 + SMALL - 1) / SMALL, nt = (x.t1 - x.t0 + SMALL - 1) / SMALL ;
+                ff_pooled += nt * (nt + 1) / 2 + (mt - nt) * nt ;
+            }
+        const bool ff_unfuse_wide_k = ff_pooled >= 2 * w_min_tiles ;
         for (const Upd &x : step)
         {
             const FrontD &f = fr [ids [x.q]] ;
@@ -580,6 +596,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 // a region big enough for k_update3 is not fused with the next dpotrf
                 i64 mt = (f.nsrow - c0 + SMALL - 1) / SMALL, nt = (x.t1 - c0 + SMALL - 1) / SMALL ;
                 if (nt * (nt + 1) / 2 + (mt - nt) * nt >= w_min_tiles) ff = false ;
+                if (ff_unfuse_wide_k && x.kk >= 512) ff = false ;
             }
             if (ff) pf_done [x.q] = x.t0 ;
             if (!x.wide && is_shared (ids [x.q]) && x.t1 > c0)
