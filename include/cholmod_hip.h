@@ -85,6 +85,9 @@ int cholmod_hip_memorysize (size_t *total_mem, size_t *available_mem) ;
 
 /* Select the device for this process (one process per GPU). */
 int cholmod_hip_set_device (int device) ;
+/* Devices this process can see (a launcher checks it before it starts one rank per GPU);
+ * no counterpart in the reference, which drives device 0 only (CHOLMOD/GPU/cholmod_gpu.c:160-164). */
+int cholmod_hip_device_count (int *count) ;
 
 /* Build the device plan of a supernodal symbolic factor: uploads the index
  * maps (super/pi/px/s exactly as in cholmod_factor, CHOLMOD/Include/

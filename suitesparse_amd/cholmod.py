@@ -131,7 +131,7 @@ API_SYMBOLS = [
     "cholmod_l_gather_factor", "cholmod_l_hip_prepare",
 ]
 HIP_SYMBOLS = [
-    "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device",
+    "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
     "cholmod_hip_get_groups",

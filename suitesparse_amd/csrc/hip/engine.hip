@@ -379,6 +379,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // fill the chip better.  CHOLMOD_HIP_UPD3_MIN_TILES overrides (0 = never).
     // (read at every plan build: tests change it between plans)
     const i64 w_min_tiles = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; return e ? (i64) atoll (e) : (i64) 2048 ; } () ;
+    // (likewise read per plan: an in-process A/B that toggles it between plans gets what it asks for)
+    const bool by_launch = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; return !(e && atoi (e) == 0) ; } () ;
     auto region_tiles = [] (const GemmGroup &G) -> i64
     {
         i64 mt = (G.m + SMALL - 1) / SMALL, nt = (G.n + SMALL - 1) / SMALL ;
@@ -394,7 +396,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             // level (a few hundred tiles each, K >= 256) together are tens of thousands of tiles -- they go with the
             // big ones when their sum reaches the threshold (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only).  Below
             // K = 256 the update is bound by the read-modify-write of C and the two kernels are on par.
-            static const bool by_launch = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; return !(e && atoi (e) == 0) ; } () ;
             i64 pooled = 0 ;
             if (by_launch) for (auto &G : small) if (G.k >= 256 || region_tiles (G) >= w_min_tiles) pooled += region_tiles (G) ;
             std::vector<GemmGroup> keep ;
@@ -569,7 +570,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         // matrix-core-sized piece of work together (4096 tiles: the mid-size fronts of one level, each below
         // the per-region threshold), the update goes to k_update3 and the diagonal blocks to a dpotrf launch
         // of their own -- as a single big region does (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only).
-        static const bool ff_by_launch = [] () { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; return !(e && atoi (e) == 0) ; } () ;
+        const bool ff_by_launch = by_launch ;
         i64 ff_pooled = 0 ;
         if (ff_by_launch && fuse_potrf && w_min_tiles > 0 && !use_big)
             for (const Upd &x : step)
@@ -2031,6 +2032,16 @@ int cholmod_hip_probe (void)
     return cnt > 0 ? 1 : 0 ;
 }
 
+int cholmod_hip_device_count (int *count)
+{
+    if (!count) return CHOLMOD_HIP_INVALID ;
+    *count = 0 ;
+    int cnt = 0 ;
+    if (hipGetDeviceCount (&cnt) != hipSuccess) { (void) hipGetLastError () ; return CHOLMOD_HIP_NO_DEVICE ; }
+    *count = cnt ;
+    return CHOLMOD_HIP_OK ;
+}
+
 int cholmod_hip_memorysize (size_t *total_mem, size_t *available_mem)
 {
     if (total_mem) *total_mem = 0 ;
@@ -2061,8 +2072,6 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     if (n > INT32_MAX || nsuper > INT32_MAX) { *status = CHOLMOD_HIP_TOO_LARGE ; return nullptr ; }
     bool host_only = (flags & CHOLMOD_HIP_PLAN_HOST_ONLY) != 0 ;
     if (!host_only && !cholmod_hip_probe ()) { *status = CHOLMOD_HIP_NO_DEVICE ; return nullptr ; }
-    cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
-    if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
     const double tpc = std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ;
     if (flags & CHOLMOD_HIP_CX_STORAGE)
     {
@@ -2080,6 +2089,10 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
         for (i64 q = 0 ; ok && q + 1 < pi [nsuper] ; q += 2) ok = (s [q] % 2 == 0) && (s [q + 1] == s [q] + 1) ;
         if (!ok) { if (status) *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
     }
+    // (the plan is allocated only once the flags and the twin structure are known to be valid:
+    // nothing to release on the early returns above)
+    cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
+    if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
     P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
     P->rank = rank ; P->world = world ;
     P->super.assign (super, super + nsuper + 1) ;

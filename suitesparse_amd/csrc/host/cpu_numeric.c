@@ -18,6 +18,10 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <time.h>
+#include <errno.h>
+#include <unistd.h>
+#include <sys/types.h>
+#include <sys/wait.h>
 
 /* ---- dense kernels --------------------------------------------------------------- */
 
@@ -44,6 +48,39 @@ static void *sym2 (void *h, const char *prefix, const char *name)
     return dlsym (h, buf) ;
 }
 
+/* 3 x 3 dpotrf and a 3 x 2 dgemm with known answers; 1 = the library computes them */
+static int lp64_probe (dgemm_fn g, dpotrf_fn p)
+{
+    double M [9] = {4, 2, 2,  0, 5, 3,  0, 0, 6} ;          /* lower triangle, column-major */
+    int n3 [2] = {3, -1}, info [2] = {-1, -1} ;
+    p ("L", n3, M, n3, info) ;
+    double Aa [6] = {1, 2, 3,  4, 5, 6}, Bb [4] = {1, 0,  0, 1}, Cc [6] = {0, 0, 0, 0, 0, 0} ;
+    int m3 [2] = {3, -1}, n2 [2] = {2, -1}, k2 [2] = {2, -1} ;
+    double one = 1.0, zero = 0.0 ;
+    g ("N", "N", m3, n2, k2, &one, Aa, m3, Bb, k2, &zero, Cc, m3) ;
+    int okp = (info [0] == 0 && fabs (M [0] - 2.0) < 1e-14 && fabs (M [1] - 1.0) < 1e-14 && fabs (M [4] - 2.0) < 1e-14
+        && fabs (M [5] - 1.0) < 1e-14 && fabs (M [8] - 2.0) < 1e-14) ;
+    int okg = 1 ;
+    for (int q = 0 ; q < 6 ; q++) if (Cc [q] != Aa [q]) okg = 0 ;
+    return okp && okg ;
+}
+
+static int lp64_self_check (dgemm_fn g, dpotrf_fn p)
+{
+    fflush (NULL) ;
+    pid_t pid = fork () ;
+    if (pid == 0) _exit (lp64_probe (g, p) ? 0 : 1) ;
+    if (pid > 0)
+    {
+        int st = 0 ;
+        pid_t w ;
+        do w = waitpid (pid, &st, 0) ; while (w < 0 && errno == EINTR) ;
+        if (w == pid) return WIFEXITED (st) && WEXITSTATUS (st) == 0 ;
+    }
+    /* no child to be had: in this process, behind the negative second words */
+    return lp64_probe (g, p) ;
+}
+
 static int try_blas (const char *path, const char *prefix)
 {
     void *h = dlopen (path, RTLD_NOW | RTLD_LOCAL) ;
@@ -53,27 +90,18 @@ static int try_blas (const char *path, const char *prefix)
     dtrsm_fn t = (dtrsm_fn) sym2 (h, prefix, "dtrsm_") ;
     dpotrf_fn p = (dpotrf_fn) sym2 (h, prefix, "dpotrf_") ;
     if (!g || !s || !t || !p) { dlclose (h) ; return 0 ; }
-    /* self-check before trusting it: the arguments below are 32-bit ints (LP64 interface); an
-     * ILP64 build found under the same soname would read garbage sizes.  3 x 3 dpotrf and a
-     * 3 x 2 dgemm with known answers. */
+    /* self-check before trusting it: the arguments are 32-bit ints (LP64 interface); an ILP64 build
+     * found under the same soname reads 8 bytes from each.  Every size therefore sits in a two-word
+     * array whose second word is -1: an ILP64 library sees a NEGATIVE dimension and leaves through
+     * its argument check (info < 0 / xerbla) instead of running over the 9- and 6-element arrays
+     * with whatever the stack held next to a lone int.  And because some xerbla implementations stop
+     * the process, the probe runs in a forked child: a crash or a STOP there rejects the library
+     * and nothing else (lp64_self_check). */
+    if (!lp64_self_check (g, p))
     {
-        double M [9] = {4, 2, 2,  0, 5, 3,  0, 0, 6} ;          /* lower triangle, column-major */
-        int n3 = 3, info = -1 ;
-        p ("L", &n3, M, &n3, &info) ;
-        double Aa [6] = {1, 2, 3,  4, 5, 6}, Bb [4] = {1, 0,  0, 1}, Cc [6] = {0, 0, 0, 0, 0, 0} ;
-        int m3 = 3, n2 = 2, k2 = 2 ;
-        double one = 1.0, zero = 0.0 ;
-        g ("N", "N", &m3, &n2, &k2, &one, Aa, &m3, Bb, &k2, &zero, Cc, &m3) ;
-        int okp = (info == 0 && fabs (M [0] - 2.0) < 1e-14 && fabs (M [1] - 1.0) < 1e-14 && fabs (M [4] - 2.0) < 1e-14
-            && fabs (M [5] - 1.0) < 1e-14 && fabs (M [8] - 2.0) < 1e-14) ;
-        int okg = 1 ;
-        for (int q = 0 ; q < 6 ; q++) if (Cc [q] != Aa [q]) okg = 0 ;
-        if (!okp || !okg)
-        {
-            fprintf (stderr, "cholmod (CPU path): %s fails the LP64 self-check (an ILP64 build?): not used\n", path) ;
-            dlclose (h) ;
-            return 0 ;
-        }
+        fprintf (stderr, "cholmod (CPU path): %s fails the LP64 self-check (an ILP64 build?): not used\n", path) ;
+        dlclose (h) ;
+        return 0 ;
     }
     g_blas.gemm = g ; g_blas.syrk = s ; g_blas.trsm = t ; g_blas.potrf = p ;
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;

@@ -84,3 +84,34 @@ def test_bench_keeps_its_line_when_the_gathered_factor_does_not_fit():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and "residual_2norm" not in d and "skipped" in d["residual_2norm_note"]
     assert d["factor_checks_distributed"]["logdet_rel_err"] < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's 1-GPU command line with N = 2):
+    bench.py starts its two ranks itself and rank 0 prints the one line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--grid", "32",
+                          "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
+    assert d["residual_2norm"] < 1e-11
+    assert d["factor_checks_distributed"]["logdet_rel_err"] < 1e-11
+
+
+def test_bench_gpus_flag_fails_loudly_without_the_devices():
+    """More ranks than visible devices over RCCL: an error message and a non-zero exit code, not a run on fewer GPUs
+    (this container has no GPU at all; a 1-GPU box has fewer than 8)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--grid", "16"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert "needs 64 visible HIP devices" in out.stderr, out.stderr[-2000:]
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    # under a launcher --gpus must agree with WORLD_SIZE
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "16"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "must agree" in out.stderr
