@@ -45,10 +45,27 @@ static inline int outer_block (int maxrows, const ObThresholds &t)
     return maxrows >= t.t3 ? 4096 : maxrows >= t.t2 ? 2048 : maxrows >= t.t1 ? 1024 : MB ;
 }
 constexpr int BIG = 128, SMALL = 64, BKK = 16 ;
+// Several GPUs: the panel of a shared front is stored by slabs of OWN_W columns, slab t on member t % g of
+// its group (owner-computes: the outer trailing updates of a slab run on its owner).  Narrower slabs balance
+// the members better (a member's columns are all own_w (g - 1) rows taller than the last member's), wider
+// ones make fewer, larger update regions.  CHOLMOD_HIP_OWN_W overrides (a multiple of 64 dividing 512).
+static inline int own_width ()
+{
+    const char *e = getenv ("CHOLMOD_HIP_OWN_W") ;
+    int w = e ? atoi (e) : 128 ;
+    return (w == 64 || w == 128 || w == 256 || w == 512) ? w : 128 ;
+}
+static inline int front_ob (const FrontD &f, int flags, const ObThresholds &t)
+{
+    return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow, t) ;
+}
+// doubles of ONE window buffer of a distributed front (it has two when it has more than one outer block)
+static inline i64 window_len (const FrontD &f, int ob) { return (i64) f.nsrow * std::min (ob, (int) f.nscol) ; }
+static inline int window_count (const FrontD &f, int ob) { return f.nscol > ob ? 2 : 1 ; }
 
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
 // the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -147,6 +164,7 @@ struct Schedule {
     std::vector<GemmGroup> gg ;
     std::vector<DgGroup> dg ;       // k_diag: diagonal sub-blocks (256-column panel chain)
     std::vector<RsGroup> rg ;       // k_rowsolve: the rows below them
+    std::vector<WinD> wg ;          // k_win_move: block columns of distributed fronts into / out of their windows
     int max_dinv_slots = 0 ;        // most diagonal sub-blocks in one launch (size of the inverse buffer)
     std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
@@ -176,6 +194,7 @@ struct RcclApi {
     ncclResult_t (*AllReduce) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr ;
     ncclResult_t (*ReduceScatter) (const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr ;
     ncclResult_t (*AllGather) (const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr ;
+    ncclResult_t (*Broadcast) (const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr ;
     ncclResult_t (*CommDestroy) (ncclComm_t) = nullptr ;
     const char *(*GetErrorString) (ncclResult_t) = nullptr ;
 } ;
@@ -204,9 +223,10 @@ static RcclApi *rccl_api ()
     api.AllReduce = (decltype (api.AllReduce)) dlsym (h, "ncclAllReduce") ;
     api.ReduceScatter = (decltype (api.ReduceScatter)) dlsym (h, "ncclReduceScatter") ;
     api.AllGather = (decltype (api.AllGather)) dlsym (h, "ncclAllGather") ;
+    api.Broadcast = (decltype (api.Broadcast)) dlsym (h, "ncclBroadcast") ;
     api.CommDestroy = (decltype (api.CommDestroy)) dlsym (h, "ncclCommDestroy") ;
     api.GetErrorString = (decltype (api.GetErrorString)) dlsym (h, "ncclGetErrorString") ;
-    if (!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.AllReduce || !api.ReduceScatter || !api.AllGather || !api.CommDestroy) return nullptr ;
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommSplit || !api.AllReduce || !api.ReduceScatter || !api.AllGather || !api.Broadcast || !api.CommDestroy) return nullptr ;
     api.h = h ;
     return &api ;
 }
@@ -300,6 +320,12 @@ struct cholmod_hip_plan {
     // One rank: lpx = px, the local array IS the factor.
     std::vector<i64> lpx ;
     i64 lx_local = 0 ;
+    // ... and of a SHARED front only the column slabs it owns (FrontD::own_w / own_g / own_r: slab t of own_w columns on
+    // member t % own_g of the front's group).  The outer block column a group is factoring lives in windows at the
+    // tail of d_Lx (win_off [s], -1: none; schedule_dense: psx_at); lx_fronts = doubles of d_Lx before the windows.
+    std::vector<i64> win_off ;
+    i64 lx_fronts = 0 ;
+    WinD *d_wg = nullptr ;
     double *d_Lx_full = nullptr ; FrontD *d_fr_full = nullptr ;
     bool full_valid = false ;
     FrontD *d_smd = nullptr ; i64 *d_sp01 = nullptr ;   // thin launches: descriptor and range of S of every front, in block order (as d_sm)
@@ -333,7 +359,7 @@ namespace {
 // of the first nscol columns of every front [panel | CB].
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
-    const char *assign_cb = nullptr)
+    const char *assign_cb = nullptr, const i64 *win = nullptr, const i32 *child = nullptr)
 {
     // The real twin of a complex factor (phi embedding, host/complex.c): every row / column pair
     // (2i, 2i+1) is (re, im) of one complex row, the odd columns of a panel are the rotations of the
@@ -366,9 +392,18 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the ranks of a multi-GPU group see different batches around the same shared
     // front and must cut its updates into the same regions.
     const ObThresholds obt = outer_block_thresholds () ;
-    auto ob_of = [&] (const FrontD &f) -> int
+    auto ob_of = [&] (const FrontD &f) -> int { return front_ob (f, flags, obt) ; } ;
+    // A distributed front (several GPUs: win [fid] >= 0) has its panel stored by column slabs on their
+    // owners; the outer block column being factored lives in a window of nsrow x OB doubles (two of them,
+    // used alternately), addressed as if the whole front were there: psx_at (fid, c) is the base to use
+    // for anything that touches column c of the front during the panel chain of c's outer block.
+    auto windowed = [&] (int fid) { return win && win [fid] >= 0 ; } ;
+    auto psx_at = [&] (int fid, int col) -> i64
     {
-        return (flags & CHOLMOD_HIP_FIXED_OB) ? MB : (flags & CHOLMOD_HIP_WIDE_OB) ? 2048 : outer_block (f.nsrow, obt) ;
+        const FrontD &f = fr [fid] ;
+        if (!windowed (fid)) return f.psx ;
+        int OBq = ob_of (f), ob = col / OBq ;
+        return win [fid] + (i64) (ob & 1) * window_len (f, OBq) - (i64) ob * OBq * f.nsrow ;
     } ;
     (void) maxrows ;
     std::vector<GemmGroup> pfv ;        // narrow updates whose first tile is factored on the spot (k_update2f)
@@ -482,11 +517,11 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (m <= 0 || ncols <= 0 || kk <= 0) return ;
         GemmGroup G ;
         memset (&G, 0, sizeof (G)) ;
-        G.a_off = f.psx + r0 + co (kc, f.nsrow) ;
+        G.a_off = psx_at (fid, kc) + r0 + co (kc, f.nsrow) ;
         G.b_off = G.a_off ;
         G.lda = f.nsrow ;
         if (to_cb) { G.c_off = f.cb ; G.ldc = f.ncb ; G.c_in_cb = 1 ; }
-        else { G.c_off = f.psx + r0 + co (r0, f.nsrow) ; G.ldc = f.nsrow ; }
+        else { G.c_off = psx_at (fid, r0) + r0 + co (r0, f.nsrow) ; G.ldc = f.nsrow ; }
         G.m = m ; G.n = ncols ; G.k = kk ; G.tri = 1 ; G.front = fid ;
         if (twin) twin_operands (G, r0, kc) ;
         G.tile_mul = 1 ; G.tile_add = 0 ;
@@ -497,6 +532,29 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
 
         bool isbig = use_big && ncols >= BIG && m >= 2 * BIG ;
         (isbig ? big : small).push_back (G) ;
+    } ;
+    // The outer update (K = OB, operands in the window of outer block kc / OB) of the in-front columns
+    // [ca, cb) of a distributed front: owner-computes -- this rank updates the slabs it stores, in place,
+    // every one a region of its own that starts on the diagonal.
+    auto add_outer_slabs = [&] (std::vector<GemmGroup> &small, const FrontD &f, int fid, int kc, int kk, int ca, int cb)
+    {
+        if (kk <= 0) return ;
+        for (int c0 = (ca / f.own_w) * f.own_w ; c0 < cb ; c0 += f.own_w)
+        {
+            if (!col_owned (f, c0)) continue ;
+            int a = std::max (c0, ca), b = std::min ({c0 + f.own_w, cb, (int) f.nscol}) ;
+            if (b <= a) continue ;
+            GemmGroup G ;
+            memset (&G, 0, sizeof (G)) ;
+            G.a_off = psx_at (fid, kc) + a + co (kc, f.nsrow) ;
+            G.b_off = G.a_off ;
+            G.lda = f.nsrow ;
+            G.c_off = f.psx + a + (i64) col_local (f, a) * f.nsrow ; G.ldc = f.nsrow ;
+            G.m = f.nsrow - a ; G.n = b - a ; G.k = kk ; G.tri = 1 ; G.front = fid ;
+            if (twin) twin_operands (G, a, kc) ;
+            G.tile_mul = 1 ; G.tile_add = 0 ;
+            small.push_back (G) ;
+        }
     } ;
     std::vector<GemmGroup> big, small ;
     auto record_last = [&] () -> int
@@ -525,7 +583,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         if (world == 1) { g = 1 ; r = 0 ; }                 // (single-rank self test of the exchange path)
         int mb = f.nsrow - c1 ;
         int R = mb > 0 ? (((mb + g - 1) / g) + 15) / 16 * 16 : 0 ;
-        return XchgD {f.psx + c0 + (i64) c0 * f.nsrow, f.nsrow, c1 - c0, mb, R, g, r} ;
+        return XchgD {psx_at (ids [q], c0) + c0 + (i64) c0 * f.nsrow, f.nsrow, c1 - c0, mb, R, g, r} ;
     } ;
     auto emit_rs = [&] (int q, int c0, int wait_ev)
     {
@@ -545,6 +603,44 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
         S.launches.push_back (La) ;
     } ;
+    // Window of a distributed front.  open: the block column [b0, b0 + MB) -- the owners' stored columns,
+    // zero elsewhere (k_win_move), then the contributions of this rank's children to those columns
+    // (extend-add into the window): the rank's partial sum, ready for the reduce-scatter.  On stream 1 behind
+    // an event when the block column is opened ahead of time (exchange look-ahead).  close: the factored
+    // columns of outer block [o0, o1) into the owners' slabs.
+    auto emit_win = [&] (int q, int mode, int ca, int cb, int stream, int wait_ev)
+    {
+        const FrontD &f = fr [ids [q]] ;
+        Launch Lw {K_WIN, 0, 0, S.wg.size (), 0, 0} ;
+        Lw.stream = stream ; Lw.wait_ev = wait_ev ;
+        int blocks = 0 ;
+        for (int b0 = ca ; b0 < cb ; b0 += MB)
+        {
+            int b1 = std::min (b0 + MB, cb) ;
+            S.wg.push_back (WinD {f.psx, psx_at (ids [q], b0), f.nsrow, b0, b1, b0, f.nsrow, f.own_w, f.own_g, f.own_r, mode, blocks}) ;
+            blocks += (b1 - b0) * ((f.nsrow - b0 + WIN_ROWS - 1) / WIN_ROWS) ;
+            Lw.bytes += 16.0 * (double) (b1 - b0) * (f.nsrow - b0) / f.own_g ;
+        }
+        Lw.ng = (int) (S.wg.size () - Lw.goff) ; Lw.grid = blocks ;
+        if (Lw.ng) S.launches.push_back (Lw) ;
+        if (mode == 0 && f.child_end != f.child_begin)
+        {
+            Launch Le {K_EA, 0, 0, S.eg.size (), 0, 0} ;
+            Le.stream = stream ;
+            Le.aux = f.nsrow >= 2048 ? 4 : EA_TW ;
+            S.eg.push_back (EaGroup {ids [q], 0, ca, cb, psx_at (ids [q], ca)}) ;
+            Le.ng = 1 ; Le.grid = (cb - ca + Le.aux - 1) / Le.aux ;
+            if (child)
+                for (int c = f.child_begin ; c < f.child_end ; c++)
+                {
+                    // (the part of the child's block that lands in these columns: priced by its share of the columns)
+                    double r = fr [child [c]].ncb ;
+                    Le.bytes += ((r * (r + 1) / 2) * 24.0 + 4.0 * r) * (double) (cb - ca) / f.nsrow ;
+                }
+            S.launches.push_back (Le) ;
+        }
+    } ;
+    std::vector<int> early_open (nf, -1) ;  // block column of front q opened ahead of time
     // One trailing-update step: for every listed front, columns [kc, kc+kk) update
     // the in-front columns [t0, t1) (all rows from t0 down) and, if cb, the
     // contribution block.  Steps with kk >= MB are `wide`: their tiles are dealt
@@ -560,7 +656,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 if (!x.wide || !is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
                 const FrontD &f = fr [ids [x.q]] ;
                 int tn = std::min (x.t0 + MB, x.t1) ;
-                add_update (big, small, f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
+                if (x.cb && windowed (ids [x.q])) add_outer_slabs (small, f, ids [x.q], x.kc, x.kk, x.t0, tn) ;
+                else add_update (big, small, f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
                 any_next = true ;
             }
         int ev_next = -1 ;
@@ -613,9 +710,10 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 {
                     GemmGroup G ;
                     memset (&G, 0, sizeof (G)) ;
-                    G.a_off = f.psx + lo + co (x.kc, f.nsrow) ;
-                    G.b_off = f.psx + c0 + co (x.kc, f.nsrow) ;
-                    G.c_off = f.psx + lo + co (c0, f.nsrow) ;
+                    const i64 wpsx = psx_at (ids [x.q], x.kc) ;
+                    G.a_off = wpsx + lo + co (x.kc, f.nsrow) ;
+                    G.b_off = wpsx + c0 + co (x.kc, f.nsrow) ;
+                    G.c_off = wpsx + lo + co (c0, f.nsrow) ;
                     G.lda = f.nsrow ; G.ldc = f.nsrow ;
                     G.m = hi - lo ; G.n = x.t1 - c0 ; G.k = x.kk ; G.tri = 0 ; G.front = ids [x.q] ;
                     G.tile_mul = 1 ; G.tile_add = 0 ;
@@ -624,7 +722,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 }
                 continue ;
             }
-            if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
+            if (x.cb && windowed (ids [x.q]))
+            {
+                // the outer update of a distributed front: its in-front columns slab by slab on their owners,
+                // the contribution block as before (partial sums, tiles dealt over the group)
+                if (x.t1 > c0) add_outer_slabs (small, f, ids [x.q], x.kc, x.kk, c0, x.t1) ;
+            }
+            else if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
             if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
         }
         flush_updates (big, small) ;
@@ -632,7 +736,15 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             for (const Upd &x : step)
             {
                 if (!x.wide || !is_shared (ids [x.q]) || x.t1 <= x.t0) continue ;
-                emit_rs (x.q, x.t0, ev_next) ;
+                int wev = ev_next ;
+                if (x.cb && windowed (ids [x.q]))
+                {
+                    // the first block column of the next outer block: into its window ahead of time, on the
+                    // exchange stream behind the update that completed it
+                    emit_win (x.q, 0, x.t0, std::min (x.t0 + MB, x.t1), 1, ev_next) ;
+                    early_open [x.q] = x.t0 ;
+                }
+                emit_rs (x.q, x.t0, wev) ;
                 early [x.q] = x.t0 ;
             }
         step.clear () ;
@@ -643,7 +755,9 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // column, as before over 64-column steps -- with e sub-blocks done and p the largest power of
     // two dividing e, the last p sub-blocks (K = 256 p) update the next p; the K = OB update
     // closes the outer block column.  Opt-in (CHOLMOD_HIP_CHAIN256): measured no faster than the 64-column chain below, see DESIGN.md section 4.
-    const bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 && !cx ;
+    // (not with distributed fronts: their block columns live in windows, see the 64-column chain below)
+    bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 && !cx ;
+    for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) chain256 = false ;
     if (chain256)
     {
         const int SB = DG_W ;
@@ -736,6 +850,16 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         // into a staging buffer, halving the volume for the root.
         if (i0 % MB == 0)
         {
+            // a distributed front entering a new outer block column: its block columns into the window
+            // (all but one opened ahead of time)
+            for (int q = 0 ; q < nf ; q++)
+            {
+                const FrontD &f = fr [ids [q]] ;
+                if (f.nscol <= i0 || !windowed (ids [q]) || i0 % ob_of (f) != 0) continue ;
+                int o1 = std::min (i0 + ob_of (f), (int) f.nscol) ;
+                int from = early_open [q] == i0 ? std::min (i0 + MB, o1) : i0 ;
+                if (o1 > from) emit_win (q, 0, from, o1, 0, -1) ;
+            }
             for (int q = 0 ; q < nf ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
@@ -751,7 +875,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             if (f.nscol <= i0) continue ;
             if (pf_done [q] == i0) continue ;       // factored by the update that preceded it
             int nb = std::min (NB, f.nscol - i0) ;
-            PfGroup G {f.psx + i0 + co (i0, f.nsrow), f.nsrow, nb, ids [q], i0} ;
+            PfGroup G {psx_at (ids [q], i0) + i0 + co (i0, f.nsrow), f.nsrow, nb, ids [q], i0} ;
             S.pg.push_back (G) ;
             Lp.flops += (double) nb * nb * nb / 3.0 ;
         }
@@ -813,8 +937,8 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             {
                 int m = hi [part] - lo [part] ;
                 if (m <= 0) continue ;
-                TrGroup G {f.psx + i0 + co (i0, f.nsrow),
-                           f.psx + lo [part] + co (i0, f.nsrow), f.nsrow, m, nb,
+                TrGroup G {psx_at (ids [q], i0) + i0 + co (i0, f.nsrow),
+                           psx_at (ids [q], i0) + lo [part] + co (i0, f.nsrow), f.nsrow, m, nb,
                            ids [q], i0, blocks} ;
                 blocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
                 S.tg.push_back (G) ;
@@ -832,6 +956,12 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
             int b0 = (i0 / MB) * MB ;
             if (i0 + NB >= std::min (b0 + MB, f.nscol)) emit_ag (q, b0) ;
+            // the outer block column of a distributed front is complete in its window: into the owners' slabs
+            if (windowed (ids [q]))
+            {
+                int OBq = ob_of (f), o0 = (i0 / OBq) * OBq, o1 = std::min (o0 + OBq, (int) f.nscol) ;
+                if (i0 + NB >= o1) emit_win (q, 1, o0, o1, 0, -1) ;
+            }
         }
         // ---- trailing updates.  Inside an outer block column of the front (OB
         // columns, ob_of): recursive doubling -- with e 64-column blocks of it
@@ -1082,16 +1212,30 @@ static int build_host (cholmod_hip_plan *P)
     }
     auto mine = [&] (i64 s) { return P->rank >= P->grp0 [s] && P->rank < P->grp0 [s] + P->grpn [s] ; } ;
     // the rank's own L: the fronts it holds, packed in supernode order (see cholmod_hip_plan::lpx)
+    // (a shared front: only the column slabs this rank owns; with one rank -- the self test of the exchange
+    // path -- that is every slab, and the front stays where the reference layout has it)
+    const bool distribute = !getenv ("CHOLMOD_HIP_NO_DISTRIBUTED_FRONTS") && !(P->flags & CHOLMOD_HIP_CX_STORAGE) ;
+    const int ownw = (P->flags & CHOLMOD_HIP_PHI_TWIN) ? std::max (own_width (), 64) : own_width () ;
     P->lpx.assign (std::max<i64> (nsuper, 1), -1) ;
+    P->win_off.assign (std::max<i64> (nsuper, 1), -1) ;
     P->lx_local = 0 ;
     for (i64 s = 0 ; s < nsuper ; s++)
     {
-        if (P->world > 1 && !mine (s)) { P->fr [s].psx = 0 ; continue ; }
+        FrontD &f = P->fr [s] ;
+        if (P->world > 1 && !mine (s)) { f.psx = 0 ; continue ; }
         P->lpx [s] = P->world > 1 ? P->lx_local : P->px [s] ;
-        P->fr [s].psx = P->lpx [s] ;
-        P->lx_local += P->px [s+1] - P->px [s] ;
+        f.psx = P->lpx [s] ;
+        i64 cols = f.nscol ;
+        if (P->owner [s] < 0 && distribute)
+        {
+            f.own_w = ownw ; f.own_g = P->world > 1 ? P->grpn [s] : 1 ; f.own_r = P->world > 1 ? P->rank - P->grp0 [s] : 0 ;
+            cols = 0 ;
+            for (int c0 = 0 ; c0 < f.nscol ; c0 += ownw) if (col_owned (f, c0)) cols += std::min (ownw, f.nscol - c0) ;
+        }
+        P->lx_local += cols * f.nsrow ;
     }
     if (P->world == 1) P->lx_local = P->xsize ;
+    P->lx_fronts = P->lx_local ;
     // thin fronts (fused LDS-resident kernel): their contribution blocks are packed
     // lower triangles, the generic fronts' full squares
     for (i64 s = 0 ; s < nsuper ; s++)
@@ -1115,7 +1259,8 @@ static int build_host (cholmod_hip_plan *P)
         P->fr [s].child_begin = acc ;
         if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++) if (mine (call [c])) acc++ ;
         P->fr [s].child_end = P->fr [s].child_begin ;
-        P->fr [s].assemble = (P->rank == P->grp0 [s]) ? 1 : 0 ;      // one rank of the group adds A
+        // one rank of the group adds A: the first one -- or, column by column, the owner (distributed fronts)
+        P->fr [s].assemble = (P->fr [s].own_w ? mine (s) : P->rank == P->grp0 [s]) ? 1 : 0 ;
     }
     P->child.assign (std::max<i32> (acc, 1), 0) ;
     for (i64 s = 0 ; s < nsuper ; s++)
@@ -1289,6 +1434,26 @@ static int build_host (cholmod_hip_plan *P)
         }
         P->sb_lvl_ptr [l+1] = (i32) P->sb_launch.size () ;
     }
+    // windows of the distributed fronts: at the tail of the rank's array, alive for the front's batch only
+    // (the region is as long as the neediest batch)
+    {
+        const ObThresholds obt = outer_block_thresholds () ;
+        i64 longest = 0 ;
+        for (const auto &bt : batches)
+        {
+            i64 at = 0 ;
+            for (i32 sf : bt)
+            {
+                const FrontD &f = P->fr [sf] ;
+                if (!mine (sf) || !f.own_w) continue ;
+                int ob = front_ob (f, P->flags, obt) ;
+                P->win_off [sf] = P->lx_fronts + at ;
+                at += window_count (f, ob) * window_len (f, ob) ;
+            }
+            longest = std::max (longest, at) ;
+        }
+        P->lx_local = P->lx_fronts + longest ;
+    }
     // launch schedule of this rank
     Schedule &S = P->sch ;
     std::vector<i32> mine_ids ;
@@ -1404,11 +1569,13 @@ static int build_host (cholmod_hip_plan *P)
                 const FrontD &f = P->fr [ids [q]] ;
                 if (f.child_end == f.child_begin) continue ;
                 bool asg = P->assign_cb [ids [q]] != 0 ;
-                int lo = phase == 0 ? 0 : f.nscol ;
+                // (a distributed front takes the contributions to its panel block column by block column,
+                // when the block column enters the window: schedule_dense, emit_win)
+                int lo = (phase == 0 && !f.own_w) ? 0 : f.nscol ;
                 int hi = phase == 0 ? (asg ? f.nscol : f.nsrow) : f.nsrow ;
                 if (phase == 1 && !asg) continue ;
                 if (hi <= lo) continue ;
-                S.eg.push_back (EaGroup {ids [q], blocks, lo, hi}) ;
+                S.eg.push_back (EaGroup {ids [q], blocks, lo, hi, -1}) ;
                 blocks += (hi - lo + tw - 1) / tw ;
                 if (phase == 0)
                     for (int c = f.child_begin ; c < f.child_end ; c++)
@@ -1421,7 +1588,7 @@ static int build_host (cholmod_hip_plan *P)
             if (Le.ng) S.launches.push_back (Le) ;
             if (phase == 0)
                 schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->grp0.data (), P->grpn.data (),
-                    P->rank, P->world, P->assign_cb.data ()) ;
+                    P->rank, P->world, P->assign_cb.data (), P->win_off.data (), P->child.data ()) ;
         }
     }
     return CHOLMOD_HIP_OK ;
@@ -1438,7 +1605,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_dinv, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1510,6 +1677,7 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_dg = dupload (P->sch.dg, e) ; HIPCHK (e) ;
     P->d_rg = dupload (P->sch.rg, e) ; HIPCHK (e) ;
+    P->d_wg = dupload (P->sch.wg, e) ; HIPCHK (e) ;
     HIPCHK (hipMalloc ((void **) &P->d_dinv, (size_t) std::max (P->sch.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     {
@@ -1692,7 +1860,15 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 if (rs)
                 {
                     move (0, seg * X.g) ;
-                    if (R) RCCLCHK (R->ReduceScatter (P->d_stage, P->d_stage + (i64) X.r * seg, (size_t) seg, ncclDouble, ncclSum, comm, cs)) ;
+                    if (R)
+                    {
+                        RCCLCHK (R->ReduceScatter (P->d_stage, P->d_stage + (i64) X.r * seg, (size_t) seg, ncclDouble, ncclSum, comm, cs)) ;
+                        // The w x w diagonal block travels in every segment, and a ring sums every segment in another
+                        // order: the members' copies of it would differ in their last bits, each would factor its own,
+                        // and a borderline pivot could fail on one member only.  One copy for all: the first member's
+                        // (2 MB at w = 512, next to the block column's 8 (w + rows) w bytes).
+                        if (X.g > 1) RCCLCHK (R->Broadcast (P->d_stage, P->d_stage + (i64) X.r * seg, (size_t) X.w * X.w, ncclDouble, 0, comm, cs)) ;
+                    }
                     else
                     {
                         HIPCHK (hipStreamSynchronize (cs)) ;
@@ -1723,6 +1899,8 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 }
             }
             break ;
+        case K_WIN:
+            hipLaunchKernelGGL (k_win_move, dim3 (L.grid), dim3 (256), 0, st, P->d_wg + L.goff, L.ng, P->d_Lx) ; break ;
         case K_ZERO:
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
@@ -1828,9 +2006,10 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     {
         HIPCHK (hipMemsetAsync (P->d_cb, 0xFF, std::max<i64> (P->arena, 1) * sizeof (double), st)) ;
         if (P->d_stage) HIPCHK (hipMemsetAsync (P->d_stage, 0xFF, (size_t) P->stage_len * sizeof (double), st)) ;
+        if (P->lx_local > P->lx_fronts) HIPCHK (hipMemsetAsync (P->d_Lx + P->lx_fronts, 0xFF, (size_t) (P->lx_local - P->lx_fronts) * sizeof (double), st)) ;
         if (P->d_ag) HIPCHK (hipMemsetAsync (P->d_ag, 0xFF, (size_t) P->ag_len * sizeof (double), st)) ;
     }
-    HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (P->lx_local, 1) * sizeof (double), st)) ;
+    HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (poison ? P->lx_fronts : P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
     if (P->n > 0 && P->amap_valid)
@@ -1960,7 +2139,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_UPD_PF: S [27] += sec ; break ;
                 case K_UPD_W: S [32] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
-                case K_EA: case K_ZERO: S [9] += sec ; break ;
+                case K_EA: case K_ZERO: case K_WIN: S [9] += sec ; break ;
                 case K_POTRF: case K_DIAG: S [11] += sec ; break ;
                 case K_ROWSOLVE: S [12] += sec ; break ;
                 case K_SMALL: S [19] += sec ; break ;
@@ -2002,10 +2181,10 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     // a quick return) is zero: in the rank's own array, the fronts it holds with those indices
     // (held fronts are packed in supernode order, so that is one tail of the array)
     i64 first_zero = sbad + ((binfo == 1 || quick) ? 0 : 1) ;
-    i64 zero_from = P->lx_local ;
+    i64 zero_from = P->lx_fronts ;
     for (i64 q = first_zero ; q < P->nsuper ; q++) if (P->lpx [q] >= 0) { zero_from = P->lpx [q] ; break ; }
-    if (zero_from < P->lx_local)
-        HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->lx_local - zero_from) * sizeof (double), st)) ;
+    if (zero_from < P->lx_fronts)
+        HIPCHK (hipMemsetAsync (P->d_Lx + zero_from, 0, (P->lx_fronts - zero_from) * sizeof (double), st)) ;
     HIPCHK (hipStreamSynchronize (st)) ;
     return CHOLMOD_HIP_NOT_POSDEF ;
 }
@@ -2238,56 +2417,100 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
                 fprintf (stderr, "cholmod_hip_gather_factor: no room for the complete factor (%.1f GB) on rank %d\n", 8e-9 * P->xsize, P->rank) ;
         }
     }
+    // everything local that can still fail comes BEFORE the agreement, and its outcome is part of the vote
+    bool setup_ok = true ;
+    if (!P->d_fr_full)
+    {
+        // (descriptors of the complete factor: the global offsets, every column in place)
+        std::vector<FrontD> ff (P->fr) ;
+        for (i64 q = 0 ; q < P->nsuper ; q++) { ff [q].psx = P->px [q] ; ff [q].own_w = 0 ; ff [q].own_g = 1 ; ff [q].own_r = 0 ; }
+        hipError_t e ;
+        P->d_fr_full = dupload (ff, e) ;
+        if (e != hipSuccess) { (void) hipGetLastError () ; if (P->d_fr_full) (void) hipFree (P->d_fr_full) ; P->d_fr_full = nullptr ; setup_ok = false ; }
+    }
+    // one number summed over all ranks, in d_xchg; < 0: the exchange itself failed
+    auto agree = [&] (double mine) -> double
+    {
+        double any = 0.0 ;
+        if (hipMemcpy (P->d_xchg, &mine, sizeof (double), hipMemcpyHostToDevice) != hipSuccess) { (void) hipGetLastError () ; mine = 1.0 ; }
+        if (P->nccl_world)
+        {
+            if (rccl_api ()->AllReduce (P->d_xchg, P->d_xchg, 1, ncclDouble, ncclSum, P->nccl_world, P->stream) != ncclSuccess) return -1.0 ;
+            if (hipStreamSynchronize (P->stream) != hipSuccess) { (void) hipGetLastError () ; return -1.0 ; }
+        }
+        else if (P->ar_fn (P->d_xchg, 1, 0, P->world, P->ar_user) != 0) return -1.0 ;
+        if (hipMemcpy (&any, P->d_xchg, sizeof (double), hipMemcpyDeviceToHost) != hipSuccess) { (void) hipGetLastError () ; return -1.0 ; }
+        return any + (mine != 0.0 && any == 0.0 ? 1.0 : 0.0) ;
+    } ;
     {
         // every rank must enter the sums below or none: a rank without room tells the others first
         // (a rank that returned on its own would leave them waiting in the collective)
-        double mine = P->d_Lx_full ? 0.0 : 1.0, any = 0.0 ;
-        HIPCHK (hipMemcpy (P->d_xchg, &mine, sizeof (double), hipMemcpyHostToDevice)) ;
-        if (P->nccl_world)
-        {
-            RCCLCHK (rccl_api ()->AllReduce (P->d_xchg, P->d_xchg, 1, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
-            HIPCHK (hipStreamSynchronize (P->stream)) ;
-        }
-        else if (P->ar_fn (P->d_xchg, 1, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
-        HIPCHK (hipMemcpy (&any, P->d_xchg, sizeof (double), hipMemcpyDeviceToHost)) ;
+        double any = agree ((P->d_Lx_full && setup_ok) ? 0.0 : 1.0) ;
         if (any != 0.0)
         {
             if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
             P->full_valid = false ;
             if (staged && !restore_own ()) return CHOLMOD_HIP_GPU_PROBLEM ;     // (another rank had no room: this one keeps its part)
-            return CHOLMOD_HIP_OUT_OF_MEMORY ;
+            return any < 0.0 ? CHOLMOD_HIP_GPU_PROBLEM : (setup_ok ? CHOLMOD_HIP_OUT_OF_MEMORY : CHOLMOD_HIP_GPU_PROBLEM) ;
         }
     }
-    if (!P->d_fr_full)
+    // From here on every rank enters every collective, whatever happens to it locally: a failure is kept in
+    // `bad`, the remaining sums are still entered (their data no longer matters), and a trailing agreement
+    // tells everybody.
+    int bad = CHOLMOD_HIP_OK ;
+    auto hold = [&] (hipError_t e) { if (e != hipSuccess) { (void) hipGetLastError () ; if (bad == CHOLMOD_HIP_OK) { bad = CHOLMOD_HIP_GPU_PROBLEM ;
+        fprintf (stderr, "cholmod_hip_gather_factor: %s on rank %d\n", hipGetErrorString (e), P->rank) ; } } } ;
+    hold (hipMemsetAsync (P->d_Lx_full, 0, std::max<i64> (P->xsize, 1) * sizeof (double), P->stream)) ;
+    auto put = [&] (i64 dst, i64 src, i64 len)      // a piece of the rank's part into its place in the complete factor
     {
-        std::vector<FrontD> ff (P->fr) ;
-        for (i64 q = 0 ; q < P->nsuper ; q++) ff [q].psx = P->px [q] ;
-        hipError_t e ;
-        P->d_fr_full = dupload (ff, e) ; HIPCHK (e) ;
-    }
-    HIPCHK (hipMemsetAsync (P->d_Lx_full, 0, std::max<i64> (P->xsize, 1) * sizeof (double), P->stream)) ;
+        if (len <= 0) return ;
+        if (staged) hold (hipMemcpyAsync (P->d_Lx_full + dst, own_host.get () + src, (size_t) len * sizeof (double), hipMemcpyHostToDevice, P->stream)) ;
+        else hold (hipMemcpyAsync (P->d_Lx_full + dst, P->d_Lx + src, (size_t) len * sizeof (double), hipMemcpyDeviceToDevice, P->stream)) ;
+    } ;
     for (i64 q = 0 ; q < P->nsuper ; )
     {
+        if (P->lpx [q] < 0) { q++ ; continue ; }
+        const FrontD &f = P->fr [q] ;
+        if (f.own_w)
+        {
+            // a distributed front: the slabs this rank owns (whole columns, contiguous in both arrays)
+            for (int c0 = 0 ; c0 < f.nscol ; c0 += f.own_w)
+                if (col_owned (f, c0))
+                    put (P->px [q] + (i64) c0 * f.nsrow, P->lpx [q] + (i64) col_local (f, c0) * f.nsrow, (i64) std::min (f.own_w, f.nscol - c0) * f.nsrow) ;
+            q++ ;
+            continue ;
+        }
         // runs of consecutive fronts this rank contributes: contiguous in both arrays
-        if (!(P->lpx [q] >= 0 && P->rank == P->grp0 [q])) { q++ ; continue ; }
+        if (P->rank != P->grp0 [q]) { q++ ; continue ; }
         i64 e = q ;
-        while (e < P->nsuper && P->lpx [e] >= 0 && P->rank == P->grp0 [e] && P->lpx [e] - P->lpx [q] == P->px [e] - P->px [q]) e++ ;
-        if (staged) HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], own_host.get () + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
-            hipMemcpyHostToDevice, P->stream)) ;
-        else HIPCHK (hipMemcpyAsync (P->d_Lx_full + P->px [q], P->d_Lx + P->lpx [q], (size_t) (P->px [e] - P->px [q]) * sizeof (double),
-            hipMemcpyDeviceToDevice, P->stream)) ;
+        while (e < P->nsuper && P->lpx [e] >= 0 && !P->fr [e].own_w && P->rank == P->grp0 [e] && P->lpx [e] - P->lpx [q] == P->px [e] - P->px [q]) e++ ;
+        put (P->px [q], P->lpx [q], P->px [e] - P->px [q]) ;
         q = e ;
     }
-    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    hold (hipStreamSynchronize (P->stream)) ;
     const i64 chunk = (i64) 1 << 27 ;
     for (i64 off = 0 ; off < P->xsize ; off += chunk)
     {
         i64 cnt = std::min (chunk, P->xsize - off) ;
         if (P->nccl_world)
-            RCCLCHK (rccl_api ()->AllReduce (P->d_Lx_full + off, P->d_Lx_full + off, (size_t) cnt, ncclDouble, ncclSum, P->nccl_world, P->stream)) ;
-        else if (P->ar_fn (P->d_Lx_full + off, cnt, 0, P->world, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+        {
+            if (rccl_api ()->AllReduce (P->d_Lx_full + off, P->d_Lx_full + off, (size_t) cnt, ncclDouble, ncclSum, P->nccl_world, P->stream) != ncclSuccess
+                && bad == CHOLMOD_HIP_OK) bad = CHOLMOD_HIP_GPU_PROBLEM ;
+        }
+        else if (P->ar_fn (P->d_Lx_full + off, cnt, 0, P->world, P->ar_user) != 0 && bad == CHOLMOD_HIP_OK) bad = CHOLMOD_HIP_GPU_PROBLEM ;
     }
-    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    hold (hipStreamSynchronize (P->stream)) ;
+    {
+        double any = agree (bad == CHOLMOD_HIP_OK ? 0.0 : 1.0) ;
+        if (any != 0.0)
+        {
+            // somebody's copy is not the factor: nobody keeps one; a rank that staged its part through the host gets it back
+            (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ;
+            P->full_valid = false ;
+            if (staged) (void) restore_own () ;
+            return bad != CHOLMOD_HIP_OK ? bad : CHOLMOD_HIP_GPU_PROBLEM ;
+        }
+    }
     P->full_valid = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -2470,7 +2693,7 @@ int cholmod_hip_upload_factor (cholmod_hip_plan *P, const double *Lx_host)
         if (!P->d_fr_full)
         {
             std::vector<FrontD> ff (P->fr) ;
-            for (i64 q = 0 ; q < P->nsuper ; q++) ff [q].psx = P->px [q] ;
+            for (i64 q = 0 ; q < P->nsuper ; q++) { ff [q].psx = P->px [q] ; ff [q].own_w = 0 ; ff [q].own_g = 1 ; ff [q].own_r = 0 ; }
             hipError_t e ;
             P->d_fr_full = dupload (ff, e) ; HIPCHK (e) ;
         }
@@ -2635,8 +2858,9 @@ int cholmod_hip_factor_checks_local (cholmod_hip_plan *P, double *out5)
     if (!P->d_Lx) return CHOLMOD_HIP_INVALID ;          // (released by a host-staged gather: the gathered factor is what there is)
     std::vector<CheckTask> t ;
     for (i64 s = 0 ; s < P->nsuper ; s++)
-        if (P->lpx [s] >= 0 && P->rank == P->grp0 [s])
-            for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS) t.push_back (CheckTask {(i32) s, c0}) ;
+        if (P->lpx [s] >= 0 && (P->fr [s].own_w || P->rank == P->grp0 [s]))
+            for (int c0 = 0 ; c0 < P->fr [s].nscol ; c0 += CHK_COLS)
+                if (col_owned (P->fr [s], c0)) t.push_back (CheckTask {(i32) s, c0}) ;       // (a slab is a multiple of CHK_COLS columns)
     if (t.empty ()) return CHOLMOD_HIP_OK ;
     hipError_t e ;
     CheckTask *dt = dupload (t, e) ; HIPCHK (e) ;

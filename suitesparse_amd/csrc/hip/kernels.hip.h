@@ -37,12 +37,23 @@ struct FrontD {
     i32 cbp;        // 1: the contribution block is stored as a packed lower triangle
                     // (column j holds rows j..ncb-1; written by k_thin_front), 0: as a
                     // full square with ld = ncb (written by the dense update kernel)
+    // Several GPUs, a front shared by a rank group (round 4): its panel is DISTRIBUTED over the group by
+    // slabs of own_w columns, slab t on member t % own_g -- a rank stores only its own slabs, packed one
+    // behind the other with ld = nsrow (psx = offset of the first one in the rank's array).  own_w == 0:
+    // the whole panel is here (private fronts, one GPU, the gathered factor).
+    i32 own_w, own_g, own_r;
+    i32 pad_;
 };
+// column c of front f: is it stored on this rank, and where (in columns from psx)
+__host__ __device__ __forceinline__ bool col_owned (const FrontD &f, int c) { return f.own_w == 0 || ((c / f.own_w) % f.own_g) == f.own_r ; }
+__host__ __device__ __forceinline__ int col_local (const FrontD &f, int c) { return f.own_w == 0 ? c : ((c / f.own_w) / f.own_g) * f.own_w + c % f.own_w ; }
 
 // what a parent needs of a child, in the order of the child lists: one load instead of the chain
 // child [ci] -> fr [child] -> (cb, rel, ncb, cbp)
 struct ChildD { i64 cb; i64 rel; i32 ncb; i32 cbp; };
-struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi; };   // extend-add into target columns [c_lo, c_hi)
+struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi;      // extend-add into target columns [c_lo, c_hi)
+                 i64 pbase; };                                        // panel columns live at pbase + c ld (-1: at the front's psx);
+                                                                      // a shared front's block column in its window (engine.hip)
 struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
 struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
 struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
@@ -164,6 +175,7 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
     if (k >= n) return ;
     const FrontD &f = fr [supermap [k]] ;
     if (f.assemble != 1) return ;      // 0: another rank's, 2: k_small_front does it
+    if (!col_owned (f, (int) (k - f.k1))) return ;     // a distributed front: the column's owner assembles it
     i64 psx = f.psx, psi = f.psi ;
     int nsrow = f.nsrow, k1 = f.k1 ;
     const i64 *rows = Ls + psi ;
@@ -173,7 +185,7 @@ __global__ void __launch_bounds__(256) k_assemble (i64 n, const i64 *Sp,
         // (the odd columns of the embedded matrix are not stored)
         if (k & 1) { for (i64 q = p ; q < pend ; q++) amap [q] = -1 ; return ; }
     }
-    double *col = Lx + psx + colx<CX> ((int) (k - k1), nsrow) ;
+    double *col = Lx + psx + colx<CX> (col_local (f, (int) (k - k1)), nsrow) ;
     for ( ; p < pend ; p++)
     {
         i64 i = Si [p] ;
@@ -221,9 +233,9 @@ __global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, c
     i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
     if (k >= n) return ;
     const FrontD &f = fr [supermap [k]] ;
-    if (f.assemble != 1) return ;
+    if (f.assemble != 1 || !col_owned (f, (int) (k - f.k1))) return ;
     if (CX && (k & 1)) return ;
-    Lx [f.psx + colx<CX> ((int) (k - f.k1), f.nsrow) + (k - f.k1)] += beta ;
+    Lx [f.psx + colx<CX> (col_local (f, (int) (k - f.k1)), f.nsrow) + (k - f.k1)] += beta ;
 }
 
 // ---- zero the contribution blocks of a level --------------------------------
@@ -267,7 +279,7 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * tw ;
     int c1 = c0 + tw < g [gi].c_hi ? c0 + tw : g [gi].c_hi ;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
-    i64 Ppsx = P.psx, Pcb = P.cb ;
+    i64 Ppsx = g [gi].pbase >= 0 ? g [gi].pbase : P.psx, Pcb = P.cb ;
     int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
     int cb = P.child_begin, ce = P.child_end ;
     for (int ci = cb ; ci < ce ; ci++)
@@ -2215,6 +2227,39 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
     }
 }
 
+// ---- the window of a distributed front (several GPUs, round 4) --------------------------------
+// A shared front's panel is stored by column slabs on their owners (FrontD::own_w); the outer block
+// column the group is factoring lives, on every member, in a WINDOW: nsrow x OB doubles addressed as
+// if the whole front were there (win = base - o0 nsrow, so column c of the front is win + c ld).
+//   mode 0 (open):  window columns [c0, c1), rows r0 .. nsrow-1  :=  the owner's stored column, zero on
+//                   the other members -- their partial sum before the children's contributions
+//                   (extend-add into the window) and the dealt tiles of the wide updates are added;
+//   mode 1 (close): the factored columns back into the owner's slabs.
+// One workgroup = one column x WIN_ROWS rows.
+#define WIN_ROWS 8192
+struct WinD { i64 store ; i64 win ; i32 ld ; i32 c0, c1 ; i32 r0 ; i32 nrows ; i32 own_w, own_g, own_r ; i32 mode ; i32 blk_start ; } ;
+__global__ void __launch_bounds__(256) k_win_move (const WinD *g, int ng, double *Lx)
+{
+    int gi = find_group (g, ng, (int) blockIdx.x, &WinD::blk_start) ;
+    const WinD W = g [gi] ;
+    const int nchunk = (W.nrows - W.r0 + WIN_ROWS - 1) / WIN_ROWS ;
+    const int b = (int) blockIdx.x - W.blk_start ;
+    const int c = W.c0 + b / nchunk ;
+    const int ra = W.r0 + (b % nchunk) * WIN_ROWS ;
+    const int rb = ra + WIN_ROWS < W.nrows ? ra + WIN_ROWS : W.nrows ;
+    if (c >= W.c1) return ;
+    const int t = c / W.own_w ;
+    const bool mine = (t % W.own_g) == W.own_r ;
+    double *wc = Lx + W.win + (i64) c * W.ld ;
+    double *sc = Lx + W.store + (i64) ((t / W.own_g) * W.own_w + c % W.own_w) * W.ld ;
+    if (W.mode == 0)
+    {
+        if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += 256) wc [i] = sc [i] ;
+        else for (int i = ra + threadIdx.x ; i < rb ; i += 256) wc [i] = 0.0 ;
+    }
+    else if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += 256) sc [i] = wc [i] ;
+}
+
 // ---- the panel chain in 256-column sub-blocks (opt-in: CHOLMOD_HIP_CHAIN256) ---------------
 // The default chain walks a front's outer block column in 64-column steps: dpotrf of the
 // diagonal block, dtrsm of ALL rows below, the K = 64 ... 256 doubling updates -- about fifteen
@@ -3138,7 +3183,7 @@ __global__ void __launch_bounds__(256) k_factor_checks (const CheckTask *tasks, 
     {
         for (int i = lane ; i < nsrow ; i += 64)
         {
-            double v = ldcx<CX> (L, i, j, nsrow) ;
+            double v = ldcx<CX> (L, i, col_local (f, j), nsrow) ;      // (a distributed front: the tasks cover this rank's slabs)
             if (i < j) { if (v != 0.0) nup += 1.0 ; }
             else
             {

@@ -5,16 +5,35 @@
 // collectives) -- the real RCCL refuses two ranks on one device, and the test box has one
 // device.  The engine binds it through CHOLMOD_HIP_RCCL_LIBRARY (engine.hip: rccl_api).
 //
-// Semantics kept: communicators, ncclCommSplit by colour / key (NCCL_SPLIT_NOCOLOR -> NULL),
-// collectives ordered with the stream they are given (the stream is synchronised, the data
-// staged through a POSIX shared-memory segment, every member sums the members' slots in rank
-// order -- so all members obtain bit-identical results, as RCCL's ring does not promise but the
-// engine must not rely on either way).  Not kept: asynchrony (every call blocks the host until
-// the collective is complete) and bandwidth.  fp64 sum / plain byte moves only.
+// Semantics kept:
+//  * communicators, ncclCommSplit by colour / key (NCCL_SPLIT_NOCOLOR -> NULL);
+//  * ASYNCHRONY (round 4): a collective call returns at once.  It records an event on the stream
+//    it is given, hands the operation to a helper thread of the process and enqueues a small
+//    kernel on that stream that waits for the helper's completion flag (host-coherent memory).
+//    The helper waits for the event ON THE DEVICE (hipStreamWaitEvent on its own stream), stages
+//    the data through a POSIX shared-memory segment, meets the peers there, writes the result back
+//    and raises the flag.  So the collective is ordered with the work before and after it on ITS
+//    stream and with nothing else: kernels on other streams run beside it, and an engine that
+//    forgot an event between its two streams reads stale data here as it would over RCCL.
+//    The operations of one process are executed in the order of the calls (one helper), which is
+//    what NCCL promises per communicator and the engine provides across communicators (every rank
+//    walks the same global launch list).  STANDIN_RCCL_SYNC=1 restores the blocking behaviour of
+//    round 3 (the host waits inside every call).
+//  * summation order: a reduce-scatter sums segment d starting with member d + 1 and ending with
+//    member d, as a ring does -- the copies of a value that travels in several segments differ in
+//    the last bits between the members, so the engine may not rely on bit-identical sums
+//    (STANDIN_RCCL_RANK_ORDER=1: every segment in rank order).  All-reduce sums in rank order and
+//    hands every member the same bits, as RCCL's ring does (reduce-scatter + all-gather).
+// Not kept: bandwidth, concurrency of two communicators of one process.  fp64 sum / plain byte moves only.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -52,8 +71,118 @@ struct Comm {
     int world_rank [MAXR] ;     // slot of every member
     bool is_world ;
     char name [64] ;
-    hipStream_t side ;          // private non-blocking stream for the staging copies
+    hipStream_t side ;          // the process's staging stream (helper thread)
 } ;
+
+// ---- the helper thread of the process -----------------------------------------------------
+// One per process, started with the first communicator.  A collective call pushes a closure
+// (the blocking implementation of round 3, run on the helper's stream) and returns.
+__global__ void k_standin_wait (const volatile unsigned *done, unsigned id)
+{
+    // (ids only grow and the helper completes them in order: >= with wrap-around)
+    while ((int) (__hip_atomic_load (done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - id) < 0) __builtin_amdgcn_s_sleep (64) ;
+}
+
+struct Helper {
+    std::mutex mu ;
+    std::condition_variable cv, idle ;
+    std::deque<std::function<ncclResult_t ()>> q ;
+    std::deque<std::pair<hipEvent_t, unsigned>> meta ;      // (event to wait for, id) of each queued closure
+    unsigned next_id = 1, done_host = 0 ;
+    volatile unsigned *done = nullptr ;                     // host-coherent, read by k_standin_wait
+    hipStream_t side = nullptr ;
+    int device = 0 ;
+    std::atomic<int> failed {0} ;                           // sticky: a staged operation failed
+    bool sync = false ;
+    std::thread th ;
+    void run ()
+    {
+        (void) hipSetDevice (device) ;
+        for ( ; ; )
+        {
+            std::function<ncclResult_t ()> fn ;
+            std::pair<hipEvent_t, unsigned> m ;
+            {
+                std::unique_lock<std::mutex> lk (mu) ;
+                cv.wait (lk, [this] { return !q.empty () ; }) ;
+                fn = std::move (q.front ()) ; m = meta.front () ;
+            }
+            ncclResult_t r = ncclSuccess ;
+            if (hipStreamWaitEvent (side, m.first, 0) != hipSuccess) r = ncclUnhandledCudaError ;
+            if (r == ncclSuccess) r = fn () ;
+            if (r == ncclSuccess && hipStreamSynchronize (side) != hipSuccess) r = ncclUnhandledCudaError ;
+            if (r != ncclSuccess)
+            {
+                fprintf (stderr, "standin_rccl: a queued collective failed (%d)\n", (int) r) ;
+                failed.store ((int) r) ;
+            }
+            (void) hipEventDestroy (m.first) ;
+            __atomic_store_n ((unsigned *) done, m.second, __ATOMIC_RELEASE) ;      // the waiting kernel goes on (also after a failure: no hang)
+            {
+                std::lock_guard<std::mutex> lk (mu) ;
+                q.pop_front () ; meta.pop_front () ;
+                done_host = m.second ;
+            }
+            idle.notify_all () ;
+        }
+    }
+} ;
+Helper *g_helper = nullptr ;
+std::mutex g_helper_mu ;
+
+Helper *helper ()
+{
+    std::lock_guard<std::mutex> lk (g_helper_mu) ;
+    if (g_helper) return g_helper ;
+    Helper *h = new Helper ;        // (never destroyed: its thread lives as long as the process)
+    if (hipGetDevice (&h->device) != hipSuccess) { delete h ; return nullptr ; }
+    if (hipStreamCreateWithFlags (&h->side, hipStreamNonBlocking) != hipSuccess) { delete h ; return nullptr ; }
+    void *p = nullptr ;
+    if (hipHostMalloc (&p, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { delete h ; return nullptr ; }
+    h->done = (volatile unsigned *) p ;
+    *h->done = 0 ;
+    const char *e = getenv ("STANDIN_RCCL_SYNC") ;
+    h->sync = e && atoi (e) != 0 ;
+    h->th = std::thread ([h] { h->run () ; }) ;
+    h->th.detach () ;
+    g_helper = h ;
+    return h ;
+}
+
+// everything queued so far has run (communicator management, blocking mode)
+void drain (Helper *h)
+{
+    std::unique_lock<std::mutex> lk (h->mu) ;
+    h->idle.wait (lk, [h] { return h->q.empty () ; }) ;
+}
+
+// The asynchronous frame of every collective: `fn` is its blocking implementation on the helper's stream.
+ncclResult_t enqueue (Comm *c, hipStream_t stream, std::function<ncclResult_t ()> fn)
+{
+    Helper *h = helper () ;
+    if (!h) return ncclUnhandledCudaError ;
+    if (h->failed.load ()) return (ncclResult_t) h->failed.load () ;
+    hipEvent_t ev ;
+    if (hipEventCreateWithFlags (&ev, hipEventDisableTiming) != hipSuccess) return ncclUnhandledCudaError ;
+    if (hipEventRecord (ev, stream) != hipSuccess) { (void) hipEventDestroy (ev) ; return ncclUnhandledCudaError ; }
+    unsigned id ;
+    {
+        std::lock_guard<std::mutex> lk (h->mu) ;
+        id = h->next_id++ ;
+        h->q.push_back (std::move (fn)) ;
+        h->meta.push_back ({ev, id}) ;
+    }
+    h->cv.notify_one () ;
+    c->shm->calls.fetch_add (1) ;
+    hipLaunchKernelGGL (k_standin_wait, dim3 (1), dim3 (1), 0, stream, h->done, id) ;
+    if (hipGetLastError () != hipSuccess) return ncclUnhandledCudaError ;
+    if (h->sync)
+    {
+        if (hipStreamSynchronize (stream) != hipSuccess) return ncclUnhandledCudaError ;
+        if (h->failed.load ()) return (ncclResult_t) h->failed.load () ;
+    }
+    return ncclSuccess ;
+}
 
 void spin_barrier (Comm *c)
 {
@@ -153,7 +282,9 @@ ncclResult_t ncclCommInitRank (ncclComm_t *comm, int nranks, ncclUniqueId id, in
     c->shm = s ; c->id = 0 ; c->nranks = nranks ; c->rank = rank ; c->is_world = true ;
     for (int q = 0 ; q < nranks ; q++) c->world_rank [q] = q ;
     snprintf (c->name, sizeof (c->name), "%s", id.internal) ;
-    if (hipStreamCreateWithFlags (&c->side, hipStreamNonBlocking) != hipSuccess) { delete c ; return ncclUnhandledCudaError ; }
+    Helper *h = helper () ;
+    if (!h) { delete c ; return ncclUnhandledCudaError ; }
+    c->side = h->side ;
     spin_barrier (c) ;
     if (rank == 0) shm_unlink (id.internal) ;       // everybody holds a mapping now
     *comm = (ncclComm_t) c ;
@@ -164,6 +295,7 @@ ncclResult_t ncclCommSplit (ncclComm_t comm, int color, int key, ncclComm_t *new
 {
     Comm *c = (Comm *) comm ;
     if (!c || !newcomm) return ncclInvalidArgument ;
+    if (Helper *h = helper ()) drain (h) ;         // (communicator management blocks the host, as ncclCommSplit does)
     Shm *s = c->shm ;
     s->color [c->id][c->rank] = color ;
     s->key [c->id][c->rank] = key ;
@@ -187,8 +319,7 @@ ncclResult_t ncclCommSplit (ncclComm_t comm, int color, int key, ncclComm_t *new
             if (mem [q].second == c->rank) n->rank = q ;
         }
         if (n->id >= MAXCOMM || n->rank < 0) { delete n ; res = ncclInternalError ; }
-        else if (hipStreamCreateWithFlags (&n->side, hipStreamNonBlocking) != hipSuccess) { delete n ; res = ncclUnhandledCudaError ; }
-        else *newcomm = (ncclComm_t) n ;
+        else { n->side = c->side ; *newcomm = (ncclComm_t) n ; }
     }
     spin_barrier (c) ;          // the scratch of the parent may be reused
     return res ;
@@ -198,7 +329,7 @@ ncclResult_t ncclCommDestroy (ncclComm_t comm)
 {
     Comm *c = (Comm *) comm ;
     if (!c) return ncclSuccess ;
-    (void) hipStreamDestroy (c->side) ;
+    if (Helper *h = helper ()) drain (h) ;         // nothing of this communicator is in flight any more
     if (c->is_world) munmap (c->shm, sizeof (Shm)) ;
     delete c ;
     return ncclSuccess ;
@@ -210,13 +341,8 @@ ncclResult_t ncclCommUserRank (const ncclComm_t comm, int *rank) { if (!comm || 
 // test hook: collectives this world has executed so far (summed over the ranks)
 long long standin_rccl_calls (ncclComm_t comm) { return comm ? ((Comm *) comm)->shm->calls.load () : -1 ; }
 
-ncclResult_t ncclAllReduce (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, ncclRedOp_t op,
-    ncclComm_t comm, hipStream_t stream)
+static ncclResult_t do_allreduce (Comm *c, const void *sendbuff, void *recvbuff, size_t count)
 {
-    Comm *c = (Comm *) comm ;
-    if (!c || dt != ncclDouble || op != ncclSum) return ncclInvalidArgument ;
-    HCHK (hipStreamSynchronize (stream)) ;
-    c->shm->calls.fetch_add (1) ;
     std::vector<double> acc ;
     for (size_t o = 0 ; o < count || (count == 0 && o == 0) ; o += CHUNK)
     {
@@ -242,13 +368,16 @@ ncclResult_t ncclAllReduce (const void *sendbuff, void *recvbuff, size_t count, 
     return ncclSuccess ;
 }
 
-ncclResult_t ncclReduce (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, ncclRedOp_t op, int root,
+ncclResult_t ncclAllReduce (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, ncclRedOp_t op,
     ncclComm_t comm, hipStream_t stream)
 {
     Comm *c = (Comm *) comm ;
-    if (!c || dt != ncclDouble || op != ncclSum || root < 0 || root >= c->nranks) return ncclInvalidArgument ;
-    HCHK (hipStreamSynchronize (stream)) ;
-    c->shm->calls.fetch_add (1) ;
+    if (!c || dt != ncclDouble || op != ncclSum) return ncclInvalidArgument ;
+    return enqueue (c, stream, [=] () { return do_allreduce (c, sendbuff, recvbuff, count) ; }) ;
+}
+
+static ncclResult_t do_reduce (Comm *c, const void *sendbuff, void *recvbuff, size_t count, int root)
+{
     std::vector<double> acc ;
     for (size_t o = 0 ; o < count ; o += CHUNK)
     {
@@ -274,15 +403,17 @@ ncclResult_t ncclReduce (const void *sendbuff, void *recvbuff, size_t count, ncc
     return ncclSuccess ;
 }
 
-ncclResult_t ncclBroadcast (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, int root,
+ncclResult_t ncclReduce (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, ncclRedOp_t op, int root,
     ncclComm_t comm, hipStream_t stream)
 {
     Comm *c = (Comm *) comm ;
-    size_t tb = type_bytes (dt) ;
-    if (!c || !tb || root < 0 || root >= c->nranks) return ncclInvalidArgument ;
-    HCHK (hipStreamSynchronize (stream)) ;
-    c->shm->calls.fetch_add (1) ;
-    size_t bytes = count * tb, cb = CHUNK * sizeof (double) ;
+    if (!c || dt != ncclDouble || op != ncclSum || root < 0 || root >= c->nranks) return ncclInvalidArgument ;
+    return enqueue (c, stream, [=] () { return do_reduce (c, sendbuff, recvbuff, count, root) ; }) ;
+}
+
+static ncclResult_t do_broadcast (Comm *c, const void *sendbuff, void *recvbuff, size_t bytes, int root)
+{
+    size_t cb = CHUNK * sizeof (double) ;
     for (size_t o = 0 ; o < bytes ; o += cb)
     {
         size_t n = std::min (cb, bytes - o) ;
@@ -299,14 +430,19 @@ ncclResult_t ncclBroadcast (const void *sendbuff, void *recvbuff, size_t count, 
     return ncclSuccess ;
 }
 
-// recvbuff (recvcount) = sum over the members of their sendbuff [rank * recvcount ...)
-ncclResult_t ncclReduceScatter (const void *sendbuff, void *recvbuff, size_t recvcount, ncclDataType_t dt, ncclRedOp_t op,
+ncclResult_t ncclBroadcast (const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, int root,
     ncclComm_t comm, hipStream_t stream)
 {
     Comm *c = (Comm *) comm ;
-    if (!c || dt != ncclDouble || op != ncclSum) return ncclInvalidArgument ;
-    HCHK (hipStreamSynchronize (stream)) ;
-    c->shm->calls.fetch_add (1) ;
+    size_t tb = type_bytes (dt) ;
+    if (!c || !tb || root < 0 || root >= c->nranks) return ncclInvalidArgument ;
+    return enqueue (c, stream, [=] () { return do_broadcast (c, sendbuff, recvbuff, count * tb, root) ; }) ;
+}
+
+// recvbuff (recvcount) = sum over the members of their sendbuff [rank * recvcount ...)
+static ncclResult_t do_reduce_scatter (Comm *c, const void *sendbuff, void *recvbuff, size_t recvcount)
+{
+    static const bool rank_order = [] () { const char *e = getenv ("STANDIN_RCCL_RANK_ORDER") ; return e && atoi (e) != 0 ; } () ;
     // the members' slots carry the piece of one destination at a time
     std::vector<double> acc ;
     for (int dest = 0 ; dest < c->nranks ; dest++)
@@ -316,10 +452,13 @@ ncclResult_t ncclReduceScatter (const void *sendbuff, void *recvbuff, size_t rec
             ncclResult_t r = staged (c, (const double *) sendbuff + (size_t) dest * recvcount + o, n * sizeof (double), [&] () -> ncclResult_t
             {
                 if (c->rank != dest) return ncclSuccess ;
-                acc.assign (n, 0.0) ;
-                for (int q = 0 ; q < c->nranks ; q++)
+                // ring order: segment d is summed starting with member d + 1 and ending with member d
+                const int q0 = rank_order ? 0 : (dest + 1) % c->nranks ;
+                const double *s0 = c->shm->slot [c->world_rank [q0]] ;
+                acc.assign (s0, s0 + n) ;
+                for (int t = 1 ; t < c->nranks ; t++)
                 {
-                    const double *s = c->shm->slot [c->world_rank [q]] ;
+                    const double *s = c->shm->slot [c->world_rank [(q0 + t) % c->nranks]] ;
                     for (size_t e = 0 ; e < n ; e++) acc [e] += s [e] ;
                 }
                 return ncclSuccess ;
@@ -334,16 +473,18 @@ ncclResult_t ncclReduceScatter (const void *sendbuff, void *recvbuff, size_t rec
     return ncclSuccess ;
 }
 
-// recvbuff [q * sendcount ...) = member q's sendbuff
-ncclResult_t ncclAllGather (const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t dt,
+ncclResult_t ncclReduceScatter (const void *sendbuff, void *recvbuff, size_t recvcount, ncclDataType_t dt, ncclRedOp_t op,
     ncclComm_t comm, hipStream_t stream)
 {
     Comm *c = (Comm *) comm ;
-    size_t tb = type_bytes (dt) ;
-    if (!c || !tb) return ncclInvalidArgument ;
-    HCHK (hipStreamSynchronize (stream)) ;
-    c->shm->calls.fetch_add (1) ;
-    size_t bytes = sendcount * tb, cb = CHUNK * sizeof (double) ;
+    if (!c || dt != ncclDouble || op != ncclSum) return ncclInvalidArgument ;
+    return enqueue (c, stream, [=] () { return do_reduce_scatter (c, sendbuff, recvbuff, recvcount) ; }) ;
+}
+
+// recvbuff [q * sendcount ...) = member q's sendbuff
+static ncclResult_t do_all_gather (Comm *c, const void *sendbuff, void *recvbuff, size_t bytes)
+{
+    size_t cb = CHUNK * sizeof (double) ;
     for (size_t o = 0 ; o < bytes ; o += cb)
     {
         size_t n = std::min (cb, bytes - o) ;
@@ -361,6 +502,15 @@ ncclResult_t ncclAllGather (const void *sendbuff, void *recvbuff, size_t sendcou
         if (r != ncclSuccess) return r ;
     }
     return ncclSuccess ;
+}
+
+ncclResult_t ncclAllGather (const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t dt,
+    ncclComm_t comm, hipStream_t stream)
+{
+    Comm *c = (Comm *) comm ;
+    size_t tb = type_bytes (dt) ;
+    if (!c || !tb) return ncclInvalidArgument ;
+    return enqueue (c, stream, [=] () { return do_all_gather (c, sendbuff, recvbuff, sendcount * tb) ; }) ;
 }
 
 ncclResult_t ncclGroupStart (void) { return ncclSuccess ; }

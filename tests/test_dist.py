@@ -297,7 +297,9 @@ def test_native_rccl_exchange_single_rank(monkeypatch, lookahead, notposdef):
 
 
 STANDIN = os.path.join(ROOT, "tests", "standin_rccl", "libstandin_rccl.so")
-NATIVE = {"DIST_TEST_EXCHANGE": "native", "CHOLMOD_HIP_RCCL_LIBRARY": STANDIN}
+# (GPU_MAX_HW_QUEUES: the stand-in's collectives are asynchronous -- a small kernel on the caller's stream waits for the
+# helper thread's flag; streams that shared a hardware queue with it would wait behind it)
+NATIVE = {"DIST_TEST_EXCHANGE": "native", "CHOLMOD_HIP_RCCL_LIBRARY": STANDIN, "GPU_MAX_HW_QUEUES": "8"}
 
 
 def test_standin_collective_library_exports_what_the_engine_binds():
