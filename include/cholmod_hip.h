@@ -257,7 +257,10 @@ int cholmod_hip_factor_checks_local (cholmod_hip_plan *plan, double *out5) ;
  *  [32] seconds in the one-wave-per-tile dense-update kernel (k_update3: the regions with
  *       >= 2048 tiles)   [33] its launches   [34] its algorithmic flops   [35] its algorithmic bytes
  *       (as [16]); the regions below that size stay with [6]-[8]
- *  [36] bytes of L this rank allocates: the fronts it holds, packed (= [5] with one rank)
+ *  [36] bytes of L this rank allocates: the fronts it holds -- of a shared front the column slabs it owns -- packed,
+ *       plus the windows of the shared fronts (= [5] with one rank)
+ *  [37] block columns of distributed fronts opened into their windows   [38] those whose window has a negative
+ *       virtual base (the window is addressed as if the whole front were there: tests make sure both signs occur)
  * Per-class seconds are only collected when profiling is enabled with
  * cholmod_hip_set_profiling(plan, 1) (it serialises the stream with events). */
 #define CHOLMOD_HIP_NSTATS 40

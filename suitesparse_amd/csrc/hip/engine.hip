@@ -469,11 +469,12 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 // blocks this rank spends on the group (see decode_tile)
                 i64 mine ;
                 G.swz = 0 ;
-                if (G.tile_mul == 1 && cnt < 1024) mine = cnt ;
+                if (G.tile_mul == 1 && cnt < 1024 && !G.tile_cnt) mine = cnt ;
                 else
                 {
                     i64 nch = (cnt + 63) / 64 ;
                     i64 mych = nch > G.tile_add ? (nch - G.tile_add + G.tile_mul - 1) / G.tile_mul : 0 ;
+                    if (G.tile_cnt) mych = std::min<i64> (G.tile_cnt, nch > G.tile_add ? nch - G.tile_add : 0) ;     // a range of chunks
                     mine = mych * 64 ;
                     G.swz = !(flags & CHOLMOD_HIP_NO_XCD_SWIZZLE) && mine >= 1024 ;
                     // one wave per tile: an XCD runs 256 tiles at a time, so a 16 x 16 super-tile (32 operand
@@ -482,13 +483,13 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     // 220 GB fetched, inside the 200^3 factorization 105.4 against 105.1 ms per launch and
                     // 478 against 462 GB (same box, top-48 launches): the tiles of an XCD drift apart in k
                     // either way, and the wider strip only widens what they drift over.
-                    if (G.swz && pass == 3 && G.tile_mul == 1 && cnt >= 8192 && getenv ("CHOLMOD_HIP_SWZ16"))
+                    if (G.swz && pass == 3 && G.tile_mul == 1 && !G.tile_cnt && cnt >= 8192 && getenv ("CHOLMOD_HIP_SWZ16"))
                     {
                         G.swz = 2 ;
                         mine = (cnt + 255) / 256 * 256 ;
                     }
                     if (G.swz) tiles = (tiles + 7) / 8 * 8 ;     // keep block % 8 == XCD aligned
-                    else if (G.tile_mul == 1) mine = cnt ;
+                    else if (G.tile_mul == 1 && !G.tile_cnt) mine = cnt ;
                 }
                 if (mine == 0) continue ;
                 G.nblk = (i32) mine ;
@@ -496,7 +497,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 tiles += mine ;
                 double elems = G.tri ? (double) G.n * (G.n + 1) / 2 + (double) (G.m - G.n) * G.n
                                      : (double) G.m * G.n ;
-                double share = G.tile_mul == 1 ? 1.0 : std::min (1.0, (double) mine / (double) cnt) ;
+                double share = (G.tile_mul == 1 && !G.tile_cnt) ? 1.0 : std::min (1.0, (double) mine / (double) cnt) ;
                 L.flops += 2.0 * elems * G.k * share ;
                 L.aux = std::max (L.aux, (int) G.k) ;
                 L.bytes += ((G.assign ? 8.0 : 16.0) * elems + 8.0 * ((double) G.m + G.n) * G.k) * share ;
@@ -641,6 +642,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         }
     } ;
     std::vector<int> early_open (nf, -1) ;  // block column of front q opened ahead of time
+    const bool balance_cb = !use_big && !getenv ("CHOLMOD_HIP_NO_CB_BALANCE") ;
     // One trailing-update step: for every listed front, columns [kc, kc+kk) update
     // the in-front columns [t0, t1) (all rows from t0 down) and, if cb, the
     // contribution block.  Steps with kk >= MB are `wide`: their tiles are dealt
@@ -729,7 +731,50 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 if (x.t1 > c0) add_outer_slabs (small, f, ids [x.q], x.kc, x.kk, c0, x.t1) ;
             }
             else if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
-            if (x.cb) add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
+            if (x.cb)
+            {
+                size_t nsm = small.size () ;
+                add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
+                if (windowed (ids [x.q]) && f.own_g > 1 && balance_cb && small.size () > nsm)
+                {
+                    // The members' own slabs of this step differ (a member has a slab more, or taller ones): the tiles
+                    // of the contribution block -- partial sums, anybody may compute any of them -- are dealt so that
+                    // every member ends up with the same number of tiles: member r takes the range of 64-tile chunks
+                    // [lo, lo + cnt) that fills it up to the common level.
+                    const int g = f.own_g ;
+                    std::vector<double> tin (g, 0.0), fill (g, 0.0) ;
+                    for (int c0 = (x.t0 / f.own_w) * f.own_w ; c0 < x.t1 ; c0 += f.own_w)
+                    {
+                        int a = std::max (c0, x.t0), b = std::min ({c0 + f.own_w, x.t1, (int) f.nscol}) ;
+                        if (b <= a) continue ;
+                        double mt = (f.nsrow - a + SMALL - 1) / SMALL, nt = (b - a + SMALL - 1) / SMALL ;
+                        tin [(c0 / f.own_w) % g] += nt * (nt + 1) / 2 + (mt - nt) * nt ;
+                    }
+                    GemmGroup &G = small.back () ;
+                    const i64 nch = (region_tiles (G) + 63) / 64 ;
+                    // water level: sum_r max (0, level - tin [r]) = 64 nch
+                    std::vector<double> srt (tin) ;
+                    std::sort (srt.begin (), srt.end ()) ;
+                    double need = 64.0 * nch, level = srt [0] ;
+                    for (int q = 0 ; q < g ; q++)
+                    {
+                        double next = q + 1 < g ? srt [q + 1] : 1e300 ;
+                        double room = (next - level) * (q + 1) ;
+                        if (room >= need) { level += need / (q + 1) ; need = 0 ; break ; }
+                        need -= room ; level = next ;
+                    }
+                    double cum = 0 ;
+                    i64 lo = 0, hi = 0 ;
+                    for (int r = 0 ; r <= f.own_r ; r++)
+                    {
+                        lo = hi ;
+                        cum += std::max (0.0, level - tin [r]) ;
+                        hi = r + 1 == g ? nch : std::min<i64> (nch, (i64) std::llround (cum / 64.0)) ;
+                    }
+                    if (hi <= lo) small.pop_back () ;
+                    else { G.tile_mul = 1 ; G.tile_add = (i32) lo ; G.tile_cnt = (i32) (hi - lo) ; }
+                }
+            }
         }
         flush_updates (big, small) ;
         if (any_next)
@@ -1575,7 +1620,7 @@ static int build_host (cholmod_hip_plan *P)
                 int hi = phase == 0 ? (asg ? f.nscol : f.nsrow) : f.nsrow ;
                 if (phase == 1 && !asg) continue ;
                 if (hi <= lo) continue ;
-                S.eg.push_back (EaGroup {ids [q], blocks, lo, hi, -1}) ;
+                S.eg.push_back (EaGroup {ids [q], blocks, lo, hi, EA_NO_PBASE}) ;
                 blocks += (hi - lo + tw - 1) / tw ;
                 if (phase == 0)
                     for (int c = f.child_begin ; c < f.child_end ; c++)
@@ -2120,6 +2165,12 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         S [22] = P->nsplit ;
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
         if (L.kind == K_EA) S [10] += L.bytes ;
+        if (L.kind == K_WIN)
+            for (int w = 0 ; w < L.ng ; w++)
+            {
+                const WinD &Wd = P->sch.wg [L.goff + w] ;
+                if (Wd.mode == 0) { S [37] += 1 ; if (Wd.win < 0) S [38] += 1 ; }
+            }
     }
     if (prof && poisoned == CHOLMOD_HIP_OK)
     {

@@ -52,8 +52,10 @@ __host__ __device__ __forceinline__ int col_local (const FrontD &f, int c) { ret
 // child [ci] -> fr [child] -> (cb, rel, ncb, cbp)
 struct ChildD { i64 cb; i64 rel; i32 ncb; i32 cbp; };
 struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi;      // extend-add into target columns [c_lo, c_hi)
-                 i64 pbase; };                                        // panel columns live at pbase + c ld (-1: at the front's psx);
+                 i64 pbase; };                                        // panel columns live at pbase + c ld (EA_NO_PBASE: at the front's psx;
+                                                                      // a window's virtual base may well be negative);
                                                                       // a shared front's block column in its window (engine.hip)
+#define EA_NO_PBASE INT64_MIN
 struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
 struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
 struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
@@ -80,6 +82,9 @@ struct GemmGroup {
     i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
     i32 pf_next, pf_col0;       // k_update2f: tile (0,0) of the region is the next 64 x 64 diagonal block of
                                 // the front (its first column: pf_col0) and is factored by the workgroup that updates it
+    i32 tile_cnt;               // multi-GPU, > 0: this rank's share of the region is the RANGE of tile_cnt 64-tile chunks
+                                // that starts at chunk tile_add (tile_mul = 1): the contribution block of a distributed
+                                // front, dealt so that it evens out what the members' own slabs differ by
 };
 
 // Contribution blocks of the generic fronts are stored as full squares, ld = ncb
@@ -279,7 +284,7 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * tw ;
     int c1 = c0 + tw < g [gi].c_hi ? c0 + tw : g [gi].c_hi ;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
-    i64 Ppsx = g [gi].pbase >= 0 ? g [gi].pbase : P.psx, Pcb = P.cb ;
+    i64 Ppsx = g [gi].pbase != EA_NO_PBASE ? g [gi].pbase : P.psx, Pcb = P.cb ;
     int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
     int cb = P.child_begin, ce = P.child_end ;
     for (int ci = cb ; ci < ce ; ci++)
@@ -1446,7 +1451,7 @@ __device__ __forceinline__ bool decode_tile (const GemmGroup &G, int u, int &I, 
     // with one wave per tile: 32 operand panels for 256 tiles)
     const int W = G.swz == 2 ? 16 : 8, LW = G.swz == 2 ? 8 : 6 ;
     int t ;
-    if (G.tile_mul == 1 && !G.swz) t = u ;
+    if (G.tile_mul == 1 && !G.swz) t = u + (G.tile_add << 6) ;
     else
     {
         int cl, within ;

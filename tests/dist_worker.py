@@ -46,6 +46,18 @@ def main():
             n, Ap, Ai, Ax = G.poisson2d(90); perm = G.geometric_nd(90, 90, 1, 4)
         elif case == "box10":
             n, Ap, Ai, Ax = G.box_stencil3d(10, 2); perm = G.geometric_nd(10, 10, 10, 3)
+        elif case == "dense_1400":
+            # one dense supernode: the root IS the factor, shared by everybody -- its window's virtual base
+            # (window start minus outer-block offset) lies below the rank's array from the second outer block on
+            rng = np.random.default_rng(7)
+            n = 1400
+            M = np.tril(rng.standard_normal((n, n)))
+            M[np.arange(n), np.arange(n)] = 2.0 * n ** 0.5 + rng.random(n)
+            import scipy.sparse as sp
+            Asp = sp.csc_matrix(M)
+            Asp.sort_indices()
+            Ap, Ai, Ax = Asp.indptr.astype(np.int64), Asp.indices.astype(np.int64), Asp.data.astype(np.float64)
+            perm = np.arange(n, dtype=np.int64)
         elif case == "p3d_16_notposdef":
             n, Ap, Ai, Ax = G.poisson3d(16); perm = G.geometric_nd(16, 16, 16, 4)
         else:
@@ -173,7 +185,9 @@ def main():
                    allreduce_calls=cb.stats["n"] if cb else int(S.hip_stats(Lf)[17]),
                    allreduce_MB=(cb.stats["bytes"] if cb else S.hip_stats(Lf)[18]) / 1e6,
                    allreduce_group_sizes=sorted(cb.stats["by_size"]) if cb else [],
-                   nsplit=int(S.hip_stats(Lf)[22]))
+                   nsplit=int(S.hip_stats(Lf)[22]), window_opens=int(S.hip_stats(Lf)[37]),
+                   window_opens_negative_base=int(S.hip_stats(Lf)[38]), L_bytes_rank=float(S.hip_stats(Lf)[36]),
+                   L_bytes_whole=float(S.hip_stats(Lf)[5]))
         if st_o == 0:
             # the rank's share of the factor invariants (its own part of L, no gathered copy) and the invariants
             # of the gathered factor: the shares must add up to them

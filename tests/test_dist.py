@@ -338,6 +338,25 @@ def test_native_exchange_between_ranks_matches_oracle(world, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,flags", [(2, 64), (3, 64 | 256), (4, 0)])
+def test_distributed_dense_root_windows(world, flags):
+    """One dense supernode of 1400 columns shared by every rank: the panel is stored by 128-column slabs on their
+    owners (a rank holds about 1 / world of it), the group factors it through windows of one outer block column
+    (512 wide with flag 64: three of them, two buffers used alternately, opened ahead of time with the exchange
+    look-ahead and in line without, flag 256).  From the second outer block on the window's virtual base is below
+    the rank's array (negative offset): both signs must occur."""
+    res = _run_ranks(world, "gpu", "dense_1400", extra_env=dict(NATIVE, CHOLMOD_TEST_HIP_FLAGS=str(flags)))
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+        assert r["nshared"] == 1 and r["nsuper"] == 1, r
+        assert r["window_opens"] >= 3 and 0 < r["window_opens_negative_base"] < r["window_opens"], r
+        # the rank's part: its slabs + two windows, not the whole factor (1400 x 1400)
+        slabs = sum(min(128, 1400 - c0) for c0 in range(0, 1400, 128) if (c0 // 128) % world == r["rank"])
+        wins = 2 * 1400 * 512           # (a front of 1400 rows has 512-column outer blocks with or without flag 64)
+        assert r["L_bytes_rank"] == 8.0 * (slabs * 1400 + wins), r
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 256, 128 | 256])
 def test_native_exchange_both_orders_and_subgroups(flags):
     """World of 4 with the heavy children of the root in sub-groups of 2 (communicator
