@@ -130,6 +130,23 @@ def cpu_baseline(sample_m):
 
 
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r03j_pmc_summary_poisson200_top48.json"}
+# counters summed per kernel over one refactorization of the thin stand-in (tools/evidence.sh PMC=1, tools/pmc_by_kernel.py)
+PMC_THIN = "r02l_pmc_by_kernel_poisson2d1259.json"
+
+
+def thin_traffic():
+    """HBM-side bytes of the thin-front kernels per factorization of the G3_circuit stand-in, from the committed
+    counter passes (FETCH_SIZE x 2 + WRITE_SIZE, KiB; the calibration of DESIGN section 4), or None."""
+    pf = os.path.join(ROOT, "profiles", PMC_THIN)
+    if not os.path.exists(pf):
+        return None
+    pj = json.load(open(pf))
+    fetch = sum(v.get("FETCH_SIZE", 0.0) for k, v in pj.items() if k.startswith(("k_thin_front", "k_leaf_pair")))
+    write = sum(v.get("WRITE_SIZE", 0.0) for k, v in pj.items() if k.startswith(("k_thin_front", "k_leaf_pair")))
+    if fetch <= 0 and write <= 0:
+        return None
+    return {"fetch_bytes": 2.0 * 1024.0 * fetch, "write_bytes": 1024.0 * write, "traffic_bytes": 2.0 * 1024.0 * fetch + 1024.0 * write,
+            "source": "profiles/" + PMC_THIN}
 
 
 def roofline_of(S, Lf, wname, world):
@@ -249,8 +266,16 @@ def secondary_line(workload, m, steps=3, warmup=1):
         # the thin configuration is priced against HBM: algorithmic bytes of the whole factorization / time
         if workload == "poisson2d":
             algo = (roof["extend_add"]["algorithmic_GB"] + tf["algorithmic_GB"]) * 1e9 + 2.0 * stats[5]   # stats[5] = 8 B x entries of L
+            tt = thin_traffic()
+            if tt is not None:
+                # the thin kernels against HBM: algorithmic bytes and time from this run, counter bytes from the committed passes
+                tf["traffic_bytes_per_factorization"] = tt["traffic_bytes"]
+                tf["traffic_over_algorithmic"] = tt["traffic_bytes"] / max(tf["algorithmic_GB"] * 1e9, 1.0)
+                tf["traffic_detail"] = tt
             out["hbm_roofline"] = {"bound": "hbm", "achieved": algo / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                   "frac": algo / dt / 8e12,
+                                   "frac": algo / dt / 8e12, "traffic": tt["traffic_bytes"] if tt else None,
+                                   "traffic_note": "HBM-side bytes of the thin-front kernels only (FETCH_SIZE x 2 + WRITE_SIZE over one refactorization); "
+                                                   "their algorithmic bytes: roofline.thin_front_kernel.algorithmic_GB" if tt else None,
                                    "algorithmic_bytes": "thin fronts (children in, panel + block out) + extend-add of the generic "
                                                         "fronts + 16 B per entry of L for the generic panels"}
     if workload in ("poisson3d", "poisson2d"):

@@ -58,15 +58,48 @@ def main():
             Asp.sort_indices()
             Ap, Ai, Ax = Asp.indptr.astype(np.int64), Asp.indices.astype(np.int64), Asp.data.astype(np.float64)
             perm = np.arange(n, dtype=np.int64)
-        elif case == "p3d_16_notposdef":
+        elif case in ("p3d_16_notposdef", "p3d_16_notposdef_root"):
             n, Ap, Ai, Ax = G.poisson3d(16); perm = G.geometric_nd(16, 16, 16, 4)
+        elif case == "p3d_20_complex":
+            pass
         else:
             raise KeyError(case)
+        if case == "p3d_20_complex":
+            # complex (Hermitian) input on several ranks: the real twin of the factor (every row / column doubled) with the
+            # even-column update kernels, its shared fronts distributed by slabs like any other (host/complex.c)
+            from tests.test_complex import hermitian_from, full_hermitian
+            n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)
+            Ap, Ai, Ax = hermitian_from(n, Ap, Ai, Ax, seed=3)
+            O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+            assert O.factorize_complex(Ax) == 0
+            S = ch.Session(rank=rank, world=world, allreduce=make_allreduce(), hip_flags=int(os.environ.get("CHOLMOD_TEST_HIP_FLAGS", "0")))
+            A = S.sparse(n, Ap, Ai, Ax, -1)
+            Lf = S.analyze(A, perm)
+            ok = S.factorize(A, Lf)
+            fv = ch.FactorView(Lf)
+            m = O.lower_mask()
+            rng = np.random.default_rng(5)
+            b = rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))
+            x = S.solve(Lf, b)
+            res.update(ok=int(ok), status=int(S.cm.status), err=float(np.linalg.norm((fv.x - O.xc)[m]) / np.linalg.norm(O.xc[m])),
+                       upper_zero=bool(np.all(fv.x[~m] == 0)),
+                       resid=float(np.linalg.norm(full_hermitian(n, Ap, Ai, Ax) @ x.T - b.T) / np.linalg.norm(b)))
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            with open(f"{out}.{rank}", "w") as f:
+                json.dump(res, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
-        if case.endswith("notposdef"):
+        if "notposdef" in case:
             sup = O.super
             cand = [s for s in range(O.nsuper // 3, O.nsuper) if sup[s + 1] - sup[s] >= 6]
             kbad = int(sup[cand[0]] + 2)
+            if case.endswith("_root"):
+                # a column in the middle of the last supernode (the root: shared by every rank), past its first 64-column step
+                kbad = int(sup[O.nsuper - 1] + min(100, (sup[O.nsuper] - sup[O.nsuper - 1]) // 2))
             Ax = Ax.copy()
             Ax[Ap[int(O.Perm[kbad])]] = -3.0
         st_o = O.factorize(Ax)

@@ -357,6 +357,37 @@ def test_distributed_dense_root_windows(world, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_complex_input(world):
+    """Hermitian input on several ranks (reference templates t_cholmod_super_numeric.c:41-83): the engine factors the
+    real twin with the even-column update kernels, shared fronts distributed by slabs (a slab boundary is an even
+    column), and every rank gathers the complex factor: against the oracle's zherk / zpotrf restatement."""
+    res = _run_ranks(world, "gpu", "p3d_20_complex")
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11 and r["upper_zero"], r
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("own_w", [64, 256, 512])
+def test_distributed_slab_widths(own_w):
+    """The slab width of the distributed fronts (default 128): one slab per tile column, half a block column, a whole one."""
+    res = _run_ranks(3, "gpu", "p3d_32", extra_env=dict(NATIVE, CHOLMOD_HIP_OWN_W=str(own_w), CHOLMOD_HIP_TEST_POISON_ARENA="1"))
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+    assert len({r["L_bytes_rank"] for r in res}) > 1 or own_w == 512, res      # (the ranks hold different slabs)
+
+
+@pytest.mark.gpu
+def test_distributed_not_posdef_inside_a_shared_front():
+    """The failing pivot lies in the root, a front shared by all ranks and factored through its windows: same minor, same
+    zero pattern as the reference's repeat-supernode pass on every rank."""
+    res = _run_ranks(3, "gpu", "p3d_16_notposdef_root", extra_env=NATIVE)
+    for r in res:
+        assert r["oracle_status"] == 1 and r["ok"] == 1 and r["status"] == ch.NOT_POSDEF, r
+        assert r["minor"] == r["oracle_minor"] and r["zero_pattern_equal"] and r["err"] < 1e-12, r
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 256, 128 | 256])
 def test_native_exchange_both_orders_and_subgroups(flags):
     """World of 4 with the heavy children of the root in sub-groups of 2 (communicator

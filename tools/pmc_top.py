@@ -25,6 +25,7 @@ if sys.argv[1] == "select":
     print(" ".join("[%d-%d]" % (i + 1, i + 1) for i in sel))
 else:
     selj, fd, wd, workload, out = sys.argv[2:7]
+    md = sys.argv[7] if len(sys.argv) > 7 else None
     sel = json.load(open(selj))
 
     def total(d, counter):
@@ -51,5 +52,25 @@ else:
            "calibration": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 counts a 128-byte request as 64), WRITE_SIZE (KiB) x 1024",
            "command": "tools/pmc_top.sh: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-include-regex ... --kernel-iteration-range ... "
                       "--kernel-trace -- python tools/one_factorization.py --grid 200 (separate passes)"}
+    if md and glob.glob(md + "/**/*counter_collection.csv", recursive=True):
+        # matrix-pipe utilisation of the same launches: MFMA busy cycles / (GPU-active cycles per XCD x 1024 SIMDs)
+        # (GRBM_GUI_ACTIVE is reported per XCD and summed over the 8 of them; 256 CUs x 4 SIMDs)
+        f = glob.glob(md + "/**/*counter_collection.csv", recursive=True)[0]
+        acc, ids = {}, set()
+        for r in csv.DictReader(open(f)):
+            if sel["kernel_substring"] not in r["Kernel_Name"]:
+                continue
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            ids.add(r.get("Dispatch_Id"))
+        tr = [r for r in trace_rows(md) if sel["kernel_substring"] in r["Kernel_Name"]]
+        secs = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in tr) * 1e-9
+        busy, act, mops = acc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), acc.get("GRBM_GUI_ACTIVE", 0.0), acc.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+        if act > 0:
+            res["mfma_utilisation"] = {
+                "launches": len(ids), "SQ_VALU_MFMA_BUSY_CYCLES": busy, "GRBM_GUI_ACTIVE_sum_over_8_XCDs": act,
+                "SQ_INSTS_VALU_MFMA_MOPS_F64": mops, "kernel_seconds_in_this_pass": secs,
+                "mfma_pipe_utilisation": busy / (act / 8.0 * 1024.0),
+                "shader_clock_GHz_under_the_counters": (act / 8.0 / secs / 1e9) if secs > 0 else None,
+                "note": "utilisation = MFMA busy cycles / (GPU-active cycles per XCD x 1024 SIMDs); a separate rocprofv3 --pmc pass over the same launches"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))

@@ -15,5 +15,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --kernel-include-regex "$RE" --kernel-iteration-range $RANGES --kernel-trace -d $O/${TAG}_pmc_$C --output-format csv -- python $R/tools/one_factorization.py --grid $GRID > $O/${TAG}_pmc_$C.log 2>&1
   echo "$C rc=$?"
 done
+# matrix-pipe utilisation of the same launches (north_star: "MFMA utilisation on fat ones"): a third pass
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-include-regex "$RE" --kernel-iteration-range $RANGES --kernel-trace -d $O/${TAG}_pmc_MFMA --output-format csv -- python $R/tools/one_factorization.py --grid $GRID > $O/${TAG}_pmc_MFMA.log 2>&1
+echo "MFMA rc=$?"
 cd $R
-python tools/pmc_top.py summarise $O/${TAG}_pmc_selection.json $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE "poisson3d_${GRID}^3_geometricND_leaf4" $O/${TAG}_pmc_summary_poisson${GRID}_top${NTOP}.json
+python tools/pmc_top.py summarise $O/${TAG}_pmc_selection.json $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE "poisson3d_${GRID}^3_geometricND_leaf4" $O/${TAG}_pmc_summary_poisson${GRID}_top${NTOP}.json $O/${TAG}_pmc_MFMA
