@@ -65,7 +65,7 @@ static inline int window_count (const FrontD &f, int ob) { return f.nscol > ob ?
 
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
 // the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_CHAINF, K_NKIND } ;
 
 struct Launch {
     int kind ;
@@ -82,6 +82,7 @@ struct Launch {
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
     int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
     int leaf_pw = 0 ;               // K_SMALL: every front is a leaf of <= 32 rows and <= leaf_pw (4/8/12/16) columns: two per wave (k_leaf_pair)
+    int ndiag = 0 ;                 // K_CHAINF: diagonal workgroups of the launch (they come first in the grid)
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -165,6 +166,8 @@ struct Schedule {
     std::vector<DgGroup> dg ;       // k_diag: diagonal sub-blocks (256-column panel chain)
     std::vector<RsGroup> rg ;       // k_rowsolve: the rows below them
     std::vector<WinD> wg ;          // k_win_move: block columns of distributed fronts into / out of their windows
+    std::vector<CfGroup> cg ;       // k_chainf: the 256-column chain in one launch (diagonal + row workgroups, flags)
+    int ncflags = 0 ;               // flag slots (one per front and sub-block column of the whole schedule)
     int max_dinv_slots = 0 ;        // most diagonal sub-blocks in one launch (size of the inverse buffer)
     std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
@@ -326,6 +329,7 @@ struct cholmod_hip_plan {
     std::vector<i64> win_off ;
     i64 lx_fronts = 0 ;
     WinD *d_wg = nullptr ;
+    CfGroup *d_cg = nullptr ; int *d_cflags = nullptr ;     // k_chainf groups; its flags ([4 slot + row block]) and, last, the error word
     double *d_Lx_full = nullptr ; FrontD *d_fr_full = nullptr ;
     bool full_valid = false ;
     FrontD *d_smd = nullptr ; i64 *d_sp01 = nullptr ;   // thin launches: descriptor and range of S of every front, in block order (as d_sm)
@@ -815,10 +819,41 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
                     emit_rs (q, i0, -1) ;
                 }
+            // fused (CHOLMOD_HIP_CHAINF, default with the 256-column chain): diagonal and row workgroups of a sub-block in
+            // ONE launch, the diagonal sub-block spread over up to four workgroups that hand their row block of L on
+            // through flags (k_chainf) -- unless a front of the batch is shared between ranks (row chunks: two parts)
+            bool fused256 = !getenv ("CHOLMOD_HIP_NO_CHAINF") ;
+            for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) fused256 = false ;
+            if (fused256)
+            {
+                Launch Lc {K_CHAINF, 0, 0, S.cg.size (), 0, 0} ;
+                int dblocks = 0, bblocks = 0, wmax = 0 ;
+                for (int q = 0 ; q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= i0) continue ;
+                    int OBq = ob_of (f) ;
+                    int o0 = (i0 / OBq) * OBq ;
+                    int o1 = std::min (o0 + OBq, (int) f.nscol) ;
+                    int b1 = std::min (i0 + SB, o1) ;
+                    int w = b1 - i0 ;
+                    int slot = (int) (S.cg.size () - Lc.goff) ;
+                    int mb = f.nsrow - b1 ;
+                    S.cg.push_back (CfGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, mb, slot, S.ncflags++, dblocks, bblocks, 0}) ;
+                    dblocks += (w + 63) / 64 ;
+                    bblocks += (mb + 63) / 64 ;
+                    wmax = std::max (wmax, w) ;
+                    Lc.flops += (double) w * w * w / 3.0 + (double) mb * w * w ;
+                    Lc.bytes += 16.0 * mb * w ;
+                }
+                Lc.ng = (int) (S.cg.size () - Lc.goff) ; Lc.grid = dblocks + bblocks ; Lc.ndiag = dblocks ; Lc.aux = wmax ;
+                S.max_dinv_slots = std::max (S.max_dinv_slots, Lc.ng) ;
+                if (Lc.ng) S.launches.push_back (Lc) ;
+            }
             Launch Ld {K_DIAG, 0, 0, S.dg.size (), 0, 0} ;
             Launch Lr {K_ROWSOLVE, 0, 0, S.rg.size (), 0, 0} ;
             int rblocks = 0 ;
-            for (int q = 0 ; q < nf ; q++)
+            for (int q = 0 ; q < nf && !fused256 ; q++)
             {
                 const FrontD &f = fr [ids [q]] ;
                 if (f.nscol <= i0) continue ;
@@ -1650,7 +1685,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_dinv, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1723,6 +1758,8 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_dg = dupload (P->sch.dg, e) ; HIPCHK (e) ;
     P->d_rg = dupload (P->sch.rg, e) ; HIPCHK (e) ;
     P->d_wg = dupload (P->sch.wg, e) ; HIPCHK (e) ;
+    P->d_cg = dupload (P->sch.cg, e) ; HIPCHK (e) ;
+    HIPCHK (hipMalloc ((void **) &P->d_cflags, (4 * (size_t) P->sch.ncflags + 4) * sizeof (int))) ;
     HIPCHK (hipMalloc ((void **) &P->d_dinv, (size_t) std::max (P->sch.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
     P->d_sm = dupload (P->sch.sm, e) ; HIPCHK (e) ;
     {
@@ -1783,6 +1820,7 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_rowsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rowsolve_lds_bytes ())) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_chainf, hipFuncAttributeMaxDynamicSharedMemorySize, (int) chainf_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
@@ -1944,6 +1982,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 }
             }
             break ;
+        case K_CHAINF:
+            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
+            hipLaunchKernelGGL (k_chainf, dim3 (L.grid), dim3 (256), chainf_lds_bytes (), st,
+                P->d_cg + L.goff, L.ng, L.ndiag, P->d_Lx, P->d_info, P->d_dinv, P->d_cflags, P->d_cflags + 4 * (size_t) P->sch.ncflags) ;
+            break ;
         case K_WIN:
             hipLaunchKernelGGL (k_win_move, dim3 (L.grid), dim3 (256), 0, st, P->d_wg + L.goff, L.ng, P->d_Lx) ; break ;
         case K_ZERO:
@@ -2057,6 +2100,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (poison ? P->lx_fronts : P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
+    if (P->d_cflags) HIPCHK (hipMemsetAsync (P->d_cflags, 0, (4 * (size_t) P->sch.ncflags + 4) * sizeof (int), st)) ;
     if (P->n > 0 && P->amap_valid)
     {
         // the resident S was assembled before: stream it through its map
@@ -2125,6 +2169,10 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (ok && P->nsuper > 0)
             hipLaunchKernelGGL (k_first_fail, dim3 ((unsigned) ((P->nsuper + 255) / 256)), dim3 (256), 0, st,
                 P->nsuper, P->d_info, P->d_first_fail) ;
+        // (k_chainf: a workgroup that waited longer than its budget for another one's flag says so here)
+        int chain_err = 0 ;
+        if (P->sch.ncflags > 0)
+            ok = ok && hipMemcpyAsync (&chain_err, P->d_cflags + 4 * (size_t) P->sch.ncflags, sizeof (int), hipMemcpyDeviceToHost, st) == hipSuccess ;
         ok = ok && hipMemcpyAsync (&first, P->d_first_fail, sizeof (int), hipMemcpyDeviceToHost, st) == hipSuccess
             && hipStreamSynchronize (st) == hipSuccess
             && hipEventElapsedTime (&ms, P->ev0, P->ev1) == hipSuccess ;
@@ -2132,6 +2180,11 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         {
             ok = hipMemcpy (&inf, P->d_info + first, sizeof (i32), hipMemcpyDeviceToHost) == hipSuccess ;
             sbad = first ; binfo = inf ;
+        }
+        if (chain_err != 0)
+        {
+            fprintf (stderr, "cholmod_hip: k_chainf: a workgroup waited for a flag beyond its budget (hand-off between workgroups failed)\n") ;
+            ok = false ;
         }
         if (!ok)
         {
@@ -2191,7 +2244,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_UPD_W: S [32] += sec ; break ;
                 case K_UPD_BIG: S [14] += sec ; break ;
                 case K_EA: case K_ZERO: case K_WIN: S [9] += sec ; break ;
-                case K_POTRF: case K_DIAG: S [11] += sec ; break ;
+                case K_POTRF: case K_DIAG: case K_CHAINF: S [11] += sec ; break ;
                 case K_ROWSOLVE: S [12] += sec ; break ;
                 case K_SMALL: S [19] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
@@ -3084,6 +3137,10 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.d_gg = dupload (S.gg, e) ; HIPCHK (e) ;
     P.d_dg = dupload (S.dg, e) ; HIPCHK (e) ;
     P.d_rg = dupload (S.rg, e) ; HIPCHK (e) ;
+    P.d_cg = dupload (S.cg, e) ; HIPCHK (e) ;
+    P.sch.ncflags = S.ncflags ;
+    HIPCHK (hipMalloc ((void **) &P.d_cflags, (4 * (size_t) S.ncflags + 4) * sizeof (int))) ;
+    HIPCHK (hipMemset (P.d_cflags, 0, (4 * (size_t) S.ncflags + 4) * sizeof (int))) ;
     HIPCHK (hipMalloc ((void **) &P.d_dinv, (size_t) std::max (S.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
     HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
     if (ncb > 0)
@@ -3105,7 +3162,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
     P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ; P.d_tu_cnt = nullptr ;
-    P.d_dg = nullptr ; P.d_rg = nullptr ; P.d_dinv = nullptr ;
+    P.d_dg = nullptr ; P.d_rg = nullptr ; P.d_dinv = nullptr ; P.d_cg = nullptr ; P.d_cflags = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

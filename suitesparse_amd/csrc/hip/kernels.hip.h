@@ -2543,6 +2543,292 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
     panel (std::integral_constant<int, 3> {}) ;
 }
 
+// ---- the 256-column chain in ONE launch (round 4): k_chainf -----------------------------------
+// k_diag + k_rowsolve fused, with the diagonal sub-block's work spread over four workgroups instead
+// of one.  Every workgroup owns 64 rows of a front's sub-block column [col0, col0 + w), w <= 256,
+// for the whole launch:
+//   * row block rb < nd = ceil (w / 64) lies INSIDE the w x w diagonal sub-block ("diagonal
+//     workgroup"): it solves its rows against the panels j < rb exactly as a row workgroup does, then
+//     subtracts its own X X' from its 64 x 64 diagonal block, eliminates it (pf_eliminate), inverts
+//     the four 16 x 16 diagonal blocks and PUBLISHES row block rb of L (its solved blocks, L_rb,rb,
+//     the inverses) -- the critical path per 64 columns is solve + syrk + elimination of ONE
+//     workgroup (k_diag: one workgroup did all four row blocks' solves and products as well);
+//   * the row blocks below the sub-block ("row workgroups") are k_rowsolve: per panel j they stage
+//     row block j of L k-major in LDS and multiply out of registers -- but wait, per panel, for
+//     diagonal workgroup j's flag instead of a kernel boundary.
+// Hand-off without an L2 write-back: everything a diagonal workgroup publishes is written with
+// relaxed agent-scope atomic stores (global_store ... sc1: write-through past the XCD's L2) and read
+// with relaxed agent-scope atomic loads (sc1: served at the coherence point); the flag follows the
+// data after an s_waitcnt (workgroup-scope release + barrier) -- no buffer_wbl2 / buffer_inv, which
+// is what made the cross-workgroup hand-off of round 2 cost 30 us.  A workgroup only ever waits for
+// workgroups with a LOWER block index (all diagonal workgroups of a launch come first, in panel
+// order per front), so in-order dispatch cannot deadlock; a wait that exceeds its budget raises
+// *err (the host reports CHOLMOD_HIP_GPU_PROBLEM) instead of hanging the device.
+// flags [4 slot + j]: low byte = stages of row block j published (s <= j: its solved blocks of the panels
+// < s; j + 1: its diagonal block and the inverses as well), then bits 8.. = 1 + nvt, nvt = valid columns
+// of the sub-block so far (w when no pivot has failed).
+struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 mbelow ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 pad ; } ;
+__device__ __forceinline__ double ld_coh (const double *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
+__device__ __forceinline__ void st_coh (double *p, double v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
+#define CF_SPIN_LIMIT (1 << 20)
+__host__ __device__ inline size_t chainf_lds_bytes () { return (size_t) (DG_W * 64 + 4 * 256 + 16) * sizeof (double) ; }
+__global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int ndiag_total, double *Lx, i32 *info,
+    double *dinv, int *flags, int *err)
+{
+    extern __shared__ __attribute__((aligned(16))) double cf_lds [] ;
+    double *Lst = cf_lds ;                  // [k][c]: -L (c0 + c, k), k-major, 64 columns wide (row workgroup phase)
+    double *Wd = Lst + DG_W * 64 ;          // four 16 x 16 diagonal-block inverses of the current panel
+    int *s_int = (int *) (Wd + 4 * 256) ;   // [0] broadcast of a polled flag, [1] s_fail
+    double *T = Lst ;                       // (diagonal phase, after the panels: the 64 x 64 block, k-major)
+    double *Lsd = Lst + PF_NB * PF2_LD ;    // (diagonal phase: -L11 k-major for the inverses)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lk = lane >> 4 ;
+    const bool isdiag = (int) blockIdx.x < ndiag_total ;
+    int gi ;
+    if (isdiag) gi = find_group (g, ng, (int) blockIdx.x, &CfGroup::dstart) ;
+    else gi = find_group (g, ng, (int) blockIdx.x - ndiag_total, &CfGroup::bstart) ;
+    const CfGroup G = g [gi] ;
+    const i64 lda = G.lda ;
+    const int w = G.w ;
+    const int nd = (w + 63) >> 6 ;
+    const int rb = isdiag ? (int) blockIdx.x - G.dstart : nd ;
+    const int row0 = isdiag ? 64 * rb : w + 64 * ((int) blockIdx.x - ndiag_total - G.bstart) ;
+    const int rowend = isdiag ? w : w + G.mbelow ;
+    const int row = row0 + 16 * wave + lr ;
+    const bool rok = row < rowend ;
+    double *Lb = Lx + G.l_off ;                               // L (0, 0) of the sub-block
+    double *B = Lb + (rok ? row : rowend - 1) ;               // this lane's row, first column of the sub-block
+    double *DI = dinv + (i64) G.slot * 4096 ;
+    int *fl = flags + 4 * (i64) G.fslot ;
+    if (isdiag) __builtin_amdgcn_s_setprio (3) ; else __builtin_amdgcn_s_setprio (1) ;
+    int nvt = w ;                                             // valid columns of the sub-block
+    {
+        const int inf = info [G.front] ;                      // a pivot of an EARLIER launch failed
+        if (inf != 0) { nvt = inf - 1 - G.col0 ; if (nvt < 0) nvt = 0 ; if (nvt > w) nvt = w ; }
+    }
+    // Row block j of L is published in stages: flag j = s (1 <= s <= j) once its solved blocks of the panels < s are
+    // written, and (j + 1) | (1 + nvt) << 8 once its diagonal block and the inverses are.  Thread 0 polls until the stage
+    // exceeds `have`; the value travels through LDS.
+    auto wait_stage = [&] (int j, int have) -> int
+    {
+        if (tid == 0)
+        {
+            int v = 0, n = 0 ;
+            while (((v = __hip_atomic_load (fl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFF) <= have)
+            {
+                __builtin_amdgcn_s_sleep (4) ;
+                if (++n > CF_SPIN_LIMIT) { atomicExch (err, 1) ; v = (j + 1) | (1 << 8) ; break ; }     // (budget exceeded: go on with "nothing valid", tell the host)
+            }
+            s_int [0] = v ;
+        }
+        __syncthreads () ;
+        return s_int [0] ;
+    } ;
+    d4 X [16] ;
+#pragma unroll
+    for (int q = 0 ; q < 16 ; q++) X [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    // one 64-column panel left of this workgroup's rows (k_rowsolve's panel; j is a compile-time constant so that X [] stays in registers)
+    auto panel = [&] (auto jc)
+    {
+        constexpr int j = decltype (jc)::value ;
+        constexpr int c0 = 64 * j ;
+        if (j < rb && c0 < w)
+        {
+            const int pw = (w - c0 < 64) ? w - c0 : 64 ;
+            d4 bj [4] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int c = 16 * jb + lk + 4 * r ; if (c > pw - 1) c = pw - 1 ;
+                    bj [jb][r] = B [(i64) (c0 + c) * lda] ;
+                }
+            // stage the rows c0 .. c0 + 63 of L, columns 0 .. c0 + 63, following diagonal workgroup j's stages: the
+            // columns of the earlier panels while it is still busy with the later ones, so that only its diagonal
+            // block (16 loads) and the inverses are left to fetch when its last flag arrives (coherent loads)
+            int have = 0, nvj = 0 ;
+            const int c = lane ;
+            const int rowL = (c0 + c < w) ? c0 + c : w - 1 ;
+            while (have < j + 1)
+            {
+                const int fv = wait_stage (j, have) ;      // (ends with a barrier: the previous panel's readers are done with Lst / Wd)
+                const int upto = fv & 0xFF ;
+                const bool fin = upto >= j + 1 ;
+                if (fin)
+                {
+                    const int pv = (fv >> 8) - 1 ;
+                    if (pv < nvt) nvt = pv ;
+                    nvj = nvt - c0 ; if (nvj < 0) nvj = 0 ; if (nvj > pw) nvj = pw ;
+                }
+                for (int p = have ; p < upto && p < j + 1 ; p++)
+                {
+                    const int kb = 64 * p ;
+                    double tmp [16] ;
+#pragma unroll
+                    for (int q = 0 ; q < 16 ; q++)
+                    {
+                        int k = kb + wave + 4 * q ; if (k > w - 1) k = w - 1 ;
+                        tmp [q] = ld_coh (Lb + rowL + (i64) k * lda) ;
+                    }
+#pragma unroll
+                    for (int q = 0 ; q < 16 ; q++)
+                    {
+                        const int k = kb + wave + 4 * q ;
+                        double v = (k == c0 + c) ? 1.0 : 0.0 ;
+                        // (columns of the earlier panels: whether row c0 + c is valid is only known with the last stage -- fixed up below)
+                        if ((p < j || c < nvj) && k < c0 + c) v = -tmp [q] ;
+                        if (p == j && c < nvj && k == c0 + c) v = tmp [q] ;
+                        Lst [k * 64 + c] = v ;
+                    }
+                }
+                have = upto < j + 1 ? upto : j + 1 ;
+            }
+            if (nvj < pw)
+            {
+                // a pivot of this panel (or an earlier one) failed: the rows past it are identity rows
+                for (int k = wave ; k < c0 ; k += 4) if (c >= nvj) Lst [k * 64 + c] = 0.0 ;
+            }
+            for (int e = tid ; e < 1024 ; e += 256) Wd [e] = ld_coh (DI + j * 1024 + e) ;
+            __syncthreads () ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+            {
+                d4 acc = bj [jb], a1 = (d4) {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1 ;
+#pragma unroll
+                for (int kb = 0 ; kb < 16 ; kb++)
+                {
+                    if (kb < 4 * j + jb)
+                    {
+                        double b [4] ;
+#pragma unroll
+                        for (int s4 = 0 ; s4 < 4 ; s4++) b [s4] = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [0], X [kb][0], acc, 0, 0, 0) ;
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [1], X [kb][1], a1, 0, 0, 0) ;
+                        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [2], X [kb][2], a2, 0, 0, 0) ;
+                        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [3], X [kb][3], a3, 0, 0, 0) ;
+                    }
+                }
+                acc = (acc + a1) + (a2 + a3) ;
+                d4 x = (d4) {0.0, 0.0, 0.0, 0.0} ;
+#pragma unroll
+                for (int s4 = 0 ; s4 < 4 ; s4++)
+                {
+                    double b = Wd [jb * 256 + (4 * s4 + lk) * 16 + lr] ;
+                    x = __builtin_amdgcn_mfma_f64_16x16x4f64 (b, acc [s4], x, 0, 0, 0) ;
+                }
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    const int c = 16 * jb + lk + 4 * r ;
+                    const double v = (c < nvj) ? x [r] : 0.0 ;
+                    x [r] = v ;
+                    if (rok && c < pw)
+                    {
+                        // (a diagonal workgroup's solved blocks are row block rb of L for everybody after it)
+                        if (isdiag) st_coh (B + (i64) (c0 + c) * lda, v) ; else B [(i64) (c0 + c) * lda] = v ;
+                    }
+                }
+                X [4 * j + jb] = x ;
+            }
+            if (isdiag)
+            {
+                // this row block's solved blocks through panel j are written: stage j + 1 (the workgroups after it prefetch them)
+                __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup") ;
+                __syncthreads () ;
+                if (tid == 0) __hip_atomic_store (fl + rb, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+            }
+        }
+    } ;
+    panel (std::integral_constant<int, 0> {}) ;
+    panel (std::integral_constant<int, 1> {}) ;
+    panel (std::integral_constant<int, 2> {}) ;
+    panel (std::integral_constant<int, 3> {}) ;
+    if (!isdiag) return ;
+    // ---- diagonal workgroup rb: its own 64 x 64 diagonal block
+    const int c0 = 64 * rb ;
+    const int pw = (w - c0 < 64) ? w - c0 : 64 ;
+    // its solved blocks X (rows of this workgroup, columns < c0) into LDS, k-major, for the X X' product of the diagonal block:
+    // the A operands are the registers themselves (accumulator layout = A-operand layout), the B operands come from here
+    __syncthreads () ;                      // (the last panel's readers are done with Lst)
+    double *Xs = Lst ;
+#pragma unroll
+    for (int kb = 0 ; kb < 12 ; kb++)
+        if (kb < 4 * rb)
+#pragma unroll
+            for (int s4 = 0 ; s4 < 4 ; s4++) Xs [(16 * kb + lk + 4 * s4) * 64 + 16 * wave + lr] = X [kb][s4] ;
+    __syncthreads () ;
+    auto tick = [] (int) {} ;
+    int nv_out = nvt ;
+    if (nvt <= c0)
+    {
+        // an earlier pivot failed: this panel's columns are zero (:889-895, :926-931), identity "inverses"
+        for (int k = wave ; k < pw ; k += 4)
+            for (int i = c0 + k + lane ; i < c0 + pw ; i += 64) st_coh (Lb + i + (i64) (c0 + k) * lda, 0.0) ;
+        for (int e = tid ; e < 1024 ; e += 256) st_coh (DI + rb * 1024 + e, ((e & 255) >> 4) == (e & 15) ? 1.0 : 0.0) ;
+    }
+    else
+    {
+        {
+            const int rowg = c0 + 16 * wave + lr ;
+            const int rowc = rowg < w ? rowg : w - 1 ;
+            d4 acc [4] ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    int col = c0 + 16 * jb + lk + 4 * r ; if (col > w - 1) col = w - 1 ;
+                    acc [jb][r] = Lb [rowc + (i64) col * lda] ;
+                }
+            // acc [jb] -= X (rows of this wave, :) X (rows 16 jb .. 16 jb + 15, :)'
+#pragma unroll
+            for (int kb = 0 ; kb < 12 ; kb++)
+                if (kb < 4 * rb)
+#pragma unroll
+                    for (int s4 = 0 ; s4 < 4 ; s4++)
+#pragma unroll
+                        for (int jb = 0 ; jb < 4 ; jb++)
+                        {
+                            const double bfv = Xs [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                            acc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bfv, X [kb][s4], acc [jb], 0, 0, 0) ;
+                        }
+            __syncthreads () ;              // (T below overlays Xs)
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+                for (int r = 0 ; r < 4 ; r++)
+                {
+                    const int i = 16 * wave + lr, j = 16 * jb + lk + 4 * r ;
+                    T [j * PF2_LD + i] = (i < pw && j < pw) ? (i >= j ? acc [jb][r] : 0.0) : (i == j ? 1.0 : 0.0) ;
+                }
+        }
+        if (tid == 0) s_int [1] = -1 ;
+        __syncthreads () ;
+        pf_eliminate (T, (pw + 15) >> 4, &s_int [1], tid, tick) ;
+        const int fail = s_int [1] ;
+        const int nvalid = fail >= 0 ? fail : pw ;
+        if (fail >= 0) { nv_out = c0 + fail ; if (tid == 0) info [G.front] = G.col0 + c0 + fail + 1 ; }
+#pragma unroll
+        for (int q = 0 ; q < 16 ; q++)
+        {
+            const int k = wave + 4 * q, i = lane ;
+            if (k < pw && i >= k && i < pw) st_coh (Lb + (c0 + i) + (i64) (c0 + k) * lda, (k < nvalid) ? T [k * PF2_LD + i] : 0.0) ;
+            double v = (i == k) ? 1.0 : 0.0 ;
+            if (i < nvalid && k < i) v = -T [k * PF2_LD + i] ;
+            if (i < nvalid && k == i) v = T [k * PF2_LD + k] ;
+            Lsd [k * 64 + i] = v ;
+        }
+        __syncthreads () ;
+        trsm_diag_inverses (Lsd, 64, Wd, 4, lane, wave, tick) ;
+        __syncthreads () ;
+        for (int e = tid ; e < 1024 ; e += 256) st_coh (DI + rb * 1024 + e, Wd [e]) ;
+    }
+    // publish: every store above has been acknowledged (s_waitcnt through the workgroup-scope release) before the flag
+    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup") ;
+    __syncthreads () ;
+    if (tid == 0) __hip_atomic_store (fl + rb, (rb + 1) | ((1 + nv_out) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+}
+
 // ---- first failing supernode (not-positive-definite protocol) ---------------------
 // out [0] = smallest supernode with info != 0 (nsuper if none), so that the host reads
 // 4 bytes per factorization instead of the whole info array (G3_circuit stand-in:

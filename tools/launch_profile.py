@@ -7,7 +7,7 @@ import numpy as np
 from bench import build_workload
 from suitesparse_amd import cholmod as ch
 
-KIND = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "allreduce", 8: "thin", 9: "update+potrf", 10: "trsm+upd+potrf", 11: "allgather", 12: "update_w", 13: "diag256", 14: "rowsolve"}
+KIND = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "allreduce", 8: "thin", 9: "update+potrf", 10: "trsm+upd+potrf", 11: "allgather", 12: "update_w", 13: "diag256", 14: "rowsolve", 15: "window", 16: "chain256f"}
 w, m = sys.argv[1], int(sys.argv[2])
 only = [int(v) for v in sys.argv[3:]]
 n, Ap, Ai, Ax, stype, perm, name = build_workload(w, m)
