@@ -575,7 +575,19 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // the chip busy.  early [q] = block column of front q already summed this way.
     const bool xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
     std::vector<int> early (nf, -1) ;
-    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !((flags & CHOLMOD_HIP_CHAIN256) && !cx) ;     // (the 256-column chain has no separate dpotrf launches to fuse)
+    // (not with distributed fronts: their block columns live in windows, see the 64-column chain below)
+    bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 && !cx ;
+    // CHOLMOD_HIP_CHAINF_AUTO=1 (tuning): the fused 256-column chain (k_chainf) for the batches it is measured to win on --
+    // fronts of at least 192 columns and at most 16 384 rows (one round of row workgroups), none shared between ranks
+    if (!chain256 && !cx && !twin && getenv ("CHOLMOD_HIP_CHAINF_AUTO") && atoi (getenv ("CHOLMOD_HIP_CHAINF_AUTO")) != 0 && !(flags & CHOLMOD_HIP_NO_FUSED_POTRF))
+    {
+        bool any_shared = false ;
+        for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) any_shared = true ;
+        const char *e1 = getenv ("CHOLMOD_HIP_CHAINF_MIN_COLS"), *e2 = getenv ("CHOLMOD_HIP_CHAINF_MAX_ROWS") ;
+        chain256 = !any_shared && maxnscol >= (e1 ? atoi (e1) : 192) && maxrows <= (e2 ? atoi (e2) : 16384) ;
+    }
+    for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) chain256 = false ;
+    const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !chain256 ;     // (the 256-column chain has no separate dpotrf launches to fuse)
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
     // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks
@@ -804,9 +816,6 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // column, as before over 64-column steps -- with e sub-blocks done and p the largest power of
     // two dividing e, the last p sub-blocks (K = 256 p) update the next p; the K = OB update
     // closes the outer block column.  Opt-in (CHOLMOD_HIP_CHAIN256): measured no faster than the 64-column chain below, see DESIGN.md section 4.
-    // (not with distributed fronts: their block columns live in windows, see the 64-column chain below)
-    bool chain256 = (flags & CHOLMOD_HIP_CHAIN256) != 0 && !cx ;
-    for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) chain256 = false ;
     if (chain256)
     {
         const int SB = DG_W ;

@@ -2626,6 +2626,26 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     d4 X [16] ;
 #pragma unroll
     for (int q = 0 ; q < 16 ; q++) X [q] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    // a diagonal workgroup: its 64 x 64 diagonal block in registers from the start (accumulator layout), updated panel by
+    // panel; Xp = the LDS rows k >= 192 of Lst, which a diagonal workgroup (panels j <= 2: k < 192) never stages into
+    double *Xp = Lst + 192 * 64 ;
+    d4 dacc [4] ;
+#pragma unroll
+    for (int jb = 0 ; jb < 4 ; jb++) dacc [jb] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+    if (isdiag)
+    {
+        const int dc0 = 64 * rb ;
+        const int rowg = dc0 + 16 * wave + lr ;
+        const int rowc = rowg < w ? rowg : w - 1 ;
+#pragma unroll
+        for (int jb = 0 ; jb < 4 ; jb++)
+#pragma unroll
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                int col = dc0 + 16 * jb + lk + 4 * r ; if (col > w - 1) col = w - 1 ;
+                dacc [jb][r] = Lb [rowc + (i64) col * lda] ;
+            }
+    }
     // one 64-column panel left of this workgroup's rows (k_rowsolve's panel; j is a compile-time constant so that X [] stays in registers)
     auto panel = [&] (auto jc)
     {
@@ -2649,56 +2669,81 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
             int have = 0, nvj = 0 ;
             const int c = lane ;
             const int rowL = (c0 + c < w) ? c0 + c : w - 1 ;
-            while (have < j + 1)
+            // one batch = 64 columns of row block j of L (coherent loads) into Lst
+            auto stage_batch = [&] (int p)
+            {
+                const int kb = 64 * p ;
+                double tmp [16] ;
+#pragma unroll
+                for (int q = 0 ; q < 16 ; q++)
+                {
+                    int k = kb + wave + 4 * q ; if (k > w - 1) k = w - 1 ;
+                    tmp [q] = ld_coh (Lb + rowL + (i64) k * lda) ;
+                }
+#pragma unroll
+                for (int q = 0 ; q < 16 ; q++)
+                {
+                    const int k = kb + wave + 4 * q ;
+                    double v = (k == c0 + c) ? 1.0 : 0.0 ;
+                    // (columns of the earlier panels: row c0 + c counts as valid -- what it feeds are output columns that
+                    // are masked if it is not, see the note at the products)
+                    if ((p < j || c < nvj) && k < c0 + c) v = -tmp [q] ;
+                    if (p == j && c < nvj && k == c0 + c) v = tmp [q] ;
+                    Lst [k * 64 + c] = v ;
+                }
+            } ;
+            // (1) the columns of the EARLIER panels, as diagonal workgroup j publishes them (it is still busy with the later ones)
+            while (have < j)
             {
                 const int fv = wait_stage (j, have) ;      // (ends with a barrier: the previous panel's readers are done with Lst / Wd)
-                const int upto = fv & 0xFF ;
-                const bool fin = upto >= j + 1 ;
-                if (fin)
-                {
-                    const int pv = (fv >> 8) - 1 ;
-                    if (pv < nvt) nvt = pv ;
-                    nvj = nvt - c0 ; if (nvj < 0) nvj = 0 ; if (nvj > pw) nvj = pw ;
-                }
-                for (int p = have ; p < upto && p < j + 1 ; p++)
-                {
-                    const int kb = 64 * p ;
-                    double tmp [16] ;
-#pragma unroll
-                    for (int q = 0 ; q < 16 ; q++)
-                    {
-                        int k = kb + wave + 4 * q ; if (k > w - 1) k = w - 1 ;
-                        tmp [q] = ld_coh (Lb + rowL + (i64) k * lda) ;
-                    }
-#pragma unroll
-                    for (int q = 0 ; q < 16 ; q++)
-                    {
-                        const int k = kb + wave + 4 * q ;
-                        double v = (k == c0 + c) ? 1.0 : 0.0 ;
-                        // (columns of the earlier panels: whether row c0 + c is valid is only known with the last stage -- fixed up below)
-                        if ((p < j || c < nvj) && k < c0 + c) v = -tmp [q] ;
-                        if (p == j && c < nvj && k == c0 + c) v = tmp [q] ;
-                        Lst [k * 64 + c] = v ;
-                    }
-                }
-                have = upto < j + 1 ? upto : j + 1 ;
+                int upto = fv & 0xFF ; if (upto > j) upto = j ;
+                for (int p = have ; p < upto ; p++) stage_batch (p) ;
+                have = upto ;
             }
-            if (nvj < pw)
-            {
-                // a pivot of this panel (or an earlier one) failed: the rows past it are identity rows
-                for (int k = wave ; k < c0 ; k += 4) if (c >= nvj) Lst [k * 64 + c] = 0.0 ;
-            }
-            for (int e = tid ; e < 1024 ; e += 256) Wd [e] = ld_coh (DI + j * 1024 + e) ;
-            __syncthreads () ;
+            // (2) ... and the products with them, BEFORE the last flag: pre [jb] = B_jb - sum_{kb < 4 j} X_kb L (16 jb .., 16 kb ..)'
+            // (a row of L past a failed pivot enters only output columns at / past that pivot, which are written as zero)
+            d4 pre [4] ;
+            if (j > 0) __syncthreads () ;
 #pragma unroll
             for (int jb = 0 ; jb < 4 ; jb++)
             {
                 d4 acc = bj [jb], a1 = (d4) {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1 ;
 #pragma unroll
-                for (int kb = 0 ; kb < 16 ; kb++)
+                for (int kb = 0 ; kb < 12 ; kb++)
                 {
-                    if (kb < 4 * j + jb)
+                    if (kb < 4 * j)
                     {
+                        double b [4] ;
+#pragma unroll
+                        for (int s4 = 0 ; s4 < 4 ; s4++) b [s4] = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [0], X [kb][0], acc, 0, 0, 0) ;
+                        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [1], X [kb][1], a1, 0, 0, 0) ;
+                        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [2], X [kb][2], a2, 0, 0, 0) ;
+                        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64 (b [3], X [kb][3], a3, 0, 0, 0) ;
+                    }
+                }
+                pre [jb] = (acc + a1) + (a2 + a3) ;
+            }
+            // (3) the last stage: its diagonal block (16 loads) and the inverses
+            {
+                const int fv = wait_stage (j, j) ;
+                const int pv = (fv >> 8) - 1 ;
+                if (pv < nvt) nvt = pv ;
+                nvj = nvt - c0 ; if (nvj < 0) nvj = 0 ; if (nvj > pw) nvj = pw ;
+                stage_batch (j) ;
+                for (int e = tid ; e < 1024 ; e += 256) Wd [e] = ld_coh (DI + j * 1024 + e) ;
+            }
+            __syncthreads () ;
+#pragma unroll
+            for (int jb = 0 ; jb < 4 ; jb++)
+            {
+                d4 acc = pre [jb], a1 = (d4) {0.0, 0.0, 0.0, 0.0}, a2 = a1, a3 = a1 ;
+#pragma unroll
+                for (int kb2 = 0 ; kb2 < 3 ; kb2++)
+                {
+                    if (kb2 < jb)
+                    {
+                        const int kb = 4 * j + kb2 ;
                         double b [4] ;
 #pragma unroll
                         for (int s4 = 0 ; s4 < 4 ; s4++) b [s4] = Lst [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
@@ -2732,7 +2777,25 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
             }
             if (isdiag)
             {
-                // this row block's solved blocks through panel j are written: stage j + 1 (the workgroups after it prefetch them)
+                // this row block's solved blocks through panel j are written (stage j + 1: the workgroups after it prefetch them)
+                // ... and its own diagonal block takes their product right away, dacc -= X_j X_j' (K = 64: B operands
+                // through LDS, A operands = the registers), so that only the LAST panel's is left when the last flag comes
+#pragma unroll
+                for (int kb2 = 0 ; kb2 < 4 ; kb2++)
+#pragma unroll
+                    for (int s4 = 0 ; s4 < 4 ; s4++) Xp [(16 * kb2 + lk + 4 * s4) * 64 + 16 * wave + lr] = X [4 * j + kb2][s4] ;
+                __syncthreads () ;
+#pragma unroll
+                for (int kb2 = 0 ; kb2 < 4 ; kb2++)
+#pragma unroll
+                    for (int s4 = 0 ; s4 < 4 ; s4++)
+#pragma unroll
+                        for (int jb = 0 ; jb < 4 ; jb++)
+                        {
+                            const double bfv = Xp [(16 * kb2 + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
+                            dacc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bfv, X [4 * j + kb2][s4], dacc [jb], 0, 0, 0) ;
+                        }
+                // (the stage flag after the product: by now the stores are acknowledged, nobody waits for them)
                 __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup") ;
                 __syncthreads () ;
                 if (tid == 0) __hip_atomic_store (fl + rb, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
@@ -2747,16 +2810,7 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     // ---- diagonal workgroup rb: its own 64 x 64 diagonal block
     const int c0 = 64 * rb ;
     const int pw = (w - c0 < 64) ? w - c0 : 64 ;
-    // its solved blocks X (rows of this workgroup, columns < c0) into LDS, k-major, for the X X' product of the diagonal block:
-    // the A operands are the registers themselves (accumulator layout = A-operand layout), the B operands come from here
-    __syncthreads () ;                      // (the last panel's readers are done with Lst)
-    double *Xs = Lst ;
-#pragma unroll
-    for (int kb = 0 ; kb < 12 ; kb++)
-        if (kb < 4 * rb)
-#pragma unroll
-            for (int s4 = 0 ; s4 < 4 ; s4++) Xs [(16 * kb + lk + 4 * s4) * 64 + 16 * wave + lr] = X [kb][s4] ;
-    __syncthreads () ;
+    __syncthreads () ;                      // (the last panel's readers are done with Lst / Xp: T and Lsd overlay Lst)
     auto tick = [] (int) {} ;
     int nv_out = nvt ;
     if (nvt <= c0)
@@ -2768,40 +2822,14 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     }
     else
     {
-        {
-            const int rowg = c0 + 16 * wave + lr ;
-            const int rowc = rowg < w ? rowg : w - 1 ;
-            d4 acc [4] ;
 #pragma unroll
-            for (int jb = 0 ; jb < 4 ; jb++)
+        for (int jb = 0 ; jb < 4 ; jb++)
 #pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                {
-                    int col = c0 + 16 * jb + lk + 4 * r ; if (col > w - 1) col = w - 1 ;
-                    acc [jb][r] = Lb [rowc + (i64) col * lda] ;
-                }
-            // acc [jb] -= X (rows of this wave, :) X (rows 16 jb .. 16 jb + 15, :)'
-#pragma unroll
-            for (int kb = 0 ; kb < 12 ; kb++)
-                if (kb < 4 * rb)
-#pragma unroll
-                    for (int s4 = 0 ; s4 < 4 ; s4++)
-#pragma unroll
-                        for (int jb = 0 ; jb < 4 ; jb++)
-                        {
-                            const double bfv = Xs [(16 * kb + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
-                            acc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bfv, X [kb][s4], acc [jb], 0, 0, 0) ;
-                        }
-            __syncthreads () ;              // (T below overlays Xs)
-#pragma unroll
-            for (int jb = 0 ; jb < 4 ; jb++)
-#pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                {
-                    const int i = 16 * wave + lr, j = 16 * jb + lk + 4 * r ;
-                    T [j * PF2_LD + i] = (i < pw && j < pw) ? (i >= j ? acc [jb][r] : 0.0) : (i == j ? 1.0 : 0.0) ;
-                }
-        }
+            for (int r = 0 ; r < 4 ; r++)
+            {
+                const int i = 16 * wave + lr, j = 16 * jb + lk + 4 * r ;
+                T [j * PF2_LD + i] = (i < pw && j < pw) ? (i >= j ? dacc [jb][r] : 0.0) : (i == j ? 1.0 : 0.0) ;
+            }
         if (tid == 0) s_int [1] = -1 ;
         __syncthreads () ;
         pf_eliminate (T, (pw + 15) >> 4, &s_int [1], tid, tick) ;
