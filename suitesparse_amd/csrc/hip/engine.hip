@@ -1377,6 +1377,25 @@ static int build_host (cholmod_hip_plan *P)
     std::vector<std::vector<i32>> batches, best_batches ;
     std::vector<i64> best_cb (std::max<i64> (nsuper, 1), 0) ;
     i64 best_arena = 0 ; int best_nsplit = 1 ;
+    if (P->arena_budget < 0)
+    {
+        // Several ranks must derive the same batch order, so the budget is nominal, not the momentary free memory: what a
+        // 288 GB part has left next to the LARGEST part of L any rank of this partition holds (its subtrees, its slabs of
+        // the shared fronts; every rank computes all of them), the index maps and a margin for windows and staging.
+        // (Rounds 1-3 budgeted the whole factor on every rank: Poisson 200^3 then swept subtrees one after the other -- more,
+        // smaller launches -- although a rank of 8 holds 27 of the 181.6 GB.)
+        std::vector<double> lxr (P->world, 0.0) ;
+        for (i64 s = 0 ; s < nsuper ; s++)
+        {
+            const double cols = P->fr [s].nscol, rows = P->fr [s].nsrow ;
+            if (P->owner [s] >= 0) lxr [P->owner [s]] += cols * rows ;
+            else for (int q = P->grp0 [s] ; q < P->grp0 [s] + P->grpn [s] ; q++)
+                lxr [q] += (distribute ? std::ceil (cols / (double) (ownw * P->grpn [s])) * ownw : cols) * rows ;
+        }
+        double worst = 0 ;
+        for (double v : lxr) worst = std::max (worst, v) ;
+        P->arena_budget = (i64) std::max (1e9, 270e9 - (8.0 * worst + 8.0 * P->ssize + 4.0 * (P->ssize - n) + 12e9)) ;
+    }
     i64 budget = P->arena_budget ;
     for (int nsplit = 1 ; ; nsplit *= 2)
     {
@@ -2400,7 +2419,7 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
         const char *e = getenv ("CHOLMOD_HIP_ARENA_BUDGET_MB") ;
         double fixed = 8.0 * P->xsize + 8.0 * P->ssize + 4.0 * (P->ssize - n) + 3e9 ;
         if (e && atof (e) > 0) P->arena_budget = (i64) (atof (e) * 1048576.0) ;
-        else if (world > 1) P->arena_budget = (i64) std::max (1e9, 270e9 - fixed) ;
+        else if (world > 1) P->arena_budget = -1 ;         // (build_host: from the largest part of L any rank holds)
         else if (!host_only)
         {
             size_t freeb = 0, totalb = 0 ;
