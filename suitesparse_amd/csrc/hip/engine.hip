@@ -1965,8 +1965,9 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 auto move = [&] (int mode, i64 total)
                 {
                     if (total <= 0) return ;
-                    unsigned grid = (unsigned) std::min<i64> ((total + 255) / 256, 8192) ;
-                    hipLaunchKernelGGL (k_xchg_move, dim3 (grid), dim3 (256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
+                    // (one workgroup per column and part: k_xchg_move)
+                    const unsigned parts = mode == 0 ? (unsigned) X.g + 1 : mode == 3 ? (unsigned) X.g : mode == 1 ? 2u : 1u ;
+                    hipLaunchKernelGGL (k_xchg_move, dim3 ((unsigned) X.w * parts), dim3 (256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
                 } ;
                 if (rs)
                 {

@@ -2189,46 +2189,64 @@ struct XchgD {
 // mode 0: Lx -> stage (all g segments: this rank's partial sums, D repeated per segment)
 // mode 1: segment r of stage -> Lx (summed D and own chunk)
 // mode 2: own chunk of Lx -> ag + r R w        mode 3: ag (all chunks but r) -> Lx
+// (round 4: one workgroup = one column of the block column x one part -- the diagonal block or one row chunk; rows
+// stream contiguously, no division per element: the element-indexed first version moved ~1 TB/s, and a rank of 8 moves
+// 67 GB through these copies per factorization of Poisson 200^3)
+// grid: w * (g + 1) workgroups for modes 0 / 3 (part g = the diagonal block; mode 3 has none), w * 2 for mode 1 (D, own
+// chunk), w for mode 2.
 __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *Lx, double *stage, double *ag)
 {
     const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w ;
-    const i64 total = (mode == 0) ? seg * X.g : (mode == 1) ? seg : (mode == 2) ? (i64) X.R * X.w : (i64) X.R * X.w * X.g ;
-    double *S = Lx + X.slab ;
-    for (i64 e = blockIdx.x * (i64) 256 + threadIdx.x ; e < total ; e += (i64) gridDim.x * 256)
+    const int j = (int) blockIdx.x % X.w, part = (int) blockIdx.x / X.w ;
+    double *S = Lx + X.slab + (i64) j * X.lda ;                   // column j of the block column, from the diagonal block's first row
+    const int tid = threadIdx.x ;
+    if (mode == 0)
     {
-        if (mode <= 1)
+        if (part == X.g)
         {
-            int q = mode == 0 ? (int) (e / seg) : X.r ;
-            i64 t = mode == 0 ? e - (i64) q * seg : e ;
-            double *p = stage + (i64) q * seg + t ;
-            if (t < (i64) X.w * X.w)
+            // the diagonal block's column j (lower part, zero above) into every segment
+            for (int i = tid ; i < X.w ; i += 256)
             {
-                int i = (int) (t % X.w), j = (int) (t / X.w) ;
-                double *d = S + i + (i64) j * X.lda ;
-                if (mode == 0) *p = (i >= j) ? *d : 0.0 ;
-                else if (i >= j) *d = *p ;
-            }
-            else
-            {
-                t -= (i64) X.w * X.w ;
-                int i = (int) (t % X.R), j = (int) (t / X.R) ;
-                i64 row = (i64) q * X.R + i ;
-                double *d = S + X.w + row + (i64) j * X.lda ;
-                if (mode == 0) *p = (row < X.mb) ? *d : 0.0 ;
-                else if (row < X.mb) *d = *p ;
+                const double v = (i >= j) ? S [i] : 0.0 ;
+                for (int q = 0 ; q < X.g ; q++) stage [(i64) q * seg + (i64) j * X.w + i] = v ;
             }
         }
         else
         {
-            int q = mode == 2 ? X.r : (int) (e / ((i64) X.R * X.w)) ;
-            i64 t = mode == 2 ? e : e - (i64) q * X.R * X.w ;
-            int i = (int) (t % X.R), j = (int) (t / X.R) ;
-            i64 row = (i64) q * X.R + i ;
-            double *d = S + X.w + row + (i64) j * X.lda ;
-            double *p = ag + (i64) q * X.R * X.w + t ;
-            if (mode == 2) *p = (row < X.mb) ? *d : 0.0 ;
-            else if (q != X.r && row < X.mb) *d = *p ;
+            const int q = part ;
+            const double *src = S + X.w + (i64) q * X.R ;
+            double *dst = stage + (i64) q * seg + (i64) X.w * X.w + (i64) j * X.R ;
+            const int nr = X.mb - q * X.R ;                      // rows of this chunk that exist
+            for (int i = tid ; i < X.R ; i += 256) dst [i] = (i < nr) ? src [i] : 0.0 ;
         }
+    }
+    else if (mode == 1)
+    {
+        const double *ps = stage + (i64) X.r * seg ;
+        if (part == 0) { for (int i = j + tid ; i < X.w ; i += 256) S [i] = ps [(i64) j * X.w + i] ; }
+        else
+        {
+            const double *src = ps + (i64) X.w * X.w + (i64) j * X.R ;
+            double *dst = S + X.w + (i64) X.r * X.R ;
+            const int nr = X.mb - X.r * X.R ;
+            for (int i = tid ; i < X.R && i < nr ; i += 256) dst [i] = src [i] ;
+        }
+    }
+    else if (mode == 2)
+    {
+        const double *src = S + X.w + (i64) X.r * X.R ;
+        double *dst = ag + (i64) X.r * X.R * X.w + (i64) j * X.R ;
+        const int nr = X.mb - X.r * X.R ;
+        for (int i = tid ; i < X.R ; i += 256) dst [i] = (i < nr) ? src [i] : 0.0 ;
+    }
+    else
+    {
+        const int q = part ;
+        if (q == X.r || q >= X.g) return ;
+        const double *src = ag + (i64) q * X.R * X.w + (i64) j * X.R ;
+        double *dst = S + X.w + (i64) q * X.R ;
+        const int nr = X.mb - q * X.R ;
+        for (int i = tid ; i < X.R && i < nr ; i += 256) dst [i] = src [i] ;
     }
 }
 

@@ -64,6 +64,16 @@ def main():
         S.refactorize_resident(Lf)
         ps = S.hip_stats(Lf)
         S.set_profiling(Lf, False)
+        if os.environ.get("WHATIF_TOP"):
+            # the longest launches of the kinds named (e.g. WHATIF_TOP=1,15: extend-add and window moves)
+            lp = S.launch_profile(Lf)
+            kinds = [int(k) for k in os.environ["WHATIF_TOP"].split(",")]
+            idx = [i for i in np.argsort(-lp["ms"]) if lp["kind"][i] in kinds][:25]
+            for i in idx:
+                print("   launch %5d kind %2d grid %7d ms %8.3f MB %9.1f" % (i, lp["kind"][i], lp["grid"][i], lp["ms"][i], lp["bytes"][i] / 1e6), file=sys.stderr)
+            for k in kinds:
+                q = lp["kind"] == k
+                print("   kind %d: %d launches %.3f s" % (k, int(q.sum()), 1e-3 * float(lp["ms"][q].sum())), file=sys.stderr)
         fv = ch.FactorView(Lf)
         owner = np.empty(fv.nsuper, dtype=np.int64)
         S.L.cholmod_hip_get_partition(fv.hip_plan, owner.ctypes.data)
