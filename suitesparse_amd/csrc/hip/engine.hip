@@ -586,7 +586,19 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         const char *e1 = getenv ("CHOLMOD_HIP_CHAINF_MIN_COLS"), *e2 = getenv ("CHOLMOD_HIP_CHAINF_MAX_ROWS") ;
         chain256 = !any_shared && maxnscol >= (e1 ? atoi (e1) : 192) && maxrows <= (e2 ? atoi (e2) : 16384) ;
     }
-    for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) chain256 = false ;
+    // A batch that holds a front shared between ranks takes the fused 256-column chain by default: the chain of a shared
+    // front is the part of a rank's work that does not shrink with the number of ranks, and its 64-column form has no fused
+    // kernels there (the diagonal blocks are replicated, the rows dealt by chunks: dpotrf, dtrsm and the narrow updates are
+    // separate launches, ~45 us per 64 columns against ~28 in k_chainf).  CHOLMOD_HIP_SHARED_CHAIN64=1: the 64-column chain.
+    {
+        bool any_win = false ;
+        for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) any_win = true ;
+        if (any_win)
+        {
+            const bool c64 = getenv ("CHOLMOD_HIP_SHARED_CHAIN64") || getenv ("CHOLMOD_HIP_NO_CHAINF") || twin || cx || (flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
+            chain256 = !c64 ;
+        }
+    }
     const bool fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !chain256 ;     // (the 256-column chain has no separate dpotrf launches to fuse)
     const bool fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
     std::vector<int> pf_done (nf, -1) ;     // column whose diagonal block a fused update has factored
@@ -822,17 +834,28 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         for (int i0 = 0 ; i0 < maxnscol ; i0 += SB)
         {
             if (i0 % MB == 0)
+            {
+                // a distributed front entering a new outer block column: its block columns into the window (as in the 64-column chain below)
+                for (int q = 0 ; q < nf ; q++)
+                {
+                    const FrontD &f = fr [ids [q]] ;
+                    if (f.nscol <= i0 || !windowed (ids [q]) || i0 % ob_of (f) != 0) continue ;
+                    int o1 = std::min (i0 + ob_of (f), (int) f.nscol) ;
+                    int from = early_open [q] == i0 ? std::min (i0 + MB, o1) : i0 ;
+                    if (o1 > from) emit_win (q, 0, from, o1, 0, -1) ;
+                }
                 for (int q = 0 ; q < nf ; q++)
                 {
                     const FrontD &f = fr [ids [q]] ;
                     if (f.nscol <= i0 || !is_shared (ids [q]) || early [q] == i0) continue ;
                     emit_rs (q, i0, -1) ;
                 }
-            // fused (CHOLMOD_HIP_CHAINF, default with the 256-column chain): diagonal and row workgroups of a sub-block in
+            }
+            // fused (default with the 256-column chain; CHOLMOD_HIP_NO_CHAINF: off): diagonal and row workgroups of a sub-block in
             // ONE launch, the diagonal sub-block spread over up to four workgroups that hand their row block of L on
-            // through flags (k_chainf) -- unless a front of the batch is shared between ranks (row chunks: two parts)
+            // through flags (k_chainf).  A front shared between ranks: the diagonal sub-block on every rank, below it the rest of
+            // the 512-wide diagonal block (every rank) and this rank's chunk of the rows (two row ranges)
             bool fused256 = !getenv ("CHOLMOD_HIP_NO_CHAINF") ;
-            for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) fused256 = false ;
             if (fused256)
             {
                 Launch Lc {K_CHAINF, 0, 0, S.cg.size (), 0, 0} ;
@@ -847,13 +870,21 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                     int b1 = std::min (i0 + SB, o1) ;
                     int w = b1 - i0 ;
                     int slot = (int) (S.cg.size () - Lc.goff) ;
-                    int mb = f.nsrow - b1 ;
-                    S.cg.push_back (CfGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, mb, slot, S.ncflags++, dblocks, bblocks, 0}) ;
+                    int m1 = f.nsrow - b1, off2 = 0, m2 = 0 ;
+                    if (is_shared (ids [q]))
+                    {
+                        XchgD X = xchg_of (q, (i0 / MB) * MB) ;
+                        int e1 = (i0 / MB) * MB + X.w ;
+                        m1 = e1 - b1 ;
+                        int lo2 = e1 + X.r * X.R, hi2 = std::min (lo2 + X.R, (int) f.nsrow) ;
+                        off2 = lo2 - i0 ; m2 = std::max (hi2 - lo2, 0) ;
+                    }
+                    S.cg.push_back (CfGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, m1, slot, S.ncflags++, dblocks, bblocks, off2, m2, 0}) ;
                     dblocks += (w + 63) / 64 ;
-                    bblocks += (mb + 63) / 64 ;
+                    bblocks += (m1 + 63) / 64 + (m2 + 63) / 64 ;
                     wmax = std::max (wmax, w) ;
-                    Lc.flops += (double) w * w * w / 3.0 + (double) mb * w * w ;
-                    Lc.bytes += 16.0 * mb * w ;
+                    Lc.flops += (double) w * w * w / 3.0 + (double) (m1 + m2) * w * w ;
+                    Lc.bytes += 16.0 * (m1 + m2) * w ;
                 }
                 Lc.ng = (int) (S.cg.size () - Lc.goff) ; Lc.grid = dblocks + bblocks ; Lc.ndiag = dblocks ; Lc.aux = wmax ;
                 S.max_dinv_slots = std::max (S.max_dinv_slots, Lc.ng) ;
@@ -872,7 +903,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 int b1 = std::min (i0 + SB, o1) ;
                 int w = b1 - i0 ;
                 int slot = (int) (S.dg.size () - Ld.goff) ;
-                S.dg.push_back (DgGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, slot, 0}) ;
+                S.dg.push_back (DgGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, slot, 0}) ;
                 Ld.flops += (double) w * w * w / 3.0 ;
                 // rows to solve: everything below the sub-block -- of a shared front the rest of the
                 // 512-wide diagonal block (every rank of the group) and this rank's chunk below it
@@ -888,7 +919,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 {
                     int m = hi [part] - lo [part] ;
                     if (m <= 0) continue ;
-                    S.rg.push_back (RsGroup {f.psx + i0 + (i64) i0 * f.nsrow, f.psx + lo [part] + (i64) i0 * f.nsrow,
+                    S.rg.push_back (RsGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, psx_at (ids [q], i0) + lo [part] + (i64) i0 * f.nsrow,
                         f.nsrow, m, w, ids [q], i0, rblocks, slot, 0}) ;
                     rblocks += (m + RS_ROWS - 1) / RS_ROWS ;
                     Lr.flops += (double) m * w * w ;
@@ -906,6 +937,11 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
                 int b0 = (i0 / MB) * MB ;
                 if (i0 + SB >= std::min (b0 + MB, f.nscol)) emit_ag (q, b0) ;
+                if (windowed (ids [q]))
+                {
+                    int OBq = ob_of (f), o0 = (i0 / OBq) * OBq, o1 = std::min (o0 + OBq, (int) f.nscol) ;
+                    if (i0 + SB >= o1) emit_win (q, 1, o0, o1, 0, -1) ;
+                }
             }
             for (int q = 0 ; q < nf ; q++)
             {

@@ -2585,7 +2585,9 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 // flags [4 slot + j]: low byte = stages of row block j published (s <= j: its solved blocks of the panels
 // < s; j + 1: its diagonal block and the inverses as well), then bits 8.. = 1 + nvt, nvt = valid columns
 // of the sub-block so far (w when no pivot has failed).
-struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 mbelow ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 pad ; } ;
+// rows below the sub-block: [w, w + m1) and, for a front shared between ranks (its block column dealt by row chunks), a
+// second range [off2, off2 + m2) -- the rest of the 512-wide diagonal block on every rank, then this rank's chunk
+struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 m1 ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 off2 ; i32 m2 ; i32 pad ; } ;
 __device__ __forceinline__ double ld_coh (const double *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 __device__ __forceinline__ void st_coh (double *p, double v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 #define CF_SPIN_LIMIT (1 << 20)
@@ -2609,8 +2611,13 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     const int w = G.w ;
     const int nd = (w + 63) >> 6 ;
     const int rb = isdiag ? (int) blockIdx.x - G.dstart : nd ;
-    const int row0 = isdiag ? 64 * rb : w + 64 * ((int) blockIdx.x - ndiag_total - G.bstart) ;
-    const int rowend = isdiag ? w : w + G.mbelow ;
+    int row0 = 64 * rb, rowend = w ;
+    if (!isdiag)
+    {
+        const int t = (int) blockIdx.x - ndiag_total - G.bstart, n1 = (G.m1 + 63) >> 6 ;
+        if (t < n1) { row0 = w + 64 * t ; rowend = w + G.m1 ; }
+        else { row0 = G.off2 + 64 * (t - n1) ; rowend = G.off2 + G.m2 ; }
+    }
     const int row = row0 + 16 * wave + lr ;
     const bool rok = row < rowend ;
     double *Lb = Lx + G.l_off ;                               // L (0, 0) of the sub-block
