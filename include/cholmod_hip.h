@@ -50,10 +50,13 @@ extern "C" {
                                          * front (no k_leaf_pair)                                */
 #define CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD 256 /* multi-GPU: all-reduce a block column only
                                          * when it is due (no overlap with updates)  */
-#define CHOLMOD_HIP_CHAIN256     8192    /* tuning / tests: the panel chain in 256-column sub-blocks (k_diag: one workgroup
-                                         * factors a diagonal sub-block; k_rowsolve: all rows below it in one launch)
-                                         * instead of the 64-column chain (k_potrf_mfma, k_trsm_mfma, k_trsm_upd,
-                                         * k_update2f): 2.3x fewer launches, measured 4-12 % slower */
+#define CHOLMOD_HIP_CHAIN256     8192    /* tuning / tests: the panel chain in 256-column sub-blocks -- one launch per sub-block
+                                         * (k_chainf: the diagonal sub-block spread over four workgroups that hand their row
+                                         * block of L to the row workgroups through flags; CHOLMOD_HIP_NO_CHAINF=1: the two
+                                         * kernels of round 3, k_diag + k_rowsolve) -- instead of the 64-column chain
+                                         * (k_potrf_mfma, k_trsm_mfma, k_trsm_upd, k_update2f).  On one GPU within +-2 % of the
+                                         * 64-column chain; the default for the batches of a multi-GPU
+                                         * plan that hold a front shared between ranks */
 #define CHOLMOD_HIP_PHI_TWIN    16384    /* the structure is the real twin of a complex factor (every supernode, row and
                                          * column doubled, host/complex.c; checked at plan creation): the update kernels
                                          * contract over the even panel columns only and rebuild the 2 x 2 blocks of the
@@ -271,7 +274,8 @@ int cholmod_hip_set_profiling (cholmod_hip_plan *plan, int on) ;
  * kind: 0 zero, 1 extend-add, 2 potrf, 3 trsm, 4 update(128), 5 update(64),
  * 7 all-reduce, 8 thin fronts, 9 update + factorization of the next diagonal block,
  * 10 solve + K = 64 update + factorization of the next diagonal block, 11 all-gather of a shared block column,
- * 12 update (one wave per tile, k_update3).  Fills at most cap entries of the arrays that are
+ * 12 update (one wave per tile, k_update3), 13 / 14 the 256-column chain as two kernels (k_diag, k_rowsolve), 15 window moves of
+ * a distributed front (k_win_move), 16 the 256-column chain in one launch (k_chainf).  Fills at most cap entries of the arrays that are
  * not NULL, returns the number of launches. */
 int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *plan, int64_t cap, int32_t *kind,
     int32_t *grid, int32_t *aux, double *ms, double *flops, double *bytes) ;
