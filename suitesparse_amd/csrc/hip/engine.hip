@@ -1778,7 +1778,16 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipExtStreamCreateWithCUMask (&P->stream, 8, m)) ;
     }
     else HIPCHK (hipStreamCreate (&P->stream)) ;
-    HIPCHK (hipStreamCreate (&P->stream2)) ;
+    {
+        // The exchange stream runs BESIDE the rest of a trailing update (look-ahead: window open, extend-add, pack, the
+        // collective): its small workgroups must get the wave slots the update's tiles free up, ahead of the update's own
+        // remaining tiles -- at default priority rocprofv3 shows k_win_move stretched over the whole 78 ms of the update it
+        // was meant to hide behind (round 4).  CHOLMOD_HIP_NO_STREAM_PRIORITY=1: as before.
+        int least = 0, greatest = 0 ;
+        if (!getenv ("CHOLMOD_HIP_NO_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange (&least, &greatest) == hipSuccess && greatest != least)
+            HIPCHK (hipStreamCreateWithPriority (&P->stream2, hipStreamDefault, greatest)) ;
+        else HIPCHK (hipStreamCreate (&P->stream2)) ;
+    }
     for (int q = 0 ; q < P->sch.nevents ; q++)
     {
         hipEvent_t e ;
@@ -1911,6 +1920,18 @@ static int thin_minw (int cls)
     return v [cls] ;
 }
 
+// CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS=1 (tuning): the kernels of the exchange stream (window open, extend-add into the window,
+// pack) as ONE-wave workgroups.  Beside a trailing update whose one-wave tiles refill every register-file slot as it frees
+// up, a four-wave workgroup needs room on all four SIMDs of a CU at once and starves until the update ends (rocprofv3:
+// k_win_move stretched over the update's 78 ms); one-wave workgroups do get in (0.3 ms) -- but run at a fraction of the
+// four-wave kernels' rate and cost a rank of 8 30 ms of compute (1.083 against 1.053 s), more than the early reduce-scatter of
+// one block column in eight can return.  Measured, left off.
+static bool narrow_xs ()
+{
+    static const bool v = [] () { const char *e = getenv ("CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS") ; return e && atoi (e) != 0 ; } () ;
+    return v ;
+}
+
 static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 {
     hipStream_t st = (serial || L.stream == 0 || !P->stream2) ? P->stream : P->stream2 ;
@@ -2003,7 +2024,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     if (total <= 0) return ;
                     // (one workgroup per column and part: k_xchg_move)
                     const unsigned parts = mode == 0 ? (unsigned) X.g + 1 : mode == 3 ? (unsigned) X.g : mode == 1 ? 2u : 1u ;
-                    hipLaunchKernelGGL (k_xchg_move, dim3 ((unsigned) X.w * parts), dim3 (256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
+                    hipLaunchKernelGGL (k_xchg_move, dim3 ((unsigned) X.w * parts), dim3 (ahead && narrow_xs () ? 64 : 256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
                 } ;
                 if (rs)
                 {
@@ -2053,12 +2074,13 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_cg + L.goff, L.ng, L.ndiag, P->d_Lx, P->d_info, P->d_dinv, P->d_cflags, P->d_cflags + 4 * (size_t) P->sch.ncflags) ;
             break ;
         case K_WIN:
-            hipLaunchKernelGGL (k_win_move, dim3 (L.grid), dim3 (256), 0, st, P->d_wg + L.goff, L.ng, P->d_Lx) ; break ;
+            // (one-wave workgroups on the exchange stream: see k_extend_add)
+            hipLaunchKernelGGL (k_win_move, dim3 (L.grid), dim3 (L.stream == 1 && !serial && narrow_xs () ? 64 : 256), 0, st, P->d_wg + L.goff, L.ng, P->d_Lx) ; break ;
         case K_ZERO:
             hipLaunchKernelGGL (k_zero, dim3 (L.grid), dim3 (256), 0, st,
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
         case K_EA:
-            CX_LAUNCH (k_extend_add, dim3 (L.grid), dim3 (256), 0, st,
+            CX_LAUNCH (k_extend_add, dim3 (L.grid), dim3 (L.stream == 1 && !serial && narrow_xs () ? 64 : 256), 0, st,
                 P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb, L.aux > 0 ? L.aux : EA_TW) ; break ;
         case K_POTRF:
             if (cx) hipLaunchKernelGGL ((k_potrf_mfma<false, true>), dim3 (L.grid), dim3 (256), 0, st,

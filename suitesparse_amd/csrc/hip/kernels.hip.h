@@ -284,6 +284,10 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     int c0 = g [gi].c_lo + ((int) blockIdx.x - g [gi].blk_start) * tw ;
     int c1 = c0 + tw < g [gi].c_hi ? c0 + tw : g [gi].c_hi ;
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63 ;
+    // (launched with four waves, or -- on the exchange stream, beside a trailing update whose one-wave workgroups refill
+    // every register file slot as it frees up -- with ONE: a four-wave workgroup needs room on all four SIMDs of a CU at
+    // once and starves there; its single wave then takes all the target columns of the block)
+    const int nwv = (int) blockDim.x >> 6 ;
     i64 Ppsx = g [gi].pbase != EA_NO_PBASE ? g [gi].pbase : P.psx, Pcb = P.cb ;
     int Pnscol = P.nscol, Pnsrow = P.nsrow, Pncb = P.ncb ;
     int cb = P.child_begin, ce = P.child_end ;
@@ -298,8 +302,8 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
         for (int j = j0 ; j < j1 ; j++)
         {
             int tc = rm [j] ;
-            if constexpr (CX) { if ((j & 1) || ((tc >> 1) & 3) != wave) continue ; }      // (an even child column lands on an even column)
-            else if ((tc & 3) != wave) continue ;
+            if constexpr (CX) { if ((j & 1) || (((tc >> 1) & 3) % nwv) != wave) continue ; }      // (an even child column lands on an even column)
+            else if (((tc & 3) % nwv) != wave) continue ;
             double *dst ;
             int roff ;
             if (tc < Pnscol) { dst = Lx + Ppsx + colx<CX> (tc, Pnsrow) ; roff = 0 ; }
@@ -2205,7 +2209,7 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
         if (part == X.g)
         {
             // the diagonal block's column j (lower part, zero above) into every segment
-            for (int i = tid ; i < X.w ; i += 256)
+            for (int i = tid ; i < X.w ; i += (int) blockDim.x)
             {
                 const double v = (i >= j) ? S [i] : 0.0 ;
                 for (int q = 0 ; q < X.g ; q++) stage [(i64) q * seg + (i64) j * X.w + i] = v ;
@@ -2217,19 +2221,19 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
             const double *src = S + X.w + (i64) q * X.R ;
             double *dst = stage + (i64) q * seg + (i64) X.w * X.w + (i64) j * X.R ;
             const int nr = X.mb - q * X.R ;                      // rows of this chunk that exist
-            for (int i = tid ; i < X.R ; i += 256) dst [i] = (i < nr) ? src [i] : 0.0 ;
+            for (int i = tid ; i < X.R ; i += (int) blockDim.x) dst [i] = (i < nr) ? src [i] : 0.0 ;
         }
     }
     else if (mode == 1)
     {
         const double *ps = stage + (i64) X.r * seg ;
-        if (part == 0) { for (int i = j + tid ; i < X.w ; i += 256) S [i] = ps [(i64) j * X.w + i] ; }
+        if (part == 0) { for (int i = j + tid ; i < X.w ; i += (int) blockDim.x) S [i] = ps [(i64) j * X.w + i] ; }
         else
         {
             const double *src = ps + (i64) X.w * X.w + (i64) j * X.R ;
             double *dst = S + X.w + (i64) X.r * X.R ;
             const int nr = X.mb - X.r * X.R ;
-            for (int i = tid ; i < X.R && i < nr ; i += 256) dst [i] = src [i] ;
+            for (int i = tid ; i < X.R && i < nr ; i += (int) blockDim.x) dst [i] = src [i] ;
         }
     }
     else if (mode == 2)
@@ -2237,7 +2241,7 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
         const double *src = S + X.w + (i64) X.r * X.R ;
         double *dst = ag + (i64) X.r * X.R * X.w + (i64) j * X.R ;
         const int nr = X.mb - X.r * X.R ;
-        for (int i = tid ; i < X.R ; i += 256) dst [i] = (i < nr) ? src [i] : 0.0 ;
+        for (int i = tid ; i < X.R ; i += (int) blockDim.x) dst [i] = (i < nr) ? src [i] : 0.0 ;
     }
     else
     {
@@ -2246,7 +2250,7 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
         const double *src = ag + (i64) q * X.R * X.w + (i64) j * X.R ;
         double *dst = S + X.w + (i64) q * X.R ;
         const int nr = X.mb - q * X.R ;
-        for (int i = tid ; i < X.R && i < nr ; i += 256) dst [i] = src [i] ;
+        for (int i = tid ; i < X.R && i < nr ; i += (int) blockDim.x) dst [i] = src [i] ;
     }
 }
 
@@ -2277,10 +2281,10 @@ __global__ void __launch_bounds__(256) k_win_move (const WinD *g, int ng, double
     double *sc = Lx + W.store + (i64) ((t / W.own_g) * W.own_w + c % W.own_w) * W.ld ;
     if (W.mode == 0)
     {
-        if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += 256) wc [i] = sc [i] ;
-        else for (int i = ra + threadIdx.x ; i < rb ; i += 256) wc [i] = 0.0 ;
+        if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += (int) blockDim.x) wc [i] = sc [i] ;
+        else for (int i = ra + threadIdx.x ; i < rb ; i += (int) blockDim.x) wc [i] = 0.0 ;
     }
-    else if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += 256) sc [i] = wc [i] ;
+    else if (mine) for (int i = ra + threadIdx.x ; i < rb ; i += (int) blockDim.x) sc [i] = wc [i] ;
 }
 
 // ---- the panel chain in 256-column sub-blocks (opt-in: CHOLMOD_HIP_CHAIN256) ---------------
