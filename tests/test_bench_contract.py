@@ -115,3 +115,25 @@ def test_bench_gpus_flag_fails_loudly_without_the_devices():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "16"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "must agree" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_exchange_selftest_at_100_cubed_over_rccl():
+    """The multi-GPU path at a BASELINE size on the one GPU there is: CHOLMOD_HIP_SHARE_AS_WORLD=8 marks the fronts an 8-rank
+    run of Poisson 100^3 would share (the 10 000-column root among them: 1024 / 2048-wide outer blocks, several windows,
+    negative window bases), the engine's native exchange runs over the real RCCL with its one rank (reduce-scatter, D
+    broadcast skipped at g = 1, all-gather, agreement), the shared fronts' chain through k_chainf -- and the factor must
+    pass the size-independent checks: residual, closed-form log det, dead triangles, finite entries."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CHOLMOD_HIP_SHARE_AS_WORLD"] = "8"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--grid", "100", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["exchange"]["self_test_share_as_world"] == 8
+    assert d["exchange"]["allreduce_calls_per_factorization"] > 50
+    assert d["residual_2norm"] < 1e-11
+    fc = d["factor_checks"]
+    assert fc["logdet_rel_err"] < 1e-11 and fc["upper_nonzeros"] == 0 and fc["nonfinite"] == 0 and fc["nonpositive_diag"] == 0, fc
