@@ -1706,7 +1706,7 @@ static int build_host (cholmod_hip_plan *P)
             // 4 / 8 / 16 / 32: the nd24k stand-in and Poisson 100^3 like 4, the 2D problem 8)
             int tw = EA_TW ;
             for (int q = 0 ; q < nf ; q++)
-                if (P->fr [ids [q]].child_end != P->fr [ids [q]].child_begin && P->fr [ids [q]].nsrow >= 2048) tw = 4 ;
+                if (P->fr [ids [q]].child_end != P->fr [ids [q]].child_begin && P->fr [ids [q]].nsrow >= 2048) tw = getenv ("CHOLMOD_HIP_EA_TW_BIG") ? atoi (getenv ("CHOLMOD_HIP_EA_TW_BIG")) : 4 ;
             Le.aux = tw ;
             for (int q = 0 ; q < nf ; q++)
             {

@@ -272,6 +272,15 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 // waves ever touch the same entry and no atomics are needed.  Reads of a child
 // CB column are contiguous (coalesced); the target rows follow the relative
 // map.  reference scatter: t_cholmod_super_numeric.c:756-772.
+// a child's contribution block is read exactly once: streamed past the caches (EA_NT=0: ordinary loads)
+#ifndef EA_NT
+#define EA_NT 1
+#endif
+#if EA_NT
+#define EA_LDV(p) __builtin_nontemporal_load (p)
+#else
+#define EA_LDV(p) (*(p))
+#endif
 #ifndef EA_TW
 #define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
 #endif
@@ -315,7 +324,7 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
             {
                 int r [8] ; double v [8], d [8] ;
 #pragma unroll
-                for (int q = 0 ; q < 8 ; q++) { r [q] = rm [i + 64 * q] - roff ; v [q] = sc [i + 64 * q] ; }
+                for (int q = 0 ; q < 8 ; q++) { r [q] = rm [i + 64 * q] - roff ; v [q] = EA_LDV (sc + i + 64 * q) ; }
 #pragma unroll
                 for (int q = 0 ; q < 8 ; q++) d [q] = dst [r [q]] ;
 #pragma unroll
@@ -324,7 +333,7 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
             for ( ; i + 192 < nc ; i += 256)
             {
                 int r0 = rm [i] - roff, r1 = rm [i + 64] - roff, r2 = rm [i + 128] - roff, r3 = rm [i + 192] - roff ;
-                double v0 = sc [i], v1 = sc [i + 64], v2 = sc [i + 128], v3 = sc [i + 192] ;
+                double v0 = EA_LDV (sc + i), v1 = EA_LDV (sc + i + 64), v2 = EA_LDV (sc + i + 128), v3 = EA_LDV (sc + i + 192) ;
                 double d0 = dst [r0], d1 = dst [r1], d2 = dst [r2], d3 = dst [r3] ;
                 dst [r0] = d0 + v0 ; dst [r1] = d1 + v1 ; dst [r2] = d2 + v2 ; dst [r3] = d3 + v3 ;
             }
