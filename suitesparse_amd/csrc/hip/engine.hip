@@ -595,7 +595,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         for (int q = 0 ; q < nf ; q++) if (windowed (ids [q])) any_win = true ;
         if (any_win)
         {
-            const bool c64 = getenv ("CHOLMOD_HIP_SHARED_CHAIN64") || getenv ("CHOLMOD_HIP_NO_CHAINF") || twin || cx || (flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
+            const bool c64 = getenv ("CHOLMOD_HIP_SHARED_CHAIN64") || getenv ("CHOLMOD_HIP_NO_CHAINF") || cx || (flags & CHOLMOD_HIP_NO_FUSED_POTRF) ;
             chain256 = !c64 ;
         }
     }
