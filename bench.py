@@ -13,9 +13,11 @@ Poisson 200^3 (8M dof, fl = 4.25e14) under geometric nested dissection (SURVEY.m
 8d) -- it fits one MI355X (L 181.6 GB + contribution blocks).  If the
 device cannot hold it the bench falls back to 160^3, then 100^3 (configs[1]), and
 names the workload it actually ran.  N>1: the SAME factorization partitioned over
-the ranks (one process per GPU): private etree subtrees per rank, the shared top
-fronts kept as partial sums and summed block column by block column with a
-sum all-reduce over RCCL (torch.distributed "nccl"); strong scaling.
+the ranks (one process per GPU): private etree subtrees per rank, the panels of the
+shared top fronts distributed by column slabs (owner-computes), each 512-column block
+column summed with a reduce-scatter by row chunks before its panel chain and gathered
+after it -- the engine calls RCCL itself; strong scaling.
+`--gpus N` without a launcher around it starts the N ranks itself.
 """
 from __future__ import annotations
 
@@ -703,8 +705,8 @@ def main():
                        "Lx_GB": 8e-9 * xsize, "arena_GB": 1e-9 * stats[4],
                        "levels": int(stats[3]), "launches_per_step": int(stats[2]),
                        "parallelism": "1 GPU" if world == 1 else
-                       f"{world} GPUs: etree subtrees per rank + shared top fronts, "
-                       f"{int(stats[17])} block-column all-reduces per factorization "
+                       f"{world} GPUs: etree subtrees per rank + shared top fronts distributed by column slabs, "
+                       f"{int(stats[17])} block-column exchanges (reduce-scatter / all-gather) per factorization "
                        f"({'RCCL, engine-native' if native else args.dist_backend + ' callback'})",
                        "input": "S=tril(PAP') resident in HBM; factor left in HBM"},
             "pct_fp64_mfma_peak_per_gpu": 100.0 * value / world / (1e3 * FP64_MFMA_PEAK_TFLOPS),
