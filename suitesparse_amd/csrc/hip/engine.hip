@@ -328,6 +328,14 @@ struct cholmod_hip_plan {
     // tail of d_Lx (win_off [s], -1: none; schedule_dense: psx_at); lx_fronts = doubles of d_Lx before the windows.
     std::vector<i64> win_off ;
     i64 lx_fronts = 0 ;
+    // contributions routed past the contribution blocks of shared fronts (build_host: passthru): per entry of the child
+    // lists the offset of that pair's relative map, the (contributor, ancestor) pairs whose maps are computed next to the
+    // child -> parent ones, the total length of the map array
+    std::vector<i64> crel ;
+    std::vector<RelPair> relpairs ;
+    i64 relsize_all = 0 ;
+    bool passthru = false ;
+    i64 *d_crel = nullptr ; RelPair *d_relpairs = nullptr ;
     WinD *d_wg = nullptr ;
     CfGroup *d_cg = nullptr ; int *d_cflags = nullptr ;     // k_chainf groups; its flags ([4 slot + row block]) and, last, the error word
     double *d_Lx_full = nullptr ; FrontD *d_fr_full = nullptr ;
@@ -759,7 +767,26 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 if (x.t1 > c0) add_outer_slabs (small, f, ids [x.q], x.kc, x.kk, c0, x.t1) ;
             }
             else if (x.t1 > c0) add_update (big, small, f, ids [x.q], c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
-            if (x.cb)
+            if (x.cb && f.cbd)
+            {
+                // a distributed contribution block: this rank's block of columns, one region that starts on the diagonal;
+                // the first outer block assigns (nothing else ever writes there)
+                if (f.cb_hi > f.cb_lo)
+                {
+                    const int a = f.nscol + f.cb_lo, b = f.nscol + f.cb_hi ;
+                    GemmGroup G ;
+                    memset (&G, 0, sizeof (G)) ;
+                    G.a_off = psx_at (ids [x.q], x.kc) + a + co (x.kc, f.nsrow) ;
+                    G.b_off = G.a_off ;
+                    G.lda = f.nsrow ;
+                    G.c_off = f.cb + f.cb_lo ; G.ldc = f.ncb ; G.c_in_cb = 1 ; G.assign = (x.kc == 0) ? 1 : 0 ;
+                    G.m = f.nsrow - a ; G.n = b - a ; G.k = x.kk ; G.tri = 1 ; G.front = ids [x.q] ;
+                    if (twin) twin_operands (G, a, x.kc) ;
+                    G.tile_mul = 1 ; G.tile_add = 0 ;
+                    small.push_back (G) ;
+                }
+            }
+            else if (x.cb)
             {
                 size_t nsm = small.size () ;
                 add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true, x.wide) ;
@@ -1341,6 +1368,13 @@ static int build_host (cholmod_hip_plan *P)
     // path -- that is every slab, and the front stays where the reference layout has it)
     const bool distribute = !getenv ("CHOLMOD_HIP_NO_DISTRIBUTED_FRONTS") && !(P->flags & CHOLMOD_HIP_CX_STORAGE) ;
     const int ownw = (P->flags & CHOLMOD_HIP_PHI_TWIN) ? std::max (own_width (), 64) : own_width () ;
+    // The contribution block of a shared front distributed like its panel (the slabs continue past column nscol, the outer
+    // updates of a slab run on its owner), and NOTHING extend-added into it: the contributions of a rank's fronts to a shared
+    // ancestor are routed past the blocks in between, straight into the ancestor whose PANEL holds the column -- every entry
+    // travels once, no member keeps a full square of partial sums, no replicated extend-add.  CHOLMOD_HIP_NO_CB_PASSTHROUGH=1:
+    // the layout of the first half of round 4 (full squares of partial sums, pulled level by level).
+    const bool passthru = distribute && !getenv ("CHOLMOD_HIP_NO_CB_PASSTHROUGH") ;
+    P->passthru = passthru ;
     P->lpx.assign (std::max<i64> (nsuper, 1), -1) ;
     P->win_off.assign (std::max<i64> (nsuper, 1), -1) ;
     P->lx_local = 0 ;
@@ -1356,6 +1390,22 @@ static int build_host (cholmod_hip_plan *P)
             f.own_w = ownw ; f.own_g = P->world > 1 ? P->grpn [s] : 1 ; f.own_r = P->world > 1 ? P->rank - P->grp0 [s] : 0 ;
             cols = 0 ;
             for (int c0 = 0 ; c0 < f.nscol ; c0 += ownw) if (col_owned (f, c0)) cols += std::min (ownw, f.nscol - c0) ;
+            if (passthru && f.ncb > 0)
+            {
+                // member q's block of contribution-block columns starts where q / g of the lower triangle's area lies to its left
+                f.cbd = 1 ;
+                auto bound = [&] (int q) -> int
+                {
+                    if (q <= 0) return 0 ;
+                    if (q >= f.own_g) return f.ncb ;
+                    const double T = 0.5 * (double) f.ncb * (f.ncb + 1) * q / f.own_g ;
+                    // area left of column j: j ncb - j (j - 1) / 2
+                    double j = f.ncb + 0.5 - std::sqrt (std::max (0.0, (f.ncb + 0.5) * (f.ncb + 0.5) - 2.0 * T)) ;
+                    int b = (int) (j / 64.0 + 0.5) * 64 ;
+                    return std::min (std::max (b, 0), (int) f.ncb) ;
+                } ;
+                f.cb_lo = bound (f.own_r) ; f.cb_hi = bound (f.own_r + 1) ;
+            }
         }
         P->lx_local += cols * f.nsrow ;
     }
@@ -1369,28 +1419,63 @@ static int build_host (cholmod_hip_plan *P)
         f.cbp = (!(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX && !(P->owner [s] < 0)) ? 1 : 0 ;
     }
     const bool cx_storage = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
-    auto cb_len = [&] (const FrontD &f) -> i64
+    auto cb_len = [&] (const FrontD &f, bool global = false) -> i64
     {
-        // (a complex front in its own storage: the even columns of the twin's square)
+        // (a distributed block: this rank's slabs -- in the layout over ALL fronts, which every rank must derive alike, its
+        // g-th part; a complex front in its own storage: the even columns of the twin's square)
+        if (f.cbd) return global ? ((i64) f.ncb * f.ncb + f.own_g - 1) / f.own_g : (i64) f.ncb * (f.cb_hi - f.cb_lo) ;
         return f.cbp ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
     } ;
+    // who releases whose block: the parent, once it has pulled it -- or, for a front whose parent is shared and whose
+    // contributions are routed to the ancestors' panels, the root of its tree (it contributes until then)
+    std::vector<std::vector<i32>> rel_list (std::max<i64> (nsuper, 1)) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        i32 p = P->fr [s].parent ;
+        if (p < 0) continue ;
+        i32 t = p ;
+        if (passthru && P->owner [p] < 0) while (P->fr [t].parent >= 0) t = P->fr [t].parent ;
+        rel_list [t].push_back ((i32) s) ;
+    }
     // this rank's view of the child lists: a shared parent pulls only the
     // contribution blocks this rank computed (its own subtrees and its partial
     // copies of shared children); the other ranks add theirs on their side and
     // the sums meet in the all-reduce of the parent's block columns
-    i32 acc = 0 ;
+    // (passthru: the list of a shared front holds its CONTRIBUTORS -- every front of its subtree this rank holds whose
+    // parent is shared, i.e. its own children and the contributors of its shared children -- each with the map of its pair)
+    std::vector<std::vector<i32>> contrib (passthru ? nsuper : 0) ;
+    P->child.clear () ; P->crel.clear () ; P->relpairs.clear () ;
+    P->relsize_all = P->relsize ;
     for (i64 s = 0 ; s < nsuper ; s++)
     {
-        P->fr [s].child_begin = acc ;
-        if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++) if (mine (call [c])) acc++ ;
-        P->fr [s].child_end = P->fr [s].child_begin ;
+        FrontD &f = P->fr [s] ;
+        f.child_begin = (i32) P->child.size () ;
+        if (mine (s))
+        {
+            const bool route = passthru && P->owner [s] < 0 ;
+            for (i32 c = cptr [s] ; c < cptr [s+1] ; c++)
+            {
+                const i32 d = call [c] ;
+                if (!mine (d)) continue ;
+                if (!route) { P->child.push_back (d) ; P->crel.push_back (P->fr [d].rel) ; continue ; }
+                contrib [s].push_back (d) ;
+                if (P->owner [d] < 0) contrib [s].insert (contrib [s].end (), contrib [d].begin (), contrib [d].end ()) ;
+            }
+            if (route)
+                for (i32 d : contrib [s])
+                {
+                    if (P->fr [d].ncb == 0) continue ;
+                    P->child.push_back (d) ;
+                    P->crel.push_back (P->relsize_all) ;
+                    P->relpairs.push_back (RelPair {d, (i32) s, P->relsize_all}) ;
+                    P->relsize_all += P->fr [d].ncb ;
+                }
+        }
+        f.child_end = (i32) P->child.size () ;
         // one rank of the group adds A: the first one -- or, column by column, the owner (distributed fronts)
-        P->fr [s].assemble = (P->fr [s].own_w ? mine (s) : P->rank == P->grp0 [s]) ? 1 : 0 ;
+        f.assemble = (f.own_w ? mine (s) : P->rank == P->grp0 [s]) ? 1 : 0 ;
     }
-    P->child.assign (std::max<i32> (acc, 1), 0) ;
-    for (i64 s = 0 ; s < nsuper ; s++)
-        if (mine (s)) for (i32 c = cptr [s] ; c < cptr [s+1] ; c++)
-            if (mine (call [c])) P->child [P->fr [s].child_end++] = call [c] ;
+    if (P->child.empty ()) { P->child.push_back (0) ; P->crel.push_back (0) ; }
     P->my_lvl_ptr.assign (nlev + 1, 0) ;
     P->my_lvl_list.clear () ;
     for (int l = 0 ; l < nlev ; l++)
@@ -1484,12 +1569,12 @@ static int build_host (cholmod_hip_plan *P)
         Arena A ;
         for (const auto &bt : batches)
         {
-            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f)) ; }
+            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f, P->world > 1)) ; }
             for (i32 sf : bt)
-                for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
+                for (i32 c : rel_list [sf])
                 {
-                    FrontD &g = P->fr [call [c]] ;
-                    A.release (g.cb, cb_len (g)) ;
+                    FrontD &g = P->fr [c] ;
+                    A.release (g.cb, cb_len (g, P->world > 1)) ;
                 }
         }
         // keep the first split that fits; if none does, the one with the smallest
@@ -1517,10 +1602,10 @@ static int build_host (cholmod_hip_plan *P)
             for (i32 sf : bt) if (mine (sf)) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f)) ; }
             for (i32 sf : bt)
                 if (mine (sf))
-                    for (i32 c = cptr [sf] ; c < cptr [sf+1] ; c++)
-                        if (mine (call [c]))
+                    for (i32 c : rel_list [sf])
+                        if (mine (c))
                         {
-                            FrontD &g = P->fr [call [c]] ;
+                            FrontD &g = P->fr [c] ;
                             A.release (g.cb, cb_len (g)) ;
                         }
         }
@@ -1681,7 +1766,8 @@ static int build_host (cholmod_hip_plan *P)
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = P->fr [ids [q]] ;
-            P->assign_cb [ids [q]] = (can_assign && f.ncb > 0 && P->owner [ids [q]] >= 0) ? 1 : 0 ;
+            // (a distributed contribution block is written slab by slab by its owners and takes nothing else: assigned too)
+            P->assign_cb [ids [q]] = (f.cbd || (can_assign && f.ncb > 0 && P->owner [ids [q]] >= 0)) ? 1 : 0 ;
         }
         Launch Lz {K_ZERO, 0, 0, S.zg.size (), 0, 0} ;
         int blocks = 0 ;
@@ -1713,6 +1799,7 @@ static int build_host (cholmod_hip_plan *P)
                 const FrontD &f = P->fr [ids [q]] ;
                 if (f.child_end == f.child_begin) continue ;
                 bool asg = P->assign_cb [ids [q]] != 0 ;
+                if (f.cbd) continue ;               // (nothing is extend-added into a distributed contribution block)
                 // (a distributed front takes the contributions to its panel block column by block column,
                 // when the block column enters the window: schedule_dense, emit_win)
                 int lo = (phase == 0 && !f.own_w) ? 0 : f.nscol ;
@@ -1749,7 +1836,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_dinv, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_crel, P->d_relpairs, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1811,6 +1898,8 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_fr = dupload (P->fr, e) ; HIPCHK (e) ;
     P->d_supermap = dupload (P->supermap, e) ; HIPCHK (e) ;
     P->d_child = dupload (P->child, e) ; HIPCHK (e) ;
+    P->d_crel = dupload (P->crel, e) ; HIPCHK (e) ;
+    P->d_relpairs = dupload (P->relpairs, e) ; HIPCHK (e) ;
     {
         std::vector<ChildD> cdv (P->child.size ()) ;
         for (size_t q = 0 ; q < P->child.size () ; q++)
@@ -1843,7 +1932,7 @@ static int upload_plan (cholmod_hip_plan *P)
     }
     P->d_sv = dupload (P->sv_tasks, e) ; HIPCHK (e) ;
     double tu2 = pnow () ;
-    HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (P->relsize, 1) * sizeof (i32))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_relmap, std::max<i64> (std::max (P->relsize, P->relsize_all), 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_first_fail, sizeof (int))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
@@ -1874,6 +1963,9 @@ static int upload_plan (cholmod_hip_plan *P)
         int grid = (int) ((P->nsuper * 64 + 255) / 256) ;
         hipLaunchKernelGGL (k_relmap, dim3 (grid), dim3 (256), 0, P->stream,
             (int) P->nsuper, P->d_fr, P->d_Ls, P->d_relmap) ;
+        if (!P->relpairs.empty ())
+            hipLaunchKernelGGL (k_relmap_pairs, dim3 ((unsigned) ((P->relpairs.size () * 64 + 255) / 256)), dim3 (256), 0, P->stream,
+                (int) P->relpairs.size (), P->d_relpairs, P->d_fr, P->d_Ls, P->d_relmap) ;
         HIPCHK (hipGetLastError ()) ;
         HIPCHK (hipStreamSynchronize (P->stream)) ;
     }
@@ -2081,7 +2173,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 P->d_zg + L.goff, L.ng, P->d_cb) ; break ;
         case K_EA:
             CX_LAUNCH (k_extend_add, dim3 (L.grid), dim3 (L.stream == 1 && !serial && narrow_xs () ? 64 : 256), 0, st,
-                P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_relmap, P->d_Lx, P->d_cb, L.aux > 0 ? L.aux : EA_TW) ; break ;
+                P->d_eg + L.goff, L.ng, P->d_fr, P->d_child, P->d_crel, P->d_relmap, P->d_Lx, P->d_cb, L.aux > 0 ? L.aux : EA_TW) ; break ;
         case K_POTRF:
             if (cx) hipLaunchKernelGGL ((k_potrf_mfma<false, true>), dim3 (L.grid), dim3 (256), 0, st,
                 P->d_pg + L.goff, P->d_Lx, P->d_info, (long long *) nullptr) ;

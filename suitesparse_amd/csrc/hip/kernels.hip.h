@@ -42,11 +42,24 @@ struct FrontD {
     // behind the other with ld = nsrow (psx = offset of the first one in the rank's array).  own_w == 0:
     // the whole panel is here (private fronts, one GPU, the gathered factor).
     i32 own_w, own_g, own_r;
-    i32 pad_;
+    // ... and so is its contribution block (cbd = 1), by BLOCKS of columns: member r stores columns [cb_lo, cb_hi) of it
+    // (boundaries at equal shares of the lower triangle's area, multiples of 64), ld = ncb, and is the one that applies
+    // the outer updates to them.  Nothing is extend-added INTO such a block: what the descendants contribute to it is
+    // routed past it, straight into the ancestor whose panel holds the column (engine.hip: contributors).
+    i32 cbd;
+    i32 cb_lo, cb_hi;
 };
 // column c of front f: is it stored on this rank, and where (in columns from psx)
 __host__ __device__ __forceinline__ bool col_owned (const FrontD &f, int c) { return f.own_w == 0 || ((c / f.own_w) % f.own_g) == f.own_r ; }
 __host__ __device__ __forceinline__ int col_local (const FrontD &f, int c) { return f.own_w == 0 ? c : ((c / f.own_w) / f.own_g) * f.own_w + c % f.own_w ; }
+// front columns < c stored on this rank (= col_local (f, c) when c itself is)
+__host__ __device__ __forceinline__ int owned_before (const FrontD &f, int c)
+{
+    if (f.own_w == 0) return c ;
+    const int t = c / f.own_w ;
+    const int full = t > f.own_r ? (t - f.own_r + f.own_g - 1) / f.own_g : 0 ;       // owned slabs before slab t
+    return full * f.own_w + ((t % f.own_g) == f.own_r ? c % f.own_w : 0) ;
+}
 
 // what a parent needs of a child, in the order of the child lists: one load instead of the chain
 // child [ci] -> fr [child] -> (cb, rel, ncb, cbp)
@@ -168,6 +181,28 @@ __global__ void __launch_bounds__(256) k_relmap (int nsuper, const FrontD *fr,
     }
 }
 
+// The same for (contributor, ancestor) pairs (several GPUs: contributions routed past the contribution blocks of shared
+// fronts): map [off + i] = position of the contributor's contribution-block row i in the ancestor's row list, -1 for the
+// rows below the ancestor's first column (consumed by a front in between).
+struct RelPair { i32 d ; i32 a ; i64 off ; } ;
+__global__ void __launch_bounds__(256) k_relmap_pairs (int npairs, const RelPair *pr, const FrontD *fr, const i64 *Ls, i32 *relmap)
+{
+    int wave = (blockIdx.x * 256 + threadIdx.x) >> 6 ;
+    int lane = threadIdx.x & 63 ;
+    if (wave >= npairs) return ;
+    const RelPair R = pr [wave] ;
+    FrontD d = fr [R.d], p = fr [R.a] ;
+    const i64 *prow = Ls + p.psi ;
+    const i64 *drow = Ls + d.psi + d.nscol ;
+    for (int i = lane ; i < d.ncb ; i += 64)
+    {
+        i64 r = drow [i] ;
+        int lo = 0, hi = p.nsrow ;
+        while (lo < hi) { int mid = (lo + hi) >> 1 ; if (prow [mid] < r) lo = mid + 1 ; else hi = mid ; }
+        relmap [R.off + i] = (r < p.k1) ? -1 : lo ;
+    }
+}
+
 // ---- assemble A into the panels ---------------------------------------------
 // reference: t_cholmod_super_numeric.c:353-431 (ASSIGN semantics, entries not
 // in the symbolic pattern are dropped, beta added to the diagonal).
@@ -286,7 +321,7 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 #endif
 template <bool CX>
 __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
-    const FrontD *fr, const i32 *child, const i32 *relmap, double *Lx, double *CB, int tw)
+    const FrontD *fr, const i32 *child, const i64 *crel, const i32 *relmap, double *Lx, double *CB, int tw)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &EaGroup::blk_start) ;
     const FrontD &P = fr [g [gi].front] ;
@@ -303,21 +338,26 @@ __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
     for (int ci = cb ; ci < ce ; ci++)
     {
         const FrontD &Cc = fr [child [ci]] ;
-        const i32 *rm = relmap + Cc.rel ;
+        // (crel: the map of THIS pair -- child -> parent, or contributor -> ancestor when the contributions of a shared
+        // front's descendants are routed past its contribution block; rows below the ancestor's first column map to -1)
+        const i32 *rm = relmap + crel [ci] ;
         int nc = Cc.ncb ;
         const double *src = CB + Cc.cb ;
+        const bool cbd = Cc.cbd != 0 ;
         int j0 = lower_bound_i32 (rm, nc, c0) ;
         int j1 = lower_bound_i32 (rm, nc, c1) ;
         for (int j = j0 ; j < j1 ; j++)
         {
             int tc = rm [j] ;
+            if (cbd && (j < Cc.cb_lo || j >= Cc.cb_hi)) continue ;      // (a distributed block: the columns this rank stores)
             if constexpr (CX) { if ((j & 1) || (((tc >> 1) & 3) % nwv) != wave) continue ; }      // (an even child column lands on an even column)
             else if (((tc & 3) % nwv) != wave) continue ;
             double *dst ;
             int roff ;
             if (tc < Pnscol) { dst = Lx + Ppsx + colx<CX> (tc, Pnsrow) ; roff = 0 ; }
             else { dst = CB + Pcb + colx<CX> (tc - Pnscol, Pncb) ; roff = Pnscol ; }
-            const double *sc = (!CX && Cc.cbp) ? src + tri_col (j, nc) : src + colx<CX> (j, nc) ;
+            const double *sc = cbd ? src + (i64) (j - Cc.cb_lo) * nc
+                             : (!CX && Cc.cbp) ? src + tri_col (j, nc) : src + colx<CX> (j, nc) ;
             // eight, then four independent gather / read-modify-write chains in flight per wave
             int i = j + lane ;
             for ( ; i + 448 < nc ; i += 512)

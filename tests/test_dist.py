@@ -379,11 +379,13 @@ def test_distributed_slab_widths(own_w):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env,flags", [({"CHOLMOD_HIP_SHARED_CHAIN64": "1"}, 0), ({"CHOLMOD_HIP_NO_CHAINF": "1"}, 8192),
-                                       ({"CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS": "1"}, 0)])
+                                       ({"CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS": "1"}, 0), ({"CHOLMOD_HIP_NO_CB_PASSTHROUGH": "1"}, 0),
+                                       ({"CHOLMOD_HIP_NO_CB_PASSTHROUGH": "1", "CHOLMOD_HIP_NO_CB_BALANCE": "1"}, 256)])
 def test_distributed_chain_variants(env, flags):
     """Shared fronts take the fused 256-column chain (k_chainf) by default; the other forms stay under test: the 64-column
-    chain on shared fronts, the two-kernel 256-column chain (k_diag + k_rowsolve) through the windows, and the exchange
-    stream's kernels as one-wave workgroups."""
+    chain on shared fronts, the two-kernel 256-column chain (k_diag + k_rowsolve) through the windows, the exchange
+    stream's kernels as one-wave workgroups, and the contribution blocks of shared fronts as full squares of partial sums
+    pulled level by level (the default routes the contributions past them, CHOLMOD_HIP_NO_CB_PASSTHROUGH)."""
     res = _run_ranks(3, "gpu", "p3d_48", extra_env=dict(NATIVE, CHOLMOD_TEST_HIP_FLAGS=str(flags), CHOLMOD_HIP_TEST_POISON_ARENA="1", **env))
     for r in res:
         assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
