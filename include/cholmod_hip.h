@@ -145,6 +145,11 @@ int cholmod_hip_rccl_unique_id (void *id128) ;
 int cholmod_hip_rccl_attach (cholmod_hip_plan *plan, const void *id128) ;
 /* back to the callback (destroys the plan's communicators) */
 int cholmod_hip_rccl_detach (cholmod_hip_plan *plan) ;
+/* test hook (several ranks): the (contributor d, shared ancestor a) pairs whose contributions this rank routes straight into a's
+ * windows, and per front the block [cb_lo, cb_hi) of contribution-block columns the rank stores (-1: not distributed).
+ * Returns the number of pairs, fills at most cap. */
+int64_t cholmod_hip_debug_routing (cholmod_hip_plan *plan, int64_t cap, int64_t *pair_d, int64_t *pair_a,
+    int64_t *cb_lo, int64_t *cb_hi) ;
 /* owner[s] = rank that factors supernode s, -1 for the shared fronts */
 int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
 /* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it

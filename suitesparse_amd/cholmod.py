@@ -134,7 +134,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
-    "cholmod_hip_get_groups",
+    "cholmod_hip_get_groups", "cholmod_hip_debug_routing",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
@@ -237,6 +237,7 @@ def lib():
     sig("cholmod_hip_set_allreduce", C.c_int, [vp, ALLREDUCE_FN, vp])
     sig("cholmod_hip_get_partition", C.c_int, [vp, vp])
     sig("cholmod_hip_get_groups", C.c_int, [vp, vp, vp])
+    sig("cholmod_hip_debug_routing", C.c_int64, [vp, C.c_int64, vp, vp, vp, vp])
     sig("cholmod_hip_gather_factor", C.c_int, [vp])
     sig("cholmod_l_gather_factor", C.c_int, [fc, cm])
     sig("cholmod_l_hip_prepare", C.c_int, [fc, cm])

@@ -2614,6 +2614,27 @@ int cholmod_hip_get_groups (cholmod_hip_plan *P, int64_t *first, int64_t *size)
     return CHOLMOD_HIP_OK ;
 }
 
+/* test hook: the (contributor, ancestor) pairs of this rank's plan -- front d extend-adds into the windows of the shared
+ * front a through a map of its own (contributions routed past the contribution blocks in between); and per front the block
+ * [cb_lo, cb_hi) of contribution-block columns this rank stores (-1, -1: the whole block, or not held).  Returns the number of
+ * pairs; fills at most cap of them. */
+int64_t cholmod_hip_debug_routing (cholmod_hip_plan *P, int64_t cap, int64_t *pair_d, int64_t *pair_a, int64_t *cb_lo, int64_t *cb_hi)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    for (size_t q = 0 ; q < P->relpairs.size () && (i64) q < cap ; q++)
+    {
+        if (pair_d) pair_d [q] = P->relpairs [q].d ;
+        if (pair_a) pair_a [q] = P->relpairs [q].a ;
+    }
+    for (i64 s = 0 ; s < P->nsuper ; s++)
+    {
+        const FrontD &f = P->fr [s] ;
+        if (cb_lo) cb_lo [s] = f.cbd ? f.cb_lo : -1 ;
+        if (cb_hi) cb_hi [s] = f.cbd ? f.cb_hi : -1 ;
+    }
+    return (int64_t) P->relpairs.size () ;
+}
+
 int cholmod_hip_get_partition (cholmod_hip_plan *P, int64_t *owner)
 {
     if (!P || !owner) return CHOLMOD_HIP_INVALID ;

@@ -114,6 +114,58 @@ def test_partition_is_consistent_and_balanced(world):
     assert all(abs(s[1] - w.sum()) < 1e-9 * w.sum() for s in stats)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_contribution_routing_is_complete_and_disjoint(world):
+    """Contributions routed past the contribution blocks of shared fronts (host side, no GPU): on every rank, a front it holds
+    whose parent is shared contributes to EVERY shared ancestor (one pair each, no pair for anybody else); over the ranks,
+    the blocks of contribution-block columns of a shared front partition [0, ncb) among the members of its group."""
+    n, Ap, Ai, Ax = G.poisson3d(24)
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, G.geometric_nd(24, 24, 24, 4))
+    fv = ch.FactorView(Lf)
+    f = Lf.contents
+    blocks, npairs_seen = {}, 0
+    for r in range(world):
+        st = C.c_int(0)
+        plan = S.L.cholmod_hip_plan_create_dist(fv.n, fv.nsuper, f.super, f.pi, f.px, f.s, ch.HIP_PLAN_HOST_ONLY, r, world, C.byref(st))
+        assert plan and st.value == 0
+        o = np.empty(fv.nsuper, dtype=np.int64); S.L.cholmod_hip_get_partition(plan, o.ctypes.data)
+        g0 = np.empty(fv.nsuper, dtype=np.int64); gn = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_get_groups(plan, g0.ctypes.data, gn.ctypes.data)
+        sp = np.empty(fv.nsuper, dtype=np.int64); lv = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_get_maps(plan, sp.ctypes.data, lv.ctypes.data, None)
+        npair = S.L.cholmod_hip_debug_routing(plan, 0, None, None, None, None)
+        pd = np.empty(max(npair, 1), dtype=np.int64); pa = np.empty(max(npair, 1), dtype=np.int64)
+        lo = np.empty(fv.nsuper, dtype=np.int64); hi = np.empty(fv.nsuper, dtype=np.int64)
+        S.L.cholmod_hip_debug_routing(plan, npair, pd.ctypes.data, pa.ctypes.data, lo.ctypes.data, hi.ctypes.data)
+        S.L.cholmod_hip_plan_destroy(plan)
+        mine = (g0 <= r) & (r < g0 + gn)
+        ncb = (fv.pi[1:] - fv.pi[:-1]) - (fv.super[1:] - fv.super[:-1])
+        want = set()
+        for d in np.where(mine & (sp >= 0))[0]:
+            if o[sp[d]] >= 0 or ncb[d] == 0:
+                continue                                        # parent private: the ordinary child -> parent extend-add
+            a = sp[d]
+            while a >= 0:
+                assert o[a] < 0 and mine[a]                     # shared towards the root, and a child's group lies in its parent's
+                want.add((int(d), int(a)))
+                a = sp[a]
+        got = list(zip(pd[:npair].tolist(), pa[:npair].tolist()))
+        assert len(got) == len(set(got)) and set(got) == want, (r, len(got), len(want))
+        npairs_seen += len(got)
+        for s_ in np.where((o < 0) & mine & (ncb > 0))[0]:
+            blocks.setdefault(int(s_), []).append((int(lo[s_]), int(hi[s_]), int(ncb[s_]), int(gn[s_])))
+        assert np.all(lo[~((o < 0) & mine & (ncb > 0))] == -1)
+    assert blocks and npairs_seen >= 2 * world
+    for s_, bl in blocks.items():
+        assert len(bl) == bl[0][3]                               # one block per member of the group
+        bl.sort()
+        assert bl[0][0] == 0 and bl[-1][1] == bl[0][2]
+        assert all(bl[q][1] == bl[q + 1][0] for q in range(len(bl) - 1)) and all(b[0] <= b[1] and b[0] % 64 == 0 for b in bl)
+    S.free_factor(Lf); S.free_sparse(A); S.finish()
+
+
 def test_partition_balance_at_the_headline_size():
     """The metric's multi-GPU workload itself (Poisson 200^3, 8 M dof, geometric ND) through the
     host-only plan of every rank: the same partition everywhere and the flop loads the
