@@ -266,6 +266,7 @@ struct cholmod_hip_plan {
     void *ar_user = nullptr ;
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
+    bool upd3_wg4 = false ;             // k_update3 with four tiles per workgroup (CHOLMOD_HIP_UPD3_WG4)
     ncclComm_t nccl_world = nullptr ;
     std::map<i64, ncclComm_t> nccl_group ;
     hipEvent_t ar_done = nullptr ;          // all-reduce on the second stream finished
@@ -1865,6 +1866,11 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipExtStreamCreateWithCUMask (&P->stream, 8, m)) ;
     }
     else HIPCHK (hipStreamCreate (&P->stream)) ;
+    // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
+    // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
+    // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
+    P->upd3_wg4 = P->world > 1 ;
+    if (const char *e = getenv ("CHOLMOD_HIP_UPD3_WG4")) P->upd3_wg4 = atoi (e) != 0 ;
     {
         // The exchange stream runs BESIDE the rest of a trailing update (look-ahead: window open, extend-add, pack, the
         // collective): its small workgroups must get the wave slots the update's tiles free up, ahead of the update's own
@@ -2210,7 +2216,14 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_UPD_W:
             // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
-            if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            if (P->upd3_wg4)
+            {
+                // (several ranks) four tiles per workgroup: see k_update3
+                const unsigned g4 = (unsigned) (((L.grid + 31) / 32) * 8) ;
+                if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, COMMA 4>, dim3 (g4), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+                else TW_LAUNCH (k_update3<2 COMMA, COMMA 4>, dim3 (g4), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            }
+            else if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             else TW_LAUNCH (k_update3<2 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
         case K_UPD_PF:

@@ -1998,14 +1998,21 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         }
 }
 
-template <int DEPTH, int TW = 0>
-__global__ void __launch_bounds__(64, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
+// WPB = 4 (several ranks): four tiles per workgroup, one per wave, nothing shared.  Wave w of block b
+// plays block ((b >> 3) * 4 + w) * 8 + (b & 7) of the one-wave launch (same XCD, b & 7, hence the same
+// tile walk).  A retiring workgroup then frees a wave slot on EVERY SIMD of its CU at once: the
+// four-wave workgroups of the exchange stream (and of RCCL) find room beside the update, which
+// one-wave workgroups -- refilled SIMD by SIMD -- never leave them.
+template <int DEPTH, int TW = 0, int WPB = 1>
+__global__ void __launch_bounds__(64 * WPB, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
 {
-    int gi = find_group (g, ng, (int) blockIdx.x, &GemmGroup::tile_start) ;
+    int vb = (int) blockIdx.x ;
+    if constexpr (WPB > 1) vb = ((vb >> 3) * WPB + (int) (threadIdx.x >> 6)) * 8 + (vb & 7) ;
+    int gi = find_group (g, ng, vb, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
-    if ((int) blockIdx.x - G.tile_start >= G.nblk) return ;
-    if (!decode_tile (G, (int) blockIdx.x - G.tile_start, I, J)) return ;
+    if (vb - G.tile_start >= G.nblk) return ;
+    if (!decode_tile (G, vb - G.tile_start, I, J)) return ;
     if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
     else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
 }
