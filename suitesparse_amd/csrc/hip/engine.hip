@@ -1869,7 +1869,7 @@ static int upload_plan (cholmod_hip_plan *P)
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
     // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
-    P->upd3_wg4 = P->world > 1 ;
+    P->upd3_wg4 = P->world > 1 || P->force_shared ;
     if (const char *e = getenv ("CHOLMOD_HIP_UPD3_WG4")) P->upd3_wg4 = atoi (e) != 0 ;
     {
         // The exchange stream runs BESIDE the rest of a trailing update (look-ahead: window open, extend-add, pack, the
