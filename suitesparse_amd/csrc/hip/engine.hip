@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <memory>
 #include <new>
 #include <queue>
@@ -83,6 +84,7 @@ struct Launch {
     int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
     int leaf_pw = 0 ;               // K_SMALL: every front is a leaf of <= 32 rows and <= leaf_pw (4/8/12/16) columns: two per wave (k_leaf_pair)
     int ndiag = 0 ;                 // K_CHAINF: diagonal workgroups of the launch (they come first in the grid)
+    int pcnt = -1 ;                 // K_UPD_W: >= 0: persistent form (k_update3p), its block of eight tile counters
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -172,6 +174,7 @@ struct Schedule {
     std::vector<i32> sm ;           // front ids handled by the fused small-front kernel
     std::vector<Launch> launches ;
     int nevents = 0 ;
+    int npcnt = 0 ;                 // persistent update launches (eight counters each)
 } ;
 
 template <typename T> static T *dupload (const std::vector<T> &v, hipError_t &err)
@@ -266,6 +269,8 @@ struct cholmod_hip_plan {
     void *ar_user = nullptr ;
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
+    int ncu = 256, la_reserve = 64 ;    // compute units of the device; workgroup slots a persistent update leaves to the panel chain
+    int *d_pcnt = nullptr ;             // tile counters of the persistent update launches (8 per launch, zeroed per factorization)
     bool upd3_wg4 = false ;             // k_update3 with four tiles per workgroup (CHOLMOD_HIP_UPD3_WG4)
     ncclComm_t nccl_world = nullptr ;
     std::map<i64, ncclComm_t> nccl_group ;
@@ -370,6 +375,13 @@ namespace {
 // Append the launches that perform the dense partial factorization of a batch
 // of fronts (all of one etree level): two-level blocked right-looking Cholesky
 // of the first nscol columns of every front [panel | CB].
+// CHOLMOD_HIP_LOOKAHEAD=1: panel look-ahead on plans of one rank (schedule_dense); read per plan
+static bool lookahead_enabled ()
+{
+    const char *e = getenv ("CHOLMOD_HIP_LOOKAHEAD") ;
+    return e && atoi (e) != 0 ;
+}
+
 static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
     const char *assign_cb = nullptr, const i64 *win = nullptr, const i32 *child = nullptr)
@@ -434,7 +446,21 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         i64 mt = (G.m + SMALL - 1) / SMALL, nt = (G.n + SMALL - 1) / SMALL ;
         return G.tri ? nt * (nt + 1) / 2 + (mt - nt) * nt : mt * nt ;
     } ;
-    auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small)
+    // Panel look-ahead (one GPU; CHOLMOD_HIP_LOOKAHEAD): la_on = this batch runs its panel chain on the second stream beside
+    // the rest of the previous outer update (decided below, before the first launch of the batch).  tag_chain marks a launch
+    // as part of the chain: second stream, behind the event the chain is waiting for (if any).
+    bool la_on = false ;
+    const bool la_persistent = !getenv ("CHOLMOD_HIP_LA_NO_PERSISTENT") ;
+    int la_wait = -1 ;              // event the next chain launch has to wait for (the update that completed its block column)
+    long la_last = -1 ;             // index of the last chain launch
+    auto tag_chain = [&] (Launch &L)
+    {
+        if (!la_on) return ;
+        L.stream = 1 ;
+        if (la_wait >= 0) { L.wait_ev = la_wait ; la_wait = -1 ; }
+        la_last = (long) S.launches.size () ;       // (the caller pushes it next)
+    } ;
+    auto flush_updates = [&] (std::vector<GemmGroup> &big, std::vector<GemmGroup> &small, int on_stream = 0)
     {
         if (w_min_tiles > 0 && !use_big)
         {
@@ -468,7 +494,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             {
                 L.ng = (int) (S.gg.size () - L.goff) ;
                 L.grid = (int) tiles ;
-                if (L.ng) S.launches.push_back (L) ;
+                if (L.ng) { if (on_stream == 1) tag_chain (L) ; S.launches.push_back (L) ; }
                 L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
                 tiles = 0 ;
             } ;
@@ -686,8 +712,61 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
     // over the rank group of a shared front and they feed the exchange look-ahead.
     struct Upd { int q, kc, kk, t0, t1 ; bool cb, wide ; } ;
     std::vector<Upd> step ;
-    auto emit_step = [&] ()
+    std::function<void ()> emit_step ;
+    auto emit_outer_la = [&] (std::vector<Upd> &outer)
     {
+        // outer updates of a look-ahead batch, on the main stream behind the chain that produced their panels: first the
+        // part that completes the NEXT outer block column of every front (the chain goes on beside what follows), then
+        // the rest of the front and the contribution block
+        int evc = -1 ;
+        if (la_last >= 0)
+        {
+            if (S.launches [la_last].rec_ev < 0) S.launches [la_last].rec_ev = S.nevents++ ;
+            evc = S.launches [la_last].rec_ev ;
+        }
+        const size_t first = S.launches.size () ;
+        for (const Upd &x : outer)
+        {
+            const FrontD &f = fr [ids [x.q]] ;
+            if (x.t1 <= x.t0) continue ;
+            int tn = std::min (x.t0 + ob_of (f), x.t1) ;
+            add_update (big, small, f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false) ;
+        }
+        flush_updates (big, small) ;
+        const bool any_next = S.launches.size () > first ;
+        int eva = any_next ? record_last () : -1 ;
+        for (const Upd &x : outer)
+        {
+            const FrontD &f = fr [ids [x.q]] ;
+            int tn = std::min (x.t0 + ob_of (f), x.t1) ;
+            if (x.t1 > tn && x.t1 > x.t0) add_update (big, small, f, ids [x.q], tn, x.kc, x.kk, f.nsrow - tn, x.t1 - tn, false) ;
+            add_update (big, small, f, ids [x.q], f.nscol, x.kc, x.kk, f.ncb, f.ncb, true) ;
+        }
+        const size_t first_rest = S.launches.size () ;
+        flush_updates (big, small) ;
+        // what runs beside the next chain leaves it room: the one-wave-per-tile launches of the rest in their persistent form
+        if (any_next && la_persistent)
+            for (size_t q = first_rest ; q < S.launches.size () ; q++)
+                if (S.launches [q].kind == K_UPD_W) S.launches [q].pcnt = S.npcnt++ ;
+        if (S.launches.size () > first && evc >= 0) S.launches [first].wait_ev = evc ;
+        if (any_next) la_wait = eva ;
+    } ;
+    emit_step = [&] ()
+    {
+        if (la_on)
+        {
+            std::vector<Upd> outer, inner ;
+            for (const Upd &x : step) (x.cb ? outer : inner).push_back (x) ;
+            if (!outer.empty ())
+            {
+                step.swap (inner) ;
+                if (!step.empty ()) emit_step () ;      // (the chain's own updates: second stream, through the code below)
+                emit_outer_la (outer) ;
+                step.clear () ;
+                return ;
+            }
+        }
+        const int chain_stream = la_on ? 1 : 0 ;
         bool any_next = false ;
         if (xla)
             for (const Upd &x : step)
@@ -832,7 +911,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 }
             }
         }
-        flush_updates (big, small) ;
+        flush_updates (big, small, chain_stream) ;
         if (any_next)
             for (const Upd &x : step)
             {
@@ -994,6 +1073,22 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
         }
         return ;
     }
+    // ---- panel look-ahead on one GPU (CHOLMOD_HIP_LOOKAHEAD=1): the chain of outer block column k + 1 (dpotrf, panel solves,
+    // the doubling updates inside the block column: launches of a few dozen to a few hundred workgroups, 25-40 us each whatever
+    // their size) runs on the second stream as soon as the part of outer update k that completes block column k + 1 is done,
+    // beside the rest of that update on the main stream; the outer update k + 1 waits for the chain.  The update kernel runs
+    // four tiles per workgroup on such plans (k_update3, WPB = 4), so the chain's four-wave workgroups find room beside it.
+    if (world == 1 && lookahead_enabled ())
+    {
+        bool any_shared = false, any_two = false ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            if (is_shared (ids [q]) || windowed (ids [q])) any_shared = true ;
+            if (fr [ids [q]].nscol > ob_of (fr [ids [q]])) any_two = true ;
+        }
+        la_on = !any_shared && any_two ;
+        if (la_on && !S.launches.empty ()) la_wait = record_last () ;       // (whatever assembled these fronts)
+    }
     for (int i0 = 0 ; i0 < maxnscol ; i0 += NB)
     {
         // ---- multi-GPU: a 512-column block column of a shared front holds per-rank
@@ -1033,7 +1128,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             Lp.flops += (double) nb * nb * nb / 3.0 ;
         }
         Lp.ng = Lp.grid = (int) (S.pg.size () - Lp.goff) ;
-        if (Lp.ng) S.launches.push_back (Lp) ;
+        if (Lp.ng) { tag_chain (Lp) ; S.launches.push_back (Lp) ; }
         // Fronts whose step is "solve, K = 64 update of the next 64 columns, factor the next
         // diagonal block" (every other step of the doubling schedule) take all three in one
         // launch (k_trsm_upd): a full panel, a full next block inside the same outer block
@@ -1065,7 +1160,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
                 pf_done [q] = i0 + NB ;
             }
             Lf_.ng = (int) (S.tg.size () - Lf_.goff) ; Lf_.grid = fblocks ; Lf_.aux = NB ;
-            if (Lf_.ng) S.launches.push_back (Lf_) ;
+            if (Lf_.ng) { tag_chain (Lf_) ; S.launches.push_back (Lf_) ; }
         }
         // trsm of the rows below
         Launch Lt {K_TRSM, 0, 0, S.tg.size (), 0, 0} ;
@@ -1100,7 +1195,7 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             }
         }
         Lt.ng = (int) (S.tg.size () - Lt.goff) ; Lt.grid = blocks ;
-        if (Lt.ng) S.launches.push_back (Lt) ;
+        if (Lt.ng) { tag_chain (Lt) ; S.launches.push_back (Lt) ; }
         // a block column of a shared front is complete on the rows of its owners: gather the
         // solved row chunks on every rank of the group before anything uses it as an operand
         for (int q = 0 ; q < nf ; q++)
@@ -1144,6 +1239,14 @@ static void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int n
             step.push_back (Upd {q, kc, t0 - kc, t0, t1, false, p * NB >= MB}) ;
         }
         emit_step () ;
+    }
+    if (la_on && la_last >= 0)
+    {
+        // whatever follows the batch on the main stream comes after the chain's last launch
+        if (S.launches [la_last].rec_ev < 0) S.launches [la_last].rec_ev = S.nevents++ ;
+        Launch Lj {K_JOIN, 0, 0, 0, 0, 0} ;
+        Lj.wait_ev = S.launches [la_last].rec_ev ;
+        S.launches.push_back (Lj) ;
     }
 }
 
@@ -1837,7 +1940,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_crel, P->d_relpairs, P->d_dinv, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_pcnt, P->d_crel, P->d_relpairs, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -1869,7 +1972,7 @@ static int upload_plan (cholmod_hip_plan *P)
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
     // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
-    P->upd3_wg4 = P->world > 1 || P->force_shared ;
+    P->upd3_wg4 = P->world > 1 || P->force_shared || lookahead_enabled () ;
     if (const char *e = getenv ("CHOLMOD_HIP_UPD3_WG4")) P->upd3_wg4 = atoi (e) != 0 ;
     {
         // The exchange stream runs BESIDE the rest of a trailing update (look-ahead: window open, extend-add, pack, the
@@ -1922,6 +2025,13 @@ static int upload_plan (cholmod_hip_plan *P)
     P->d_pg = dupload (P->sch.pg, e) ; HIPCHK (e) ;
     P->d_tg = dupload (P->sch.tg, e) ; HIPCHK (e) ;
     HIPCHK (hipMalloc ((void **) &P->d_tu_cnt, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32))) ;
+    if (P->sch.npcnt > 0)
+    {
+        HIPCHK (hipMalloc ((void **) &P->d_pcnt, 8 * (size_t) P->sch.npcnt * sizeof (int))) ;
+        int dev = 0, ncu = 0 ;
+        if (hipGetDevice (&dev) == hipSuccess && hipDeviceGetAttribute (&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) P->ncu = ncu ;
+        if (const char *e = getenv ("CHOLMOD_HIP_LA_RESERVE")) P->la_reserve = atoi (e) ;
+    }
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_dg = dupload (P->sch.dg, e) ; HIPCHK (e) ;
     P->d_rg = dupload (P->sch.rg, e) ; HIPCHK (e) ;
@@ -2216,7 +2326,19 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
             break ;
         case K_UPD_W:
             // operand sets in flight: four for long contractions, two for short ones (tools/upd3.py)
-            if (P->upd3_wg4)
+            if (L.pcnt >= 0 && !serial)
+            {
+                // persistent form beside a panel chain: 2 workgroups per CU minus the reserve (CHOLMOD_HIP_LA_RESERVE, default 64)
+                int slots = 2 * P->ncu - P->la_reserve ;
+                if (slots < 8) slots = 8 ;
+                unsigned gp = (unsigned) std::min<long> (((long) L.grid + 3) / 4, (long) slots) ;
+                static const int rsv = [] () { const char *e = getenv ("CHOLMOD_HIP_LA_RESERVE_CU") ; return e ? atoi (e) : 0 ; } () ;
+                if (rsv > 0) gp = (unsigned) (4 * P->ncu) ;         // (2 per CU stay, the others are burnt on the reserved CUs)
+                int *cnt = P->d_pcnt + 8 * (size_t) L.pcnt ;
+                if (L.aux >= 1024) TW_LAUNCH (k_update3p<4 COMMA, >, dim3 (gp), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, L.grid, cnt, P->d_Lx, P->d_cb, rsv) ;
+                else TW_LAUNCH (k_update3p<2 COMMA, >, dim3 (gp), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, L.grid, cnt, P->d_Lx, P->d_cb, rsv) ;
+            }
+            else if (P->upd3_wg4)
             {
                 // (several ranks) four tiles per workgroup: see k_update3
                 const unsigned g4 = (unsigned) (((L.grid + 31) / 32) * 8) ;
@@ -2292,6 +2414,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (poison ? P->lx_fronts : P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
+    if (P->d_pcnt) HIPCHK (hipMemsetAsync (P->d_pcnt, 0, 8 * (size_t) P->sch.npcnt * sizeof (int), st)) ;
     if (P->d_cflags) HIPCHK (hipMemsetAsync (P->d_cflags, 0, (4 * (size_t) P->sch.ncflags + 4) * sizeof (int), st)) ;
     if (P->n > 0 && P->amap_valid)
     {
@@ -3355,6 +3478,13 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     HIPCHK (hipMalloc ((void **) &P.d_cflags, (4 * (size_t) S.ncflags + 4) * sizeof (int))) ;
     HIPCHK (hipMemset (P.d_cflags, 0, (4 * (size_t) S.ncflags + 4) * sizeof (int))) ;
     HIPCHK (hipMalloc ((void **) &P.d_dinv, (size_t) std::max (S.max_dinv_slots, 1) * 4096 * sizeof (double))) ;
+    P.sch.npcnt = S.npcnt ;
+    if (S.npcnt > 0)
+    {
+        HIPCHK (hipMalloc ((void **) &P.d_pcnt, 8 * (size_t) S.npcnt * sizeof (int))) ;
+        HIPCHK (hipMemset (P.d_pcnt, 0, 8 * (size_t) S.npcnt * sizeof (int))) ;
+    }
+    P.upd3_wg4 = lookahead_enabled () ;
     HIPCHK (hipMemcpy (P.d_Lx, F, nsrow * nscol * sizeof (double), hipMemcpyHostToDevice)) ;
     if (ncb > 0)
         HIPCHK (hipMemcpy2D (P.d_cb, ncb * sizeof (double), F + nscol + nscol * nsrow,
@@ -3375,7 +3505,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
     P.stream = nullptr ; P.stream2 = nullptr ; P.sync_ev.clear () ;
     P.d_Lx = P.d_cb = nullptr ; P.d_info = nullptr ;
     P.d_pg = nullptr ; P.d_tg = nullptr ; P.d_gg = nullptr ; P.d_tu_cnt = nullptr ;
-    P.d_dg = nullptr ; P.d_rg = nullptr ; P.d_dinv = nullptr ; P.d_cg = nullptr ; P.d_cflags = nullptr ;
+    P.d_dg = nullptr ; P.d_rg = nullptr ; P.d_dinv = nullptr ; P.d_cg = nullptr ; P.d_cflags = nullptr ; P.d_pcnt = nullptr ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -2017,6 +2017,41 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_update3 (const GemmGroup *g, in
     else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
 }
 
+// Persistent form (panel look-ahead on one GPU): the launch has FEWER workgroups than the chip has room for (engine.hip:
+// 2 per CU minus a reserve), every wave takes tiles from a counter until none is left -- the reserve stays free for the
+// panel chain of the next outer block column, which runs beside this update on the second stream and would otherwise find
+// every register file taken for a whole tile time (0.2 - 0.9 ms).  cnt [x] counts the virtual blocks == x (mod 8) handed
+// out: a wave on XCD x takes those first (the tile walk of decode_tile assumes block b on XCD b % 8), then helps the others.
+template <int DEPTH, int TW = 0>
+__global__ void __launch_bounds__(256, 2) k_update3p (const GemmGroup *g, int ng, int nvb, int *cnt, double *Lx, double *CB, int rsv)
+{
+    // rsv > 0 (tuning, CHOLMOD_HIP_LA_RESERVE_CU): workgroups that land on a compute unit with HW_ID.cu_id < rsv leave at once --
+    // those CUs stay free of update waves (the launch then has spare workgroups to burn, engine.hip): fp64 work of another
+    // kernel that shares a SIMD with this one's matrix-core stream runs 8 - 20 x slower (measured), so room in the register
+    // file is not enough for the panel chain, it needs compute units of its own
+    if (rsv > 0 && (int) ((__builtin_amdgcn_s_getreg ((31 << 11) | 4) >> 8) & 0xF) < rsv) return ;
+    const int xcc = (int) (__builtin_amdgcn_s_getreg ((31 << 11) | 20) & 7) ;      // HW_REG_XCC_ID
+    for (int o = 0 ; o < 8 ; o++)
+    {
+        const int x = (xcc + o) & 7 ;
+        for ( ; ; )
+        {
+            int t = 0 ;
+            if ((threadIdx.x & 63) == 0) t = atomicAdd (cnt + x, 1) ;
+            t = __builtin_amdgcn_readfirstlane (t) ;
+            const int vb = t * 8 + x ;
+            if (vb >= nvb) break ;
+            int gi = find_group (g, ng, vb, &GemmGroup::tile_start) ;
+            GemmGroup G = g [gi] ;
+            int I, J ;
+            if (vb - G.tile_start >= G.nblk) continue ;
+            if (!decode_tile (G, vb - G.tile_start, I, J)) continue ;
+            if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
+            else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
+        }
+    }
+}
+
 // ---- trailing update that also factors the next diagonal block ------------------
 // The narrow (K < 512) updates of the panel chain are followed, on the same stream, by
 // the dpotrf of the block they have just finished updating: tile (0,0) of their region.

@@ -400,6 +400,21 @@ def test_bench_matrix_file_reader_path():
     assert d["residual_2norm"] < 1e-11
 
 
+# ---- panel look-ahead on one GPU (opt-in) ------------------------------------------------------
+
+@pytest.mark.parametrize("name,reserve", [("box42_r3_nd", "64"), ("p3d_64_nd", "448"), ("p2d_1259_nd", "64")])
+def test_panel_lookahead_matches_oracle(name, reserve, monkeypatch):
+    """CHOLMOD_HIP_LOOKAHEAD=1: the panel chain of outer block column k + 1 on the second stream beside the rest of outer
+    update k (its one-wave-per-tile launches in their persistent form, k_update3p: tiles handed out by counters), the
+    update kernel with four tiles per workgroup -- against the oracle, with the contribution-block arena poisoned so that
+    a launch running ahead of what it depends on shows.  A reserve of 448 leaves the persistent launches 64 workgroups:
+    every workgroup walks several XCDs' tile lists."""
+    monkeypatch.setenv("CHOLMOD_HIP_LOOKAHEAD", "1")
+    monkeypatch.setenv("CHOLMOD_HIP_LA_RESERVE", reserve)
+    monkeypatch.setenv("CHOLMOD_HIP_TEST_POISON_ARENA", "1")
+    _compare(name, again=True)
+
+
 # ---- the 256-column panel chain (opt-in) ----------------------------------------------------
 
 @pytest.mark.parametrize("name", ["box42_r3_nd", "p3d_64_nd", "p2d_1259_nd"])
