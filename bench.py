@@ -131,9 +131,9 @@ def cpu_baseline(sample_m):
                       f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas}, host cores {cores}"}
 
 
-PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r04p_pmc_summary_poisson200_top48.json"}
+PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r04zq_pmc_summary_poisson200_top48.json"}
 # counters summed per kernel over one refactorization of the thin stand-in (tools/evidence.sh PMC=1, tools/pmc_by_kernel.py)
-PMC_THIN = "r04p_pmc_by_kernel_poisson2d1259.json"
+PMC_THIN = "r04zq_pmc_by_kernel_poisson2d1259.json"
 
 
 def thin_traffic():

@@ -2289,6 +2289,22 @@ struct XchgD {
 // 67 GB through these copies per factorization of Poisson 200^3)
 // grid: w * (g + 1) workgroups for modes 0 / 3 (part g = the diagonal block; mode 3 has none), w * 2 for mode 1 (D, own
 // chunk), w for mode 2.
+// n doubles from src to dst, those at index >= nr as zeros (pad) or not at all: four independent loads per thread in flight
+// (the pack of a block column and the unpack of the gathered chunks are 48 GB each per rank of 8 and factorization)
+__device__ __forceinline__ void xm_copy (double *dst, const double *src, int n, int nr, int tid, int nt, bool pad)
+{
+    int i = tid ;
+    for ( ; i + 3 * nt < n ; i += 4 * nt)
+    {
+        double v [4] ;
+#pragma unroll
+        for (int u = 0 ; u < 4 ; u++) { const int e = i + u * nt ; v [u] = (e < nr) ? __builtin_nontemporal_load (src + e) : 0.0 ; }
+#pragma unroll
+        for (int u = 0 ; u < 4 ; u++) { const int e = i + u * nt ; if (pad || e < nr) dst [e] = v [u] ; }
+    }
+    for ( ; i < n ; i += nt) { if (i < nr) dst [i] = __builtin_nontemporal_load (src + i) ; else if (pad) dst [i] = 0.0 ; }
+}
+
 __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *Lx, double *stage, double *ag)
 {
     const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w ;
@@ -2312,7 +2328,7 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
             const double *src = S + X.w + (i64) q * X.R ;
             double *dst = stage + (i64) q * seg + (i64) X.w * X.w + (i64) j * X.R ;
             const int nr = X.mb - q * X.R ;                      // rows of this chunk that exist
-            for (int i = tid ; i < X.R ; i += (int) blockDim.x) dst [i] = (i < nr) ? src [i] : 0.0 ;
+            xm_copy (dst, src, X.R, nr, tid, (int) blockDim.x, true) ;
         }
     }
     else if (mode == 1)
@@ -2341,7 +2357,7 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
         const double *src = ag + (i64) q * X.R * X.w + (i64) j * X.R ;
         double *dst = S + X.w + (i64) q * X.R ;
         const int nr = X.mb - q * X.R ;
-        for (int i = tid ; i < X.R && i < nr ; i += (int) blockDim.x) dst [i] = src [i] ;
+        xm_copy (dst, src, X.R < nr ? X.R : nr, nr, tid, (int) blockDim.x, false) ;
     }
 }
 

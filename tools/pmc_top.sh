@@ -4,8 +4,8 @@
 # launches of ONE factorization -- a counter pass over every launch of a 200^3 factorization does not
 # finish (rounds 1 and 2).  Pass 0 is a plain --kernel-trace of the same command: it yields the
 # per-kernel iteration index and the duration of every launch, i.e. the selection.
-# usage (repo root, on the GPU box):  bash tools/pmc_top.sh <tag> [grid=200] [regex='k_update3<4, 0>'] [ntop=48]
-TAG=${1:-r03}; GRID=${2:-200}; RE=${3:-k_update3<4, 0>}; NTOP=${4:-48}
+# usage (repo root, on the GPU box):  bash tools/pmc_top.sh <tag> [grid=200] [regex='k_update3<4, 0, 1>'] [ntop=48]
+TAG=${1:-r03}; GRID=${2:-200}; RE=${3:-k_update3<4, 0, 1>}; NTOP=${4:-48}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace -d $O/${TAG}_pmctrace --output-format csv -- python $R/tools/one_factorization.py --grid $GRID > $O/${TAG}_pmctrace.log 2>&1
