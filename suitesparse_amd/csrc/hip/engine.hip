@@ -269,6 +269,7 @@ struct cholmod_hip_plan {
     void *ar_user = nullptr ;
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
+    int jitter_us = 0 ; unsigned long long jitter_state = 0 ;     // test hook CHOLMOD_HIP_TEST_JITTER (run_launch)
     int ncu = 256, la_reserve = 64 ;    // compute units of the device; workgroup slots a persistent update leaves to the panel chain
     int *d_pcnt = nullptr ;             // tile counters of the persistent update launches (8 per launch, zeroed per factorization)
     bool upd3_wg4 = false ;             // k_update3 with four tiles per workgroup (CHOLMOD_HIP_UPD3_WG4)
@@ -1969,6 +1970,15 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipExtStreamCreateWithCUMask (&P->stream, 8, m)) ;
     }
     else HIPCHK (hipStreamCreate (&P->stream)) ;
+    if (const char *e = getenv ("CHOLMOD_HIP_TEST_JITTER"))
+    {
+        unsigned long long seed = 0 ; int mx = 2000 ;
+        if (sscanf (e, "%llu:%d", &seed, &mx) >= 1 && mx > 0)
+        {
+            P->jitter_us = mx ;
+            P->jitter_state = seed * 0x9E3779B97F4A7C15ull + (unsigned long long) (P->rank + 1) * 0xD1B54A32D192ED03ull ;
+        }
+    }
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
     // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
@@ -2150,7 +2160,25 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 // the update kernels: 0 real, 1 twin (even-column contraction), 2 complex storage
 #define TW_LAUNCH(KA, KB, ...) do { if (cx) hipLaunchKernelGGL ((KA 2 KB), __VA_ARGS__) ; else if (twin) hipLaunchKernelGGL ((KA 1 KB), __VA_ARGS__) ; \
                                     else hipLaunchKernelGGL ((KA 0 KB), __VA_ARGS__) ; } while (0)
-    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    // (test hook CHOLMOD_HIP_TEST_DROP_WAITS=1: the cross-stream waits of the schedule are skipped -- the mutation the jitter
+    // test must catch, tests/test_gpu_scale.py::test_stream_jitter_catches_a_dropped_wait)
+    static const bool drop_waits = getenv ("CHOLMOD_HIP_TEST_DROP_WAITS") != nullptr ;
+    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS && !drop_waits) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    if (P->jitter_us > 0 && !serial)
+    {
+        // test hook CHOLMOD_HIP_TEST_JITTER=seed[:max_us]: ahead of one launch in three, its stream is held up for a random
+        // time (mostly tens of microseconds, now and then max_us): a launch whose input comes from the OTHER stream without
+        // an event between them then runs before its producer -- with the arena and the windows poisoned that shows in
+        // the factor (tests/test_dist.py, tools/dist_soak.py).  The schedule itself is what ships.
+        P->jitter_state = P->jitter_state * 6364136223846793005ull + 1442695040888963407ull ;
+        const unsigned r = (unsigned) (P->jitter_state >> 33) ;
+        if (r % 3 == 0)
+        {
+            const unsigned u = (r >> 8) % 100 ;
+            const long long us = u < 90 ? 5 + (long long) ((r >> 16) % 60) : (long long) ((r >> 16) % (unsigned) P->jitter_us) ;
+            hipLaunchKernelGGL (k_spin, dim3 (1), dim3 (64), 0, st, us * 100) ;
+        }
+    }
     switch (L.kind)
     {
         case K_JOIN: break ;

@@ -2289,6 +2289,13 @@ struct XchgD {
 // 67 GB through these copies per factorization of Poisson 200^3)
 // grid: w * (g + 1) workgroups for modes 0 / 3 (part g = the diagonal block; mode 3 has none), w * 2 for mode 1 (D, own
 // chunk), w for mode 2.
+// test hook (CHOLMOD_HIP_TEST_JITTER): keeps its stream busy for about `ticks` ticks of the 100 MHz wall clock
+__global__ void k_spin (long long ticks)
+{
+    const long long t0 = (long long) wall_clock64 () ;
+    while ((long long) wall_clock64 () - t0 < ticks) __builtin_amdgcn_s_sleep (20) ;
+}
+
 // n doubles from src to dst, those at index >= nr as zeros (pad) or not at all: four independent loads per thread in flight
 // (the pack of a block column and the unpack of the gathered chunks are 48 GB each per rank of 8 and factorization)
 __device__ __forceinline__ void xm_copy (double *dst, const double *src, int n, int nr, int tid, int nt, bool pad)

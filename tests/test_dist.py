@@ -444,6 +444,27 @@ def test_distributed_chain_variants(env, flags):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,case,seed", [(4, "p3d_32", 1), (3, "p3d_48", 2), (2, "dense_1400", 3)])
+def test_distributed_under_stream_jitter(world, case, seed):
+    """CHOLMOD_HIP_TEST_JITTER: ahead of one launch in three its stream is held up for a random time (tens of microseconds,
+    now and then up to 1.5 ms), differently on every rank -- a launch that reads what the other stream (or a collective)
+    produces without an event in between then runs before its producer, and with the arena, the windows and the staging
+    buffers poisoned that shows in the factor."""
+    res = _run_ranks(world, "gpu", case, extra_env=dict(NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER=f"{seed}:1500"))
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 and r["resid"] < 1e-11, r
+
+
+@pytest.mark.gpu
+def test_distributed_jitter_catches_dropped_waits():
+    """The mutation the jitter must catch: the same run with the schedule's cross-stream waits skipped
+    (CHOLMOD_HIP_TEST_DROP_WAITS) does not reproduce the oracle's factor."""
+    res = _run_ranks(3, "gpu", "p3d_48", extra_env=dict(NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="5:1500",
+                                                         CHOLMOD_HIP_TEST_DROP_WAITS="1"))
+    assert not all(r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 for r in res), res
+
+
+@pytest.mark.gpu
 def test_distributed_not_posdef_inside_a_shared_front():
     """The failing pivot lies in the root, a front shared by all ranks and factored through its windows: same minor, same
     zero pattern as the reference's repeat-supernode pass on every rank."""
