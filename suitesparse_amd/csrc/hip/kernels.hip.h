@@ -445,7 +445,20 @@ __device__ __forceinline__ double readlane_f64 (double v, int l)
 // identity-padded to nblk 16-column panels).
 // *s_fail (preset to -1) receives the first column with a pivot <= 0.  All 256
 // threads of the workgroup call it; it ends with a barrier.
-template <typename Tick>
+// PHI: the block is the phi embedding of a complex Hermitian block (rows / columns 2k, 2k+1 = re, im; complex storage):
+// the panel phase then eliminates COMPLEX columns -- the pair (2p, 2p+1) in one step.  Column 2p+1 is the rotation of
+// column 2p (entry (r, 2p+1) = -/+ entry (r ^ 1, 2p)), so it is never eliminated, only rebuilt at the end; with
+// t = column 2p / d and s (r) = +t (r + 1) on even rows, -t (r - 1) on odd rows (a lane swap inside the pair), a trailing
+// even column 2j takes  a -= t x_j + s y_j  (x_j, y_j = rows 2j, 2j+1 of column 2p: the complex multiply-add of zpotrf's
+// rank-1 step): 8 pivots, reciprocals and 56 (read-lane pair, two fma) steps per 16 twin columns instead of 16 and 120.
+__device__ __forceinline__ double lane_xor1_f64 (double v)
+{
+    int lo = __double2loint (v), hi = __double2hiint (v) ;
+    lo = __builtin_amdgcn_update_dpp (0, lo, 0xB1, 0xF, 0xF, true) ;       // quad_perm [1, 0, 3, 2]
+    hi = __builtin_amdgcn_update_dpp (0, hi, 0xB1, 0xF, 0xF, true) ;
+    return __hiloint2double (hi, lo) ;
+}
+template <bool PHI = false, typename Tick>
 __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, int tid, Tick tick)
 {
     const int lane = tid & 63, wave = tid >> 6 ;
@@ -453,7 +466,56 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
     for (int jb = 0 ; jb < nblk ; jb++)
     {
         int c0 = 16 * jb ;
-        if (wave == 0)
+        if (PHI && wave == 0)
+        {
+            int row = c0 + lane ;
+            int rr = row < PF_NB ? row : PF_NB - 1 ;
+            const bool odd = (lane & 1) != 0 ;
+            double a [8] ;                      // the even columns c0 + 2 p of the panel
+#pragma unroll
+            for (int p = 0 ; p < 8 ; p++) a [p] = T [(c0 + 2 * p) * PF2_LD + rr] ;
+            int fail = -1 ;
+            double dv = 1.0 ;                   // lane 2 p keeps the pivot of complex column p
+#pragma unroll
+            for (int p = 0 ; p < 8 ; p++)
+            {
+                double d = readlane_f64 (a [p], 2 * p) ;
+                if (fail < 0 && d <= 0.0) fail = c0 + 2 * p ;
+                double x = __builtin_amdgcn_rcp (d) ;
+                double e = __builtin_fma (-d, x, 1.0) ;
+                double t0 = a [p] * x ;
+                double u [8], v [8] ;
+#pragma unroll
+                for (int j = p + 1 ; j < 8 ; j++) { u [j] = readlane_f64 (a [p], 2 * j) ; v [j] = readlane_f64 (a [p], 2 * j + 1) ; }
+                __builtin_amdgcn_sched_barrier (0) ;
+                double t = __builtin_fma (t0, e, t0) ;
+                double sw = lane_xor1_f64 (t) ;
+                double sgn = odd ? -sw : sw ;
+#pragma unroll
+                for (int j = p + 1 ; j < 8 ; j++) { a [j] = __builtin_fma (-t, u [j], a [j]) ; a [j] = __builtin_fma (-sgn, v [j], a [j]) ; }
+                if (lane == 2 * p) dv = d ;
+                __builtin_amdgcn_sched_barrier (0) ;
+            }
+            tick (1) ;
+            double r, ri ;
+            sqrt_rsqrt (dv, r, ri) ;
+            if (row < PF_NB)
+            {
+#pragma unroll
+                for (int p = 0 ; p < 8 ; p++)
+                {
+                    double rc = readlane_f64 (r, 2 * p), ric = readlane_f64 (ri, 2 * p) ;
+                    double ev = (lane == 2 * p) ? rc : a [p] * ric ;
+                    if (fail >= 0 && c0 + 2 * p >= fail) ev = 0.0 ;
+                    double sw = lane_xor1_f64 (ev) ;
+                    T [(c0 + 2 * p) * PF2_LD + row] = ev ;
+                    T [(c0 + 2 * p + 1) * PF2_LD + row] = odd ? sw : -sw ;        // (its entry above the diagonal is never read)
+                }
+            }
+            if (fail >= 0 && lane == 0) (*s_fail) = fail ;
+            tick (2) ;
+        }
+        else if (wave == 0)
         {
             // panel rows c0 .. 63: lane = row c0 + lane (lanes past the block idle)
             int row = c0 + lane ;
@@ -601,7 +663,7 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
     if (tid == 0) s_fail = -1 ;
     __syncthreads () ;
     tick (0) ;
-    pf_eliminate (T, nblk, &s_fail, tid, tick) ;
+    pf_eliminate<CX> (T, nblk, &s_fail, tid, tick) ;
     int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + fail + 1 ;
     // write-back of the lower triangle (columns at / beyond a failed pivot: zero)
@@ -2092,7 +2154,7 @@ __global__ void __launch_bounds__(256, 2) k_update2f (const GemmGroup *g, int ng
         return ;
     }
     auto tick = [] (int) {} ;
-    pf_eliminate (sm, PF_NB / 16, &s_fail, tid, tick) ;
+    pf_eliminate<TW == 2> (sm, PF_NB / 16, &s_fail, tid, tick) ;
     const int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.pf_col0 + fail + 1 ;
     pf_store<TW == 2> (A, lda, sm, PF_NB, fail, lane, wave) ;
@@ -2257,7 +2319,7 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
             T [j * PF2_LD + i] = (i >= j) ? cj [jt][r] : 0.0 ;
         }
     __syncthreads () ;
-    pf_eliminate (T, PF_NB / 16, &s_fail, tid, tick) ;
+    pf_eliminate<CX> (T, PF_NB / 16, &s_fail, tid, tick) ;
     const int fail = s_fail ;
     if (fail >= 0 && tid == 0) info [G.front] = G.col0 + 64 + fail + 1 ;
     pf_store<CX> (A, lda, T, PF_NB, fail, lane, wave) ;
