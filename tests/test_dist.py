@@ -459,8 +459,11 @@ def test_distributed_under_stream_jitter(world, case, seed):
 def test_distributed_jitter_catches_dropped_waits():
     """The mutation the jitter must catch: the same run with the schedule's cross-stream waits skipped
     (CHOLMOD_HIP_TEST_DROP_WAITS) does not reproduce the oracle's factor."""
-    res = _run_ranks(3, "gpu", "p3d_48", extra_env=dict(NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="5:1500",
-                                                         CHOLMOD_HIP_TEST_DROP_WAITS="1"))
+    try:
+        res = _run_ranks(3, "gpu", "p3d_48", extra_env=dict(NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="5:1500",
+                                                             CHOLMOD_HIP_TEST_DROP_WAITS="1"))
+    except (AssertionError, RuntimeError, subprocess.SubprocessError):
+        return                      # (a rank that reads a poisoned buffer too early may just as well die: noticed all the same)
     assert not all(r["ok"] == 1 and r["status"] == 0 and r["err"] < 1e-12 for r in res), res
 
 
