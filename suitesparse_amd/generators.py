@@ -42,6 +42,26 @@ def poisson3d(m: int, my: int | None = None, mz: int | None = None):
     x = p % mx
     y = (p // mx) % my
     z = p // (mx * my)
+    # column p holds rows p, p + 1, p + mx, p + mx my (those that exist), already in ascending order: the CSC arrays are
+    # written in place, without the sort of the general path (8 M columns: seconds instead of minutes)
+    if mx >= 2 and my >= 2:
+        masks = (x + 1 < mx, y + 1 < my, z + 1 < mz)
+        offs = (1, mx, mx * my)
+        cnt = np.ones(n, dtype=np.int64)
+        for mk in masks:
+            cnt += mk
+        Ap = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(cnt, out=Ap[1:])
+        Ai = np.empty(int(Ap[-1]), dtype=np.int64)
+        Ax = np.full(int(Ap[-1]), -1.0)
+        pos = Ap[:-1].copy()
+        Ai[pos] = p
+        Ax[pos] = 6.0
+        pos += 1
+        for mk, off in zip(masks, offs):
+            Ai[pos[mk]] = p[mk] + off
+            pos += mk
+        return n, Ap, Ai, Ax
     rows = [p]
     cols = [p]
     vals = [np.full(n, 6.0)]

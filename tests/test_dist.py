@@ -42,10 +42,15 @@ def _run_ranks(world, mode, case, timeout=600, extra_env=None):
     return [json.load(open(f"{out}.{r}")) for r in range(world)]
 
 
-def _host_plans(world, n, Ap, Ai, Ax, perm, postorder=True, ranks=None):
-    S = ch.Session(use_gpu=0, postorder=postorder)
-    A = S.sparse(n, Ap, Ai, Ax, -1)
-    Lf = S.analyze(A, perm)
+def _host_plans(world, n, Ap, Ai, Ax, perm, postorder=True, ranks=None, analysed=None):
+    """Host-only plans of the given ranks of a world.  analysed = (S, A, Lf) of an earlier call (kept by the caller, who
+    frees it): the analysis is not repeated."""
+    if analysed is None:
+        S = ch.Session(use_gpu=0, postorder=postorder)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.analyze(A, perm)
+    else:
+        S, A, Lf = analysed
     fv = ch.FactorView(Lf)
     f = Lf.contents
     owners, stats, levels = [], [], None
@@ -70,7 +75,8 @@ def _host_plans(world, n, Ap, Ai, Ax, perm, postorder=True, ranks=None):
         S.L.cholmod_hip_plan_destroy(plan)
     nscol = np.diff(fv.super).astype(float)
     nsrow = np.diff(fv.pi).astype(float)
-    S.free_factor(Lf); S.free_sparse(A); S.finish()
+    if analysed is None:
+        S.free_factor(Lf); S.free_sparse(A); S.finish()
     return owners, stats, levels, nscol, nsrow
 
 
@@ -175,9 +181,12 @@ def test_partition_balance_at_the_headline_size():
     m = 200
     n, Ap, Ai, Ax = G.poisson3d(m)
     perm = G.geometric_nd(m, m, m, 4)
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)                          # (once for the three worlds)
     for world in (8, 4, 2):
         owners, stats, (sparent, level), nscol, nsrow = _host_plans(world, n, Ap, Ai, Ax, perm,
-                                                                   ranks=(0, world - 1))
+                                                                   ranks=(0, world - 1), analysed=(S, A, Lf))
         o = owners[0]
         assert np.array_equal(o, owners[1])
         g0, gn = _host_plans.groups[0]
@@ -190,6 +199,7 @@ def test_partition_balance_at_the_headline_size():
         print("world", world, "loads / mean", np.round(loads / loads.mean(), 4), "shared fronts", int(shared.sum()))
         assert loads.max() <= 1.05 * loads.mean() and loads.min() >= 0.95 * loads.mean(), loads / loads.mean()
         assert int(shared.sum()) <= 64                  # a handful of shared fronts, the rest private subtrees
+    S.free_factor(Lf); S.free_sparse(A); S.finish()
 
 
 @pytest.mark.parametrize("world", [2, 5, 8])
