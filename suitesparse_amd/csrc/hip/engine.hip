@@ -1522,6 +1522,8 @@ static int build_host (cholmod_hip_plan *P)
     {
         FrontD &f = P->fr [s] ;
         f.cbp = (!(P->flags & CHOLMOD_HIP_NO_SMALL_FRONTS) && f.nsrow <= SM_MAX && !(P->owner [s] < 0)) ? 1 : 0 ;
+        // (a complex front in its own storage: thin all the same, its block the even columns of a square like everybody's: 2)
+        if (f.cbp && (P->flags & CHOLMOD_HIP_CX_STORAGE)) f.cbp = 2 ;
     }
     const bool cx_storage = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
     auto cb_len = [&] (const FrontD &f, bool global = false) -> i64
@@ -1529,7 +1531,7 @@ static int build_host (cholmod_hip_plan *P)
         // (a distributed block: this rank's slabs -- in the layout over ALL fronts, which every rank must derive alike, its
         // g-th part; a complex front in its own storage: the even columns of the twin's square)
         if (f.cbd) return global ? ((i64) f.ncb * f.ncb + f.own_g - 1) / f.own_g : (i64) f.ncb * (f.cb_hi - f.cb_lo) ;
-        return f.cbp ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
+        return f.cbp == 1 ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
     } ;
     // who releases whose block: the parent, once it has pulled it -- or, for a front whose parent is shared and whose
     // contributions are routed to the ancestors' panels, the root of its tree (it contributes until then)
@@ -1834,7 +1836,7 @@ static int build_host (cholmod_hip_plan *P)
                 if (bucket [c].empty ()) continue ;
                 Launch Ls_ {K_SMALL, (int) bucket [c].size (), (int) bucket [c].size (), S.sm.size (), 0, 0} ;
                 int mx = 0, mxc = 0, mxt = 0 ;
-                bool leaves = !(P->flags & CHOLMOD_HIP_NO_LEAF_PAIRS) ;
+                bool leaves = !(P->flags & CHOLMOD_HIP_NO_LEAF_PAIRS) && !(P->flags & CHOLMOD_HIP_CX_STORAGE) ;
                 for (i32 sid : bucket [c])
                 {
                     FrontD &f = P->fr [sid] ;
@@ -2114,6 +2116,7 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_chainf, hipFuncAttributeMaxDynamicSharedMemorySize, (int) chainf_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
+    HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     done = true ;
     return CHOLMOD_HIP_OK ;
 }
@@ -2194,7 +2197,18 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     P->d_sm + L.goff, P->d_smd + L.goff, P->d_sp01 + 2 * L.goff, P->d_cdesc, P->d_relmap, P->d_Ls, P->d_Sp, \
                     P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta, \
                     P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, tim)
-                if (L.leaf_pw && P->cur_mapped && !P->s_unpacked && !tim)
+                if (cx)
+                {
+                    // complex storage: one wave per front up to 64 twin rows, four above
+#define THIN_LAUNCH_CX(NW_, MINW_) \
+                    hipLaunchKernelGGL ((k_thin_front<NW_, false, MINW_, true>), dim3 (L.grid), dim3 (64 * NW_), thin_front_lds_bytes (L.aux), st, \
+                        P->d_sm + L.goff, P->d_smd + L.goff, P->d_sp01 + 2 * L.goff, P->d_cdesc, P->d_relmap, P->d_Ls, P->d_Sp, \
+                        P->s_unpacked ? P->d_Snz : nullptr, P->d_Si, P->d_Sx, P->cur_beta, \
+                        P->d_Lx, P->d_cb, P->d_info, L.aux, P->d_amap, P->cur_mapped, (long long *) nullptr)
+                    if (L.aux > 64) THIN_LAUNCH_CX (4, 2) ; else THIN_LAUNCH_CX (1, 4) ;
+#undef THIN_LAUNCH_CX
+                }
+                else if (L.leaf_pw && P->cur_mapped && !P->s_unpacked && !tim)
                 {
                     // leaf fronts two to a wave, once the assembly map of the resident S exists
 #define LEAF_LAUNCH(PW_, MINW_) \
@@ -2704,7 +2718,10 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
         // complex storage: the twin's index space, the generic kernels only (the LDS-resident thin-front
         // kernels and the 256-column chain have no complex-storage form), one rank
         if (world > 1) { if (status) *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
-        flags |= CHOLMOD_HIP_PHI_TWIN | CHOLMOD_HIP_NO_SMALL_FRONTS ;
+        // (round 4: the thin-front kernel has a complex-storage form, k_thin_front<..., CX>; CHOLMOD_HIP_CX_NO_THIN=1: the
+        // generic kernels for every front, as before)
+        flags |= CHOLMOD_HIP_PHI_TWIN ;
+        if (getenv ("CHOLMOD_HIP_CX_NO_THIN")) flags |= CHOLMOD_HIP_NO_SMALL_FRONTS ;
         flags &= ~(CHOLMOD_HIP_CHAIN256 | CHOLMOD_HIP_TILE128) ;
     }
     if (flags & CHOLMOD_HIP_PHI_TWIN)

@@ -939,7 +939,10 @@ template <int NW> __device__ __forceinline__ void tf_barrier ()
 // thread's row; `own` tells whether this thread is the one that stores them
 // (diagonal rows: wave 0 only).
 typedef double d2 __attribute__((ext_vector_type(2))) ;
-template <int PW, int NW>
+// CX (a complex front in its own storage): only the even twin columns go to Lx -- Lp points at stored column c0 / 2, stored
+// column (c0 + c) / 2 follows at (c / 2) ns -- and the imaginary part of a diagonal entry (row c + 1 of an even column c, a
+// rounding residue of the embedded elimination) as the exact zero zpotrf leaves there (as pf_store<CX>).
+template <int PW, int NW, bool CX = false>
 __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0, int pc,
     int lane, int wave, int &fail, double *Lp, double *bc)
 {
@@ -1023,7 +1026,8 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
             if (c < pc && row >= c0 + c)
             {
                 F [o + row] = a [c] ;
-                if (fail < 0 || c0 + c < fail) Lr [(i64) c * ns] = a [c] ;
+                if constexpr (CX) { if (!(c & 1) && (fail < 0 || c0 + c < fail)) Lr [(i64) (c >> 1) * ns] = (row == c0 + c + 1) ? 0.0 : a [c] ; }
+                else if (fail < 0 || c0 + c < fail) Lr [(i64) c * ns] = a [c] ;
             }
             if (c + 1 < pc) o += ns - (c0 + c) - 1 ;
         }
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
 // (packed, HBM); otherwise it goes back into the LDS front.  All offsets come from
 // 24-bit multiplies and increments (tri_col (j+4) - tri_col (j) = 4 m - 4 j - 10).
 __device__ __forceinline__ int tri_col24 (int j, int m) { return __mul24 (j, m) - (__mul24 (j, j + 1) >> 1) ; }
-template <int G, int KS, bool TO_CB>
+template <int G, int KS, bool TO_CB, bool CX = false>
 __device__ __forceinline__ void tf_tiles (double *F, int ns, int c0, int pc, int i0, int j0, int lane,
     double *Co, int nc, int ncb, bool czero)
 {
@@ -1097,7 +1101,9 @@ __device__ __forceinline__ void tf_tiles (double *F, int ns, int c0, int pc, int
 #pragma unroll
             for (int r = 0 ; r < 4 ; r++)
             {
-                if (i < ns && j <= ic) Co [o + ic] = acc [g][r] ;
+                // (CX: the even columns of the block, a square with ld = ncb: stored column j / 2)
+                if constexpr (CX) { if (i < ns && j <= ic && !(j & 1)) Co [(j >> 1) * ncb + ic] = acc [g][r] ; }
+                else if (i < ns && j <= ic) Co [o + ic] = acc [g][r] ;
                 o += 4 * ncb - 4 * j - 10 ; j += 4 ;
             }
     }
@@ -1115,7 +1121,7 @@ __device__ __forceinline__ void tf_tiles (double *F, int ns, int c0, int pc, int
             }
     }
 }
-template <int KS, bool TO_CB>
+template <int KS, bool TO_CB, bool CX = false>
 __device__ __forceinline__ void tf_tile_row (double *F, int ns, int c0, int pc, int t0, int I, int lane,
     double *Co, int nc, int ncb, bool czero)
 {
@@ -1123,12 +1129,17 @@ __device__ __forceinline__ void tf_tile_row (double *F, int ns, int c0, int pc, 
     for (int J = 0 ; J <= I ; )
     {
         int left = I + 1 - J, j0 = t0 + 16 * J ;
-        if (left >= 4) { tf_tiles<4, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 4 ; }
-        else if (left >= 2) { tf_tiles<2, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 2 ; }
-        else { tf_tiles<1, KS, TO_CB> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 1 ; }
+        if (left >= 4) { tf_tiles<4, KS, TO_CB, CX> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 4 ; }
+        else if (left >= 2) { tf_tiles<2, KS, TO_CB, CX> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 2 ; }
+        else { tf_tiles<1, KS, TO_CB, CX> (F, ns, c0, pc, i0, j0, lane, Co, nc, ncb, czero) ; J += 1 ; }
     }
 }
-template <int NW, bool TIMED = false, int MINW = (NW == 1 ? 6 : 2)>
+// CX: a complex front in its own storage (the twin's index space; the front in LDS is the whole twin block, assembled from
+// phi (S) like any real front).  The children's blocks hold their even twin columns only (squares with ld = ncb, written by
+// the generic kernels or by this one): every stored entry (i, 2 jj) is added at its place AND as the entry of the odd
+// column it rotates into -- (i ^ 1, 2 jj + 1), negated for odd i -- where that lies in the lower triangle.  The panel and
+// the contribution block leave as even columns (tf_panel, tf_tiles).
+template <int NW, bool TIMED = false, int MINW = (NW == 1 ? 6 : 2), bool CX = false>
 __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts,
     const FrontD *frl, const i64 *sp01, const ChildD *cd, const i32 *relmap, const i64 *Ls,
     const i64 *Sp, const i64 *Snz, const i64 *Si, const double *Sx, double beta,
@@ -1181,8 +1192,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     auto child_at = [&] (int ci, Cur &c)
     {
         const ChildD &cf = cd [ci] ;
-        c.ci = ci ; c.base = 0 ; c.m = cf.ncb ; c.sq = !cf.cbp ;
-        c.tot = cf.cbp ? cf.ncb * (cf.ncb + 1) / 2 : cf.ncb * cf.ncb ;
+        c.ci = ci ; c.base = 0 ; c.m = cf.ncb ; c.sq = CX || cf.cbp != 1 ;
+        c.tot = CX ? (cf.ncb >> 1) * cf.ncb : cf.cbp == 1 ? cf.ncb * (cf.ncb + 1) / 2 : cf.ncb * cf.ncb ;
         c.src = CB + cf.cb ; c.rel = cf.rel ;
     } ;
     auto advance = [&] (Cur &c) -> bool                      // next chunk; false when the stream is over
@@ -1236,7 +1247,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
         int e = c.base + nq * tid, i, j ;
         if (__builtin_amdgcn_readfirstlane (e) >= c.tot) return ;
         const int m = c.m ;
-        if (c.sq) { j = e / m ; i = e - j * m ; }
+        if (c.sq) { j = e / m ; i = e - j * m ; if constexpr (CX) j *= 2 ; }
         else tri_decode (e < c.tot ? e : c.tot - 1, m, i, j) ;
 #pragma unroll
         for (int q = 0 ; q < NLD ; q++)
@@ -1246,11 +1257,18 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
             // one child never meet in the same entry, the barrier above separates children)
             if (e < c.tot && i >= j)
                 (void) __hip_atomic_fetch_add (&F [tri_col24 (rmc [j], ns) + rmc [i]], v [q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+            if constexpr (CX)
+            {
+                // the odd twin column this entry rotates into: (i ^ 1, j + 1), negated for odd i
+                const int i2 = i ^ 1 ;
+                if (e < c.tot && i2 >= j + 1)
+                    (void) __hip_atomic_fetch_add (&F [tri_col24 (rmc [j + 1], ns) + rmc [i2]], (i & 1) ? -v [q] : v [q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+            }
             e++ ; i++ ;
             const bool wrap = i >= m ;                      // next column (branch-free)
-            j = wrap ? j + 1 : j ;
+            j = wrap ? j + (CX ? 2 : 1) : j ;
             i = wrap ? (c.sq ? 0 : j) : i ;
-            if (j >= m) { j = m - 1 ; i = m - 1 ; e = c.tot ; }     // past the last entry
+            if (j >= m) { j = m - (CX ? 2 : 1) ; i = m - 1 ; e = c.tot ; }     // past the last entry
         }
     } ;
     double vA [NLD], vB [NLD] ;
@@ -1326,11 +1344,11 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     for (int c0 = 0 ; c0 < nc ; c0 += TF_PW)
     {
         const int pc = nc - c0 < TF_PW ? nc - c0 : TF_PW ;
-        double *Lp = Lx + psx + (i64) c0 * ns ;
-        if (pc <= 4) tf_panel<4, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
-        else if (pc <= 8) tf_panel<8, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
-        else if (pc <= 12) tf_panel<12, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
-        else tf_panel<16, NW> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        double *Lp = Lx + psx + (i64) (CX ? c0 >> 1 : c0) * ns ;
+        if (pc <= 4) tf_panel<4, NW, CX> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else if (pc <= 8) tf_panel<8, NW, CX> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else if (pc <= 12) tf_panel<12, NW, CX> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
+        else tf_panel<16, NW, CX> (F, &s_fail, ns, c0, pc, lane, wave, fail, Lp, s_bc + 128 * wave) ;
         tick (3) ;
         tf_barrier<NW> () ;
         tick (4) ;
@@ -1351,13 +1369,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
                 if (side && I == pr) break ;
                 if (last)
                 {
-                    if (pc <= 4) tf_tile_row<1, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
-                    else if (pc <= 8) tf_tile_row<2, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
-                    else if (pc <= 12) tf_tile_row<3, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
-                    else tf_tile_row<4, true> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    if (pc <= 4) tf_tile_row<1, true, CX> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else if (pc <= 8) tf_tile_row<2, true, CX> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else if (pc <= 12) tf_tile_row<3, true, CX> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    else tf_tile_row<4, true, CX> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
                 }
                 else        // (only with more than 16 columns: the panel before the last is full)
-                    tf_tile_row<4, false> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
+                    tf_tile_row<4, false, CX> (F, ns, c0, pc, t0, I, lane, Co, nc, ncb, czero) ;
             }
         }
         if (!last) tf_barrier<NW> () ;
@@ -1367,7 +1385,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) k_thin_front (const i32 *fronts
     {
         if (tid == 0) info [fronts [blockIdx.x]] = fail + 1 ;
         // the ancestors of a failed front compute values nobody keeps; give them zeros
-        const int tot = ncb * (ncb + 1) / 2 ;
+        const int tot = CX ? (ncb >> 1) * ncb : ncb * (ncb + 1) / 2 ;
         for (int e = tid ; e < tot ; e += NT) CB [cbo + e] = 0.0 ;
     }
     if constexpr (TIMED) { if (tid == 0 && blockIdx.x == gridDim.x / 2) for (int q = 0 ; q < 10 ; q++) tim [q] = tc [q] ; }

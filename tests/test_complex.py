@@ -329,7 +329,7 @@ def test_twin_flag_is_checked_at_plan_creation():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", ["default", "wave_tiles_everywhere", "four_wave_tiles_only", "no_fused_potrf", "no_fused_trsm", "wide_ob"])
+@pytest.mark.parametrize("variant", ["default", "wave_tiles_everywhere", "four_wave_tiles_only", "no_fused_potrf", "no_fused_trsm", "wide_ob", "generic_kernels_only"])
 @pytest.mark.parametrize("storage", ["complex_storage", "twin_even_columns", "plain_embedding"])
 @pytest.mark.parametrize("name", ["p3d_24_nd", "box16r2_nd"])
 def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, storage, variant):
@@ -354,6 +354,10 @@ def test_complex_gpu_twin_update_variants(golden_dir, monkeypatch, name, storage
         kw["hip_flags"] = ch.HIP_NO_FUSED_TRSM
     elif variant == "wide_ob":
         kw["hip_flags"] = ch.HIP_WIDE_OB
+    elif variant == "generic_kernels_only":
+        if storage != "complex_storage":
+            pytest.skip("the thin-front kernel's complex form belongs to complex storage")
+        monkeypatch.setenv("CHOLMOD_HIP_CX_NO_THIN", "1")           # (the default runs thin fronts through k_thin_front<..., CX>)
     _check(name, golden_dir, use_gpu=1, dense_check=False, session_kwargs=kw)
 
 
@@ -458,6 +462,33 @@ def test_complex_storage_is_half_the_twin(golden_dir, monkeypatch):
     assert abs(a[0] - b[0]) < 1e-11 * abs(b[0]) and abs(a[3] - b[3]) < 1e-11 * b[3] and a[1] == b[1] == 0 and a[2] == b[2] == 0 and a[4] == b[4] == 0, (a, b)
     assert sizes[False][0] == 8.0 * 2 * sizes[False][1]
     assert sizes[True][0] == 8.0 * 4 * sizes[True][1]
+
+
+@pytest.mark.gpu
+def test_complex_storage_thin_fronts_take_the_thin_kernel(golden_dir, monkeypatch):
+    """Complex storage runs the fronts of up to 136 twin rows through the LDS-resident thin-front kernel in its complex
+    form (cholmod_hip_get_stats [21] = fronts handled there); CHOLMOD_HIP_CX_NO_THIN=1 sends every front to the generic
+    kernels, as before round 4.  Both against the oracle (a 2D problem: nearly every front is thin)."""
+    n, Ap, Ai, Ax, perm = _case("p2d_40_nat", golden_dir)
+    seen = {}
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("CHOLMOD_HIP_CX_NO_THIN", "1")
+        S = ch.Session(use_gpu=1, factor_on_device=True)
+        A = S.sparse(n, Ap, Ai, Ax, -1)
+        Lf = S.analyze(A, perm)
+        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+        T = C.cast(Lf.contents.cx_twin, C.POINTER(ch.Factor))
+        st = np.zeros(ch.CHOLMOD_HIP_NSTATS)
+        S.L.cholmod_hip_get_stats(T.contents.hip_plan, st.ctypes.data)
+        seen[generic] = (int(st[21]), int(T.contents.hip_is_twin))
+        S.free_factor(Lf)
+        S.free_sparse(A)
+        S.finish()
+    assert seen[False][1] == 2 and seen[True][1] == 2
+    assert seen[False][0] > 0 and seen[True][0] == 0, seen
+    monkeypatch.delenv("CHOLMOD_HIP_CX_NO_THIN")
+    _check("p2d_40_nat", golden_dir, use_gpu=1, dense_check=False)
 
 
 @pytest.mark.gpu
