@@ -270,6 +270,7 @@ struct cholmod_hip_plan {
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
     int jitter_us = 0 ; unsigned long long jitter_state = 0 ;     // test hook CHOLMOD_HIP_TEST_JITTER (run_launch)
+    int la_reserve_cu = 0 ;             // CHOLMOD_HIP_LA_RESERVE_CU (tuning, read per plan): CUs with cu_id below it stay free of persistent update waves
     int ncu = 256, la_reserve = 64 ;    // compute units of the device; workgroup slots a persistent update leaves to the panel chain
     int *d_pcnt = nullptr ;             // tile counters of the persistent update launches (8 per launch, zeroed per factorization)
     bool upd3_wg4 = false ;             // k_update3 with four tiles per workgroup (CHOLMOD_HIP_UPD3_WG4)
@@ -2043,6 +2044,7 @@ static int upload_plan (cholmod_hip_plan *P)
         int dev = 0, ncu = 0 ;
         if (hipGetDevice (&dev) == hipSuccess && hipDeviceGetAttribute (&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0) P->ncu = ncu ;
         if (const char *e = getenv ("CHOLMOD_HIP_LA_RESERVE")) P->la_reserve = atoi (e) ;
+        if (const char *e = getenv ("CHOLMOD_HIP_LA_RESERVE_CU")) P->la_reserve_cu = atoi (e) ;
     }
     P->d_gg = dupload (P->sch.gg, e) ; HIPCHK (e) ;
     P->d_dg = dupload (P->sch.dg, e) ; HIPCHK (e) ;
@@ -2374,7 +2376,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 int slots = 2 * P->ncu - P->la_reserve ;
                 if (slots < 8) slots = 8 ;
                 unsigned gp = (unsigned) std::min<long> (((long) L.grid + 3) / 4, (long) slots) ;
-                static const int rsv = [] () { const char *e = getenv ("CHOLMOD_HIP_LA_RESERVE_CU") ; return e ? atoi (e) : 0 ; } () ;
+                const int rsv = P->la_reserve_cu ;
                 if (rsv > 0) gp = (unsigned) (4 * P->ncu) ;         // (2 per CU stay, the others are burnt on the reserved CUs)
                 int *cnt = P->d_pcnt + 8 * (size_t) L.pcnt ;
                 if (L.aux >= 1024) TW_LAUNCH (k_update3p<4 COMMA, >, dim3 (gp), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, L.grid, cnt, P->d_Lx, P->d_cb, rsv) ;
