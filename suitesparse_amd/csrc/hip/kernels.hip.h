@@ -970,6 +970,38 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
     // three; never in a single process -- round 3, tests/test_dist.py, tools/flaky_dist.sh).
     if constexpr (NW > 1) tf_barrier<NW> () ;
     double dv = 1.0 ;                                       // lane c keeps the pivot of column c
+    const bool odd_lane = (lane & 1) != 0 ;                 // (= odd row: c0, PW and 64 - PW are even)
+    if constexpr (CX)
+    {
+        // complex columns (as pf_eliminate<PHI>): the pair (c, c + 1) in one step, the odd column never eliminated -- it is
+        // the rotation of the even one and is rebuilt below; a trailing even column 2 j takes a -= t x_j + s y_j
+#pragma unroll
+        for (int c = 0 ; c < PW ; c += 2)
+        {
+            bc [lane] = a [c] ;
+            asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+            double u [PW] ;
+#pragma unroll
+            for (int c2 = c ; c2 < PW ; c2 += 2)
+            {
+                d2 v = *(const d2 *) (bc + c2) ;
+                u [c2] = v.x ; u [c2 + 1] = v.y ;
+            }
+            asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+            double d = u [c] ;
+            double x = __builtin_amdgcn_rcp (d) ;
+            double e = __builtin_fma (-d, x, 1.0) ;
+            x = __builtin_fma (x, e, x) ;
+            double t = a [c] * x ;
+            double sw = lane_xor1_f64 (t) ;
+            double sg = odd_lane ? -sw : sw ;
+#pragma unroll
+            for (int c2 = c + 2 ; c2 < PW ; c2 += 2) { a [c2] = __builtin_fma (-t, u [c2], a [c2]) ; a [c2] = __builtin_fma (-sg, u [c2 + 1], a [c2]) ; }
+            if (lane == c) dv = d ;
+            __builtin_amdgcn_sched_barrier (0) ;
+        }
+    }
+    else
 #pragma unroll
     for (int c = 0 ; c < PW ; c++)
     {
@@ -1010,7 +1042,13 @@ __device__ __forceinline__ void tf_panel (double *F, int *s_fail, int ns, int c0
     {
         d2 rv = *(const d2 *) (bc + c), iv = *(const d2 *) (bc + 64 + c) ;
         a [c] = (lane == c) ? rv.x : a [c] * iv.x ;
-        a [c + 1] = (lane == c + 1) ? rv.y : a [c + 1] * iv.y ;
+        if constexpr (CX)
+        {
+            // the odd column: the rotation of the finished even one (its diagonal entry = the even column's)
+            double sw = lane_xor1_f64 (a [c]) ;
+            a [c + 1] = odd_lane ? sw : -sw ;
+        }
+        else a [c + 1] = (lane == c + 1) ? rv.y : a [c + 1] * iv.y ;
         if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
         if (fail >= 0 && c0 + c + 1 >= fail) a [c + 1] = 0.0 ;
     }
