@@ -379,6 +379,117 @@ def launch_ranks(n, backend):
     return subprocess.call(cmd, env=env)
 
 
+METRIC = "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)"
+
+
+class Watchdog:
+    """A hung collective (or a rank that died) must end in a JSON line with "error", not in the driver's kill: a thread per
+    rank watches a per-phase deadline and an overall one.  On expiry -- or when the launcher sends SIGTERM because a peer
+    failed -- rank 0 prints the error line (phase, steps completed, time of the last completed step, and which exchange of
+    the factorization its device has entered and not left: cholmod_hip_progress) and every rank exits non-zero; the other
+    ranks report their own progress on stderr and give rank 0 a few seconds' head start so that its line gets out before
+    the launcher tears the job down."""
+
+    def __init__(self, rank, world, out_fd, overall_s):
+        import threading
+        self.rank, self.world, self.out_fd = rank, world, out_fd
+        self.t_start = time.monotonic()
+        self.overall = overall_s
+        self.phase, self.deadline = "start", None
+        self.steps_done, self.last_step_ms, self.step_ms = 0, None, []
+        self.lib, self.plan, self.info, self.fallback = None, None, {}, None
+        self.done = False
+        self._lock = threading.Lock()
+        self._rfd = None
+        try:        # SIGTERM / SIGINT while the main thread sits in a native call: a wakeup pipe this thread reads
+            import signal
+            r, w = os.pipe()
+            os.set_blocking(w, False)
+            os.set_blocking(r, False)
+            signal.signal(signal.SIGTERM, lambda *a: None)
+            signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+            self._rfd = r
+        except Exception:
+            pass
+        self._thr = threading.Thread(target=self._run, daemon=True)
+        self._thr.start()
+
+    def arm(self, phase, seconds):
+        self.phase = phase
+        self.deadline = None if seconds is None else time.monotonic() + seconds
+
+    def step_done(self, ms):
+        self.steps_done += 1
+        self.last_step_ms = ms
+        self.step_ms.append(ms)
+
+    def finish(self):
+        self.done = True
+
+    def progress(self):
+        if self.lib is None or not self.plan:
+            return None
+        o = (C.c_int64 * 12)()
+        if self.lib.cholmod_hip_progress(self.plan, o) != 0:
+            return None
+        d = {"factorizations_started": o[0], "launches_enqueued": o[1], "launches_in_schedule": o[2],
+             "exchanges_enqueued": o[3], "exchanges_in_schedule": o[4],
+             "exchange_entered_on_device": o[5], "exchange_left_on_device": o[6]}
+        if o[5] > o[6]:
+            d["pending_exchange"] = {"sequence": o[5], "collective": {7: "reduce-scatter (+ broadcast of the diagonal block)",
+                                                                      11: "all-gather"}.get(o[7], str(o[7])),
+                                     "rank_group": [o[8], o[8] + o[9] - 1], "block_column_width": o[10], "rows_below": o[11]}
+        return d
+
+    def _fire(self, why):
+        with self._lock:
+            if self.done:
+                return
+            self.done = True
+        line = {"metric": METRIC, "value": None, "unit": "GFLOP/s", "n_gpus": self.world, "higher_is_better": True,
+                "error": why, "phase": self.phase, "rank": self.rank,
+                "seconds_since_start": time.monotonic() - self.t_start,
+                "steps_completed": self.steps_done, "last_completed_step_ms": self.last_step_ms,
+                "completed_step_ms": self.step_ms, "progress": self.progress()}
+        line.update(self.info)
+        rc = 3
+        if self.fallback is not None:
+            # the timed region is complete: the measurement goes out, marked as cut short
+            line = dict(self.fallback, truncated=why + " -- sections after the timed region are missing from this line")
+            rc = 0
+        txt = json.dumps(line)
+        if self.rank == 0:
+            os.write(self.out_fd, (txt + "\n").encode())
+        else:
+            time.sleep(8.0)             # rank 0's line first
+        sys.stderr.write(f"[bench watchdog rank {self.rank}] {txt}\n")
+        sys.stderr.flush()
+        os._exit(rc)
+
+    def _run(self):
+        import select
+        while not self.done:
+            if self._rfd is not None:
+                r, _, _ = select.select([self._rfd], [], [], 0.5)
+                if r:
+                    try:
+                        sig = os.read(self._rfd, 64)
+                    except OSError:
+                        sig = b""
+                    if sig and not self.done:
+                        self._fire("signal %s from the launcher (a peer rank failed or the job was cancelled) during phase '%s'"
+                                   % (",".join(str(b) for b in sig), self.phase))
+            else:
+                time.sleep(0.5)
+            now = time.monotonic()
+            if self.done:
+                return
+            if self.deadline is not None and now > self.deadline:
+                self._fire(f"deadline of phase '{self.phase}' exceeded")
+            if self.overall and now - self.t_start > self.overall:
+                self._fire(f"overall deadline of {self.overall:.0f} s exceeded in phase '{self.phase}'")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,6 +514,11 @@ def main():
     ap.add_argument("--ordering", default="geometric", choices=["geometric", "builtin"],
                     help="geometric = the nested dissection SURVEY 8d prescribes for the metric (default); "
                          "builtin = cholmod_l_analyze's own ordering (host/order.c), for information")
+    ap.add_argument("--deadline", type=float, default=1500.0,
+                    help="seconds after which a run that has not printed its line prints an error line instead and exits 3 "
+                         "(0 = never); phases (attach, first factorization, every timed step) have deadlines of their own")
+    ap.add_argument("--step-deadline", type=float, default=0.0,
+                    help="seconds one factorization step may take (default: max (120, 10 x the first factorization))")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (RCCL) or gloo (ranks sharing a GPU, tests)")
     ap.add_argument("--exchange", default="native", choices=["native", "callback"],
                     help="native: the engine calls RCCL itself (default with the nccl backend); callback: "
@@ -430,6 +546,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    wd = Watchdog(rank, world, real_stdout, args.deadline)
+    wd.arm("process group / device set-up", 600)
     dist = None
     # CHOLMOD_HIP_SHARE_AS_WORLD=k with one rank: the engine's self test of the
     # exchange path (fronts a k-rank run would share go through pack / RCCL
@@ -486,6 +604,8 @@ def main():
             perm = None
             wname = wname.split("_geometricND")[0] + "_builtinND"
 
+        wd.info = {"config": {"workload": wname, "n": int(n)}}
+        wd.arm(f"analyze ({wname})", 900)
         A = S.sparse(n, Ap, Ai, Ax, stype)
         t0 = time.perf_counter()
         Lf = S.analyze(A, perm)
@@ -494,6 +614,7 @@ def main():
         fv = ch.FactorView(Lf)
         # reserve HBM for L and the contribution blocks (no collective in here)
         t0 = time.perf_counter()
+        wd.arm("plan build + reservation of HBM (cholmod_l_hip_prepare)", 600)
         ok = S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm))
         short = (ok != 1 and S.cm.status == ch.OUT_OF_MEMORY)
         if dist is not None:
@@ -510,7 +631,11 @@ def main():
             S.finish()
             continue
         assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+        wd.lib, wd.plan = S.L, ch.FactorView(Lf).hip_plan
+        if world > 1 or selftest:
+            S.L.cholmod_hip_progress_enable(wd.plan, 1)     # (markers around every exchange: what a hung rank was waiting in)
         if native:
+            wd.arm("RCCL attach (ncclCommInitRank + one ncclCommSplit per rank group)", 420)
             # one 128-byte RCCL id from rank 0 to everybody, then every rank attaches its plan
             import torch
             idb = np.zeros(128, dtype=np.uint8)
@@ -541,7 +666,10 @@ def main():
             assert S.L.cholmod_hip_get_groups(ch.FactorView(Lf).hip_plan, g0.ctypes.data, gn.ctypes.data) == 0
             allreduce.create_groups(sorted(set(zip(g0[gn > 1].tolist(), gn[gn > 1].tolist()))))
         # first factorization: uploads S (H2D, outside the timed region)
+        wd.arm("first factorization (upload of S, first pass over every collective)", 600)
+        tf0 = time.perf_counter()
         ok = S.factorize(A, Lf)
+        t_first_fact = time.perf_counter() - tf0
         t_first = time.perf_counter() - t0
         assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
         break
@@ -552,16 +680,31 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup - 1, 0)):
+    step_dl = args.step_deadline if args.step_deadline > 0 else max(120.0, 10.0 * t_first_fact)
+    for k in range(max(args.warmup - 1, 0)):
+        wd.arm(f"warm-up step {k + 1}", step_dl)
         assert S.refactorize_resident(Lf) == 1
+    wd.arm("barrier before the timed region", step_dl)
     barrier()
     t0 = time.perf_counter()
     dev_s = 0.0
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        wd.arm(f"timed step {k + 1} of {args.steps}", step_dl)
+        ts = time.perf_counter()
         assert S.refactorize_resident(Lf) == 1     # synchronises the engine stream
+        wd.step_done(1e3 * (time.perf_counter() - ts))
         dev_s += S.hip_stats(Lf)[0]
+    wd.arm("barrier after the timed region", step_dl)
     barrier()
     elapsed = time.perf_counter() - t0
+    # from here on the measurement exists: should the sections that follow (API steps, profiled pass, checks, CPU baseline,
+    # secondary workloads) run into the overall deadline, the watchdog prints THIS line (marked truncated) instead of an error
+    wd.fallback = {"metric": METRIC, "value": fl * args.steps / elapsed / 1e9, "unit": "GFLOP/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+                   "data": "file" if args.matrix else "synthetic", "config": {"workload": wname, "n": int(n), "fl": fl},
+                   "ms_per_step_resident": 1e3 * elapsed / args.steps}
+    wd.arm("after the timed region (API steps, profiled pass, checks, secondary workloads)", None)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
@@ -695,7 +838,7 @@ def main():
         mpeak = max(data_pts) * 1e12 if data_pts else 0.0
         value = fl * args.steps / elapsed / 1e9        # one job, all ranks together
         line = {
-            "metric": "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)",
+            "metric": METRIC,
             "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -750,7 +893,12 @@ def main():
                                 "allreduce_GB_by_group_size": {str(k): 1e-9 * v / nfac for k, v in sorted(allreduce.stats["by_size"].items())},
                                 "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        with wd._lock:
+            already = wd.done
+            wd.done = True
+        if not already:
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    wd.finish()
     if dist is not None:
         dist.destroy_process_group()
 

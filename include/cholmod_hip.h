@@ -150,6 +150,23 @@ int cholmod_hip_rccl_detach (cholmod_hip_plan *plan) ;
  * Returns the number of pairs, fills at most cap. */
 int64_t cholmod_hip_debug_routing (cholmod_hip_plan *plan, int64_t cap, int64_t *pair_d, int64_t *pair_a,
     int64_t *cb_lo, int64_t *cb_hi) ;
+/* test hook: fingerprint (16 words) of the rank's plan -- fronts, routing, layout, every group array, the launch list */
+int cholmod_hip_debug_schedule_hash (cholmod_hip_plan *plan, uint64_t *out16) ;
+/* Progress of the factorization that is running (or ran last) on this plan, for a watchdog thread of the caller (bench.py
+ * --gpus N: a hung collective must end in an error line, not in the driver's kill).  cholmod_hip_progress_enable (plan, 1)
+ * allocates two words of pinned host memory the device marks, in stream order, around every block-column exchange.
+ * cholmod_hip_progress: out [12] = [0] factorizations started, [1] launches of the schedule enqueued by the host in the current
+ * one, [2] launches in the schedule, [3] exchanges enqueued, [4] exchanges in the schedule, [5] / [6] exchange the DEVICE has
+ * entered / left (-1 without markers), and of the exchange entered and not left: [7] kind (7 = reduce-scatter + broadcast of
+ * the diagonal block, 11 = all-gather), [8] first rank and [9] size of its rank group, [10] columns of the block column,
+ * [11] rows below its diagonal block.  May be called from another thread while a factorization runs. */
+int cholmod_hip_progress_enable (cholmod_hip_plan *plan, int enable) ;
+int cholmod_hip_progress (cholmod_hip_plan *plan, int64_t *out12) ;
+/* The batch order every rank of a partition must derive alike (the collectives of a group are issued in batch order):
+ * batch_of[s] = index of the batch front s is factored in, counted over ALL fronts, *global_arena = length (doubles) of the
+ * contribution-block arena laid out over all fronts, from which the memory-aware split was chosen; returns the number of
+ * subtrees swept one after the other (1 = plain level order).  Either pointer may be NULL. */
+int64_t cholmod_hip_get_batches (cholmod_hip_plan *plan, int64_t *batch_of, int64_t *global_arena) ;
 /* owner[s] = rank that factors supernode s, -1 for the shared fronts */
 int cholmod_hip_get_partition (cholmod_hip_plan *plan, int64_t *owner) ;
 /* rank group of every supernode: ranks [first[s], first[s]+size[s]) hold it

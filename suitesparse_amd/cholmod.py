@@ -15,6 +15,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CHOLMOD_AMD_LIB") or os.path.join(_HERE, "lib", "libcholmod_amd.so")   # (override: A/B builds while tuning)
+# the same library with the engine's test hooks compiled in (CHOLMOD_HIP_TEST_*): tests only, see csrc/Makefile
+HOOKS_LIB_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_testhooks.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 CHOLMOD_MAXMETHODS = 9
@@ -134,7 +136,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
-    "cholmod_hip_get_groups", "cholmod_hip_debug_routing",
+    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_debug_routing",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
@@ -154,7 +156,6 @@ PROBE_SYMBOLS = [
     "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_probe_cu_mask", "cholmod_hip_probe_overlap", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
 ]
 
-_lib = None
 _probes = None
 
 
@@ -162,19 +163,26 @@ def build(force: bool = False) -> str:
     """Compile the host C layer and the HIP engine for gfx950 (in-tree)."""
     if force:
         subprocess.check_call(["make", "-C", CSRC, "-s", "clean"])
-    subprocess.check_call(["make", "-C", CSRC, "-s"])
+    subprocess.check_call(["make", "-C", CSRC, "-s", "-j3"])
     return LIB_PATH
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+_libs = {}
+
+
+def lib(hooks=None):
+    """The product library; hooks=True: its twin with the engine's test hooks compiled in (tests that inject jitter,
+    poison, failures).  hooks=None: the product library unless SSAMD_TEST_HOOKS_LIB=1 (worker processes of such tests)."""
+    if hooks is None:
+        hooks = os.environ.get("SSAMD_TEST_HOOKS_LIB") == "1"
+    path = HOOKS_LIB_PATH if hooks else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no fallback path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i64, dbl, sz = C.c_void_p, C.c_int64, C.c_double, C.c_size_t
     cm = C.POINTER(Common)
     sp, dn, fc = C.POINTER(Sparse), C.POINTER(Dense), C.POINTER(Factor)
@@ -237,6 +245,10 @@ def lib():
     sig("cholmod_hip_set_allreduce", C.c_int, [vp, ALLREDUCE_FN, vp])
     sig("cholmod_hip_get_partition", C.c_int, [vp, vp])
     sig("cholmod_hip_get_groups", C.c_int, [vp, vp, vp])
+    sig("cholmod_hip_get_batches", i64, [vp, vp, vp])
+    sig("cholmod_hip_progress_enable", C.c_int, [vp, C.c_int])
+    sig("cholmod_hip_progress", C.c_int, [vp, vp])
+    sig("cholmod_hip_debug_schedule_hash", C.c_int, [vp, vp])
     sig("cholmod_hip_debug_routing", C.c_int64, [vp, C.c_int64, vp, vp, vp, vp])
     sig("cholmod_hip_gather_factor", C.c_int, [vp])
     sig("cholmod_l_gather_factor", C.c_int, [fc, cm])
@@ -260,7 +272,7 @@ def lib():
     sig("cholmod_hip_rccl_attach", C.c_int, [vp, vp])
     sig("cholmod_hip_rccl_detach", C.c_int, [vp])
     sig("cholmod_hip_version", C.c_char_p, [])
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -305,12 +317,12 @@ class Session:
 
     def __init__(self, supernodal=SUPERNODAL, use_gpu=1, print_level=0, postorder=True,
                  factor_on_device=False, hip_flags=0, rank=0, world=1, allreduce=None,
-                 ordering="natural"):
+                 ordering="natural", hooks=None):
         """ordering (used by analyze() when no permutation is passed): "natural"
         (the harness default: tests pin results to the oracle's natural order),
         "default" (cholmod_l_start's strategy: the built-in nested dissection) or
-        "nesdis"."""
-        self.L = lib()
+        "nesdis".  hooks=True: the library with the engine's test hooks (lib ())."""
+        self.L = lib(hooks)
         self.cm = Common()
         self.L.cholmod_l_start(C.byref(self.cm))
         if ordering == "natural":

@@ -8,6 +8,7 @@
 
 #include <rccl/rccl.h>      // types only: the library itself is bound with dlopen (cholmod_hip_rccl_attach)
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -23,6 +24,16 @@
 #include <chrono>
 
 using namespace sship ;
+
+// Test hooks (CHOLMOD_HIP_TEST_*: stream jitter, poisoned arena, dropped waits, injected failures, a hung exchange) exist
+// only in the library built with -DCHOLMOD_HIP_TEST_HOOKS (lib/libcholmod_amd_testhooks.so, loaded by the tests that need
+// them); in the product library the names do not even appear as strings: no environment variable can make it compute a
+// wrong factor or fail on purpose.
+#ifdef CHOLMOD_HIP_TEST_HOOKS
+#define TEST_ENV(name) getenv (name)
+#else
+#define TEST_ENV(name) ((const char *) nullptr)
+#endif
 
 namespace {
 
@@ -255,6 +266,8 @@ struct cholmod_hip_plan {
     std::vector<i32> lvl_ptr, lvl_list ;        // fronts by level
     i64 relsize = 0, arena = 0 ;
     i64 arena_budget = 0 ;                  // bytes the CB arena may take (0 = no limit)
+    i64 global_arena = 0 ;                  // arena of the layout over ALL fronts (doubles): what the batch split was chosen by
+    std::vector<i32> batch_of ;             // global batch index of every front (the same on every rank)
     int nsplit = 1 ;                        // subtrees swept one after the other (memory)
     int nlevels = 0 ;
     // multi-GPU: one process per GPU; owner[s] = rank that factors front s, or
@@ -270,6 +283,8 @@ struct cholmod_hip_plan {
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
     int jitter_us = 0 ; unsigned long long jitter_state = 0 ;     // test hook CHOLMOD_HIP_TEST_JITTER (run_launch)
+    bool test_drop_waits = false ;          // test hook CHOLMOD_HIP_TEST_DROP_WAITS (read per plan, upload_plan)
+    int test_hang_rank = -1 ; long test_hang_xchg = -1 ;     // test hook CHOLMOD_HIP_TEST_HANG_EXCHANGE=rank:seq (bench.py's watchdog)
     int la_reserve_cu = 0 ;             // CHOLMOD_HIP_LA_RESERVE_CU (tuning, read per plan): CUs with cu_id below it stay free of persistent update waves
     int ncu = 256, la_reserve = 64 ;    // compute units of the device; workgroup slots a persistent update leaves to the panel chain
     int *d_pcnt = nullptr ;             // tile counters of the persistent update launches (8 per launch, zeroed per factorization)
@@ -363,6 +378,11 @@ struct cholmod_hip_plan {
     // solve workspace
     double *d_X = nullptr, *d_Y = nullptr ; i64 x_cap = 0 ;
     i64 *d_perm = nullptr ;
+    // progress of the running factorization, readable from another host thread (cholmod_hip_progress): the host side
+    // counts what it has enqueued; with markers enabled the device writes, in stream order, the sequence number of the
+    // exchange it has entered / left into pinned host memory (prog_dev [0] / [1])
+    volatile long long prog_fact = 0, prog_launch = 0, prog_xchg_enq = 0 ;
+    long long *prog_dev = nullptr ;
     // stats
     bool profiling = false ;
     double stats [CHOLMOD_HIP_NSTATS] = {0} ;
@@ -1481,6 +1501,19 @@ static int build_host (cholmod_hip_plan *P)
     // the layout of the first half of round 4 (full squares of partial sums, pulled level by level).
     const bool passthru = distribute && !getenv ("CHOLMOD_HIP_NO_CB_PASSTHROUGH") ;
     P->passthru = passthru ;
+    // member q's block of a distributed contribution block (ncb columns, group of g) starts where q / g of the lower
+    // triangle's area lies to its left (multiples of 64); a function of (ncb, g, q) only: every rank can evaluate it for
+    // every member of every group
+    auto cb_bound = [] (int ncb, int g, int q) -> int
+    {
+        if (q <= 0) return 0 ;
+        if (q >= g) return ncb ;
+        const double T = 0.5 * (double) ncb * (ncb + 1) * q / g ;
+        // area left of column j: j ncb - j (j - 1) / 2
+        double j = ncb + 0.5 - std::sqrt (std::max (0.0, (ncb + 0.5) * (ncb + 0.5) - 2.0 * T)) ;
+        int b = (int) (j / 64.0 + 0.5) * 64 ;
+        return std::min (std::max (b, 0), ncb) ;
+    } ;
     P->lpx.assign (std::max<i64> (nsuper, 1), -1) ;
     P->win_off.assign (std::max<i64> (nsuper, 1), -1) ;
     P->lx_local = 0 ;
@@ -1500,17 +1533,7 @@ static int build_host (cholmod_hip_plan *P)
             {
                 // member q's block of contribution-block columns starts where q / g of the lower triangle's area lies to its left
                 f.cbd = 1 ;
-                auto bound = [&] (int q) -> int
-                {
-                    if (q <= 0) return 0 ;
-                    if (q >= f.own_g) return f.ncb ;
-                    const double T = 0.5 * (double) f.ncb * (f.ncb + 1) * q / f.own_g ;
-                    // area left of column j: j ncb - j (j - 1) / 2
-                    double j = f.ncb + 0.5 - std::sqrt (std::max (0.0, (f.ncb + 0.5) * (f.ncb + 0.5) - 2.0 * T)) ;
-                    int b = (int) (j / 64.0 + 0.5) * 64 ;
-                    return std::min (std::max (b, 0), (int) f.ncb) ;
-                } ;
-                f.cb_lo = bound (f.own_r) ; f.cb_hi = bound (f.own_r + 1) ;
+                f.cb_lo = cb_bound (f.ncb, f.own_g, f.own_r) ; f.cb_hi = cb_bound (f.ncb, f.own_g, f.own_r + 1) ;
             }
         }
         P->lx_local += cols * f.nsrow ;
@@ -1527,13 +1550,31 @@ static int build_host (cholmod_hip_plan *P)
         if (f.cbp && (P->flags & CHOLMOD_HIP_CX_STORAGE)) f.cbp = 2 ;
     }
     const bool cx_storage = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
-    auto cb_len = [&] (const FrontD &f, bool global = false) -> i64
+    auto cb_len = [&] (const FrontD &f) -> i64
     {
-        // (a distributed block: this rank's slabs -- in the layout over ALL fronts, which every rank must derive alike, its
-        // g-th part; a complex front in its own storage: the even columns of the twin's square)
-        if (f.cbd) return global ? ((i64) f.ncb * f.ncb + f.own_g - 1) / f.own_g : (i64) f.ncb * (f.cb_hi - f.cb_lo) ;
+        // (a distributed block: this rank's block of columns; a complex front in its own storage: the even columns of the
+        // twin's square)
+        if (f.cbd) return (i64) f.ncb * (f.cb_hi - f.cb_lo) ;
         return f.cbp == 1 ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
     } ;
+    // The same length in the layout over ALL fronts, from which the batch split is chosen: every rank must derive the same
+    // number for every front, whether it holds the front or not -- so nothing here may read f.cbd / f.own_g / f.cb_lo (set
+    // for the fronts of THIS rank only; round-4 advisor item: a member of a sub-group counted ncb^2 / g, a non-member ncb^2,
+    // and `8 A.top <= budget` could pick different splits on different ranks).  A distributed block counts as its LARGEST
+    // member share, ncb * max_q (cb_hi - cb_lo): what the neediest member really allocates.
+    std::vector<i64> cb_len_all (std::max<i64> (nsuper, 1), 0) ;
+    for (i64 s = 0 ; s < nsuper ; s++)
+    {
+        const FrontD &f = P->fr [s] ;
+        if (P->world > 1 && passthru && P->owner [s] < 0 && f.ncb > 0)
+        {
+            const int g = P->grpn [s] ;
+            int widest = 0 ;
+            for (int q = 0 ; q < g ; q++) widest = std::max (widest, cb_bound (f.ncb, g, q + 1) - cb_bound (f.ncb, g, q)) ;
+            cb_len_all [s] = (i64) f.ncb * widest ;
+        }
+        else cb_len_all [s] = f.cbp == 1 ? (i64) f.ncb * (f.ncb + 1) / 2 : cx_storage ? (i64) f.ncb * (f.ncb / 2) : (i64) f.ncb * f.ncb ;
+    }
     // who releases whose block: the parent, once it has pulled it -- or, for a front whose parent is shared and whose
     // contributions are routed to the ancestors' panels, the root of its tree (it contributes until then)
     std::vector<std::vector<i32>> rel_list (std::max<i64> (nsuper, 1)) ;
@@ -1677,12 +1718,12 @@ static int build_host (cholmod_hip_plan *P)
         Arena A ;
         for (const auto &bt : batches)
         {
-            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (cb_len (f, P->world > 1)) ; }
+            for (i32 sf : bt) { FrontD &f = P->fr [sf] ; f.cb = A.alloc (P->world > 1 ? cb_len_all [sf] : cb_len (f)) ; }
             for (i32 sf : bt)
                 for (i32 c : rel_list [sf])
                 {
                     FrontD &g = P->fr [c] ;
-                    A.release (g.cb, cb_len (g, P->world > 1)) ;
+                    A.release (g.cb, P->world > 1 ? cb_len_all [c] : cb_len (g)) ;
                 }
         }
         // keep the first split that fits; if none does, the one with the smallest
@@ -1698,6 +1739,9 @@ static int build_host (cholmod_hip_plan *P)
     for (i64 s = 0 ; s < nsuper ; s++) P->fr [s].cb = best_cb [s] ;
     P->arena = best_arena ;
     P->nsplit = best_nsplit ;
+    P->global_arena = best_arena ;
+    P->batch_of.assign (std::max<i64> (nsuper, 1), -1) ;
+    for (size_t b = 0 ; b < batches.size () ; b++) for (i32 sf : batches [b]) P->batch_of [sf] = (i32) b ;
     if (P->world > 1)
     {
         // The batch order above is laid out over ALL fronts so that every rank takes
@@ -1935,6 +1979,7 @@ static int build_host (cholmod_hip_plan *P)
 
 static void free_device (cholmod_hip_plan *P)
 {
+    if (P->prog_dev) { (void) hipHostFree (P->prog_dev) ; P->prog_dev = nullptr ; }
     if (RcclApi *R = (P->nccl_world ? rccl_api () : nullptr))
     {
         for (auto &g : P->nccl_group) (void) R->CommDestroy (g.second) ;
@@ -1973,7 +2018,7 @@ static int upload_plan (cholmod_hip_plan *P)
         HIPCHK (hipExtStreamCreateWithCUMask (&P->stream, 8, m)) ;
     }
     else HIPCHK (hipStreamCreate (&P->stream)) ;
-    if (const char *e = getenv ("CHOLMOD_HIP_TEST_JITTER"))
+    if (const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_JITTER"))
     {
         unsigned long long seed = 0 ; int mx = 2000 ;
         if (sscanf (e, "%llu:%d", &seed, &mx) >= 1 && mx > 0)
@@ -1982,6 +2027,8 @@ static int upload_plan (cholmod_hip_plan *P)
             P->jitter_state = seed * 0x9E3779B97F4A7C15ull + (unsigned long long) (P->rank + 1) * 0xD1B54A32D192ED03ull ;
         }
     }
+    P->test_drop_waits = TEST_ENV ("CHOLMOD_HIP_TEST_DROP_WAITS") != nullptr ;
+    if (const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_HANG_EXCHANGE")) (void) sscanf (e, "%d:%ld", &P->test_hang_rank, &P->test_hang_xchg) ;
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
     // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
@@ -2066,7 +2113,7 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_info, std::max<i64> (P->nsuper, 1) * sizeof (i32))) ;
     HIPCHK (hipMalloc ((void **) &P->d_first_fail, sizeof (int))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
-    if (getenv ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    if (TEST_ENV ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
@@ -2167,8 +2214,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                                     else hipLaunchKernelGGL ((KA 0 KB), __VA_ARGS__) ; } while (0)
     // (test hook CHOLMOD_HIP_TEST_DROP_WAITS=1: the cross-stream waits of the schedule are skipped -- the mutation the jitter
     // test must catch, tests/test_gpu_scale.py::test_stream_jitter_catches_a_dropped_wait)
-    static const bool drop_waits = getenv ("CHOLMOD_HIP_TEST_DROP_WAITS") != nullptr ;
-    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS && !drop_waits) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS && !P->test_drop_waits) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     if (P->jitter_us > 0 && !serial)
     {
         // test hook CHOLMOD_HIP_TEST_JITTER=seed[:max_us]: ahead of one launch in three, its stream is held up for a random
@@ -2271,6 +2317,18 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     comm = it->second ;
                 }
                 const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w, chunk = (i64) X.R * X.w ;
+                const long long xseq = ++P->prog_xchg_enq ;
+                if (P->prog_dev) hipLaunchKernelGGL (k_mark, dim3 (1), dim3 (1), 0, cs, P->prog_dev, (P->prog_fact << 32) | xseq) ;
+#ifdef CHOLMOD_HIP_TEST_HOOKS
+                // test hook CHOLMOD_HIP_TEST_HANG_EXCHANGE=rank:seq: that rank never issues exchange `seq` of its second
+                // factorization (its host thread sleeps here; nothing hangs on the device) -- its peers then wait for it in
+                // the collective, which is what bench.py's watchdog must turn into an error line (tests/test_bench_contract.py)
+                if (P->rank == P->test_hang_rank && xseq == P->test_hang_xchg && P->prog_fact >= 2)
+                {
+                    (void) hipStreamSynchronize (cs) ;
+                    for ( ; ; ) sleep (3600) ;
+                }
+#endif
                 auto move = [&] (int mode, i64 total)
                 {
                     if (total <= 0) return ;
@@ -2309,6 +2367,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     }
                     move (3, chunk * X.g) ;
                 }
+                if (P->prog_dev) hipLaunchKernelGGL (k_mark, dim3 (1), dim3 (1), 0, cs, P->prog_dev + 1, (P->prog_fact << 32) | xseq) ;
                 if (ahead)
                 {
                     if (R)
@@ -2447,7 +2506,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     // test hook CHOLMOD_HIP_TEST_POISON_ARENA=1: the contribution-block arena (and the exchange staging) start every
     // factorization as NaNs -- an entry somebody reads before anybody has written it then shows in the factor,
     // whatever a fresh allocation happens to hold (tests/test_gpu_parity.py, tests/test_dist.py)
-    const bool poison = getenv ("CHOLMOD_HIP_TEST_POISON_ARENA") != nullptr ;
+    const bool poison = TEST_ENV ("CHOLMOD_HIP_TEST_POISON_ARENA") != nullptr ;
     if (poison)
     {
         HIPCHK (hipMemsetAsync (P->d_cb, 0xFF, std::max<i64> (P->arena, 1) * sizeof (double), st)) ;
@@ -2487,10 +2546,12 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     }
     if (prof) HIPCHK (hipEventRecord (P->evpool [1], st)) ;
     int fail_rank = -1 ; long fail_launch = -1 ;
-    if (const char *e = getenv ("CHOLMOD_HIP_TEST_FAIL_LAUNCH")) (void) sscanf (e, "%d:%ld", &fail_rank, &fail_launch) ;
+    if (const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_FAIL_LAUNCH")) (void) sscanf (e, "%d:%ld", &fail_rank, &fail_launch) ;
+    P->prog_fact = P->prog_fact + 1 ; P->prog_launch = 0 ; P->prog_xchg_enq = 0 ;
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
+        P->prog_launch = (long long) q + 1 ;
         if (prof && poisoned == CHOLMOD_HIP_OK) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
         if (poisoned != CHOLMOD_HIP_OK)
         {
@@ -2818,6 +2879,67 @@ int64_t cholmod_hip_debug_routing (cholmod_hip_plan *P, int64_t cap, int64_t *pa
     return (int64_t) P->relpairs.size () ;
 }
 
+/* Progress of the factorization that is running (or ran last), for a watchdog thread of the caller:
+ * enable != 0 allocates two words of pinned host memory the device marks, in stream order, around every block-column
+ * exchange (two one-thread kernels per exchange: microseconds next to the collective). */
+int cholmod_hip_progress_enable (cholmod_hip_plan *P, int enable)
+{
+    if (!P || P->host_only) return CHOLMOD_HIP_INVALID ;
+    if (enable && !P->prog_dev)
+    {
+        HIPCHK (hipHostMalloc ((void **) &P->prog_dev, 2 * sizeof (long long), hipHostMallocDefault)) ;
+        P->prog_dev [0] = P->prog_dev [1] = 0 ;
+    }
+    else if (!enable && P->prog_dev)
+    {
+        (void) hipStreamSynchronize (P->stream) ;
+        if (P->stream2) (void) hipStreamSynchronize (P->stream2) ;
+        (void) hipHostFree (P->prog_dev) ; P->prog_dev = nullptr ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+/* out [0] factorizations started on this plan, [1] launches of the schedule the host has enqueued in the current one,
+ * [2] launches in the schedule, [3] exchanges enqueued, [4] exchanges in the schedule, [5] / [6] exchange the DEVICE has
+ * entered / left in the current factorization (markers; -1 without cholmod_hip_progress_enable), and of the exchange
+ * entered and not left ([5] > [6]): [7] kind (7 = reduce-scatter + broadcast, 11 = all-gather), [8] first rank and [9]
+ * size of its group, [10] columns of its block column, [11] rows below that block column's diagonal block.  Safe to call from another thread while a factorization runs. */
+int cholmod_hip_progress (cholmod_hip_plan *P, int64_t *out)
+{
+    if (!P || !out) return CHOLMOD_HIP_INVALID ;
+    for (int q = 0 ; q < 12 ; q++) out [q] = 0 ;
+    const long long fact = P->prog_fact ;
+    out [0] = fact ; out [1] = P->prog_launch ; out [2] = (int64_t) P->sch.launches.size () ; out [3] = P->prog_xchg_enq ;
+    i64 nx = 0 ;
+    for (const Launch &L : P->sch.launches) if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) nx++ ;
+    out [4] = nx ; out [5] = out [6] = -1 ;
+    if (P->prog_dev)
+    {
+        const long long a = ((volatile long long *) P->prog_dev) [0], b = ((volatile long long *) P->prog_dev) [1] ;
+        out [5] = (a >> 32) == fact ? (a & 0xFFFFFFFFll) : 0 ;
+        out [6] = (b >> 32) == fact ? (b & 0xFFFFFFFFll) : 0 ;
+        if (out [5] > out [6])
+        {
+            i64 seq = 0 ;
+            for (const Launch &L : P->sch.launches)
+                if ((L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) && ++seq == out [5])
+                {
+                    out [7] = L.kind ; out [8] = L.ar_g0 ; out [9] = L.ar_gn ; out [10] = L.xd.w ; out [11] = L.xd.mb ;
+                    break ;
+                }
+        }
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+int64_t cholmod_hip_get_batches (cholmod_hip_plan *P, int64_t *batch_of, int64_t *global_arena)
+{
+    if (!P) return CHOLMOD_HIP_INVALID ;
+    if (batch_of) for (i64 q = 0 ; q < P->nsuper ; q++) batch_of [q] = P->batch_of [q] ;
+    if (global_arena) *global_arena = P->global_arena ;
+    return P->nsplit ;
+}
+
 int cholmod_hip_get_partition (cholmod_hip_plan *P, int64_t *owner)
 {
     if (!P || !owner) return CHOLMOD_HIP_INVALID ;
@@ -2841,7 +2963,7 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     HIPCHK (hipStreamSynchronize (P->stream)) ;
     // test hooks: CHOLMOD_HIP_TEST_FAIL_GATHER=r: rank r finds no room for the complete factor at all;
     // CHOLMOD_HIP_TEST_GATHER_STAGED=r: rank r finds none next to its own part (the host-staged way below)
-    const char *tfg = getenv ("CHOLMOD_HIP_TEST_FAIL_GATHER"), *tgs = getenv ("CHOLMOD_HIP_TEST_GATHER_STAGED") ;
+    const char *tfg = TEST_ENV ("CHOLMOD_HIP_TEST_FAIL_GATHER"), *tgs = TEST_ENV ("CHOLMOD_HIP_TEST_GATHER_STAGED") ;
     const bool fail_here = tfg && atoi (tfg) == P->rank, staged_here = tgs && atoi (tgs) == P->rank ;
     // (nothing newer than the gathered copy: the same on every rank -- full_valid is set by a complete gather
     // and cleared by a factorization, collectively both)
@@ -3458,6 +3580,47 @@ int64_t cholmod_hip_get_launch_profile (cholmod_hip_plan *P, int64_t cap, int32_
         if (bytes) bytes [q] = L.bytes ;
     }
     return nl ;
+}
+
+// test hook: a fingerprint of everything build_host derives for this rank -- fronts, child lists and routing pairs, the
+// rank's layout of L and of the arena, every group array and the launch list (FNV-1a over the fields).  Host-only plans
+// have it too: tests/test_schedule_fingerprint.py pins the schedules of a battery of problems, worlds and flags, so that a
+// restructuring of the scheduler that changes any launch is caught without a GPU.
+int cholmod_hip_debug_schedule_hash (cholmod_hip_plan *P, uint64_t *out16)
+{
+    if (!P || !out16) return CHOLMOD_HIP_INVALID ;
+    auto fnv = [] (uint64_t h, const void *p, size_t nbytes) -> uint64_t
+    {
+        const unsigned char *b = (const unsigned char *) p ;
+        for (size_t q = 0 ; q < nbytes ; q++) { h ^= b [q] ; h *= 0x100000001b3ull ; }
+        return h ;
+    } ;
+    const uint64_t H0 = 0xcbf29ce484222325ull ;
+    auto hv = [&] (const auto &v) -> uint64_t
+    {
+        return v.empty () ? H0 : fnv (H0, v.data (), v.size () * sizeof (v [0])) ;
+    } ;
+    const Schedule &S = P->sch ;
+    out16 [0] = hv (S.zg) ; out16 [1] = hv (S.eg) ; out16 [2] = hv (S.pg) ; out16 [3] = hv (S.tg) ;
+    out16 [4] = hv (S.gg) ; out16 [5] = hv (S.dg) ; out16 [6] = hv (S.rg) ; out16 [7] = hv (S.wg) ;
+    out16 [8] = hv (S.cg) ; out16 [9] = hv (S.sm) ;
+    uint64_t h = H0 ;
+    for (const Launch &L : S.launches)
+    {
+        const i64 v [] = {L.kind, L.grid, L.ng, (i64) L.goff, L.stream, L.wait_ev, L.rec_ev, L.ar_g0, L.ar_gn, L.aux, L.leaf_T, L.leaf_pw, L.ndiag,
+            L.xd.slab, L.xd.lda, L.xd.w, L.xd.mb, L.xd.R, L.xd.g, L.xd.r} ;
+        h = fnv (h, v, sizeof (v)) ;
+        const double d [] = {L.flops, L.bytes} ;
+        h = fnv (h, d, sizeof (d)) ;
+    }
+    out16 [10] = h ;
+    out16 [11] = hv (P->fr) ;
+    out16 [12] = fnv (hv (P->child), P->crel.data (), P->crel.size () * sizeof (i64)) ;
+    out16 [13] = P->relpairs.empty () ? H0 : fnv (H0, P->relpairs.data (), P->relpairs.size () * sizeof (RelPair)) ;
+    const i64 w [] = {S.ncflags, S.max_dinv_slots, S.nevents, P->arena, P->lx_local, P->lx_fronts, P->nsplit, P->relsize_all, P->global_arena} ;
+    out16 [14] = fnv (H0, w, sizeof (w)) ;
+    out16 [15] = fnv (fnv (hv (P->lpx), P->win_off.data (), P->win_off.size () * sizeof (i64)), P->assign_cb.data (), P->assign_cb.size ()) ;
+    return CHOLMOD_HIP_OK ;
 }
 
 // tuning: the update regions of launch `launch` (an update launch of any kind), 12 numbers per

@@ -2414,6 +2414,14 @@ __global__ void k_spin (long long ticks)
     while ((long long) wall_clock64 () - t0 < ticks) __builtin_amdgcn_s_sleep (20) ;
 }
 
+// progress marker (cholmod_hip_progress_enable): one word into host-visible memory, in stream order -- a watchdog
+// thread of the host reads which exchange of the factorization a hung rank has entered and not left
+__global__ void k_mark (volatile long long *p, long long v)
+{
+    *p = v ;
+    __threadfence_system () ;
+}
+
 // n doubles from src to dst, those at index >= nr as zeros (pad) or not at all: four independent loads per thread in flight
 // (the pack of a block column and the unpack of the gathered chunks are 48 GB each per rank of 8 and factorization)
 __device__ __forceinline__ void xm_copy (double *dst, const double *src, int n, int nr, int tid, int nt, bool pad)
@@ -2813,7 +2821,8 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 // Hand-off without an L2 write-back: everything a diagonal workgroup publishes is written with
 // relaxed agent-scope atomic stores (global_store ... sc1: write-through past the XCD's L2) and read
 // with relaxed agent-scope atomic loads (sc1: served at the coherence point); the flag follows the
-// data after an s_waitcnt (workgroup-scope release + barrier) -- no buffer_wbl2 / buffer_inv, which
+// data after an explicit s_waitcnt vmcnt(0) in every wave + the workgroup barrier (cf_drain_stores;
+// checked in the gfx950 ISA: waitcnt, s_barrier, flag store) -- no buffer_wbl2 / buffer_inv, which
 // is what made the cross-workgroup hand-off of round 2 cost 30 us.  A workgroup only ever waits for
 // workgroups with a LOWER block index (all diagonal workgroups of a launch come first, in panel
 // order per front), so in-order dispatch cannot deadlock; a wait that exceeds its budget raises
@@ -2826,7 +2835,11 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 m1 ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 off2 ; i32 m2 ; i32 pad ; } ;
 __device__ __forceinline__ double ld_coh (const double *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 __device__ __forceinline__ void st_coh (double *p, double v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
-#define CF_SPIN_LIMIT (1 << 20)
+// polls (s_sleep 4 + one coherent load, ~1.5 us each) before a hand-off counts as failed: ~6 s, far beyond any jitter
+// hold or time slice another process of the device can cause (the host then reports CHOLMOD_HIP_GPU_PROBLEM on all ranks)
+#define CF_SPIN_LIMIT (1 << 22)
+// all of this wave's global stores (and loads) acknowledged; also a compiler barrier for memory operations
+__device__ __forceinline__ void cf_drain_stores () { asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ; }
 __host__ __device__ inline size_t chainf_lds_bytes () { return (size_t) (DG_W * 64 + 4 * 256 + 16) * sizeof (double) ; }
 __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int ndiag_total, double *Lx, i32 *info,
     double *dinv, int *flags, int *err)
@@ -2862,6 +2875,8 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     int *fl = flags + 4 * (i64) G.fslot ;
     if (isdiag) __builtin_amdgcn_s_setprio (3) ; else __builtin_amdgcn_s_setprio (1) ;
     int nvt = w ;                                             // valid columns of the sub-block
+    bool dead = false ;                                       // a hand-off timed out (wait_stage): no store into L from here on
+    if (tid == 0) s_int [2] = 0 ;                             // (read after wait_stage's barrier only)
     {
         const int inf = info [G.front] ;                      // a pivot of an EARLIER launch failed
         if (inf != 0) { nvt = inf - 1 - G.col0 ; if (nvt < 0) nvt = 0 ; if (nvt > w) nvt = w ; }
@@ -2877,11 +2892,18 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
             while (((v = __hip_atomic_load (fl + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFF) <= have)
             {
                 __builtin_amdgcn_s_sleep (4) ;
-                if (++n > CF_SPIN_LIMIT) { atomicExch (err, 1) ; v = (j + 1) | (1 << 8) ; break ; }     // (budget exceeded: go on with "nothing valid", tell the host)
+                // budget exceeded (or somebody else's was: no second full wait behind a dead workgroup): tell the host, go
+                // on as "nothing valid" and DEAD -- a dead workgroup stores nothing into L any more, it only keeps
+                // publishing its flags so that the workgroups behind it come to an end as well
+                if (++n > CF_SPIN_LIMIT || ((n & 1023) == 0 && __hip_atomic_load (err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                {
+                    atomicExch (err, 1) ; v = (j + 1) | (1 << 8) ; s_int [2] = 1 ; break ;
+                }
             }
             s_int [0] = v ;
         }
         __syncthreads () ;
+        if (s_int [2]) dead = true ;
         return s_int [0] ;
     } ;
     d4 X [16] ;
@@ -3028,7 +3050,7 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
                     const int c = 16 * jb + lk + 4 * r ;
                     const double v = (c < nvj) ? x [r] : 0.0 ;
                     x [r] = v ;
-                    if (rok && c < pw)
+                    if (rok && c < pw && !dead)
                     {
                         // (a diagonal workgroup's solved blocks are row block rb of L for everybody after it)
                         if (isdiag) st_coh (B + (i64) (c0 + c) * lda, v) ; else B [(i64) (c0 + c) * lda] = v ;
@@ -3056,8 +3078,10 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
                             const double bfv = Xp [(16 * kb2 + 4 * s4 + lk) * 64 + 16 * jb + lr] ;
                             dacc [jb] = __builtin_amdgcn_mfma_f64_16x16x4f64 (-bfv, X [4 * j + kb2][s4], dacc [jb], 0, 0, 0) ;
                         }
-                // (the stage flag after the product: by now the stores are acknowledged, nobody waits for them)
-                __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup") ;
+                // (the stage flag after the product: every wave drains ITS stores -- s_waitcnt vmcnt(0), stores count in
+                // vmcnt on gfx9 -- before the barrier the flag store follows; a workgroup-scope release fence emits lgkmcnt only
+                // and s_barrier waits for nothing.  By now the stores are acknowledged, so the wait is free.)
+                cf_drain_stores () ;
                 __syncthreads () ;
                 if (tid == 0) __hip_atomic_store (fl + rb, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
             }
@@ -3074,7 +3098,8 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     __syncthreads () ;                      // (the last panel's readers are done with Lst / Xp: T and Lsd overlay Lst)
     auto tick = [] (int) {} ;
     int nv_out = nvt ;
-    if (nvt <= c0)
+    if (dead) { }
+    else if (nvt <= c0)
     {
         // an earlier pivot failed: this panel's columns are zero (:889-895, :926-931), identity "inverses"
         for (int k = wave ; k < pw ; k += 4)
@@ -3112,8 +3137,9 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
         __syncthreads () ;
         for (int e = tid ; e < 1024 ; e += 256) st_coh (DI + rb * 1024 + e, Wd [e]) ;
     }
-    // publish: every store above has been acknowledged (s_waitcnt through the workgroup-scope release) before the flag
-    __builtin_amdgcn_fence (__ATOMIC_RELEASE, "workgroup") ;
+    // publish: every wave waits for the acknowledgement of its own write-through stores (vmcnt(0)), the barrier collects the
+    // four waves, then the flag goes out -- data before flag at the coherence point, still without buffer_wbl2 / buffer_inv
+    cf_drain_stores () ;
     __syncthreads () ;
     if (tid == 0) __hip_atomic_store (fl + rb, (rb + 1) | ((1 + nv_out) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
 }

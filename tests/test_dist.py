@@ -120,6 +120,62 @@ def test_partition_is_consistent_and_balanced(world):
     assert all(abs(s[1] - w.sum()) < 1e-9 * w.sum() for s in stats)
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_batch_split_is_identical_on_every_rank(world):
+    """The memory-aware batch split (engine.hip: build_host) is chosen from an arena laid out over ALL fronts, and the
+    collectives of a group are issued in batch order: every rank must derive the same arena length, the same number of
+    subtrees and the same batch for every front -- also where a shared front's group is a strict subset of the world (a
+    member and a non-member once counted its distributed contribution block differently; round-4 advisor item).  Budgets
+    swept across the whole range in which the decision changes."""
+    n, Ap, Ai, Ax = G.poisson3d(24)
+    S = ch.Session(use_gpu=0)
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, G.geometric_nd(24, 24, 24, 4))
+    fv = ch.FactorView(Lf)
+    f = Lf.contents
+
+    def plans(budget_mb):
+        out = []
+        old = os.environ.get("CHOLMOD_HIP_ARENA_BUDGET_MB")
+        if budget_mb is not None:
+            os.environ["CHOLMOD_HIP_ARENA_BUDGET_MB"] = repr(budget_mb)
+        try:
+            for r in range(world):
+                st = C.c_int(0)
+                plan = S.L.cholmod_hip_plan_create_dist(fv.n, fv.nsuper, f.super, f.pi, f.px, f.s,
+                                                        ch.HIP_PLAN_HOST_ONLY, r, world, C.byref(st))
+                assert plan and st.value == 0
+                b = np.empty(fv.nsuper, dtype=np.int64)
+                ga = C.c_int64(0)
+                ns = S.L.cholmod_hip_get_batches(plan, b.ctypes.data, C.byref(ga))
+                g0 = np.empty(fv.nsuper, dtype=np.int64); gn = np.empty(fv.nsuper, dtype=np.int64)
+                S.L.cholmod_hip_get_groups(plan, g0.ctypes.data, gn.ctypes.data)
+                out.append((ns, ga.value, b, gn))
+                S.L.cholmod_hip_plan_destroy(plan)
+        finally:
+            if budget_mb is not None:
+                if old is None:
+                    del os.environ["CHOLMOD_HIP_ARENA_BUDGET_MB"]
+                else:
+                    os.environ["CHOLMOD_HIP_ARENA_BUDGET_MB"] = old
+        return out
+
+    base = plans(None)
+    gn = base[0][3]
+    assert ((gn > 1) & (gn < world)).any()          # the case in question: a group smaller than the world
+    full_mb = 8.0 * base[0][1] / 1048576.0
+    seen = set()
+    for frac in [None] + [0.02 * k for k in range(1, 60)]:
+        res = plans(None if frac is None else full_mb * frac)
+        ns0, ga0, b0, _ = res[0]
+        assert b0.min() >= 0
+        for ns, ga, b, _ in res[1:]:
+            assert ns == ns0 and ga == ga0 and np.array_equal(b, b0), (frac, ns, ns0, ga, ga0)
+        seen.add(ns0)
+    assert len(seen) >= 2, seen                     # the sweep did cross at least one split decision
+    S.free_factor(Lf); S.free_sparse(A); S.finish()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_contribution_routing_is_complete_and_disjoint(world):
     """Contributions routed past the contribution blocks of shared fronts (host side, no GPU): on every rank, a front it holds
