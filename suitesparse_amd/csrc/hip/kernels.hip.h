@@ -16,94 +16,9 @@
 #include <stdint.h>
 #include <type_traits>
 
-typedef long long i64;
-typedef int i32;
+#include "descriptors.hip.h"
 
 namespace sship {
-
-// ---- device-side descriptors ------------------------------------------------
-
-struct FrontD {
-    i64 psx;        // offset of the panel in Lx            (L->px[s])
-    i64 psi;        // offset of the row list in Ls         (L->pi[s])
-    i64 cb;         // offset of the contribution block in the arena
-    i64 rel;        // offset of this front's child->parent relative map
-    i32 k1;         // first column                         (L->super[s])
-    i32 nscol, nsrow, ncb;
-    i32 parent;     // supernodal etree parent or -1
-    i32 child_begin, child_end;   // range in the child index array (this rank's view)
-    i32 assemble;   // 1: k_assemble scatters A into this front on this rank, 2: the
-                    // fused thin-front kernel does, 0: another rank does
-    i32 cbp;        // 1: the contribution block is stored as a packed lower triangle
-                    // (column j holds rows j..ncb-1; written by k_thin_front), 0: as a
-                    // full square with ld = ncb (written by the dense update kernel)
-    // Several GPUs, a front shared by a rank group (round 4): its panel is DISTRIBUTED over the group by
-    // slabs of own_w columns, slab t on member t % own_g -- a rank stores only its own slabs, packed one
-    // behind the other with ld = nsrow (psx = offset of the first one in the rank's array).  own_w == 0:
-    // the whole panel is here (private fronts, one GPU, the gathered factor).
-    i32 own_w, own_g, own_r;
-    // ... and so is its contribution block (cbd = 1), by BLOCKS of columns: member r stores columns [cb_lo, cb_hi) of it
-    // (boundaries at equal shares of the lower triangle's area, multiples of 64), ld = ncb, and is the one that applies
-    // the outer updates to them.  Nothing is extend-added INTO such a block: what the descendants contribute to it is
-    // routed past it, straight into the ancestor whose panel holds the column (engine.hip: contributors).
-    i32 cbd;
-    i32 cb_lo, cb_hi;
-};
-// column c of front f: is it stored on this rank, and where (in columns from psx)
-__host__ __device__ __forceinline__ bool col_owned (const FrontD &f, int c) { return f.own_w == 0 || ((c / f.own_w) % f.own_g) == f.own_r ; }
-__host__ __device__ __forceinline__ int col_local (const FrontD &f, int c) { return f.own_w == 0 ? c : ((c / f.own_w) / f.own_g) * f.own_w + c % f.own_w ; }
-// front columns < c stored on this rank (= col_local (f, c) when c itself is)
-__host__ __device__ __forceinline__ int owned_before (const FrontD &f, int c)
-{
-    if (f.own_w == 0) return c ;
-    const int t = c / f.own_w ;
-    const int full = t > f.own_r ? (t - f.own_r + f.own_g - 1) / f.own_g : 0 ;       // owned slabs before slab t
-    return full * f.own_w + ((t % f.own_g) == f.own_r ? c % f.own_w : 0) ;
-}
-
-// what a parent needs of a child, in the order of the child lists: one load instead of the chain
-// child [ci] -> fr [child] -> (cb, rel, ncb, cbp)
-struct ChildD { i64 cb; i64 rel; i32 ncb; i32 cbp; };
-struct EaGroup { i32 front; i32 blk_start; i32 c_lo; i32 c_hi;      // extend-add into target columns [c_lo, c_hi)
-                 i64 pbase; };                                        // panel columns live at pbase + c ld (EA_NO_PBASE: at the front's psx;
-                                                                      // a window's virtual base may well be negative);
-                                                                      // a shared front's block column in its window (engine.hip)
-#define EA_NO_PBASE INT64_MIN
-struct ZeroGroup { i64 off; i64 len; i32 blk_start; i32 pad; };
-struct PfGroup { i64 off; i32 lda; i32 nb; i32 front; i32 col0; };
-struct TrGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 nb; i32 front;
-                 i32 col0; i32 blk_start; };
-// the 256-column panel chain (k_diag / k_rowsolve): a diagonal sub-block of a front and the
-// rows below it
-struct DgGroup { i64 off; i32 lda; i32 w; i32 front; i32 col0; i32 slot; i32 pad; };
-struct RsGroup { i64 l_off; i64 b_off; i32 lda; i32 m; i32 w; i32 front; i32 col0; i32 blk_start; i32 slot; i32 pad; };
-struct GemmGroup {
-    i64 a_off, b_off, c_off;    // a/b index Lx; c indexes Lx or the CB arena
-    i32 lda, ldc;
-    i32 m, n, k;                // target region m x n, contraction length k
-    i32 tri;                    // 1: region starts on the diagonal (row0==col0):
-                                //    only tiles with I>=J, and i>=j inside
-    i32 c_in_cb;                // 1: C lives in the CB arena
-    i32 tile_start;             // first block of this group in the launch
-    i32 mt, nt;                 // tile grid
-    i32 front;
-    i32 tile_mul, tile_add;     // multi-GPU: 64-tile chunk c of a shared front's outer
-                                // update belongs to the rank with c % tile_mul == tile_add
-    i32 ntiles;                 // tiles of the region (all ranks)
-    i32 nblk;                   // blocks this launch spends on the group (this rank)
-    i32 swz;                    // 1: XCD-aware super-tile walk (big groups)
-    i32 assign;                 // 1: C = -A*B' (first update of a contribution block: no zero-fill, no read)
-    i32 pf_next, pf_col0;       // k_update2f: tile (0,0) of the region is the next 64 x 64 diagonal block of
-                                // the front (its first column: pf_col0) and is factored by the workgroup that updates it
-    i32 tile_cnt;               // multi-GPU, > 0: this rank's share of the region is the RANGE of tile_cnt 64-tile chunks
-                                // that starts at chunk tile_add (tile_mul = 1): the contribution block of a distributed
-                                // front, dealt so that it evens out what the members' own slabs differ by
-};
-
-// Contribution blocks of the generic fronts are stored as full squares, ld = ncb
-// (lower part used); those of the thin fronts as packed lower triangles:
-// element (i,j), i >= j, of a packed triangle of order m lives at tri_col(j,m) + i.
-__host__ __device__ __forceinline__ int tri_col (int j, int m) { return j * m - ((j * (j + 1)) >> 1) ; }
 
 typedef double d4 __attribute__((ext_vector_type(4))) ;
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8))) ;
@@ -184,7 +99,6 @@ __global__ void __launch_bounds__(256) k_relmap (int nsuper, const FrontD *fr,
 // The same for (contributor, ancestor) pairs (several GPUs: contributions routed past the contribution blocks of shared
 // fronts): map [off + i] = position of the contributor's contribution-block row i in the ancestor's row list, -1 for the
 // rows below the ancestor's first column (consumed by a front in between).
-struct RelPair { i32 d ; i32 a ; i64 off ; } ;
 __global__ void __launch_bounds__(256) k_relmap_pairs (int npairs, const RelPair *pr, const FrontD *fr, const i64 *Ls, i32 *relmap)
 {
     int wave = (blockIdx.x * 256 + threadIdx.x) >> 6 ;
@@ -281,8 +195,6 @@ __global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, c
 // ---- zero the contribution blocks of a level --------------------------------
 // Only the lower triangle is ever read (extend-add, k_small_front) or kept, so
 // only it is cleared: a block owns ZERO_COLS columns and clears rows j0..ncb-1.
-#define ZERO_CHUNK 8192
-#define ZERO_COLS 8
 __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, double *CB)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &ZeroGroup::blk_start) ;
@@ -315,9 +227,6 @@ __global__ void __launch_bounds__(256) k_zero (const ZeroGroup *g, int ng, doubl
 #define EA_LDV(p) __builtin_nontemporal_load (p)
 #else
 #define EA_LDV(p) (*(p))
-#endif
-#ifndef EA_TW
-#define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
 #endif
 template <bool CX>
 __global__ void __launch_bounds__(256) k_extend_add (const EaGroup *g, int ng,
@@ -417,7 +326,6 @@ __device__ __forceinline__ void sqrt_rsqrt (double d, double &r, double &ri)
     ri = __builtin_ldexp (ri, sh >> 1) ;
 }
 
-#define PF_NB 64
 // ---- diagonal-block Cholesky, second generation --------------------------------
 // Same contract as k_potrf.  Four waves; the block is eliminated in 16-column
 // panels:
@@ -433,7 +341,6 @@ __device__ __forceinline__ void sqrt_rsqrt (double d, double &r, double &ri)
 //      v_mfma_f64_16x16x4 straight out of the k-major LDS copy.
 // 1/d from v_rcp_f64 plus one Newton step is within ~1.5 ulp, the result
 // differs from a division-based dpotrf by rounding only (parity tests: 1e-12).
-#define PF2_LD 64
 __device__ __forceinline__ double readlane_f64 (double v, int l)
 {
     int lo = __double2loint (v), hi = __double2hiint (v) ;
@@ -687,7 +594,6 @@ __global__ void __launch_bounds__(256) k_potrf_mfma (const PfGroup *g, double *L
 //                solves column q by forward substitution, reciprocals of the
 //                diagonal precomputed so the 16-step chain is mul + fma
 // Solved blocks and intermediates stay in registers (see the layout note below).
-#define TRM_ROWS 64
 __host__ __device__ inline size_t trsm_mfma_lds_bytes (int ldl)
 {
     return (size_t) (ldl * ldl + (ldl / 16) * 256) * sizeof (double) ;
@@ -897,8 +803,6 @@ __global__ void __launch_bounds__(256) k_trsm_mfma (const TrGroup *g, int ng,
 //  (4) the trailing update runs on the matrix cores out of the packed front; the
 //      one after the last panel IS the contribution block and is written to HBM
 //      from the accumulators (packed), never back to LDS.
-#define SM_MAX 136
-#define TF_PW 16
 __host__ __device__ inline size_t thin_front_lds_bytes (int ns_max)
 {
     int nsp = (ns_max + 1) & ~1 ;
@@ -2135,41 +2039,6 @@ __global__ void __launch_bounds__(64 * WPB, 2) k_update3 (const GemmGroup *g, in
     else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
 }
 
-// Persistent form (panel look-ahead on one GPU): the launch has FEWER workgroups than the chip has room for (engine.hip:
-// 2 per CU minus a reserve), every wave takes tiles from a counter until none is left -- the reserve stays free for the
-// panel chain of the next outer block column, which runs beside this update on the second stream and would otherwise find
-// every register file taken for a whole tile time (0.2 - 0.9 ms).  cnt [x] counts the virtual blocks == x (mod 8) handed
-// out: a wave on XCD x takes those first (the tile walk of decode_tile assumes block b on XCD b % 8), then helps the others.
-template <int DEPTH, int TW = 0>
-__global__ void __launch_bounds__(256, 2) k_update3p (const GemmGroup *g, int ng, int nvb, int *cnt, double *Lx, double *CB, int rsv)
-{
-    // rsv > 0 (tuning, CHOLMOD_HIP_LA_RESERVE_CU): workgroups that land on a compute unit with HW_ID.cu_id < rsv leave at once --
-    // those CUs stay free of update waves (the launch then has spare workgroups to burn, engine.hip): fp64 work of another
-    // kernel that shares a SIMD with this one's matrix-core stream runs 8 - 20 x slower (measured), so room in the register
-    // file is not enough for the panel chain, it needs compute units of its own
-    if (rsv > 0 && (int) ((__builtin_amdgcn_s_getreg ((31 << 11) | 4) >> 8) & 0xF) < rsv) return ;
-    const int xcc = (int) (__builtin_amdgcn_s_getreg ((31 << 11) | 20) & 7) ;      // HW_REG_XCC_ID
-    for (int o = 0 ; o < 8 ; o++)
-    {
-        const int x = (xcc + o) & 7 ;
-        for ( ; ; )
-        {
-            int t = 0 ;
-            if ((threadIdx.x & 63) == 0) t = atomicAdd (cnt + x, 1) ;
-            t = __builtin_amdgcn_readfirstlane (t) ;
-            const int vb = t * 8 + x ;
-            if (vb >= nvb) break ;
-            int gi = find_group (g, ng, vb, &GemmGroup::tile_start) ;
-            GemmGroup G = g [gi] ;
-            int I, J ;
-            if (vb - G.tile_start >= G.nblk) continue ;
-            if (!decode_tile (G, vb - G.tile_start, I, J)) continue ;
-            if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
-            else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
-        }
-    }
-}
-
 // ---- trailing update that also factors the next diagonal block ------------------
 // The narrow (K < 512) updates of the panel chain are followed, on the same stream, by
 // the dpotrf of the block they have just finished updating: tile (0,0) of their region.
@@ -2391,14 +2260,6 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
 // :997-1002) on those rows only, and the solved chunks travel back with one all-gather
 // (XchgD::ag: g x R x w).  Same volume as the all-reduce it replaces; the dtrsm and the
 // narrow updates of the block column are no longer repeated by every rank of the group.
-struct XchgD {
-    i64 slab ;      // offset in Lx of entry (b0, b0) of the front
-    i32 lda ;       // nsrow
-    i32 w ;         // columns of the block column
-    i32 mb ;        // rows below the diagonal block (nsrow - b0 - w)
-    i32 R ;         // rows per chunk (g R >= mb)
-    i32 g, r ;      // group size, this rank's index in the group
-} ;
 // mode 0: Lx -> stage (all g segments: this rank's partial sums, D repeated per segment)
 // mode 1: segment r of stage -> Lx (summed D and own chunk)
 // mode 2: own chunk of Lx -> ag + r R w        mode 3: ag (all chunks but r) -> Lx
@@ -2503,8 +2364,6 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
 //                   (extend-add into the window) and the dealt tiles of the wide updates are added;
 //   mode 1 (close): the factored columns back into the owner's slabs.
 // One workgroup = one column x WIN_ROWS rows.
-#define WIN_ROWS 8192
-struct WinD { i64 store ; i64 win ; i32 ld ; i32 c0, c1 ; i32 r0 ; i32 nrows ; i32 own_w, own_g, own_r ; i32 mode ; i32 blk_start ; } ;
 __global__ void __launch_bounds__(256) k_win_move (const WinD *g, int ng, double *Lx)
 {
     int gi = find_group (g, ng, (int) blockIdx.x, &WinD::blk_start) ;
@@ -2555,7 +2414,6 @@ __global__ void __launch_bounds__(256) k_win_move (const WinD *g, int ng, double
 // CU-masked stream would need.
 // Not-positive-definite protocol as everywhere: the first pivot <= 0 goes to info [front]
 // (1-based, relative to the front), every later column of the front is written as zero.
-#define DG_W 256
 template <typename Tick>
 __device__ __forceinline__ void dg_left_looking (d4 (&acc) [4], const double *A, i64 lda, int rowc, int c0, int w, int lr, int lk, Tick)
 {
@@ -2691,7 +2549,6 @@ __global__ void __launch_bounds__(256) k_diag (const DgGroup *g, double *Lx, i32
     if constexpr (TIMED) { if (tid == 0) for (int q = 0 ; q < 8 ; q++) tim [q] = tc [q] ; }
 }
 
-#define RS_ROWS 64
 __host__ __device__ inline size_t rowsolve_lds_bytes () { return (size_t) (DG_W * 64 + 4 * 256) * sizeof (double) ; }
 __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, double *Lx, const i32 *info, const double *dinv)
 {
@@ -2832,7 +2689,6 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 // of the sub-block so far (w when no pivot has failed).
 // rows below the sub-block: [w, w + m1) and, for a front shared between ranks (its block column dealt by row chunks), a
 // second range [off2, off2 + m2) -- the rest of the 512-wide diagonal block on every rank, then this rank's chunk
-struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 m1 ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 off2 ; i32 m2 ; i32 pad ; } ;
 __device__ __forceinline__ double ld_coh (const double *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 __device__ __forceinline__ void st_coh (double *p, double v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 // polls (s_sleep 4 + one coherent load, ~1.5 us each) before a hand-off counts as failed: ~6 s, far beyond any jitter
@@ -3160,7 +3016,6 @@ __global__ void __launch_bounds__(256) k_first_fail (i64 nsuper, const i32 *info
 // the level.  Forward: x1 = L1 \ x1 ; X[Ls2] -= L2 * x1 (children of one parent
 // may hit the same rows, hence the atomic add).  Backward: x1 = L1' \ (x1 -
 // L2' * X[Ls2]) needs no atomics.
-struct SolveTask { i32 front ; i32 c0, c1 ; i32 below ; } ;   // columns [c0,c1) of a supernode
 
 template <bool CX>
 __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
@@ -3244,9 +3099,6 @@ __global__ void __launch_bounds__(256) k_lsolve (const SolveTask *tasks,
 }
 
 // column block of the big-supernode walk (k_solve_fwd_blk / k_solve_bwd_blk below)
-#define SOLVE_IB 64          /* diagonal blocks with an explicit inverse (k_diag_inv64) */
-#define SOLVE_SB 256         /* column block of the big-front walk: four inverse blocks */
-#define SOLVE_BIG_COLS 256   /* fronts wider than this (or > 512 KB) take the multi-workgroup walk */
 
 template <bool CX>
 __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
@@ -3351,7 +3203,6 @@ __global__ void __launch_bounds__(256) k_ltsolve (const SolveTask *tasks,
 // Inverse layout (per 64-block, 2 x 4096 doubles): Wm [k*64 + r] = W(r,k) and
 // WmT [k*64 + c] = W(k,c), both zero outside the lower triangle and
 // identity-padded past the supernode's last column.
-struct InvTask { i32 front ; i32 jb ; i64 w_off ; } ;
 
 template <bool CX>
 __global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const FrontD *fr,
@@ -3402,7 +3253,6 @@ __global__ void __launch_bounds__(64) k_diag_inv64 (const InvTask *tasks, const 
 
 // One step of the walk for every big supernode of a level at once: task t = block
 // [jb, jb+w) of one supernode, workgroups wg_start .. of the launch belong to it.
-struct SolveBlk { i32 front, jb, w, wg_start, inv, slot ; } ;   // inv: index of its first 64 x 64 inverse
 
 __device__ __forceinline__ int find_solve_task (const SolveBlk *t, int nt, int b)
 {
@@ -3751,8 +3601,6 @@ __global__ void k_perm (i64 n, const i64 *perm, const double *src, double *dst,
 //   out[4] += diagonal entries <= 0
 // A workgroup owns CHK_COLS columns of one supernode; wave w takes the columns
 // == w (mod 4), lanes stride the rows (coalesced).
-#define CHK_COLS 64
-struct CheckTask { i32 front ; i32 c0 ; } ;
 // ---- even columns of the factor (complex input through the real embedding) ---------
 // The engine factors the 2n x 2n embedding of a complex matrix (host/complex.c); the
 // interleaved complex column j of a supernode is the even column 2j of the real one.

@@ -35,13 +35,60 @@ def main():
         res["ok"] = bool(np.allclose(buf, np.arange(10) * sum(range(1, world + 1))))
         res["calls"] = cb.stats["n"]
     else:
-        from oracle.oracle import OracleFactor
+        from oracle.oracle import OracleFactor, bind_blas
+        if case.startswith("checks_p3d_"):
+            # a BASELINE-size problem no oracle can follow in a test (Poisson 100^3: configs[1]) on `world` real peers: the
+            # factor stays distributed; every rank checks its own part (cholmod_hip_factor_checks_local), the five sums meet
+            # in an all-reduce and are held against the closed forms -- log det A of the Dirichlet Laplacian and
+            # ||L||_F^2 = trace A -- after the first factorization and after a resident refactorization
+            import ctypes as C
+            import torch
+            m = int(case.split("_")[-1])
+            n, Ap, Ai, Ax = G.poisson3d(m); perm = G.geometric_nd(m, m, m, 4)
+            S = ch.Session(rank=rank, world=world, allreduce=None, factor_on_device=True)
+            A = S.sparse(n, Ap, Ai, Ax, -1)
+            Lf = S.analyze(A, perm)
+            assert S.L.cholmod_l_hip_prepare(Lf, C.byref(S.cm)) == 1, S.cm.status
+            idb = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                assert S.L.cholmod_hip_rccl_unique_id(idb.ctypes.data) == 0
+            box = [idb.tobytes()]
+            dist.broadcast_object_list(box, src=0)
+            idb = np.frombuffer(box[0], dtype=np.uint8).copy()
+            assert S.L.cholmod_hip_rccl_attach(ch.FactorView(Lf).hip_plan, idb.ctypes.data) == 0
+            ld = G.poisson_logdet(m, m, m)
+            errs = []
+            for it in range(2):
+                ok = S.factorize(A, Lf) if it == 0 else S.refactorize_resident(Lf)
+                assert ok == 1 and S.cm.status == ch.OK, (ok, S.cm.status)
+                loc = torch.from_numpy(np.asarray(S.factor_checks_local(Lf), dtype=np.float64).copy())
+                dist.all_reduce(loc)
+                v = loc.numpy()
+                errs.append(dict(logdet_rel_err=float(abs(2.0 * v[0] - ld) / abs(ld)), upper_nonzeros=int(v[1]), nonfinite=int(v[2]),
+                                 trace_rel_err=float(abs(v[3] - 6.0 * n) / (6.0 * n)), nonpositive_diag=int(v[4])))
+            st = S.hip_stats(Lf)
+            res.update(ok=1, status=int(S.cm.status), checks=errs, exchanges=int(st[17]), L_bytes_rank=float(st[36]),
+                       L_bytes_whole=float(st[5]), arena_bytes=float(st[4]))
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            S.finish()
+            with open(f"{out}.{rank}", "w") as f:
+                json.dump(res, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        if case in ("p3d_64", "p3d_32_notposdef_root"):
+            bind_blas()                 # (the oracle's dense kernels through a BLAS: 64^3 in seconds instead of minutes)
         if case == "p3d_20":
             n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)
         elif case == "p3d_32":
             n, Ap, Ai, Ax = G.poisson3d(32); perm = G.geometric_nd(32, 32, 32, 4)
         elif case == "p3d_48":
             n, Ap, Ai, Ax = G.poisson3d(48); perm = G.geometric_nd(48, 48, 48, 4)
+        elif case == "p3d_64":
+            n, Ap, Ai, Ax = G.poisson3d(64); perm = G.geometric_nd(64, 64, 64, 4)
+        elif case == "p3d_32_notposdef_root":
+            n, Ap, Ai, Ax = G.poisson3d(32); perm = G.geometric_nd(32, 32, 32, 4)
         elif case == "p2d_90":
             n, Ap, Ai, Ax = G.poisson2d(90); perm = G.geometric_nd(90, 90, 1, 4)
         elif case == "box10":

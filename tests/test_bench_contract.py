@@ -77,7 +77,7 @@ def test_bench_keeps_its_line_when_the_gathered_factor_does_not_fit():
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "24", "--steps", "1", "--warmup", "1",
                           "--dist-backend", "gloo", "--check"],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CHOLMOD_HIP_TEST_FAIL_GATHER="1"))
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, CHOLMOD_HIP_TEST_FAIL_GATHER="1", SSAMD_TEST_HOOKS_LIB="1"))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout
@@ -100,6 +100,35 @@ def test_bench_gpus_flag_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
     assert d["residual_2norm"] < 1e-11
     assert d["factor_checks_distributed"]["logdet_rel_err"] < 1e-11
+
+
+@pytest.mark.gpu
+def test_bench_watchdog_turns_a_hung_collective_into_an_error_line():
+    """First hardware contact must not be able to fail silently (round-4 review, item 1b): rank 1 of 2 stops issuing its
+    collectives in the middle of the second timed step (test hook: its host thread sleeps before exchange 3; nothing hangs
+    on the device), rank 0 waits for it in the exchange.  The per-step deadline expires: rank 0 prints ONE JSON line with
+    "error", the phase, the completed step's time and the exchange its device has entered and not left, and the job exits
+    non-zero -- instead of sitting there until the driver's 1800 s kill."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SSAMD_TEST_HOOKS_LIB="1", CHOLMOD_HIP_TEST_HANG_EXCHANGE="1:3:3")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "32", "--steps", "2", "--warmup", "1",
+                          "--dist-backend", "gloo", "--step-deadline", "15"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode != 0, out.stdout[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out.stdout, out.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and "deadline" in d["error"] and d["n_gpus"] == 2, d
+    assert d["phase"] == "timed step 2 of 2" and d["steps_completed"] == 1 and d["last_completed_step_ms"] > 0, d
+    pg = d["progress"]
+    assert pg["exchange_entered_on_device"] == 3 and pg["exchange_left_on_device"] == 2, pg
+    assert pg["pending_exchange"]["sequence"] == 3 and pg["pending_exchange"]["rank_group"] == [0, 1], pg
 
 
 def test_bench_gpus_flag_fails_loudly_without_the_devices():

@@ -35,6 +35,8 @@ def _run_ranks(world, mode, case, timeout=600, extra_env=None):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
         env.update(extra_env or {})
+        if any(k.startswith("CHOLMOD_HIP_TEST_") for k in env):
+            env["SSAMD_TEST_HOOKS_LIB"] = "1"      # the engine's test hooks exist only in lib/libcholmod_amd_testhooks.so
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"),
                                        mode, case, out], env=env, cwd=ROOT))
     rcs = [p.wait(timeout=timeout) for p in procs]
@@ -453,6 +455,57 @@ def test_native_exchange_between_ranks_matches_oracle(world, case):
     full = np.array(res[0]["checks_full"])
     assert abs(tot[0] - full[0]) <= 1e-11 * abs(full[0]) and abs(tot[3] - full[3]) <= 1e-11 * full[3], (tot, full)
     assert tot[1] == full[1] == 0 and tot[2] == full[2] == 0 and tot[4] == full[4] == 0, (tot, full)
+
+
+# ---- the headline world size with real peers (round-4 review, item 1) -----------------------------------------------------
+# Eight processes share GPU 0 and drive the engine-native exchange through the asynchronous stand-in: the nested 8 / 4 / 2
+# group structure an 8-rank partition produces (sub-communicators by ncclCommSplit, collectives of different groups
+# interleaved on every rank), streams jittered, arena / windows / staging poisoned.
+
+JIT8 = dict(CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="11:1200")
+
+
+@pytest.mark.gpu
+def test_world8_on_one_gpu_matches_oracle_at_64_cubed():
+    res = _run_ranks(8, "gpu", "p3d_64", timeout=1500, extra_env=dict(NATIVE, **JIT8))
+    sizes = set()
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0, r
+        assert r["err"] < 1e-12 and r["resid"] < 1e-11, r
+        assert r["nshared"] > 0 and r["nshared"] + sum(r["owned"]) == r["nsuper"], r
+        assert r["allreduce_calls"] > 0
+        sizes.update(r["allreduce_group_sizes"])
+    assert 8 in sizes and (4 in sizes or 2 in sizes), sizes         # groups smaller than the world took part
+    assert len({json.dumps(r["owned"]) for r in res}) == 1
+    tot = np.sum([r["checks_local"] for r in res], axis=0)
+    full = np.array(res[0]["checks_full"])
+    assert abs(tot[0] - full[0]) <= 1e-11 * abs(full[0]) and abs(tot[3] - full[3]) <= 1e-11 * full[3], (tot, full)
+    assert tot[1] == full[1] == 0 and tot[2] == full[2] == 0 and tot[4] == full[4] == 0, (tot, full)
+
+
+@pytest.mark.gpu
+def test_world8_on_one_gpu_at_100_cubed_distributed_checks():
+    """BASELINE configs[1] (Poisson 100^3, 1 M dof) on eight peers: the factor stays distributed (1 / 8 of L + windows per
+    rank), its invariants are summed over the ranks and held against the closed forms (log det A, trace A), first
+    factorization and resident refactorization."""
+    res = _run_ranks(8, "gpu", "checks_p3d_100", timeout=1500, extra_env=dict(NATIVE, **JIT8))
+    for r in res:
+        assert r["ok"] == 1 and r["status"] == 0, r
+        for c in r["checks"]:
+            assert c["logdet_rel_err"] < 1e-11 and c["trace_rel_err"] < 1e-11, c
+            assert c["upper_nonzeros"] == 0 and c["nonfinite"] == 0 and c["nonpositive_diag"] == 0, c
+        assert r["exchanges"] > 20 and r["L_bytes_rank"] < 0.4 * r["L_bytes_whole"], r
+
+
+@pytest.mark.gpu
+def test_world8_not_posdef_agreement():
+    """A failing pivot in the middle of the root (shared by all eight ranks, past its first 64-column step): every rank
+    returns the same minor and the oracle's zero pattern."""
+    res = _run_ranks(8, "gpu", "p3d_32_notposdef_root", timeout=900, extra_env=dict(NATIVE, **JIT8))
+    for r in res:
+        assert r["oracle_status"] == 1 and r["ok"] == 1 and r["status"] == ch.NOT_POSDEF, r
+        assert r["minor"] == r["oracle_minor"], r
+        assert r["zero_pattern_equal"] and r["err"] < 1e-12, r
 
 
 @pytest.mark.gpu

@@ -135,7 +135,7 @@ def test_device_allocation_failure_is_loud_or_degrades_on_request(monkeypatch):
     O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
     assert O.factorize(Ax) == 0
     monkeypatch.setenv("CHOLMOD_HIP_TEST_FAIL_ALLOC", "1")
-    S = ch.Session()
+    S = ch.Session(hooks=True)          # (the engine's test hooks live in lib/libcholmod_amd_testhooks.so only)
     A = S.sparse(n, Ap, Ai, Ax, -1)
     Lf = S.analyze(A, perm)
     assert Lf.contents.useGPU == 1

@@ -337,7 +337,7 @@ def test_nothing_reads_the_arena_before_it_is_written(golden_dir, monkeypatch):
         n, Ap, Ai, Ax, stype, perm = _case(name, golden_dir)
         O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=True)
         assert O.factorize(Ax) == 0
-        S = ch.Session()
+        S = ch.Session(hooks=True)      # (test hooks: lib/libcholmod_amd_testhooks.so)
         A = S.sparse(n, Ap, Ai, Ax, stype)
         Lf = S.analyze(A, perm)
         m = O.lower_mask()

@@ -400,58 +400,6 @@ def test_bench_matrix_file_reader_path():
     assert d["residual_2norm"] < 1e-11
 
 
-# ---- panel look-ahead on one GPU (opt-in) ------------------------------------------------------
-
-@pytest.mark.parametrize("name,reserve", [("box42_r3_nd", "64"), ("p3d_64_nd", "448"), ("p2d_1259_nd", "64")])
-def test_panel_lookahead_matches_oracle(name, reserve, monkeypatch):
-    """CHOLMOD_HIP_LOOKAHEAD=1: the panel chain of outer block column k + 1 on the second stream beside the rest of outer
-    update k (its one-wave-per-tile launches in their persistent form, k_update3p: tiles handed out by counters), the
-    update kernel with four tiles per workgroup -- against the oracle, with the contribution-block arena poisoned so that
-    a launch running ahead of what it depends on shows.  A reserve of 448 leaves the persistent launches 64 workgroups:
-    every workgroup walks several XCDs' tile lists."""
-    monkeypatch.setenv("CHOLMOD_HIP_LOOKAHEAD", "1")
-    monkeypatch.setenv("CHOLMOD_HIP_LA_RESERVE", reserve)
-    monkeypatch.setenv("CHOLMOD_HIP_TEST_POISON_ARENA", "1")
-    monkeypatch.setenv("CHOLMOD_HIP_TEST_JITTER", reserve + ":800")       # (random hold-ups of either stream: tests/test_dist.py)
-    _compare(name, again=True)
-
-
-def test_stream_jitter_catches_a_dropped_wait():
-    """The detector has teeth: with the schedule's cross-stream waits skipped (CHOLMOD_HIP_TEST_DROP_WAITS, a mutation of
-    the look-ahead schedule) the jittered, poisoned run must NOT reproduce the oracle's factor.  In a child process: the
-    hook is read once per process."""
-    import subprocess, sys, textwrap
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent("""
-        import sys, numpy as np
-        sys.path.insert(0, %r); sys.path.insert(0, %r)
-        import test_gpu_scale as T
-        from suitesparse_amd import cholmod as ch
-        n, Ap, Ai, Ax, perm, O, mask = T._oracle("box42_r3_nd")
-        S = ch.Session()
-        A = S.sparse(n, Ap, Ai, Ax, -1)
-        Lf = S.analyze(A, perm)
-        ok = S.factorize(A, Lf)
-        fv = ch.FactorView(Lf)
-        x = np.nan_to_num(fv.x, nan=1e300)
-        err = np.linalg.norm((x - O.x)[mask]) / np.linalg.norm(O.x[mask])
-        print("RESULT", int(ok), int(S.cm.status), float(min(err, 1e300)))
-    """) % (ROOT, os.path.join(ROOT, "tests"))
-    def run(extra):
-        env = dict(os.environ, CHOLMOD_HIP_LOOKAHEAD="1", CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="7:800", **extra)
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("RESULT")]
-        if not line and extra:
-            return 0, -1, 1e300     # (the mutated run died on what it read too early: noticed all the same)
-        assert line, out.stderr[-2000:]
-        _, ok, status, err = line[0].split()
-        return int(ok), int(status), float(err)
-    ok, status, err = run({})
-    assert ok == 1 and status == 0 and err < TOL_L, (ok, status, err)
-    ok, status, err = run({"CHOLMOD_HIP_TEST_DROP_WAITS": "1"})
-    assert not (ok == 1 and status == 0 and err < TOL_L), "a schedule without its cross-stream waits went unnoticed"
-
-
 # ---- the 256-column panel chain (opt-in) ----------------------------------------------------
 
 @pytest.mark.parametrize("name", ["box42_r3_nd", "p3d_64_nd", "p2d_1259_nd"])

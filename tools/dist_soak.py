@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.chdir(ROOT)
 import tests.test_dist as T
-env = dict(T.NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1")
+env = dict(T.NATIVE, CHOLMOD_HIP_TEST_POISON_ARENA="1", SSAMD_TEST_HOOKS_LIB="1")
 bad = 0
 JIT = len(sys.argv) > 1 and sys.argv[1] == "jitter"        # random hold-ups of the streams (CHOLMOD_HIP_TEST_JITTER), a new seed per round
 for it in range(12):
