@@ -92,9 +92,11 @@ def cpu_baseline(sample_m):
     the reference's left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU
     supernodal path") timed on the host cores on a bounded sample of the same workload family, in
     child processes (the BLAS binding and its thread pool are per process).  Not the oracle: nothing
-    under oracle/ is timed.  The same sample at 1 thread, at 16 and at min(cores, 64): `value` is the
-    best of them and `cores` the thread count that gave it, so the stated baseline is not an accidental
-    pessimisation by oversubscribed BLAS threads; every point is in `by_threads`."""
+    under oracle/ is timed.  The sample is BASELINE configs[1] itself (Poisson 100^3, fl = 6.3e12: about half a minute
+    per factorization) at 16, 32 and 64 threads; `value` is the best of them and `cores` the thread count that gave it,
+    every point is in `by_threads`.  (Rounds 3-4 used 56^3 and saw 64 threads 6 x slower than 16: the threaded BLAS woke
+    every thread for each of the several hundred thousand tiny updates; host/cpu_numeric.c now sizes the thread count
+    of every dense call by its flops.)"""
     import subprocess
     base = dict(os.environ, BENCH_ROOT=ROOT, BENCH_CPU_M=str(sample_m))
     if "CHOLMOD_BLAS_LIBRARY" not in base:
@@ -102,15 +104,19 @@ def cpu_baseline(sample_m):
         if b:
             base["CHOLMOD_BLAS_LIBRARY"] = b
     cores = os.cpu_count() or 1
+    big = sample_m >= 80            # (a BASELINE-size sample: tens of seconds per factorization)
     if "OMP_NUM_THREADS" in os.environ:
         counts = [int(os.environ["OMP_NUM_THREADS"])]
+    elif big:
+        counts = sorted({min(cores, 16), min(cores, 32), min(cores, 64)})      # up to one socket's cores (EPYC 9575F: 64)
     else:
         counts = sorted({1, min(cores, 16), min(cores, 64)})
+    base["BENCH_CPU_REPS"] = os.environ.get("BENCH_CPU_REPS", "1" if big else "2")
     pts, blas, fl, err = [], None, None, None
     for t in counts:
         env = dict(base, OMP_NUM_THREADS=str(t), OPENBLAS_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
         try:
-            out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=600)
+            out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=900)
             r = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:      # report, never fail the bench line
             err = repr(e)
@@ -126,8 +132,10 @@ def cpu_baseline(sample_m):
             "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
             "by_threads": pts,
             "speedup_over_one_thread": (top["GFLOPs"] / one["GFLOPs"]) if one else None,
-            "sample": f"poisson3d {sample_m}^3 geometric ND, best of two factorizations per thread count "
-                      f"({', '.join(str(q['threads']) for q in pts)} threads; OpenMP loops and BLAS threads alike), "
+            "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)),
+            "sample": f"poisson3d {sample_m}^3 geometric ND" + (" (BASELINE configs[1], the whole factorization)" if sample_m == 100 else "")
+                      + f", best of {base['BENCH_CPU_REPS']} factorization(s) per thread count "
+                      f"({', '.join(str(q['threads']) for q in pts)} threads; every dense call gets one BLAS thread per ~4 Mflop, at most that many), "
                       f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas}, host cores {cores}"}
 
 
@@ -200,6 +208,7 @@ def roofline_of(S, Lf, wname, world):
     other = {"kernel": "k_update2<64,64,16,2,false>" if use_w else "k_update3", "seconds": ps[6] if use_w else ps[32],
              "launches": int(ps[7] if use_w else ps[33]),
              "TFLOPs": ((ps[8] / ps[6]) if use_w and ps[6] > 0 else (ps[34] / ps[32]) if (not use_w and ps[32] > 0) else 0.0) / 1e12}
+    roofline_of.last_profile = lp
     return {"bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
             # `traffic` is a per-launch mean over the launches the counter passes covered; the algorithmic
@@ -228,6 +237,99 @@ def roofline_of(S, Lf, wname, world):
                                  "total_profiled": ps[0]}}
 
 
+KIND_NAMES = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "reduce_scatter", 8: "thin",
+              9: "update+potrf", 10: "trsm+upd+potrf", 11: "all_gather", 12: "update_w", 13: "diag256", 14: "rowsolve",
+              15: "window", 16: "chain256f"}
+SM_MAX = 136            # rows up to which a front runs in the thin-front kernel (descriptors.hip.h)
+UPD3_STANDALONE_TFLOPS = 75.0    # k_update3 on a 16 384^2 x 4096 region (printed live as measured_update_kernel_*)
+
+
+def critical_path(S, Lf, lp, ms_step):
+    """Where a mid-size factorization stands against its dependency bound (round-4 review, item 2).
+
+    critical_path_ms: the longest root-to-leaf path of the supernodal etree, priced as
+        (64-column steps on the path) x (measured floor of one step of the panel chain)
+      + (levels of thin fronts on the path) x (measured floor of a thin-front launch)
+      + (all update flops of the factorization) / (k_update3's standalone rate)
+    -- the panel chain of a front cannot start before its children are done and cannot go faster than its dependent
+    64-column steps, and the updates cannot beat the update kernel; everything else (extend-add, zero-fill, assembly) is
+    taken as free.  The per-step floor is measured in THIS run: the chain alternates `trsm+upd+potrf` | `trsm`,
+    `update+potrf`, i.e. three launches per 128 columns, each at the shortest duration any launch of its kind had.
+    launch_list_bound_ms: the launch list the engine actually issued, every launch at max (floor of its kind, its
+    algorithmic work at the roofline: flops at the standalone update rate / bytes at 8 TB/s) -- what this schedule would
+    take if every kernel were perfect; measured / launch_list_bound > 1.15 means the kernels lose time, measured /
+    critical_path >> 1 with launch_list_bound close to measured means the schedule (level-synchronous batches) does."""
+    from suitesparse_amd import cholmod as ch
+    fv = ch.FactorView(Lf)
+    nsuper = fv.nsuper
+    sp = np.empty(nsuper, dtype=np.int64)
+    lv = np.empty(nsuper, dtype=np.int64)
+    S.L.cholmod_hip_get_maps(Lf.contents.hip_plan, sp.ctypes.data, lv.ctypes.data, None)
+    nscol = np.diff(fv.super)
+    nsrow = np.diff(fv.pi)
+    thin = nsrow <= SM_MAX
+    steps = np.where(thin, 0, (nscol + 63) // 64).astype(np.int64)
+    # longest path by levels: children have lower indices' levels; process in increasing level
+    order = np.argsort(lv, kind="stable")
+    best_steps = np.zeros(nsuper, dtype=np.int64)      # steps on the heaviest path ending in s (s included)
+    best_thin = np.zeros(nsuper, dtype=np.int64)
+    acc_steps = np.zeros(nsuper, dtype=np.int64)       # best over children, gathered at the parent
+    acc_thin = np.zeros(nsuper, dtype=np.int64)
+    kinds, msl = lp["kind"], lp["ms"]
+
+    def floor(k):
+        q = (kinds == k) & (msl > 0)
+        return float(msl[q].min()) if q.any() else 0.0
+    f_tu, f_tr, f_uf, f_pf, f_thin = floor(10), floor(3), floor(9), floor(2), floor(8)
+    # one step of the chain: (trsm+upd+potrf) then (trsm, update+potrf) per 128 columns; without the fusions potrf + trsm + update
+    if f_tu > 0 and f_uf > 0:
+        step_floor = (f_tu + f_tr + f_uf) / 2.0
+    else:
+        step_floor = f_pf + f_tr + floor(5)
+    w_thin = 1.0 if f_thin > 0 else 0.0
+    for s_ in order:
+        a, b = acc_steps[s_], acc_thin[s_]
+        best_steps[s_] = a + steps[s_]
+        best_thin[s_] = b + (1 if thin[s_] else 0)
+        p_ = sp[s_]
+        if p_ >= 0:
+            # path cost in time decides which child path the parent continues
+            if (best_steps[s_] * step_floor + best_thin[s_] * f_thin * w_thin) > (acc_steps[p_] * step_floor + acc_thin[p_] * f_thin * w_thin):
+                acc_steps[p_], acc_thin[p_] = best_steps[s_], best_thin[s_]
+    roots = np.where(sp < 0)[0]
+    tcost = best_steps[roots] * step_floor + best_thin[roots] * f_thin
+    r = roots[int(np.argmax(tcost))]
+    path_steps, path_thin = int(best_steps[r]), int(best_thin[r])
+    ncb = (nsrow - nscol).astype(np.float64)
+    c = nscol.astype(np.float64)
+    upd_flops = float((ncb * ncb * c + ncb * c * c).sum() + ((c * c * c / 3.0) * (1.0 - 1.0 / np.maximum(c / 64.0, 1.0) ** 2)).sum())
+    t_chain = path_steps * step_floor
+    t_thin = path_thin * f_thin
+    t_upd = upd_flops / (UPD3_STANDALONE_TFLOPS * 1e12) * 1e3
+    cp = t_chain + t_thin + t_upd
+    # the launch list at floor-or-roofline
+    upd_kinds = (4, 5, 9, 12)
+    bound = 0.0
+    for k in set(kinds.tolist()):
+        q = kinds == k
+        fk = floor(k)
+        if k in upd_kinds or k in (2, 3, 10, 13, 14, 16):
+            roof = lp["flops"][q] / (UPD3_STANDALONE_TFLOPS * 1e12) * 1e3
+        else:
+            roof = lp["bytes"][q] / 8e12 * 1e3
+        bound += float(np.maximum(roof, fk).sum())
+    by_kind = {KIND_NAMES.get(int(k), str(int(k))): {"launches": int((kinds == k).sum()), "ms": float(msl[kinds == k].sum()),
+                                                      "floor_us": 1e3 * floor(k)} for k in sorted(set(kinds.tolist()))}
+    return {"critical_path_ms": cp, "ms_per_step_over_critical_path": ms_step / cp if cp > 0 else None,
+            "critical_path_detail": {"steps_of_64_columns_on_the_longest_path": path_steps, "step_floor_us": 1e3 * step_floor,
+                                     "chain_ms": t_chain, "thin_levels_on_the_path": path_thin, "thin_launch_floor_us": 1e3 * f_thin,
+                                     "thin_ms": t_thin, "update_flops": upd_flops, "update_ms_at_standalone_rate": t_upd,
+                                     "standalone_update_TFLOPs": UPD3_STANDALONE_TFLOPS,
+                                     "etree_levels": int(lv.max()) + 1 if nsuper else 0},
+            "launch_list_bound_ms": bound, "ms_per_step_over_launch_list_bound": ms_step / bound if bound > 0 else None,
+            "profiled_ms_by_kind": by_kind, "profiled_ms_total": float(msl.sum())}
+
+
 def secondary_line(workload, m, steps=3, warmup=1):
     """One of the other single-GPU configurations of BASELINE.json (configs[1]: Poisson 100^3; SURVEY 8d's
     stand-ins of nd24k and G3_circuit), same step as the headline: resident refactorizations, then
@@ -241,11 +343,16 @@ def secondary_line(workload, m, steps=3, warmup=1):
     fl = S.cm.fl
     assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
     for _ in range(warmup):
+        t0 = time.perf_counter()
         assert S.refactorize_resident(Lf) == 1
+        dt0 = time.perf_counter() - t0
+    # (a 5 ms step timed over three repetitions is noise: at least a quarter of a second per timing loop)
+    steps = max(steps, min(100, int(0.25 / max(dt0, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(steps):
         assert S.refactorize_resident(Lf) == 1
     dt = (time.perf_counter() - t0) / steps
+    assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
     t0 = time.perf_counter()
     for _ in range(steps):
         assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
@@ -256,13 +363,23 @@ def secondary_line(workload, m, steps=3, warmup=1):
     x = S.solve(Lf, b)
     r = G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b
     checks = S.factor_checks(Lf)
-    out = {"workload": wname, "n": int(n), "fl": fl, "executed_flops": stats[1], "value": fl / dt / 1e9, "unit": "GFLOP/s",
-           "ms_per_step": 1e3 * dt, "ms_per_step_api": 1e3 * dt_api, "steps": steps,
-           "pct_fp64_mfma_peak": 100.0 * fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+    # quoted on SURVEY 8d's step: cholmod_l_factorize (A, L, Common) from the host matrix (CHOLMOD/Cholesky/
+    # cholmod_factorize.c:97-288; the demo's convention, cholmod_l_demo.c:293, :691-692) -- values-only H2D + gather + the
+    # factorization; the step on the resident S stands beside it
+    out = {"workload": wname, "n": int(n), "fl": fl, "executed_flops": stats[1], "value": fl / dt_api / 1e9, "unit": "GFLOP/s",
+           "ms_per_step": 1e3 * dt_api, "ms_per_step_api": 1e3 * dt_api, "ms_per_step_resident": 1e3 * dt, "steps": steps,
+           "step": "cholmod_l_factorize(A, L, Common), A in host memory, L left in HBM (SURVEY 8d t_factorize)",
+           "pct_fp64_mfma_peak": 100.0 * fl / dt_api / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+           "value_resident": fl / dt / 1e9, "pct_fp64_mfma_peak_resident": 100.0 * fl / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
            "launches_per_step": int(stats[2]), "Lx_GB": 8e-9 * ch.FactorView(Lf).xsize,
            "residual_2norm": float(np.linalg.norm(r) / np.linalg.norm(b)),
            "upper_nonzeros": checks["upper_nonzeros"], "nonfinite": checks["nonfinite"],
            "solve_device_ms": 1e3 * float(S.hip_stats(Lf)[24]), "roofline": roof}
+    if roof is not None:
+        try:
+            out.update(critical_path(S, Lf, roofline_of.last_profile, 1e3 * dt))
+        except Exception as e:          # (a diagnostic: never lose the line to it)
+            out["critical_path_error"] = repr(e)
     if roof is not None:
         tf = roof["thin_front_kernel"]
         # the thin configuration is priced against HBM: algorithmic bytes of the whole factorization / time
@@ -498,7 +615,8 @@ def main():
     ap.add_argument("--workload", default="poisson3d")
     ap.add_argument("--grid", "--m", dest="m", type=int, default=0,
                     help="grid points per side (default: 200, falling back to 160 / 100 if HBM is short)")
-    ap.add_argument("--cpu-sample-m", type=int, default=56)
+    ap.add_argument("--cpu-sample-m", type=int, default=100,
+                    help="CPU baseline: Poisson m^3 through the product's CPU path (default 100 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -866,6 +984,11 @@ def main():
             "mfma_ceiling_sweep": sweep,
             "ms_per_step_resident": 1e3 * elapsed / args.steps,
             "ms_per_step_api": 1e3 * elapsed_api / api_steps,
+            "value_api": fl * api_steps / elapsed_api / 1e9,
+            "pct_fp64_mfma_peak_api_per_gpu": 100.0 * fl * api_steps / elapsed_api / 1e12 / world / FP64_MFMA_PEAK_TFLOPS,
+            "value_note": "`value` / `ms_per_step` time the step with S = tril(PAP') already resident in HBM (the bench contract: inputs "
+                          "resident when the timed region starts); `value_api` / `ms_per_step_api` time cholmod_l_factorize (A, L, Common) "
+                          "with A in host memory (SURVEY 8d's t_factorize); the secondary lines quote the API step as their `value`",
             "api_step": "cholmod_l_factorize(A, L, Common) called again on a matrix with the same pattern (hash of p / i "
                         "checked on every call): H2D of A->x, gather into the resident S on the device, factorization on the "
                         "cached plan, L left in HBM; a new pattern takes the host permutation + full upload again",

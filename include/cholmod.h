@@ -254,6 +254,8 @@ int cholmod_l_error (int status, const char *file, int line, const char *message
 void *cholmod_l_malloc (size_t n, size_t size, cholmod_common *Common) ;
 void *cholmod_l_calloc (size_t n, size_t size, cholmod_common *Common) ;
 void *cholmod_l_free (size_t n, size_t size, void *p, cholmod_common *Common) ;
+/* CHOLMOD/Core/cholmod_memory.c:232-330; *n: current size in, new size out (unchanged on failure, old block returned) */
+void *cholmod_l_realloc (size_t nnew, size_t size, void *p, size_t *n, cholmod_common *Common) ;
 
 cholmod_sparse *cholmod_l_allocate_sparse (size_t nrow, size_t ncol, size_t nzmax,
     int sorted, int packed, int stype, int xtype, cholmod_common *Common) ;
@@ -309,6 +311,12 @@ cholmod_dense *cholmod_l_solve (int sys, cholmod_factor *L, cholmod_dense *B,
 int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_sparse *Bset,
     cholmod_dense **X_Handle, cholmod_sparse **Xset_Handle, cholmod_dense **Y_Handle,
     cholmod_dense **E_Handle, cholmod_common *Common) ;
+/* CHOLMOD/Include/cholmod_cholesky.h:601-614: (min diag L / max diag L)^2; -1 error, 0 singular / NaN / failed factor */
+double cholmod_l_rcond (cholmod_factor *L, cholmod_common *Common) ;
+/* CHOLMOD/Include/cholmod_core.h:1852-1872; here: supernodal symbolic <-> supernodal numeric (the simplicial forms:
+ * CHOLMOD_NOT_INSTALLED) */
+int cholmod_l_change_factor (int to_xtype, int to_ll, int to_super, int to_packed, int to_monotonic,
+    cholmod_factor *L, cholmod_common *Common) ;
 int cholmod_l_etree (cholmod_sparse *A, SuiteSparse_long *Parent, cholmod_common *Common) ;
 SuiteSparse_long cholmod_l_postorder (SuiteSparse_long *Parent, size_t n,
     SuiteSparse_long *Weight, SuiteSparse_long *Post, cholmod_common *Common) ;

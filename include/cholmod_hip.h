@@ -240,6 +240,10 @@ int cholmod_hip_solve (cholmod_hip_plan *plan, int which, double *X,
 int cholmod_hip_get_maps (cholmod_hip_plan *plan, int64_t *sparent,
     int64_t *level, int64_t *relmap) ;
 
+/* out3 = {min L_jj, max L_jj, number of NaN or negative diagonal entries} of the resident factor (one pass over the n
+ * diagonal entries on the device): what cholmod_l_rcond needs (CHOLMOD/Cholesky/cholmod_rcond.c:64-161).  Several ranks:
+ * after cholmod_hip_gather_factor. */
+int cholmod_hip_diag_minmax (cholmod_hip_plan *plan, double *out3) ;
 /* Size-independent invariants of the device-resident factor, one pass over Lx
  * (the checks CHOLMOD/Check/cholmod_check.c:1823-2000 cannot do on values, at
  * sizes no CPU oracle reaches):  out5[0] = sum_j log L(j,j)  (= logdet(A)/2,

@@ -124,6 +124,8 @@ API_SYMBOLS = [
     "cholmod_l_gpu_stats", "cholmod_l_sdmult", "cholmod_l_norm_dense", "cholmod_l_norm_sparse",
     "cholmod_l_analyze", "cholmod_l_analyze_p", "cholmod_l_analyze_p2",
     "cholmod_l_factorize", "cholmod_l_factorize_p", "cholmod_l_solve", "cholmod_l_solve2",
+    "cholmod_l_rcond", "cholmod_l_change_factor", "cholmod_l_realloc",
+    "SuiteSparse_start", "SuiteSparse_finish", "SuiteSparse_malloc", "SuiteSparse_calloc", "SuiteSparse_realloc", "SuiteSparse_free",
     "cholmod_l_etree", "cholmod_l_postorder", "cholmod_l_rowcolcounts",
     "cholmod_l_super_symbolic", "cholmod_l_super_symbolic2", "cholmod_l_super_numeric",
     "cholmod_l_super_lsolve", "cholmod_l_super_ltsolve",
@@ -136,7 +138,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
-    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_debug_routing",
+    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_diag_minmax", "cholmod_hip_debug_routing",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
@@ -219,6 +221,8 @@ def lib(hooks=None):
     sig("cholmod_l_factorize", C.c_int, [sp, fc, cm])
     sig("cholmod_l_factorize_p", C.c_int, [sp, C.POINTER(dbl * 2), vp, sz, fc, cm])
     sig("cholmod_l_solve", dn, [C.c_int, fc, dn, cm])
+    sig("cholmod_l_rcond", dbl, [fc, cm])
+    sig("cholmod_l_change_factor", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fc, cm])
     sig("cholmod_l_etree", C.c_int, [sp, vp, cm])
     sig("cholmod_l_postorder", i64, [vp, sz, vp, vp, cm])
     sig("cholmod_l_rowcolcounts", C.c_int, [sp, vp, sz, vp, vp, vp, vp, vp, vp, cm])

@@ -806,12 +806,25 @@ int cholmod_hip_set_device (int device)
     return hipSetDevice (device) == hipSuccess ? CHOLMOD_HIP_OK : CHOLMOD_HIP_NO_DEVICE ;
 }
 
+static cholmod_hip_plan *plan_create_impl (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
+    int flags, int rank, int world, int *status) ;
+
 cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
     int flags, int rank, int world, int *status)
 {
     int st_local ;
     if (!status) status = &st_local ;
+    // the plan builder works in C++ containers: their allocation failures end here, as a status, not in the caller's C frames
+    try { return plan_create_impl (n, nsuper, super, pi, px, s, flags, rank, world, status) ; }
+    catch (const std::bad_alloc &) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
+}
+
+static cholmod_hip_plan *plan_create_impl (int64_t n, int64_t nsuper,
+    const int64_t *super, const int64_t *pi, const int64_t *px, const int64_t *s,
+    int flags, int rank, int world, int *status)
+{
     *status = CHOLMOD_HIP_OK ;
     if (n < 0 || nsuper < 0 || !super || !pi || !px || !s || world < 1 || rank < 0 || rank >= world)
     { *status = CHOLMOD_HIP_INVALID ; return nullptr ; }
@@ -843,6 +856,9 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     // nothing to release on the early returns above)
     cholmod_hip_plan *P = new (std::nothrow) cholmod_hip_plan ;
     if (!P) { *status = CHOLMOD_HIP_OUT_OF_MEMORY ; return nullptr ; }
+    // (whatever way this function is left without handing P over -- a failed step, a std::bad_alloc on its way to the
+    // caller's catch -- the plan and what it holds on the device are released)
+    struct Guard { cholmod_hip_plan *P ; ~Guard () { if (P) { free_device (P) ; delete P ; } } } guard {P} ;
     P->n = n ; P->nsuper = nsuper ; P->flags = flags ; P->host_only = host_only ;
     P->rank = rank ; P->world = world ;
     P->super.assign (super, super + nsuper + 1) ;
@@ -874,10 +890,8 @@ cholmod_hip_plan *cholmod_hip_plan_create_dist (int64_t n, int64_t nsuper,
     if (*status == CHOLMOD_HIP_OK && !host_only) *status = upload_plan (P) ;
     if (ptiming) fprintf (stderr, "cholmod_hip_plan_create: copy maps %.3f s, build_host %.3f s, upload_plan %.3f s\n",
         tp0 - tpc, tp1 - tp0, pnow () - tp1) ;
-    if (*status != CHOLMOD_HIP_OK)
-    {
-        free_device (P) ; delete P ; return nullptr ;
-    }
+    if (*status != CHOLMOD_HIP_OK) return nullptr ;
+    guard.P = nullptr ;
     return P ;
 }
 
@@ -1496,6 +1510,30 @@ int cholmod_hip_factor_checks (cholmod_hip_plan *P, double *out5)
     HIPCHK (hipGetLastError ()) ;
     HIPCHK (hipMemcpyAsync (out5, P->d_chk_out, 5 * sizeof (double), hipMemcpyDeviceToHost, P->stream)) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+/* Smallest and largest diagonal entry of the resident factor, and the number of NaN / negative ones: what
+ * cholmod_l_rcond needs (reference CHOLMOD/Cholesky/cholmod_rcond.c:102-124 walks Lx [psx + jj + jj nsrow] on the host;
+ * here L stays in HBM and three numbers come back).  Several ranks: after cholmod_hip_gather_factor. */
+int cholmod_hip_diag_minmax (cholmod_hip_plan *P, double *out3)
+{
+    if (!P || P->host_only || !out3) return CHOLMOD_HIP_INVALID ;
+    out3 [0] = out3 [1] = out3 [2] = 0 ;
+    if (P->n == 0) return CHOLMOD_HIP_OK ;
+    if (!whole_factor (P) || !whole_fronts (P)) return CHOLMOD_HIP_INVALID ;
+    { int rc = ensure_check_tasks (P) ; if (rc != CHOLMOD_HIP_OK) return rc ; }     // (d_chk_out: five doubles of scratch)
+    unsigned long long seed [3] ;
+    const double inf = INFINITY, zero = 0.0 ;
+    memcpy (&seed [0], &inf, 8) ; memcpy (&seed [1], &zero, 8) ; seed [2] = 0 ;
+    HIPCHK (hipMemcpyAsync (P->d_chk_out, seed, sizeof (seed), hipMemcpyHostToDevice, P->stream)) ;
+    const bool cxs = (P->flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
+    CXS_LAUNCH (k_diag_minmax, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, P->stream,
+        P->n, P->d_supermap, whole_fronts (P), whole_factor (P), (unsigned long long *) P->d_chk_out) ;
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipMemcpyAsync (seed, P->d_chk_out, sizeof (seed), hipMemcpyDeviceToHost, P->stream)) ;
+    HIPCHK (hipStreamSynchronize (P->stream)) ;
+    memcpy (&out3 [0], &seed [0], 8) ; memcpy (&out3 [1], &seed [1], 8) ; out3 [2] = (double) seed [2] ;
     return CHOLMOD_HIP_OK ;
 }
 

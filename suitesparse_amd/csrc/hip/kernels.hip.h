@@ -3000,6 +3000,39 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     if (tid == 0) __hip_atomic_store (fl + rb, (rb + 1) | ((1 + nv_out) << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
 }
 
+// ---- extreme diagonal entries of L (cholmod_l_rcond on a device-resident factor) ---------------------
+// out [0] = min L_jj, out [1] = max L_jj (as ordered bit patterns of NON-NEGATIVE doubles: the caller seeds them with
+// +inf / 0), out [2] += number of NaN or negative diagonal entries.  One thread per column; CX: a complex factor in its own
+// storage, the diagonal of the complex L is the (real) entry (2j, 2j) of the twin, kept in the even column 2j.
+template <bool CX>
+__global__ void __launch_bounds__(256) k_diag_minmax (i64 n, const i32 *supermap, const FrontD *fr, const double *Lx, unsigned long long *out)
+{
+    const i64 k = blockIdx.x * (i64) 256 + threadIdx.x ;
+    double v = 0 ;
+    bool have = false, bad = false ;
+    if (k < n && !(CX && (k & 1)))
+    {
+        const FrontD f = fr [supermap [k]] ;
+        const int jj = (int) (k - f.k1) ;
+        v = Lx [f.psx + jj + colx<CX> (jj, f.nsrow)] ;
+        have = true ;
+        if (!(v >= 0.0)) { bad = true ; have = false ; }        // (NaN or negative: counted, kept out of the extremes)
+    }
+    double lo = have ? v : __builtin_inf (), hi = have ? v : 0.0 ;
+    for (int o = 32 ; o > 0 ; o >>= 1)
+    {
+        const double l2 = __shfl_xor (lo, o), h2 = __shfl_xor (hi, o) ;
+        lo = l2 < lo ? l2 : lo ; hi = h2 > hi ? h2 : hi ;
+    }
+    const unsigned long long nbad = __popcll (__ballot (bad)) ;
+    if ((threadIdx.x & 63) == 0)
+    {
+        atomicMin (out, (unsigned long long) __double_as_longlong (lo)) ;
+        atomicMax (out + 1, (unsigned long long) __double_as_longlong (hi)) ;
+        if (nbad) atomicAdd (out + 2, nbad) ;
+    }
+}
+
 // ---- first failing supernode (not-positive-definite protocol) ---------------------
 // out [0] = smallest supernode with info != 0 (nsuper if none), so that the host reads
 // 4 bytes per factorization instead of the whole info array (G3_circuit stand-in:

@@ -23,7 +23,7 @@
  * (reference Cholesky/cholmod_etree.c:81-223, stype > 0 branch). */
 int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent)
 {
-    Int *anc = malloc ((n > 0 ? n : 1) * sizeof (Int)) ;
+    Int *anc = SuiteSparse_malloc ((size_t) (n > 0 ? n : 1), sizeof (Int)) ;
     if (!anc) return FALSE ;
     for (Int j = 0 ; j < n ; j++) { Parent [j] = EMPTY ; anc [j] = EMPTY ; }
     for (Int j = 0 ; j < n ; j++)
@@ -42,7 +42,7 @@ int ssamd_etree_upper (Int n, const Int *Up, const Int *Ui, Int *Parent)
             }
         }
     }
-    free (anc) ;
+    SuiteSparse_free (anc) ;
     return TRUE ;
 }
 
@@ -85,7 +85,7 @@ Int ssamd_postorder (Int n, const Int *Parent, const Int *Weight, Int *Post, Int
          * then push them on their parents' lists from heaviest to lightest so
          * that every list ends up lightest-first */
         Int *bucket = stack ;                   /* n counters, reused as stack later */
-        Int *order = malloc ((n > 0 ? n : 1) * sizeof (Int)) ;
+        Int *order = SuiteSparse_malloc ((size_t) (n > 0 ? n : 1), sizeof (Int)) ;
         if (!order) return EMPTY ;
         for (Int w = 0 ; w < n ; w++) bucket [w] = 0 ;
         for (Int j = 0 ; j < n ; j++)
@@ -106,7 +106,7 @@ Int ssamd_postorder (Int n, const Int *Parent, const Int *Weight, Int *Post, Int
             Int p = Parent [j] ;
             if (p >= 0 && p < n) { sibling [j] = first_child [p] ; first_child [p] = j ; }
         }
-        free (order) ;
+        SuiteSparse_free (order) ;
     }
     Int k = 0 ;
     for (Int r = 0 ; r < n ; r++)
@@ -520,7 +520,8 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
         if (mptr) cholmod_l_free (nsuper + 2, sizeof (Int), mptr, Common) ;
 #undef SSAMD_LS_OF
         for (Int s = 0 ; s < nsuper && ok ; s++) if (fill [s] != Lpi [s+1]) ok = FALSE ;
-        if (!ok) ERROR (CHOLMOD_INVALID, "invalid symbolic structure (ColCount/Parent mismatch)") ;
+        /* (a failed allocation above has already said CHOLMOD_OUT_OF_MEMORY: that is not a structure error) */
+        if (!ok && Common->status == CHOLMOD_OK) ERROR (CHOLMOD_INVALID, "invalid symbolic structure (ColCount/Parent mismatch)") ;
     }
     Int maxcsize = 1, maxesize = 1 ;
     if (ok && want_px)
@@ -740,7 +741,11 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
         if (ok && Common->postorder)
         {
             double t4a = ssamd_now () ;
-            if (ssamd_postorder (n, Parent, ColCount, Post, work) == n)
+            /* (EMPTY: its workspace could not be allocated -- an error, not a reason to skip the postorder silently;
+             * found by the fault loop of tests/test_memory_faults.py) */
+            const Int npost = ssamd_postorder (n, Parent, ColCount, Post, work) ;
+            if (npost == EMPTY) ok = FALSE ;
+            else if (npost == n)
             {
                 double t4b = ssamd_now () ;
                 Int *tmp = work, *inv = work + n ;

@@ -87,6 +87,89 @@ int cholmod_l_finish (cholmod_common *Common)
     return TRUE ;
 }
 
+/* ---- SuiteSparse_config (reference: SuiteSparse_config/SuiteSparse_config.c:57-330) --- */
+
+static int ssc_divcomplex (double ar, double ai, double br, double bi, double *cr, double *ci)
+{
+    /* (ar + i ai) / (br + i bi), Smith's method as the reference (SuiteSparse_config.c:455-527); 1 if the divisor is zero */
+    double tr, ti, r, den ;
+    if (fabs (br) >= fabs (bi))
+    {
+        r = bi / br ; den = br + r * bi ;
+        tr = (ar + ai * r) / den ; ti = (ai - ar * r) / den ;
+    }
+    else
+    {
+        r = br / bi ; den = r * br + bi ;
+        tr = (ar * r + ai) / den ; ti = (ai * r - ar) / den ;
+    }
+    *cr = tr ; *ci = ti ;
+    return den == 0.0 ;
+}
+
+struct SuiteSparse_config_struct SuiteSparse_config = { malloc, calloc, realloc, free, printf, hypot, ssc_divcomplex } ;
+
+void SuiteSparse_start (void)
+{
+    SuiteSparse_config.malloc_func = malloc ; SuiteSparse_config.calloc_func = calloc ;
+    SuiteSparse_config.realloc_func = realloc ; SuiteSparse_config.free_func = free ;
+    SuiteSparse_config.printf_func = printf ; SuiteSparse_config.hypot_func = hypot ;
+    SuiteSparse_config.divcomplex_func = ssc_divcomplex ;
+}
+void SuiteSparse_finish (void) { }
+
+static int ssc_too_large (size_t nitems, size_t size)
+{
+    return size == 0 || nitems >= SIZE_MAX / size || nitems >= (size_t) INT64_MAX / size ;
+}
+void *SuiteSparse_malloc (size_t nitems, size_t size_of_item)
+{
+    if (nitems < 1) nitems = 1 ;
+    if (size_of_item < 1) size_of_item = 1 ;
+    if (ssc_too_large (nitems, size_of_item)) return NULL ;
+    return SuiteSparse_config.malloc_func (nitems * size_of_item) ;
+}
+void *SuiteSparse_calloc (size_t nitems, size_t size_of_item)
+{
+    if (nitems < 1) nitems = 1 ;
+    if (size_of_item < 1) size_of_item = 1 ;
+    if (ssc_too_large (nitems, size_of_item)) return NULL ;
+    return SuiteSparse_config.calloc_func (nitems, size_of_item) ;
+}
+void *SuiteSparse_realloc (size_t nitems_new, size_t nitems_old, size_t size_of_item, void *p, int *ok)
+{
+    if (nitems_new < 1) nitems_new = 1 ;
+    if (nitems_old < 1) nitems_old = 1 ;
+    if (size_of_item < 1) size_of_item = 1 ;
+    if (ssc_too_large (nitems_new, size_of_item)) { *ok = 0 ; return p ; }
+    if (!p)
+    {
+        p = SuiteSparse_malloc (nitems_new, size_of_item) ;
+        *ok = p != NULL ;
+        return p ;
+    }
+    if (nitems_old == nitems_new) { *ok = 1 ; return p ; }
+    void *pnew = SuiteSparse_config.realloc_func (p, nitems_new * size_of_item) ;
+    if (!pnew)
+    {
+        /* a failed shrink leaves the (larger) old block in place and counts as done (SuiteSparse_config.c:266-278) */
+        *ok = nitems_new < nitems_old ;
+        return p ;
+    }
+    *ok = 1 ;
+    return pnew ;
+}
+void *SuiteSparse_free (void *p)
+{
+    if (p) SuiteSparse_config.free_func (p) ;
+    return NULL ;
+}
+double SuiteSparse_hypot (double x, double y) { return SuiteSparse_config.hypot_func (x, y) ; }
+int SuiteSparse_divcomplex (double ar, double ai, double br, double bi, double *cr, double *ci)
+{
+    return SuiteSparse_config.divcomplex_func (ar, ai, br, bi, cr, ci) ;
+}
+
 /* ---- memory (reference: Core/cholmod_memory.c:111-230) ------------------------- */
 
 void *cholmod_l_malloc (size_t n, size_t size, cholmod_common *Common)
@@ -98,7 +181,7 @@ void *cholmod_l_malloc (size_t n, size_t size, cholmod_common *Common)
         ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
         return NULL ;
     }
-    void *p = malloc ((n > 0 ? n : 1) * size) ;
+    void *p = SuiteSparse_malloc (n, size) ;
     if (!p) { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return NULL ; }
     Common->malloc_count++ ;
     Common->memory_inuse += n * size ;
@@ -108,9 +191,46 @@ void *cholmod_l_malloc (size_t n, size_t size, cholmod_common *Common)
 
 void *cholmod_l_calloc (size_t n, size_t size, cholmod_common *Common)
 {
-    void *p = cholmod_l_malloc (n, size, Common) ;
-    if (p) memset (p, 0, (n > 0 ? n : 1) * size) ;
+    if (!Common) return NULL ;
+    if (size == 0) { ERROR (CHOLMOD_INVALID, "sizeof(item) must be > 0") ; return NULL ; }
+    if (n >= (SIZE_MAX / size) || n >= (size_t) INT64_MAX / size)
+    {
+        ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
+        return NULL ;
+    }
+    void *p = SuiteSparse_calloc (n, size) ;
+    if (!p) { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return NULL ; }
+    Common->malloc_count++ ;
+    Common->memory_inuse += n * size ;
+    if (Common->memory_inuse > Common->memory_usage) Common->memory_usage = Common->memory_inuse ;
     return p ;
+}
+
+/* reference: Core/cholmod_memory.c:232-330.  *n is the current size on input and the new size on output (unchanged on
+ * failure, when the old block is returned intact). */
+void *cholmod_l_realloc (size_t nnew, size_t size, void *p, size_t *n, cholmod_common *Common)
+{
+    if (!Common) return NULL ;
+    if (size == 0) { ERROR (CHOLMOD_INVALID, "sizeof(item) must be > 0") ; return p ; }
+    if (!p)
+    {
+        p = cholmod_l_malloc (nnew, size, Common) ;
+        *n = p ? nnew : 0 ;
+        return p ;
+    }
+    if (*n == nnew) return p ;
+    if (nnew >= (SIZE_MAX / size) || nnew >= (size_t) INT64_MAX / size)
+    {
+        ERROR (CHOLMOD_TOO_LARGE, "problem too large") ;
+        return p ;
+    }
+    int ok = 1 ;
+    void *pnew = SuiteSparse_realloc (nnew, *n, size, p, &ok) ;
+    if (!ok) { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return p ; }
+    Common->memory_inuse += (nnew - *n) * size ;
+    if (Common->memory_inuse > Common->memory_usage) Common->memory_usage = Common->memory_inuse ;
+    *n = nnew ;
+    return pnew ;
 }
 
 void *cholmod_l_free (size_t n, size_t size, void *p, cholmod_common *Common)
@@ -118,7 +238,7 @@ void *cholmod_l_free (size_t n, size_t size, void *p, cholmod_common *Common)
     if (!Common) return NULL ;
     if (p)
     {
-        free (p) ;
+        SuiteSparse_free (p) ;
         Common->malloc_count-- ;
         Common->memory_inuse -= n * size ;
     }
@@ -225,6 +345,16 @@ int ssamd_host_threads (void)
     const char *e = getenv ("CHOLMOD_HOST_THREADS") ;
     if (e && atoi (e) > 0) return atoi (e) ;
     return nt > 32 ? 32 : nt ;
+}
+
+/* threads the caller allows (OMP_NUM_THREADS / the OpenMP default), not capped: the dense calls of the CPU path */
+int ssamd_host_threads_uncapped (void)
+{
+    int nt = 1 ;
+#ifdef _OPENMP
+    nt = omp_get_max_threads () ;
+#endif
+    return nt > 0 ? nt : 1 ;
 }
 
 /* Symmetric permutation C = P A P' (Perm may be NULL), upper_out selects the

@@ -33,13 +33,30 @@ typedef void (*dtrsm_fn) (const char *, const char *, const char *, const char *
     const double *, const double *, const int *, double *, const int *) ;
 typedef void (*dpotrf_fn) (const char *, const int *, double *, const int *, int *) ;
 
+typedef void (*set_threads_fn) (int) ;
 static struct
 {
     int tried ;
     void *handle ;
     dgemm_fn gemm ; dsyrk_fn syrk ; dtrsm_fn trsm ; dpotrf_fn potrf ;
+    set_threads_fn set_threads ;    /* openblas_set_num_threads / MKL_Set_Num_Threads / bli_thread_set_num_threads, or NULL */
+    int max_threads, cur_threads ;
     char name [256] ;
 } g_blas ;
+
+/* Threads for ONE dense call, by its flop count.  The left-looking loop issues its BLAS calls one after the other, and
+ * almost all of them are tiny (Poisson 100^3 under AMD: 97 % of 601 338 updates have <= 16 columns): a threaded
+ * BLAS that wakes 64 threads for each of them spends its time in the wake-up, not in the arithmetic -- rounds 3-4 measured
+ * 36 GFLOP/s at 64 threads against 216 at 16.  So a call gets one thread per ~4 Mflop, at most what the caller allows
+ * (OMP_NUM_THREADS): small calls run on the calling thread, the few big ones (which hold the flops) on all of them, and
+ * more threads never cost.  Without a thread-control entry point in the bound library the BLAS decides for itself. */
+static void blas_threads_for (double flops)
+{
+    if (!g_blas.set_threads) return ;
+    int t = flops < 2e6 ? 1 : (int) (flops / 4e6) + 1 ;
+    if (t > g_blas.max_threads) t = g_blas.max_threads ;
+    if (t != g_blas.cur_threads) { g_blas.set_threads (t) ; g_blas.cur_threads = t ; }
+}
 
 static void *sym2 (void *h, const char *prefix, const char *name)
 {
@@ -65,19 +82,12 @@ static int lp64_probe (dgemm_fn g, dpotrf_fn p)
     return okp && okg ;
 }
 
+/* In this process, behind the negative second words (round-4 advisor item: no fork () inside a library -- the host process
+ * may be multi-threaded with the HIP runtime, RCCL and OpenMP loaded, and a child that runs BLAS code after fork can
+ * deadlock on a lock whose owner no longer exists).  An ILP64 library reads (n, -1) as a negative 64-bit dimension and
+ * leaves through its argument check. */
 static int lp64_self_check (dgemm_fn g, dpotrf_fn p)
 {
-    fflush (NULL) ;
-    pid_t pid = fork () ;
-    if (pid == 0) _exit (lp64_probe (g, p) ? 0 : 1) ;
-    if (pid > 0)
-    {
-        int st = 0 ;
-        pid_t w ;
-        do w = waitpid (pid, &st, 0) ; while (w < 0 && errno == EINTR) ;
-        if (w == pid) return WIFEXITED (st) && WEXITSTATUS (st) == 0 ;
-    }
-    /* no child to be had: in this process, behind the negative second words */
     return lp64_probe (g, p) ;
 }
 
@@ -94,9 +104,7 @@ static int try_blas (const char *path, const char *prefix)
      * found under the same soname reads 8 bytes from each.  Every size therefore sits in a two-word
      * array whose second word is -1: an ILP64 library sees a NEGATIVE dimension and leaves through
      * its argument check (info < 0 / xerbla) instead of running over the 9- and 6-element arrays
-     * with whatever the stack held next to a lone int.  And because some xerbla implementations stop
-     * the process, the probe runs in a forked child: a crash or a STOP there rejects the library
-     * and nothing else (lp64_self_check). */
+     * with whatever the stack held next to a lone int (lp64_self_check). */
     if (!lp64_self_check (g, p))
     {
         fprintf (stderr, "cholmod (CPU path): %s fails the LP64 self-check (an ILP64 build?): not used\n", path) ;
@@ -104,6 +112,13 @@ static int try_blas (const char *path, const char *prefix)
         return 0 ;
     }
     g_blas.gemm = g ; g_blas.syrk = s ; g_blas.trsm = t ; g_blas.potrf = p ;
+    /* per-call thread control, where the library offers it (blas_threads_for) */
+    g_blas.set_threads = (set_threads_fn) sym2 (h, prefix, "openblas_set_num_threads") ;
+    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "openblas_set_num_threads") ;
+    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "MKL_Set_Num_Threads") ;
+    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "bli_thread_set_num_threads") ;
+    g_blas.max_threads = ssamd_host_threads_uncapped () ;
+    g_blas.cur_threads = -1 ;
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;
     g_blas.handle = h ;         /* (last: everything above is in place when a reader sees the handle) */
     return 1 ;
@@ -338,6 +353,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
                     const double one = 1.0, zero = 0.0 ;
                     int in1 = (int) n1, idk = (int) dk, ild = (int) drows, ildc = (int) n2, in3 = (int) (n2 - n1) ;
                     t0 = now_s () ;
+                    blas_threads_for ((double) n1 * (double) n2 * (double) dk * 2.0) ;     /* (syrk + gemm of this descendant) */
                     g_blas.syrk ("L", "N", &in1, &idk, &one, Ld, &ild, &zero, C, &ildc) ;
                     t_syrk += now_s () - t0 ; n_syrk++ ;
                     if (in3 > 0)
@@ -374,6 +390,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
             if (have_blas)
             {
                 int in = (int) good, ild = (int) nsrow, iinfo = 0 ;
+                blas_threads_for ((double) good * (double) good * (double) good / 3.0) ;
                 g_blas.potrf ("L", &in, Fs, &ild, &iinfo) ;
                 info = iinfo ;
             }
@@ -396,6 +413,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
             {
                 const double one = 1.0 ;
                 int im = (int) (nsrow - good), in = (int) good, ild = (int) nsrow ;
+                blas_threads_for ((double) (nsrow - good) * (double) good * (double) good) ;
                 g_blas.trsm ("R", "L", "C", "N", &im, &in, &one, Fs, &ild, Fs + good, &ild) ;
             }
             else k_trsm (nsrow - good, good, Fs, nsrow, Fs + good, nsrow) ;

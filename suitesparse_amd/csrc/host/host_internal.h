@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "../../../include/SuiteSparse_config.h"
 #include "../../../include/cholmod.h"
 #include "../../../include/cholmod_hip.h"
 
@@ -33,6 +34,7 @@ typedef SuiteSparse_long Int ;
 
 /* core.c */
 int ssamd_host_threads (void) ;
+int ssamd_host_threads_uncapped (void) ;
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common) ;
 cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,

@@ -430,6 +430,110 @@ int cholmod_l_factor_to_host (cholmod_factor *L, cholmod_common *Common)
     return TRUE ;
 }
 
+/* ---- cholmod_l_rcond -------------------------------------------------------------------------- */
+
+/* reference: Cholesky/cholmod_rcond.c:64-161.  (min L_jj / max L_jj)^2 over the diagonal of the supernodal LL' factor:
+ * -1 on error, 1 for a 0-by-0 matrix, 0 if the factorization failed (L->minor < n) or a diagonal entry is NaN.  A factor
+ * that lives in HBM is not downloaded for this: one pass over its n diagonal entries on the device
+ * (cholmod_hip_diag_minmax) returns the two extremes. */
+double cholmod_l_rcond (cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (EMPTY) ;
+    RETURN_IF_NULL (L, EMPTY) ;
+    if (L->xtype < CHOLMOD_REAL || L->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "invalid xtype") ; return EMPTY ; }
+    Common->status = CHOLMOD_OK ;
+    if (L->n == 0) return 1 ;
+    if (L->minor < L->n) return 0 ;
+    if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factors not built") ; return EMPTY ; }
+    double lmin, lmax ;
+    cholmod_factor *D = L->cx_twin ? (cholmod_factor *) L->cx_twin : L ;      /* (complex L: the engine's factor) */
+    if (D->hip_plan && D->hip_on_device && !L->hip_host_valid)
+    {
+        if (Common->hip_world > 1)
+        {
+            int rg = cholmod_hip_gather_factor ((cholmod_hip_plan *) D->hip_plan) ;
+            if (rg != CHOLMOD_HIP_OK) { map_hip_status (rg, Common, "factor gather failed") ; return EMPTY ; }
+        }
+        double out [3] ;
+        int rc = cholmod_hip_diag_minmax ((cholmod_hip_plan *) D->hip_plan, out) ;
+        if (rc != CHOLMOD_HIP_OK) { map_hip_status (rc, Common, "diagonal scan failed") ; return EMPTY ; }
+        if (out [2] > 0) return 0 ;             /* a NaN on the diagonal (:31-41) */
+        lmin = out [0] ; lmax = out [1] ;
+    }
+    else
+    {
+        if (!L->x) { ERROR (CHOLMOD_INVALID, "no numeric values") ; return EMPTY ; }
+        const Int *Super = L->super, *Lpi = L->pi, *Lpx = L->px ;
+        const double *Lx = L->x ;
+        const Int e = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+        lmin = lmax = Lx [0] ;
+        if (lmin != lmin) return 0 ;
+        for (Int s = 0 ; s < (Int) L->nsuper ; s++)
+        {
+            const Int nscol = Super [s+1] - Super [s], nsrow = Lpi [s+1] - Lpi [s], psx = Lpx [s] ;
+            for (Int jj = 0 ; jj < nscol ; jj++)
+            {
+                const double ljj = Lx [e * (psx + jj + jj * nsrow)] ;
+                if (ljj != ljj) return 0 ;
+                if (ljj < lmin) lmin = ljj ; else if (ljj > lmax) lmax = ljj ;
+            }
+        }
+    }
+    double rcond = lmin / lmax ;
+    if (L->is_ll) rcond = rcond * rcond ;
+    return rcond ;
+}
+
+/* ---- cholmod_l_change_factor ---------------------------------------------------------------------- */
+
+/* reference: Core/cholmod_change_factor.c:1005-1230, the supernodal conversions (the simplicial forms are not built):
+ *   supernodal numeric  -> supernodal symbolic  (ll_super_to_super_symbolic, :373-393): the values are discarded -- L->x
+ *                                                freed, the engine's resident copy forgotten (the plan, a function of the
+ *                                                symbolic factor, stays) --, xtype = PATTERN, minor = n;
+ *   supernodal symbolic -> supernodal numeric   (super_symbolic_to_ll_super, :946-989): L->x allocated, contents
+ *                                                undefined, xtype = to_xtype, minor = n -- what cholmod_l_super_numeric
+ *                                                does on entry (cholmod_super_numeric.c:212-223);
+ *   supernodal numeric  -> supernodal numeric   nothing to do.
+ * to_ll / to_packed / to_monotonic only concern simplicial factors.  A failed conversion leaves L as it was. */
+int cholmod_l_change_factor (int to_xtype, int to_ll, int to_super, int to_packed, int to_monotonic,
+    cholmod_factor *L, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (FALSE) ;
+    RETURN_IF_NULL (L, FALSE) ;
+    (void) to_ll ; (void) to_packed ; (void) to_monotonic ;
+    if (L->xtype < CHOLMOD_PATTERN || L->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "invalid xtype") ; return FALSE ; }
+    if (to_xtype < CHOLMOD_PATTERN || to_xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "xtype invalid") ; return FALSE ; }
+    Common->status = CHOLMOD_OK ;
+    if (to_super && to_xtype == CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "supernodal zomplex L not supported") ; return FALSE ; }
+    if (!to_super || !L->is_super)
+    {
+        /* any conversion from or to a simplicial factor (:1053-1062, :1138-1224) */
+        ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factors are not built: only supernodal symbolic <-> numeric") ;
+        return FALSE ;
+    }
+    if (to_xtype == CHOLMOD_PATTERN)
+    {
+        if (L->xtype == CHOLMOD_PATTERN) return TRUE ;
+        const size_t w = (L->xtype == CHOLMOD_COMPLEX) ? 2 : 1 ;
+        if (L->x) L->x = cholmod_l_free (L->xsize, w * sizeof (double), L->x, Common) ;
+        if (L->cx_twin) cholmod_l_free_factor ((cholmod_factor **) &L->cx_twin, Common) ;
+        L->xtype = CHOLMOD_PATTERN ; L->dtype = CHOLMOD_DOUBLE ;
+        L->minor = L->n ; L->is_ll = TRUE ;
+        L->hip_on_device = FALSE ; L->hip_host_valid = FALSE ; L->hip_apat_valid = FALSE ;
+        return TRUE ;
+    }
+    if (L->xtype != CHOLMOD_PATTERN) return TRUE ;       /* already numeric (:1129-1136: nothing to do) */
+    if (!ssamd_factor_has_cholesky_sizes (L))
+    { ERROR (CHOLMOD_INVALID, "L was analysed for SPQR (no Cholesky sizes)") ; return FALSE ; }
+    const size_t w = (to_xtype == CHOLMOD_REAL) ? 1 : 2 ;
+    double *Lx = cholmod_l_malloc (L->xsize, w * sizeof (double), Common) ;
+    if (!Lx) return FALSE ;                                 /* out of memory: L unchanged */
+    if (L->xsize == 1) { Lx [0] = 0 ; if (w == 2) Lx [1] = 0 ; }
+    L->x = Lx ; L->xtype = to_xtype ; L->dtype = CHOLMOD_DOUBLE ; L->minor = L->n ; L->is_ll = TRUE ;
+    L->hip_on_device = FALSE ; L->hip_host_valid = TRUE ;   /* (what the caller sees is L->x) */
+    return TRUE ;
+}
+
 int cholmod_l_hip_prepare (cholmod_factor *L, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (FALSE) ;

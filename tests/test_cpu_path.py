@@ -157,6 +157,25 @@ def test_env_default_is_cpu_like_the_reference(monkeypatch):
         S.finish()
 
 
+def _check_demo_output(out):
+    """What examples/cholmod_l_demo.c prints on bcsstk01 with the reference's recorded permutation: the reference's symbolic
+    profile, three solve methods and the refinement step with residuals at rounding level, rcond as numpy has
+    it for the same factor, nothing left allocated."""
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "7 supernodes, ssize 101, xsize 1064, maxcsize 169, maxesize 13" in txt, txt
+    assert "Analyze: flop 6009 lnz 489" in txt, txt
+    assert "minor 48, status 0" in txt, txt
+    assert "ints in L:             221, doubles in L:            1064" in txt or "doubles in L:            1064" in txt, txt
+    res = [float(v) for v in txt.split("residual (|Ax-b|/(|A||x|+|b|)):")[1].split("\n")[0].split()]
+    assert len(res) == 3 and all(0 <= r < 1e-12 for r in res), res
+    assert float(txt.split("residual ")[-1].split()[0]) < 1e-12 and "after iterative refinement" in txt
+    assert "solve2  walltime" in txt and "(100 trials)" in txt
+    rc = float(txt.split("rcond")[1].split()[0])
+    assert 1e-7 < rc < 1e-4, rc                       # ((min L_jj / max L_jj)^2 of bcsstk01: 5.7e-06 under this ordering family)
+    assert "malloc_count 0 memory_inuse 0" in txt
+
+
 def test_c_demo_on_cpu_path(golden_dir, tmp_path):
     """BASELINE.json configs[0]: the demo flow on bcsstk01 with Common->useGPU = 0."""
     rec = json.load(open(os.path.join(golden_dir, "reference_recorded.json")))["bcsstk01"]
@@ -168,11 +187,5 @@ def test_c_demo_on_cpu_path(golden_dir, tmp_path):
     permfile = tmp_path / "perm.txt"
     permfile.write_text(" ".join(str(v) for v in rec["Perm"]))
     with open(os.path.join(golden_dir, "bcsstk01.tri")) as f:
-        out = subprocess.run([exe, str(permfile), "cpu"], stdin=f, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    txt = out.stdout
-    assert "nsuper 7 ssize 101 xsize 1064 maxcsize 169 maxesize 13" in txt, txt
-    assert "fl 6009 lnz 489" in txt, txt
-    assert "status 0 minor 48" in txt, txt
-    assert float(txt.split("residual")[1].split()[0]) < 1e-12
-    assert "malloc_count 0 memory_inuse 0" in txt
+        out = subprocess.run([exe, "-cpu", "-perm", str(permfile)], stdin=f, capture_output=True, text=True, timeout=300)
+    _check_demo_output(out)

@@ -124,6 +124,80 @@ def test_upper_stored_and_unpacked_unsorted_input():
     S.finish()
 
 
+def test_every_host_allocation_may_fail_gpu_path():
+    """The Tcov-shaped fault loop of tests/test_memory_faults.py on the GPU path: the k-th allocation of the host C layer
+    fails, k = 0, 1, ... through analyze -> plan build -> factorize (engine) -> solve (device).  After every run
+    Common->malloc_count / memory_inuse are back where they were, a failed run reports CHOLMOD_OUT_OF_MEMORY, and a
+    factorization that fails on a symbolic L hands it back symbolic (CHOLMOD/Supernodal/cholmod_super_numeric.c:235-248)."""
+    from test_memory_faults import FaultAllocator, run_once
+    n, Ap, Ai, Ax = G.poisson3d(7)
+    perm = G.geometric_nd(7, 7, 7, 3)
+    b = G.demo_rhs(n)
+    S = ch.Session(use_gpu=1, ordering="default")
+    S.cm.error_handler = ch.ERRFUNC(0)
+    # (once without faults: device context, kernels loaded)
+    stage, res = run_once(S, n, Ap, Ai, Ax, -1, perm, b)
+    assert stage == "done" and res < 1e-11
+    count0, inuse0 = S.cm.malloc_count, S.cm.memory_inuse
+    stages = set()
+    with FaultAllocator(S.L) as fa:
+        k, done = 0, False
+        while not done:
+            assert k < 5000
+            S.cm.status = ch.OK
+            fa.arm(k)
+            stage, res = run_once(S, n, Ap, Ai, Ax, -1, perm, b)
+            failed = fa.failed
+            fa.arm(-1)
+            assert S.cm.malloc_count == count0 and S.cm.memory_inuse == inuse0, (k, stage, S.cm.malloc_count, S.cm.memory_inuse)
+            if failed:
+                assert stage != "done" and S.cm.status == ch.OUT_OF_MEMORY, (k, stage, S.cm.status)
+                stages.add(stage)
+            else:
+                assert stage == "done" and res < 1e-11, (k, stage, res)
+                done = True
+            k += 1
+    assert k > 20 and {"analyze", "factorize", "solve"} <= stages, (k, stages)
+    S.finish()
+
+
+def test_rcond_and_change_factor_on_the_device(golden_dir):
+    """cholmod_l_rcond on a factor that lives in HBM (one pass over the diagonal on the device, nothing downloaded:
+    CHOLMOD/Cholesky/cholmod_rcond.c:64-161 restated) against the CPU path's value; cholmod_l_change_factor numeric ->
+    symbolic forgets the resident values (the plan stays), the next factorization brings them back."""
+    for case in ("p3d", "bcsstk01"):
+        if case == "p3d":
+            n, Ap, Ai, Ax = G.poisson3d(12)
+            stype, perm = -1, G.geometric_nd(12, 12, 12, 3)
+        else:
+            n, Ap, Ai, Ax, stype = G.read_triplet(os.path.join(golden_dir, "bcsstk01.tri"))
+            perm = None
+        rc = {}
+        for use_gpu, on_device in ((0, False), (1, False), (1, True)):
+            S = ch.Session(use_gpu=use_gpu, factor_on_device=on_device, ordering="default")
+            A = S.sparse(n, Ap, Ai, Ax, stype)
+            Lf = S.analyze(A, perm)
+            assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+            if on_device:
+                assert not Lf.contents.hip_host_valid
+            rc[(use_gpu, on_device)] = S.L.cholmod_l_rcond(Lf, C.byref(S.cm))
+            if on_device:
+                assert not Lf.contents.hip_host_valid              # rcond did not download the factor
+                assert S.L.cholmod_l_change_factor(ch.PATTERN, 1, 1, 1, 1, Lf, C.byref(S.cm)) == 1
+                assert Lf.contents.xtype == ch.PATTERN and not Lf.contents.x and not Lf.contents.hip_on_device
+                S.cm.error_handler = ch.ERRFUNC(0)
+                assert S.L.cholmod_l_rcond(Lf, C.byref(S.cm)) == -1 and S.cm.status == ch.INVALID
+                assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+                assert abs(S.L.cholmod_l_rcond(Lf, C.byref(S.cm)) - rc[(1, True)]) <= 1e-14 * rc[(1, True)]
+            S.free_factor(Lf)
+            S.free_sparse(A)
+            assert S.cm.malloc_count == 0
+            S.finish()
+        ref = rc[(0, False)]
+        assert 0 < ref < 1
+        assert abs(rc[(1, False)] - ref) < 1e-12 * ref and abs(rc[(1, True)] - ref) < 1e-12 * ref, rc
+
+
 def test_device_allocation_failure_is_loud_or_degrades_on_request(monkeypatch):
     """The reservation of L in HBM fails (test hook): by default the factorization
     fails with CHOLMOD_OUT_OF_MEMORY and L stays symbolic
@@ -189,15 +263,10 @@ def test_c_demo_driver_on_bcsstk01(golden_dir, tmp_path):
     permfile = tmp_path / "perm.txt"
     permfile.write_text(" ".join(str(v) for v in rec["Perm"]))
     with open(os.path.join(golden_dir, "bcsstk01.tri")) as f:
-        out = subprocess.run([exe, str(permfile)], stdin=f, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout + out.stderr
-    txt = out.stdout
-    assert "nsuper 7 ssize 101 xsize 1064 maxcsize 169 maxesize 13" in txt, txt
-    assert "fl 6009 lnz 489" in txt, txt
-    assert "status 0 minor 48" in txt, txt
-    res = float(txt.split("residual")[1].split()[0])
-    assert res < 1e-12
-    assert "malloc_count 0 memory_inuse 0" in txt
+        out = subprocess.run([exe, "-perm", str(permfile)], stdin=f, capture_output=True, text=True, timeout=300)
+    from test_cpu_path import _check_demo_output
+    _check_demo_output(out)
+    assert "(HIP engine)" in out.stdout and "kernel launches 0" not in out.stdout
 
 
 def test_big_supernode_block_walk_solves_multi_rhs():
