@@ -139,6 +139,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             return
+        import time
+        t_w0 = time.perf_counter()
         O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
         if "notposdef" in case:
             sup = O.super
@@ -150,6 +152,7 @@ def main():
             Ax = Ax.copy()
             Ax[Ap[int(O.Perm[kbad])]] = -3.0
         st_o = O.factorize(Ax)
+        t_w1 = time.perf_counter()
         # exchange: the torch.distributed callback (gloo staging), or -- DIST_TEST_EXCHANGE=native --
         # the engine's own path (cholmod_hip_rccl_attach: communicators, splits, stream-ordered
         # reduce-scatter / all-gather / all-reduce) on the collective library named by
@@ -171,7 +174,10 @@ def main():
             dist.broadcast_object_list(box, src=0)
             idb = np.frombuffer(box[0], dtype=np.uint8).copy()
             assert S.L.cholmod_hip_rccl_attach(ch.FactorView(Lf).hip_plan, idb.ctypes.data) == 0
+        t_w2 = time.perf_counter()
         ok = S.factorize(A, Lf)
+        t_w3 = time.perf_counter()
+        res["seconds"] = {"oracle": t_w1 - t_w0, "analyze_attach": t_w2 - t_w1, "factorize_gather_download": t_w3 - t_w2}
         if resident:
             # factor left distributed on the devices: a second factorization clears only the
             # slabs of Lx this rank holds; the gather (factor_to_host) then fills the rest, and

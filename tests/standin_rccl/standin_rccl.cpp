@@ -285,6 +285,10 @@ ncclResult_t ncclCommInitRank (ncclComm_t *comm, int nranks, ncclUniqueId id, in
     Helper *h = helper () ;
     if (!h) { delete c ; return ncclUnhandledCudaError ; }
     c->side = h->side ;
+    // the staging slots as pinned memory of this process: the copies between the device and the segment are then plain DMA
+    // (a pageable shared mapping moves at a few GB/s through the runtime's bounce buffers; eight ranks at Poisson 100^3
+    // stage ~8 GB per factorization).  Best effort: without it the copies still work.
+    if (hipHostRegister ((void *) s->slot, sizeof (s->slot), hipHostRegisterDefault) != hipSuccess) (void) hipGetLastError () ;
     spin_barrier (c) ;
     if (rank == 0) shm_unlink (id.internal) ;       // everybody holds a mapping now
     *comm = (ncclComm_t) c ;
@@ -330,7 +334,7 @@ ncclResult_t ncclCommDestroy (ncclComm_t comm)
     Comm *c = (Comm *) comm ;
     if (!c) return ncclSuccess ;
     if (Helper *h = helper ()) drain (h) ;         // nothing of this communicator is in flight any more
-    if (c->is_world) munmap (c->shm, sizeof (Shm)) ;
+    if (c->is_world) { (void) hipHostUnregister ((void *) c->shm->slot) ; (void) hipGetLastError () ; munmap (c->shm, sizeof (Shm)) ; }
     delete c ;
     return ncclSuccess ;
 }

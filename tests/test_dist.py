@@ -34,6 +34,11 @@ def _run_ranks(world, mode, case, timeout=600, extra_env=None):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+        # (several processes on one host: the cores are shared out -- eight ranks that each start a full-width OpenMP /
+        # OpenBLAS team for the oracle and the analysis spend their time spinning on each other)
+        share = str(max(1, (os.cpu_count() or 1) // world))
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env.setdefault(k, share)
         env.update(extra_env or {})
         if any(k.startswith("CHOLMOD_HIP_TEST_") for k in env):
             env["SSAMD_TEST_HOOKS_LIB"] = "1"      # the engine's test hooks exist only in lib/libcholmod_amd_testhooks.so
