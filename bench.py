@@ -140,6 +140,38 @@ def cpu_baseline(sample_m):
 
 
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r04zq_pmc_summary_poisson200_top48.json"}
+# counters of EVERY launch of one refactorization of the mid-size workloads, summed per kernel (tools/pmc_workload.sh: three
+# separate rocprofv3 --pmc passes; round-4 review, item 3) -- matched by the start of the workload name
+PMC_BY_KERNEL = {"poisson3d_100^3": "r05_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r05_pmc_by_kernel_box42r3.json",
+                 "poisson2d_1259^2": "r05_pmc_by_kernel_p2d1259.json"}
+CHAIN_KERNELS = ("k_update2f", "k_trsm_upd", "k_trsm_mfma", "k_potrf_mfma", "k_extend_add", "k_update2", "k_update3", "k_thin_front",
+                 "k_leaf_pair")
+
+
+def pmc_by_kernel(wname):
+    """(dict kernel -> counters, file name) of the committed per-kernel counter summary of this workload, or (None, None)."""
+    for pre, fn in PMC_BY_KERNEL.items():
+        if wname.startswith(pre):
+            pf = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(pf):
+                return json.load(open(pf)), fn
+    return None, None
+
+
+def pmc_kernel_rows(pj, prefix):
+    """Counters of every instantiation of a kernel (k_update3<4, 0, 1>, k_update3<2, 0, 1>, ...) added up."""
+    acc = {}
+    for k, v in pj.items():
+        if k == prefix or k.startswith(prefix + "<"):
+            for c, x in v.items():
+                acc[c] = acc.get(c, 0.0) + x
+    if not acc:
+        return None
+    act = acc.get("GRBM_GUI_ACTIVE", 0.0)
+    return {"launches": int(acc.get("dispatches", 0)),
+            "traffic_bytes": 2.0 * 1024.0 * acc.get("FETCH_SIZE", 0.0) + 1024.0 * acc.get("WRITE_SIZE", 0.0),
+            "fetch_bytes": 2.0 * 1024.0 * acc.get("FETCH_SIZE", 0.0), "write_bytes": 1024.0 * acc.get("WRITE_SIZE", 0.0),
+            "mfma_utilisation": (acc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (act / 8.0 * 1024.0)) if act > 0 else None}
 # counters summed per kernel over one refactorization of the thin stand-in (tools/evidence.sh PMC=1, tools/pmc_by_kernel.py)
 PMC_THIN = "r04zq_pmc_by_kernel_poisson2d1259.json"
 
@@ -205,6 +237,32 @@ def roofline_of(S, Lf, wname, world):
                         "launches of a 200^3 factorization does not finish" % (k, 100 * traffic_detail["share_of_kernel_time"]))
     else:
         traffic_note = "no PMC summary under profiles/ for this workload and kernel"
+    mfma_util, chain = None, None
+    bk, bk_file = pmc_by_kernel(wname) if world == 1 else (None, None)
+    if bk is not None and traffic is None:
+        # all launches of one refactorization, summed per kernel: the dominant kernel's bytes per launch beside the algorithmic
+        # bytes per launch of THIS run (same launch list: the schedule is a function of the symbolic factor)
+        row = pmc_kernel_rows(bk, "k_update3" if use_w else "k_update2")
+        if row and row["launches"] > 0:
+            traffic = row["traffic_bytes"] / row["launches"]
+            mfma_util = row["mfma_utilisation"]
+            traffic_detail = {
+                "launches": row["launches"], "selection": "every launch of this kernel in one refactorization",
+                "share_of_kernel_time": 1.0, "ms_per_launch": 1e3 * sec / max(nl, 1),
+                "algorithmic_bytes_per_launch": by_ / max(nl, 1), "algorithmic_flops_per_launch": fl_ / max(nl, 1),
+                "TFLOPs_on_these_launches": ach,
+                "fetch_bytes_per_launch": row["fetch_bytes"] / row["launches"], "write_bytes_per_launch": row["write_bytes"] / row["launches"],
+                "traffic_over_algorithmic": traffic / max(by_ / max(nl, 1), 1.0),
+                "TBps_at_the_memory_side": traffic / (sec / max(nl, 1)) / 1e12,
+                "launches_in_this_run": int(nl), "source": "profiles/" + bk_file}
+            traffic_note = ("FETCH_SIZE x 2 + WRITE_SIZE summed over every launch of the kernel in one refactorization "
+                            "(tools/pmc_workload.sh), per launch")
+        # the kernels the mid-size configurations wait for: counters per kernel, times from this run's profiled pass
+        chain = {}
+        for kn in CHAIN_KERNELS:
+            r = pmc_kernel_rows(bk, kn)
+            if r:
+                chain[kn] = {"launches": r["launches"], "traffic_GB": r["traffic_bytes"] / 1e9, "mfma_utilisation": r["mfma_utilisation"]}
     other = {"kernel": "k_update2<64,64,16,2,false>" if use_w else "k_update3", "seconds": ps[6] if use_w else ps[32],
              "launches": int(ps[7] if use_w else ps[33]),
              "TFLOPs": ((ps[8] / ps[6]) if use_w and ps[6] > 0 else (ps[34] / ps[32]) if (not use_w and ps[32] > 0) else 0.0) / 1e12}
@@ -219,7 +277,8 @@ def roofline_of(S, Lf, wname, world):
             "traffic_over_algorithmic": traffic_detail["traffic_over_algorithmic"] if traffic_detail else None,
             "traffic_TBps_at_the_memory_side": traffic_detail["TBps_at_the_memory_side"] if traffic_detail else None,
             "traffic_source": traffic_detail["source"] if traffic_detail else None,
-            "mfma_utilisation": pj.get("mfma_utilisation") if (pj is not None and traffic_detail) else None,
+            "mfma_utilisation": pj.get("mfma_utilisation") if (pj is not None and traffic_detail and mfma_util is None) else mfma_util,
+            "counters_by_kernel": chain, "counters_by_kernel_source": ("profiles/" + bk_file) if chain else None,
             "traffic_note": traffic_note, "traffic_detail": traffic_detail,
             "algorithmic_bytes_per_launch_all_launches": by_ / max(nl, 1),
             "algorithmic_flops_per_launch": fl_ / max(nl, 1),

@@ -212,6 +212,15 @@ int cholmod_hip_factorize_resident (cholmod_hip_plan *plan, double beta,
 int cholmod_hip_set_value_map (cholmod_hip_plan *plan, const int64_t *src, int64_t snz,
     int64_t nvalues) ;
 int cholmod_hip_refresh_values (cholmod_hip_plan *plan, const double *values, int64_t nvalues) ;
+/* The same upload as a pipeline the caller drives (round 5): cholmod_hip_values_staging hands out a PINNED host buffer of
+ * nvalues doubles owned by the plan; the caller fills it chunk by chunk (with its own threads) and calls
+ * cholmod_hip_values_push (offset, count) after every chunk -- an asynchronous DMA, no host wait; cholmod_hip_values_commit
+ * (plan, 1) then enqueues the gather into the resident S and an event the ASSEMBLY of the next cholmod_hip_factorize_resident
+ * waits for (the clearing of L runs beside the upload); commit = 0 abandons what was pushed (the pattern changed after all)
+ * and waits until nothing is in flight.  The caller's own array may be reused as soon as it has been copied out. */
+int cholmod_hip_values_staging (cholmod_hip_plan *plan, double **host_buffer, int64_t *nvalues) ;
+int cholmod_hip_values_push (cholmod_hip_plan *plan, int64_t offset, int64_t count) ;
+int cholmod_hip_values_commit (cholmod_hip_plan *plan, int commit) ;
 
 /* Copy the device-resident packed Lx (xsize doubles) to the host. */
 int cholmod_hip_download_factor (cholmod_hip_plan *plan, double *Lx_host) ;

@@ -138,7 +138,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
-    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_diag_minmax", "cholmod_hip_debug_routing",
+    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_diag_minmax", "cholmod_hip_values_staging", "cholmod_hip_values_push", "cholmod_hip_values_commit", "cholmod_hip_debug_routing",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",

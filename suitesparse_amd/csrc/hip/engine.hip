@@ -55,6 +55,8 @@ namespace {
 static void free_device (cholmod_hip_plan *P)
 {
     if (P->prog_dev) { (void) hipHostFree (P->prog_dev) ; P->prog_dev = nullptr ; }
+    if (P->h_vals) { (void) hipHostFree (P->h_vals) ; P->h_vals = nullptr ; }
+    if (P->values_ev) { (void) hipEventDestroy (P->values_ev) ; P->values_ev = nullptr ; }
     if (RcclApi *R = (P->nccl_world ? rccl_api () : nullptr))
     {
         for (auto &g : P->nccl_group) (void) R->CommDestroy (g.second) ;
@@ -563,6 +565,13 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
     if (P->d_cflags) HIPCHK (hipMemsetAsync (P->d_cflags, 0, (4 * (size_t) P->sch.ncflags + 4) * sizeof (int), st)) ;
+    if (P->values_pending)
+    {
+        // (cholmod_hip_values_commit: the new values of S arrive on the exchange stream; everything above -- the clearing of
+        // L -- ran beside their upload, the assembly is the first to read them)
+        HIPCHK (hipStreamWaitEvent (st, P->values_ev, 0)) ;
+        P->values_pending = false ;
+    }
     if (P->n > 0 && P->amap_valid)
     {
         // the resident S was assembled before: stream it through its map
@@ -1327,6 +1336,57 @@ int cholmod_hip_refresh_values (cholmod_hip_plan *P, const double *values, int64
         hipLaunchKernelGGL (k_gather_values, dim3 ((unsigned) ((P->vsrc_nz + 255) / 256)), dim3 (256), 0, P->stream,
             P->vsrc_nz, P->d_vsrc, P->d_vals, P->d_Sx) ;
     HIPCHK (hipStreamSynchronize (P->stream)) ;     // the caller may reuse `values` at once
+    return CHOLMOD_HIP_OK ;
+}
+
+/* The same, pipelined (round 5: the API step of the small configurations is a third H2D + host work): the caller copies
+ * A->x chunk by chunk into a pinned staging buffer of the plan (its own threads, cholmod_hip_values_staging) and pushes every
+ * chunk as soon as it is filled (cholmod_hip_values_push: DMA on the exchange stream, no host wait); while the last chunks
+ * travel it does what else it has to do (the pattern hash), then commits (gather into the resident S, an event the next
+ * factorization's ASSEMBLY waits for -- its clearing of L, 1 to 10 GB of memset, runs beside the upload) or cancels. */
+int cholmod_hip_values_staging (cholmod_hip_plan *P, double **host_buffer, int64_t *nvalues)
+{
+    if (!P || P->host_only || !host_buffer || !nvalues || !P->d_vsrc || P->vsrc_nz != P->s_cur_nz) return CHOLMOD_HIP_INVALID ;
+    if (!P->h_vals || P->h_vals_n != P->vals_n)
+    {
+        if (P->h_vals) { (void) hipHostFree (P->h_vals) ; P->h_vals = nullptr ; }
+        if (hipHostMalloc ((void **) &P->h_vals, (size_t) std::max<i64> (P->vals_n, 1) * sizeof (double), hipHostMallocDefault) != hipSuccess)
+        {
+            (void) hipGetLastError () ;
+            P->h_vals = nullptr ;
+            return CHOLMOD_HIP_OUT_OF_MEMORY ;
+        }
+        P->h_vals_n = P->vals_n ;
+    }
+    if (!P->values_ev) HIPCHK (hipEventCreateWithFlags (&P->values_ev, hipEventDisableTiming)) ;
+    *host_buffer = P->h_vals ; *nvalues = P->vals_n ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_values_push (cholmod_hip_plan *P, int64_t offset, int64_t count)
+{
+    if (!P || !P->h_vals || offset < 0 || count < 0 || offset + count > P->vals_n) return CHOLMOD_HIP_INVALID ;
+    if (count) HIPCHK (hipMemcpyAsync (P->d_vals + offset, P->h_vals + offset, (size_t) count * sizeof (double), hipMemcpyHostToDevice, P->stream2)) ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_values_commit (cholmod_hip_plan *P, int commit)
+{
+    if (!P || !P->h_vals) return CHOLMOD_HIP_INVALID ;
+    if (!commit)
+    {
+        // (the pattern turned out to be another one: nothing of the staged values may reach the resident S, and whoever
+        // rewrites S next must not meet a copy in flight)
+        HIPCHK (hipStreamSynchronize (P->stream2)) ;
+        P->values_pending = false ;
+        return CHOLMOD_HIP_OK ;
+    }
+    if (P->vsrc_nz)
+        hipLaunchKernelGGL (k_gather_values, dim3 ((unsigned) ((P->vsrc_nz + 255) / 256)), dim3 (256), 0, P->stream2,
+            P->vsrc_nz, P->d_vsrc, P->d_vals, P->d_Sx) ;
+    HIPCHK (hipGetLastError ()) ;
+    HIPCHK (hipEventRecord (P->values_ev, P->stream2)) ;
+    P->values_pending = true ;
     return CHOLMOD_HIP_OK ;
 }
 

@@ -326,6 +326,8 @@ struct cholmod_hip_plan {
     int *d_first_fail = nullptr ;           // k_first_fail result
     i64 *d_vsrc = nullptr ; double *d_vals = nullptr ;      // value map of the resident S (cholmod_hip_set_value_map)
     i64 vsrc_nz = 0, vals_n = 0, s_cur_nz = 0 ;
+    double *h_vals = nullptr ; i64 h_vals_n = 0 ;           // pinned staging of the value upload (cholmod_hip_values_staging)
+    hipEvent_t values_ev = nullptr ; bool values_pending = false ;     // ... and the event behind its gather into S
     int cur_mapped = 0 ;
     i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace

@@ -348,22 +348,46 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
      * host-side permutation, the pattern upload and the assembly search are skipped. */
     const int vmap_ok = (A->xtype == CHOLMOD_REAL && A->packed && L->hip_plan && Common->hip_world <= 1
         && ssamd_resolve_use_gpu (Common) == 1) ;
-    uint64_t hash2 = 0 ;
-    uint64_t hash = vmap_ok ? pattern_hash (A, &hash2) : 0 ;
+    uint64_t hash2 = 0, hash = 0 ;
+    int hashed = FALSE ;
     size_t annz = vmap_ok ? (size_t) ((Int *) A->p) [A->ncol] : 0 ;
-    if (vmap_ok && L->hip_apat_valid && L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2 && L->hip_apat_nnz == annz
-        && (L->xtype == CHOLMOD_REAL || L->xtype == CHOLMOD_PATTERN))
+    if (vmap_ok && L->hip_apat_valid && L->hip_apat_nnz == annz && (L->xtype == CHOLMOD_REAL || L->xtype == CHOLMOD_PATTERN))
     {
-        int rc = cholmod_hip_refresh_values ((cholmod_hip_plan *) L->hip_plan, A->x, (int64_t) annz) ;
-        if (rc == CHOLMOD_HIP_OK)
+        /* The values travel first, the proof that they belong there is computed while they are on their way: A->x goes
+         * chunk by chunk into the plan's pinned staging buffer (all host threads) and every chunk leaves by DMA as soon as
+         * it is filled; the hash of the pattern is taken while the last chunks are in flight; then commit (gather on the
+         * device, the factorization's assembly waits for it -- its clearing of L runs beside the upload) or cancel. */
+        cholmod_hip_plan *plan = (cholmod_hip_plan *) L->hip_plan ;
+        double *stage = NULL ;
+        int64_t cap = 0 ;
+        int rc = cholmod_hip_values_staging (plan, &stage, &cap) ;
+        if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz)
         {
-            int64_t minor = (int64_t) L->n ;
-            rc = cholmod_hip_factorize_resident ((cholmod_hip_plan *) L->hip_plan, beta ? beta [0] : 0.0,
-                Common->quick_return_if_not_posdef, &minor) ;
-            return finish_numeric (rc, minor, L, Common) ;
+            const double *Ax = A->x ;
+            const int64_t CH = (int64_t) 1 << 20 ;          /* 8 MB per push */
+            const int nth = ssamd_host_threads () ;
+            for (int64_t o = 0 ; o < cap && rc == CHOLMOD_HIP_OK ; o += CH)
+            {
+                const int64_t cnt = (cap - o < CH) ? cap - o : CH ;
+                const int64_t PIECE = 32768 ;               /* 256 KB per thread and turn */
+#pragma omp parallel for schedule(static) num_threads(nth) if (cnt > 4 * PIECE)
+                for (int64_t q = 0 ; q < cnt ; q += PIECE)
+                    memcpy (stage + o + q, Ax + o + q, (size_t) ((cnt - q < PIECE) ? cnt - q : PIECE) * sizeof (double)) ;
+                rc = cholmod_hip_values_push (plan, o, cnt) ;
+            }
+            hash = pattern_hash (A, &hash2) ;
+            hashed = TRUE ;
+            const int same = (rc == CHOLMOD_HIP_OK && L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2) ;
+            if (cholmod_hip_values_commit (plan, same) == CHOLMOD_HIP_OK && same)
+            {
+                int64_t minor = (int64_t) L->n ;
+                rc = cholmod_hip_factorize_resident (plan, beta ? beta [0] : 0.0, Common->quick_return_if_not_posdef, &minor) ;
+                return finish_numeric (rc, minor, L, Common) ;
+            }
         }
         L->hip_apat_valid = FALSE ;         /* no usable map after all: the long way */
     }
+    if (vmap_ok && !hashed) hash = pattern_hash (A, &hash2) ;
     cholmod_sparse *S = NULL ;
     Int *src = NULL ;
     int natural = (L->ordering == CHOLMOD_NATURAL) ;

@@ -25,9 +25,9 @@ def test_headers_and_symbol_lists_agree():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     declared = set()
-    for h in ("cholmod.h", "cholmod_hip.h"):
+    for h in ("cholmod.h", "cholmod_hip.h", "SuiteSparse_config.h"):
         txt = open(os.path.join(root, "include", h)).read()
-        declared |= set(re.findall(r"\b(cholmod_(?:l|hip|gpu)_[a-z0-9_]+)\s*\(", txt))
+        declared |= set(re.findall(r"\b(cholmod_(?:l|hip|gpu)_[a-z0-9_]+|SuiteSparse_(?:start|finish|malloc|calloc|realloc|free))\s*\(", txt))
     assert declared == set(ch.API_SYMBOLS + ch.HIP_SYMBOLS)
 
 
