@@ -10,6 +10,7 @@
  * CHOLMOD/Supernodal/cholmod_super_numeric.c, cholmod_super_solve.c;
  * CHOLMOD/GPU/cholmod_gpu.c. */
 #include "host_internal.h"
+#include <time.h>
 
 /* ---- GPU entry points (reference CHOLMOD/GPU/cholmod_gpu.c:71-486) ---------------- */
 
@@ -149,9 +150,23 @@ static void absorb_stats (cholmod_factor *L, cholmod_common *Common)
 
 /* ---- cholmod_l_super_numeric ------------------------------------------------------------ */
 
+/* a factorization that cannot hand its result over leaves L symbolic, as the reference does when it runs out of memory on
+ * a symbolic L (cholmod_super_numeric.c:235-248): the values on the device are forgotten, the plan stays */
+static int back_to_symbolic (cholmod_factor *L)
+{
+    L->xtype = CHOLMOD_PATTERN ; L->minor = L->n ;
+    L->hip_on_device = FALSE ; L->hip_host_valid = FALSE ;
+    return FALSE ;
+}
+
 static int finish_numeric (int rc, int64_t minor, cholmod_factor *L, cholmod_common *Common)
 {
-    if (rc < 0) return map_hip_status (rc, Common, "HIP factorization failed") ;
+    const int was_symbolic = (L->xtype == CHOLMOD_PATTERN && !L->x) ;
+    if (rc < 0)
+    {
+        if (was_symbolic) back_to_symbolic (L) ;
+        return map_hip_status (rc, Common, "HIP factorization failed") ;
+    }
     L->xtype = CHOLMOD_REAL ;
     L->dtype = CHOLMOD_DOUBLE ;
     L->is_ll = TRUE ;
@@ -163,12 +178,16 @@ static int finish_numeric (int rc, int64_t minor, cholmod_factor *L, cholmod_com
         if (Common->hip_world > 1)
         {
             int rg = cholmod_hip_gather_factor ((cholmod_hip_plan *) L->hip_plan) ;
-            if (rg != CHOLMOD_HIP_OK) return map_hip_status (rg, Common, "factor gather failed") ;
+            if (rg != CHOLMOD_HIP_OK) { if (was_symbolic) back_to_symbolic (L) ; return map_hip_status (rg, Common, "factor gather failed") ; }
         }
         if (!L->x) L->x = cholmod_l_malloc (L->xsize, sizeof (double), Common) ;
-        if (!L->x) return FALSE ;
+        if (!L->x) return was_symbolic ? back_to_symbolic (L) : FALSE ;     /* (found by the fault loop, tests/test_memory_faults.py) */
         int r2 = cholmod_hip_download_factor ((cholmod_hip_plan *) L->hip_plan, L->x) ;
-        if (r2 != CHOLMOD_HIP_OK) return map_hip_status (r2, Common, "factor download failed") ;
+        if (r2 != CHOLMOD_HIP_OK)
+        {
+            if (was_symbolic) { L->x = cholmod_l_free (L->xsize, sizeof (double), L->x, Common) ; back_to_symbolic (L) ; }
+            return map_hip_status (r2, Common, "factor download failed") ;
+        }
         L->hip_host_valid = TRUE ;
     }
     absorb_stats (L, Common) ;
@@ -283,6 +302,13 @@ int cholmod_l_refactorize_resident (double beta [2], cholmod_factor *L, cholmod_
 
 /* ---- cholmod_l_factorize ---------------------------------------------------------------- */
 
+static double api_now (void)
+{
+    struct timespec ts ;
+    clock_gettime (CLOCK_MONOTONIC, &ts) ;
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec ;
+}
+
 /* 64-bit hash of a packed pattern (dimensions, stype, p, i): the key under which the
  * engine's value map of a matrix is remembered */
 /* Two independent 64-bit fingerprints of the pattern (p and i arrays): the values-only fast
@@ -360,6 +386,8 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         cholmod_hip_plan *plan = (cholmod_hip_plan *) L->hip_plan ;
         double *stage = NULL ;
         int64_t cap = 0 ;
+        const int timing = getenv ("CHOLMOD_API_TIMING") != NULL ;
+        double tq0 = timing ? api_now () : 0, tq1 = 0, tq2 = 0 ;
         int rc = cholmod_hip_values_staging (plan, &stage, &cap) ;
         if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz)
         {
@@ -375,13 +403,17 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
                     memcpy (stage + o + q, Ax + o + q, (size_t) ((cnt - q < PIECE) ? cnt - q : PIECE) * sizeof (double)) ;
                 rc = cholmod_hip_values_push (plan, o, cnt) ;
             }
+            if (timing) tq1 = api_now () ;
             hash = pattern_hash (A, &hash2) ;
             hashed = TRUE ;
+            if (timing) tq2 = api_now () ;
             const int same = (rc == CHOLMOD_HIP_OK && L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2) ;
             if (cholmod_hip_values_commit (plan, same) == CHOLMOD_HIP_OK && same)
             {
                 int64_t minor = (int64_t) L->n ;
                 rc = cholmod_hip_factorize_resident (plan, beta ? beta [0] : 0.0, Common->quick_return_if_not_posdef, &minor) ;
+                if (timing) fprintf (stderr, "cholmod_l_factorize (values only): stage + push %.3f ms, pattern hash %.3f ms, commit + factorization %.3f ms\n",
+                    1e3 * (tq1 - tq0), 1e3 * (tq2 - tq1), 1e3 * (api_now () - tq2)) ;
                 return finish_numeric (rc, minor, L, Common) ;
             }
         }
