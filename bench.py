@@ -70,6 +70,24 @@ sys.path.insert(0, os.environ["BENCH_ROOT"])
 from suitesparse_amd import cholmod as ch, generators as G
 import ctypes as C
 m = int(os.environ["BENCH_CPU_M"])
+# BENCH_CPU_PIN=1 (off by default): the threads of this process (OpenMP team, the BLAS's own pool -- they inherit the mask) on
+# the first T physical cores of NUMA node 0.  Measured in round 5 on the 2 x 64-core EPYC 9575F box, Poisson 100^3: pinned
+# 315 / 294 / 111 GFLOP/s at 16 / 32 / 64 threads against 480 / 330 / 221 un-pinned -- sixteen threads spread over all the
+# CCDs have more L3 and memory channels than sixteen neighbours, and the bound OpenBLAS (scipy's pthread build) loses
+# beyond 16 threads either way: its dpotrf / dsyrk on the top fronts, not this loop, is what does not scale.
+pinned = None
+try:
+    T = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    if T > 0 and os.environ.get("BENCH_CPU_PIN", "0") != "0":
+        txt = open("/sys/devices/system/node/node0/cpulist").read().strip()
+        first = txt.split(",")[0]                      # (the first range = the physical cores; later ranges are their SMT siblings)
+        lo, hi = (int(v) for v in (first.split("-") + [first])[:2])
+        cpus = list(range(lo, hi + 1))[:T]
+        if len(cpus) == T:
+            os.sched_setaffinity(0, cpus)
+            pinned = "cpus %d-%d of NUMA node 0" % (cpus[0], cpus[-1])
+except Exception:
+    pinned = None
 n, Ap, Ai, Ax = G.poisson3d(m)
 perm = G.geometric_nd(m, m, m, 4)
 S = ch.Session(use_gpu=0)
@@ -83,7 +101,7 @@ for _ in range(int(os.environ.get("BENCH_CPU_REPS", "2"))):
     assert ok == 1 and S.cm.status == 0
 S.L.ssamd_cpu_blas_name.restype = C.c_char_p
 print(json.dumps({"fl": S.cm.fl, "seconds": secs, "blas": S.L.ssamd_cpu_blas_name().decode(),
-                  "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count()}))
+                  "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count(), "pinned": pinned}))
 """
 
 
@@ -108,7 +126,7 @@ def cpu_baseline(sample_m):
     if "OMP_NUM_THREADS" in os.environ:
         counts = [int(os.environ["OMP_NUM_THREADS"])]
     elif big:
-        counts = sorted({min(cores, 16), min(cores, 32), min(cores, 64)})      # up to one socket's cores (EPYC 9575F: 64)
+        counts = sorted({min(cores, 8), min(cores, 16), min(cores, 32), min(cores, 64)})      # up to one socket's cores (EPYC 9575F: 64)
     else:
         counts = sorted({1, min(cores, 16), min(cores, 64)})
     base["BENCH_CPU_REPS"] = os.environ.get("BENCH_CPU_REPS", "1" if big else "2")
@@ -123,7 +141,8 @@ def cpu_baseline(sample_m):
             continue
         blas, fl = r["blas"], r["fl"]
         best = min(r["seconds"])
-        pts.append({"threads": t, "GFLOPs": r["fl"] / best / 1e9, "seconds_best": best, "seconds_first": r["seconds"][0]})
+        pts.append({"threads": t, "GFLOPs": r["fl"] / best / 1e9, "seconds_best": best, "seconds_first": r["seconds"][0],
+                    "pinned": r.get("pinned")})
     if not pts:
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {err}"}
     top = max(pts, key=lambda q: q["GFLOPs"])
@@ -135,7 +154,7 @@ def cpu_baseline(sample_m):
             "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)),
             "sample": f"poisson3d {sample_m}^3 geometric ND" + (" (BASELINE configs[1], the whole factorization)" if sample_m == 100 else "")
                       + f", best of {base['BENCH_CPU_REPS']} factorization(s) per thread count "
-                      f"({', '.join(str(q['threads']) for q in pts)} threads; every dense call gets one BLAS thread per ~4 Mflop, at most that many), "
+                      f"({', '.join(str(q['threads']) for q in pts)} threads; every dense call gets one BLAS thread per ~128 Mflop, at most that many), "
                       f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas}, host cores {cores}"}
 
 

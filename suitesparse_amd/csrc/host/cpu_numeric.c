@@ -41,19 +41,25 @@ static struct
     dgemm_fn gemm ; dsyrk_fn syrk ; dtrsm_fn trsm ; dpotrf_fn potrf ;
     set_threads_fn set_threads ;    /* openblas_set_num_threads / MKL_Set_Num_Threads / bli_thread_set_num_threads, or NULL */
     int max_threads, cur_threads ;
+    double grain ;                  /* flops of a dense call per BLAS thread */
     char name [256] ;
 } g_blas ;
 
 /* Threads for ONE dense call, by its flop count.  The left-looking loop issues its BLAS calls one after the other, and
  * almost all of them are tiny (Poisson 100^3 under AMD: 97 % of 601 338 updates have <= 16 columns): a threaded
  * BLAS that wakes 64 threads for each of them spends its time in the wake-up, not in the arithmetic -- rounds 3-4 measured
- * 36 GFLOP/s at 64 threads against 216 at 16.  So a call gets one thread per ~4 Mflop, at most what the caller allows
+ * 36 GFLOP/s at 64 threads against 216 at 16.  So a call gets one thread per ~128 Mflop, at most what the caller allows
  * (OMP_NUM_THREADS): small calls run on the calling thread, the few big ones (which hold the flops) on all of them, and
  * more threads never cost.  Without a thread-control entry point in the bound library the BLAS decides for itself. */
 static void blas_threads_for (double flops)
 {
     if (!g_blas.set_threads) return ;
-    int t = flops < 2e6 ? 1 : (int) (flops / 4e6) + 1 ;
+    /* (one thread per 128 Mflop -- a few milliseconds of dgemm per thread.  Poisson 100^3 on 2 x EPYC 9575F with scipy's
+     * OpenBLAS, GFLOP/s at 16 / 32 / 64 threads: 542 / 286 / 149 with 4 Mflop per thread, 466 / 304 / 179 with 32, 480 / 330 /
+     * 221 with 128; rounds 3-4, every call on all threads: 216 at 16, 36 at 64.  What is left of the drop beyond 16 threads
+     * is the BLAS's own scaling on the few top fronts.) */
+    const double grain = g_blas.grain ;          /* (CHOLMOD_CPU_MFLOP_PER_THREAD, read when the BLAS is bound) */
+    int t = flops < grain ? 1 : (int) (flops / grain) + 1 ;
     if (t > g_blas.max_threads) t = g_blas.max_threads ;
     if (t != g_blas.cur_threads) { g_blas.set_threads (t) ; g_blas.cur_threads = t ; }
 }
@@ -118,6 +124,7 @@ static int try_blas (const char *path, const char *prefix)
     if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "MKL_Set_Num_Threads") ;
     if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "bli_thread_set_num_threads") ;
     g_blas.max_threads = ssamd_host_threads_uncapped () ;
+    { const char *ge = getenv ("CHOLMOD_CPU_MFLOP_PER_THREAD") ; g_blas.grain = (ge && atof (ge) > 0) ? 1e6 * atof (ge) : 128e6 ; }
     g_blas.cur_threads = -1 ;
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;
     g_blas.handle = h ;         /* (last: everything above is in place when a reader sees the handle) */

@@ -136,7 +136,7 @@ def test_bcsstk01_golden_values(L, golden_dir):
     assert S.factorize(A, Lf) == 1
     fv = ch.FactorView(Lf)
     np.testing.assert_allclose(fv.x[:4], rec["Lx_head"], rtol=1e-13)
-    np.testing.assert_allclose(np.linalg.norm(fv.x), rec["Lx_fro"], rtol=1e-13)
+    np.testing.assert_allclose(np.linalg.norm(fv.x), rec["Lx_fro"], rtol=1e-13)      # (= sqrt (trace A): pins the input, not the reference)
     S.free_factor(Lf)
     S.free_sparse(A)
     S.finish()

@@ -53,6 +53,8 @@ def test_bcsstk01_matches_reference(rec, golden_dir, postorder):
     check_factor_invariants(L)
     assert L.factorize(Ax) == 0 and L.minor == n
     np.testing.assert_allclose(L.x[:4], g["Lx_head"], rtol=1e-14)
+    # (NOT a pin of the reference: ||L||_F^2 = trace (A) for any Cholesky factor under any permutation -- this checks
+    # the input file and the identity, nothing about the algorithm)
     np.testing.assert_allclose(np.linalg.norm(L.x), g["Lx_fro"], rtol=1e-14)
     c = g["blas_calls"]
     assert list(L.calls) == [c["syrk"], c["gemm"], c["potrf"], c["trsm"]]
