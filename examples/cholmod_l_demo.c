@@ -1,7 +1,7 @@
 /* cholmod_l_demo.c -- the sequence of the reference's demo driver (CHOLMOD/Demo/cholmod_l_demo.c:52-733, BASELINE.json
  * configs[0]) on this library, written against include/cholmod.h:
  *
- *   read a symmetric matrix (stdin or a file)            (:133-178 of the reference driver)
+ *   read a matrix (stdin or a file); unsymmetric: A*A'+beta*I is factorized   (:133-178 of the reference driver)
  *   norms of A, the right-hand side b(i) = 1 + i/n       (:180-243)
  *   cholmod_l_analyze, timed                             (:249-277)
  *   cholmod_l_factorize, timed                           (:279-297)
@@ -63,9 +63,19 @@ static const char *ordering_name (int ordering)
 static double residual (cholmod_sparse *A, cholmod_dense *X, cholmod_dense *B, double anorm, double bnorm,
     cholmod_dense **Rout, cholmod_common *cm)
 {
-    double one [2] = {1, 0}, minusone [2] = {-1, 0} ;
+    double one [2] = {1, 0}, minusone [2] = {-1, 0}, zero [2] = {0, 0} ;
     cholmod_dense *R = cholmod_l_copy_dense (B, cm) ;
-    cholmod_l_sdmult (A, 0, minusone, one, X, R, cm) ;
+    if (A->stype == 0)
+    {
+        /* (A*A' + beta*I) x = b was solved (:537-575): W = A' x, R = b - beta x - A W */
+        cholmod_dense *W = cholmod_l_allocate_dense (A->ncol, 1, A->ncol, CHOLMOD_REAL, cm) ;
+        cholmod_l_sdmult (A, 1, one, zero, X, W, cm) ;
+        double *Rx = R->x, *Xx = X->x ;
+        for (size_t i = 0 ; i < A->nrow ; i++) Rx [i] -= 1e-6 * Xx [i] ;
+        cholmod_l_sdmult (A, 0, minusone, one, W, R, cm) ;
+        cholmod_l_free_dense (&W, cm) ;
+    }
+    else cholmod_l_sdmult (A, 0, minusone, one, X, R, cm) ;
     double rnorm = cholmod_l_norm_dense (R, 0, cm), xnorm = cholmod_l_norm_dense (X, 0, cm) ;
     double scale = anorm * xnorm + bnorm + ((A->nrow == 0) ? 1 : 0) ;
     if (Rout) *Rout = R ; else cholmod_l_free_dense (&R, cm) ;
@@ -97,16 +107,13 @@ int main (int argc, char **argv)
     cholmod_sparse *A = cholmod_l_read_sparse (f, cm) ;
     if (matrix_file) fclose (f) ;
     if (!A) { printf ("no matrix read\n") ; return 1 ; }
-    if (A->stype == 0 || A->nrow != A->ncol)
-    {
-        printf ("the matrix must be symmetric (A*A' factorization is not built)\n") ;
-        cholmod_l_free_sparse (&A, cm) ;
-        return 1 ;
-    }
+    /* an unsymmetric matrix: A*A' + beta*I is factorized, beta = 1e-6 (:124-127, :280-286 of the reference driver) */
+    const int aat = (A->stype == 0) ;
+    double beta [2] = {1e-6, 0} ;
     const size_t n = A->nrow ;
     const int xtype = A->xtype ;
     double anorm = cholmod_l_norm_sparse (A, 0, cm) ;
-    printf ("A: %zu-by-%zu, nnz stored %ld, stype %d, %s\n", n, n, (long) cholmod_l_nnz (A, cm), A->stype,
+    printf ("A: %zu-by-%zu, nnz stored %ld, stype %d, %s\n", n, A->ncol, (long) cholmod_l_nnz (A, cm), A->stype,
         xtype == CHOLMOD_REAL ? "real" : "complex") ;
     printf ("norm (A,inf) = %g\nnorm (A,1)   = %g\n", anorm, cholmod_l_norm_sparse (A, 1, cm)) ;
     SuiteSparse_long *perm = NULL ;
@@ -139,9 +146,9 @@ int main (int argc, char **argv)
         L->nsuper, L->ssize, L->xsize, L->maxcsize, L->maxesize, L->ordering, L->useGPU) ;
 
     /* ---- factorize */
-    printf ("Factorizing A\n") ;
+    printf (aat ? "Factorizing A*A'+beta*I\n" : "Factorizing A\n") ;
     t = wall () ;
-    cholmod_l_factorize (A, L, cm) ;
+    if (aat) cholmod_l_factorize_p (A, beta, NULL, 0, L, cm) ; else cholmod_l_factorize (A, L, cm) ;
     double tf = wall () - t ;
     printf ("L: supernodal numeric LL', minor %zu, status %d\n", L->minor, cm->status) ;
     /* integers and doubles of the supernodal L (:300-315) */
@@ -195,7 +202,7 @@ int main (int argc, char **argv)
 
     /* ---- one step of iterative refinement (real symmetric case, :605-631): X += A \\ (B - A X) */
     double resid2 = -1 ;
-    if (xtype == CHOLMOD_REAL)
+    if (xtype == CHOLMOD_REAL && !aat)
     {
         cholmod_dense *R = NULL ;
         (void) residual (A, X, B, anorm, bnorm, &R, cm) ;
@@ -226,7 +233,7 @@ int main (int argc, char **argv)
     const double tot = ta + tf + ts [0] ;
     printf ("ints in L: %15.0f, doubles in L: %15.0f\n", isize, xsize) ;
     printf ("factor flops %g nnz(L) %15.0f (w/no amalgamation)\n", cm->fl, cm->lnz) ;
-    printf ("nnz(A*A'): %15.0f\n", cm->anz) ;
+    printf (aat ? "nnz(A*A'): %15.0f\n" : "nnz(A):    %15.0f\n", cm->anz) ;
     if (cm->lnz > 0) printf ("flops / nnz(L):  %8.1f\n", cm->fl / cm->lnz) ;
     if (cm->anz > 0) printf ("nnz(L) / nnz(A): %8.1f\n", cm->lnz / cm->anz) ;
     printf ("analyze walltime: %12.4f\n", ta) ;

@@ -37,8 +37,10 @@
  *    CHOLMOD_OUT_OF_MEMORY) unless Common->hip_cpu_fallback asks for the
  *    reference's silent degradation to the CPU path;
  *  - the supernode partition is the CPU one on both paths (no devBuffSize splits);
- *  - A*A' (stype 0) factorization, update/downdate, Bset solves, complex triplets
- *    and complex Matrix Market files: CHOLMOD_NOT_INSTALLED / CHOLMOD_INVALID.
+ *  - an unsymmetric A (stype 0: factorize A*A' + beta*I) is served by forming tril (A*A') on
+ *    the host and taking the symmetric path (real A; a column subset fset: NOT_INSTALLED);
+ *  - update/downdate, Bset solves and every simplicial form of L, complex triplets and
+ *    complex Matrix Market files: CHOLMOD_NOT_INSTALLED / CHOLMOD_INVALID.
  */
 #ifndef CHOLMOD_AMD_H
 #define CHOLMOD_AMD_H

@@ -288,9 +288,18 @@ int cholmod_l_super_symbolic2 (int for_whom, cholmod_sparse *A, cholmod_sparse *
     RETURN_IF_NULL (A, FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (Parent, FALSE) ;
-    (void) Fm ;
     if (A->stype < 0) { ERROR (CHOLMOD_INVALID, "symmetric lower not supported") ; return FALSE ; }
-    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' supernodal analysis not built") ; return FALSE ; }
+    if (A->stype == 0)
+    {
+        /* A*F, F = A(:,f)' (cholmod_super_symbolic.c:167-181 requires F): the upper pattern of the product, formed, takes
+         * the symmetric route */
+        if (!Fm) { ERROR (CHOLMOD_INVALID, "F is required for the unsymmetric case") ; return FALSE ; }
+        cholmod_sparse *C = ssamd_aat (A, Fm, 0, FALSE, Common) ;
+        if (!C) return FALSE ;
+        int okc = cholmod_l_super_symbolic2 (for_whom, C, NULL, Parent, L, Common) ;
+        cholmod_l_free_sparse (&C, Common) ;
+        return okc ;
+    }
     if (L->is_super || L->xtype != CHOLMOD_PATTERN)
     { ERROR (CHOLMOD_INVALID, "L must be symbolic on input") ; return FALSE ; }
     if (!A->packed) { ERROR (CHOLMOD_NOT_INSTALLED, "unpacked input not built") ; return FALSE ; }
@@ -644,8 +653,14 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
     double tt [8] ; tt [0] = ssamd_now () ;
     if (A->stype == 0)
     {
-        ERROR (CHOLMOD_NOT_INSTALLED, "analysis of A*A' (stype 0) not built") ;
-        return NULL ;
+        /* unsymmetric A: analyse A*A' (cholmod_analyze.c:402-418 orders and counts A(:,f)*A(:,f)').  Here its pattern is formed
+         * (core.c: ssamd_aat) and analysed as the symmetric matrix it is; a column subset f is not built. */
+        if (fset) { ERROR (CHOLMOD_NOT_INSTALLED, "analysis of A(:,f)*A(:,f)' (fset) not built") ; return NULL ; }
+        cholmod_sparse *C = ssamd_aat (A, NULL, 0, TRUE, Common) ;
+        if (!C) return NULL ;
+        cholmod_factor *LC = cholmod_l_analyze_p2 (for_whom, C, UserPerm, NULL, 0, Common) ;
+        cholmod_l_free_sparse (&C, Common) ;
+        return LC ;
     }
     if (A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "matrix invalid") ; return NULL ; }
     if (Common->supernodal == CHOLMOD_SIMPLICIAL)

@@ -587,6 +587,131 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
     return ssamd_sym_permute (A, values, Perm, !(A->stype > 0), Common) ;
 }
 
+/* C = A * F as a symmetric matrix, one triangle stored (lower: stype -1, else upper: stype 1), columns sorted; F = A' (or
+ * A(:,f)') is taken if given, else formed.  values = 0: pattern only.  Real matrices.
+ *
+ * This is how this build serves the reference's unsymmetric input form (A->stype == 0: "factorize A*A' + beta*I",
+ * CHOLMOD/Cholesky/cholmod_factorize.c:197-224, CHOLMOD/Supernodal/t_cholmod_super_numeric.c:223-237 and :385-418, where
+ * every column of A*F is assembled on the fly): the product is FORMED once on the host (Gustavson's row-merge, one dense
+ * accumulator) and then takes the symmetric path unchanged -- the same L, at the price of holding tril (A*A').
+ * Reference for the product itself: CHOLMOD/Core/cholmod_aat.c. */
+cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int lower, cholmod_common *Common)
+{
+    if (A->xtype != CHOLMOD_REAL && values) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*A' not built") ; return NULL ; }
+    const Int m = (Int) A->nrow, ncol = (Int) A->ncol ;
+    cholmod_sparse *Fown = NULL ;
+    if (!F)
+    {
+        Fown = cholmod_l_ptranspose (A, values ? 1 : 0, NULL, NULL, 0, Common) ;
+        if (!Fown) return NULL ;
+        F = Fown ;
+    }
+    if ((Int) F->nrow != ncol || (Int) F->ncol != m)
+    {
+        if (Fown) cholmod_l_free_sparse (&Fown, Common) ;
+        ERROR (CHOLMOD_INVALID, "A and F dimensions do not match") ;
+        return NULL ;
+    }
+    const Int *Ap = A->p, *Ai = A->i, *Anz = A->nz, *Fp = F->p, *Fi = F->i, *Fnz = F->nz ;
+    const double *Ax = A->x, *Fx = F->x ;
+    const int av = values && Ax && Fx ;
+    Int *mark = cholmod_l_malloc (m > 0 ? m : 1, sizeof (Int), Common) ;
+    Int *Cp = cholmod_l_malloc (m + 1, sizeof (Int), Common) ;
+    double *w = av ? cholmod_l_calloc (m > 0 ? m : 1, sizeof (double), Common) : NULL ;
+    cholmod_sparse *C = NULL ;
+    int ok = mark && Cp && (!av || w) ;
+    if (ok)
+    {
+        /* pass 1: entries per column of the stored triangle */
+        for (Int i = 0 ; i < m ; i++) mark [i] = EMPTY ;
+        Int nz = 0 ;
+        for (Int j = 0 ; j < m ; j++)
+        {
+            Cp [j] = nz ;
+            Int p = Fp [j], pend = F->packed ? Fp [j+1] : p + Fnz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int k = Fi [p] ;
+                Int q = Ap [k], qend = A->packed ? Ap [k+1] : q + Anz [k] ;
+                for ( ; q < qend ; q++)
+                {
+                    Int i = Ai [q] ;
+                    if ((lower ? i < j : i > j) || mark [i] == j) continue ;
+                    mark [i] = j ; nz++ ;
+                }
+            }
+        }
+        Cp [m] = nz ;
+        C = cholmod_l_allocate_sparse (m, m, nz, TRUE, TRUE, lower ? -1 : 1, av ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+        ok = (C != NULL) ;
+    }
+    if (ok)
+    {
+        Int *Cpp = C->p, *Ci = C->i ;
+        double *Cx = C->x ;
+        for (Int j = 0 ; j <= m ; j++) Cpp [j] = Cp [j] ;
+        for (Int i = 0 ; i < m ; i++) mark [i] = EMPTY ;
+        for (Int j = 0 ; j < m ; j++)
+        {
+            Int dst = Cp [j] ;
+            Int p = Fp [j], pend = F->packed ? Fp [j+1] : p + Fnz [j] ;
+            for ( ; p < pend ; p++)
+            {
+                Int k = Fi [p] ;
+                const double fkj = av ? Fx [p] : 0.0 ;
+                Int q = Ap [k], qend = A->packed ? Ap [k+1] : q + Anz [k] ;
+                for ( ; q < qend ; q++)
+                {
+                    Int i = Ai [q] ;
+                    if (lower ? i < j : i > j) continue ;
+                    if (mark [i] != j) { mark [i] = j ; Ci [dst++] = i ; }
+                    if (av) w [i] += Ax [q] * fkj ;
+                }
+            }
+            /* sort the column (short lists: insertion sort; long ones: by a counting pass over the marks would need O(m)) */
+            Int len = dst - Cp [j] ;
+            Int *col = Ci + Cp [j] ;
+            if (len > 64)
+            {
+                /* heap sort, in place */
+                for (Int start = len / 2 - 1 ; start >= 0 ; start--)
+                    for (Int r = start ; ; )
+                    {
+                        Int c = 2 * r + 1 ; if (c >= len) break ;
+                        if (c + 1 < len && col [c + 1] > col [c]) c++ ;
+                        if (col [r] >= col [c]) break ;
+                        Int t = col [r] ; col [r] = col [c] ; col [c] = t ; r = c ;
+                    }
+                for (Int end = len - 1 ; end > 0 ; end--)
+                {
+                    Int t = col [0] ; col [0] = col [end] ; col [end] = t ;
+                    for (Int r = 0 ; ; )
+                    {
+                        Int c = 2 * r + 1 ; if (c >= end) break ;
+                        if (c + 1 < end && col [c + 1] > col [c]) c++ ;
+                        if (col [r] >= col [c]) break ;
+                        Int t2 = col [r] ; col [r] = col [c] ; col [c] = t2 ; r = c ;
+                    }
+                }
+            }
+            else
+                for (Int a = 1 ; a < len ; a++)
+                {
+                    Int v = col [a], b = a - 1 ;
+                    while (b >= 0 && col [b] > v) { col [b + 1] = col [b] ; b-- ; }
+                    col [b + 1] = v ;
+                }
+            if (av) for (Int a = 0 ; a < len ; a++) { Cx [Cp [j] + a] = w [col [a]] ; w [col [a]] = 0.0 ; }
+        }
+    }
+    if (mark) cholmod_l_free (m > 0 ? m : 1, sizeof (Int), mark, Common) ;
+    if (Cp) cholmod_l_free (m + 1, sizeof (Int), Cp, Common) ;
+    if (w) cholmod_l_free (m > 0 ? m : 1, sizeof (double), w, Common) ;
+    if (Fown) cholmod_l_free_sparse (&Fown, Common) ;
+    if (!ok && C) cholmod_l_free_sparse (&C, Common) ;
+    return ok ? C : NULL ;
+}
+
 cholmod_sparse *cholmod_l_transpose (cholmod_sparse *A, int values, cholmod_common *Common)
 {
     return cholmod_l_ptranspose (A, values, NULL, NULL, 0, Common) ;

@@ -35,6 +35,7 @@ typedef SuiteSparse_long Int ;
 /* core.c */
 int ssamd_host_threads (void) ;
 int ssamd_host_threads_uncapped (void) ;
+cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int lower, cholmod_common *Common) ;
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common) ;
 cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,

@@ -204,15 +204,27 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (A, FALSE) ;
-    (void) F ;
     if (A->xtype < CHOLMOD_REAL || A->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "A must be numeric") ; return FALSE ; }
+    if (A->stype == 0)
+    {
+        /* L L' = A*F + beta*I with F = A(:,f)' (t_cholmod_super_numeric.c:223-237, :385-418: the reference assembles every
+         * column of A*F on the fly): tril (A*F) is formed on the host (core.c: ssamd_aat) and factorized as the symmetric
+         * matrix it is */
+        if (!F) { ERROR (CHOLMOD_INVALID, "F is required for the unsymmetric case") ; return FALSE ; }
+        if (A->xtype != CHOLMOD_REAL || F->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*F not built") ; return FALSE ; }
+        if (A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
+        cholmod_sparse *C = ssamd_aat (A, F, 1, TRUE, Common) ;
+        if (!C) return FALSE ;
+        int okc = cholmod_l_super_numeric (C, NULL, beta, L, Common) ;
+        cholmod_l_free_sparse (&C, Common) ;
+        return okc ;
+    }
     /* a numeric L keeps its kind: real for real A, complex for complex or zomplex A
      * (reference cholmod_super_numeric.c:160-175) */
     const int want = (A->xtype == CHOLMOD_REAL) ? CHOLMOD_REAL : CHOLMOD_COMPLEX ;
     if (L->xtype != CHOLMOD_PATTERN && L->xtype != want)
     { ERROR (CHOLMOD_INVALID, "complex type mismatch") ; return FALSE ; }
     if (A->stype > 0) { ERROR (CHOLMOD_INVALID, "symmetric upper case not supported") ; return FALSE ; }
-    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "unsymmetric (A*F) case not built") ; return FALSE ; }
     if (A->nrow != A->ncol || A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_INVALID, "L not supernodal") ; return FALSE ; }
     if (!ssamd_factor_has_cholesky_sizes (L))
@@ -362,11 +374,24 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (A, FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
-    (void) fset ; (void) fsize ;
+    (void) fsize ;
     if (A->xtype < CHOLMOD_REAL || A->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "A must be numeric") ; return FALSE ; }
-    if (A->nrow != L->n || A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
-    if (A->stype == 0) { ERROR (CHOLMOD_NOT_INSTALLED, "A*A' factorization not built") ; return FALSE ; }
+    if (A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
+    if (A->stype == 0)
+    {
+        /* factorize A*A' + beta*I (cholmod_factorize.c:197-224: S = A(p,f), F = S', super_numeric (S, F, beta)): tril (A*A')
+         * is formed on the host and takes the symmetric branch below -- permutation, upload and, from the second call with
+         * the same pattern on, the values-only path included.  A(:,f)*A(:,f)' (fset) is not built. */
+        if (fset) { ERROR (CHOLMOD_NOT_INSTALLED, "factorization of A(:,f)*A(:,f)' (fset) not built") ; return FALSE ; }
+        if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*A' not built") ; return FALSE ; }
+        cholmod_sparse *C = ssamd_aat (A, NULL, 1, TRUE, Common) ;
+        if (!C) return FALSE ;
+        int okc = cholmod_l_factorize_p (C, beta, NULL, 0, L, Common) ;
+        cholmod_l_free_sparse (&C, Common) ;
+        return okc ;
+    }
+    if (A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
     Common->status = CHOLMOD_OK ;
     double zero [2] = {0, 0} ;
     /* Same pattern as the matrix the engine already holds (hash of p / i, nnz): only the

@@ -189,3 +189,26 @@ def test_c_demo_on_cpu_path(golden_dir, tmp_path):
     with open(os.path.join(golden_dir, "bcsstk01.tri")) as f:
         out = subprocess.run([exe, "-cpu", "-perm", str(permfile)], stdin=f, capture_output=True, text=True, timeout=300)
     _check_demo_output(out)
+
+
+def test_c_demo_on_an_unsymmetric_matrix(tmp_path):
+    """The demo driver on a rectangular A (stype 0): it factorizes A*A' + 1e-6 I as the reference driver does
+    (CHOLMOD/Demo/cholmod_l_demo.c:280-286) and checks (A*A' + beta*I) x = b (:537-575)."""
+    import scipy.sparse as sp
+    m, n = 40, 70
+    M = sp.random(m, n, density=0.08, random_state=1, format="coo")
+    M = (M + sp.coo_matrix((np.ones(m), (np.arange(m), np.arange(m))), shape=(m, n))).tocoo()
+    f = tmp_path / "rect.tri"
+    f.write_text(f"{m} {n} {M.nnz} 0\n" + "".join(f"{i} {j} {v!r}\n" for i, j, v in zip(M.row, M.col, M.data)))
+    exe = str(tmp_path / "cholmod_l_demo")
+    lib = os.path.join(ROOT, "suitesparse_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "cholmod_l_demo.c"), "-L", lib, "-lcholmod_amd",
+                           f"-Wl,-rpath,{lib}", "-lm", "-o", exe])
+    out = subprocess.run([exe, "-cpu", str(f)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "A: 40-by-70" in txt and "Factorizing A*A'+beta*I" in txt and "minor 40, status 0" in txt, txt
+    res = [float(v) for v in txt.split("residual (|Ax-b|/(|A||x|+|b|)):")[1].split("\n")[0].split()]
+    assert len(res) == 3 and all(0 <= r < 1e-12 for r in res), res
+    assert "malloc_count 0 memory_inuse 0" in txt
