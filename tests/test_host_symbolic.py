@@ -176,12 +176,16 @@ def test_invalid_arguments():
     with pytest.raises(RuntimeError):
         S.analyze(A, np.zeros(n, dtype=np.int64))       # not a permutation
     assert S.cm.status == ch.INVALID
+    # an unsymmetric matrix is analysed as A*A' (round 5, tests/test_aat.py); what is not built is a column subset
     A0 = S.sparse(n, Ap, Ai, Ax, 0)
-    with pytest.raises(RuntimeError):
-        S.analyze(A0)
-    assert S.cm.status == ch.NOT_INSTALLED
+    L0 = S.analyze(A0)
+    assert L0 and S.cm.status == ch.OK and L0.contents.n == n
+    S.free_factor(L0)
+    fset = np.arange(3, dtype=np.int64)
+    assert not S.L.cholmod_l_analyze_p(A0, None, fset.ctypes.data, 3, C.byref(S.cm)) and S.cm.status == ch.NOT_INSTALLED
     S.free_sparse(A)
     S.free_sparse(A0)
+    assert S.cm.malloc_count == 0
     S.finish()
 
 
