@@ -329,11 +329,23 @@ static double api_now (void)
  * parallel and deterministic); the two use different keys, different mixers (the splitmix64
  * and murmur3 finalisers) and are folded differently, so a pattern change must defeat 128
  * bits, not 64 (round-2 review: one 64-bit sum folded by addition was thin). */
+/* Threads for the two short host loops of every cholmod_l_factorize call (staging copy of A->x, pattern hash: a few hundred
+ * microseconds each).  Measured on the 2 x 64-core box (2D 1259^2, wall around the call, resident step 5.26 ms): a team of 32
+ * 7.4 / 8.5 / 10.6 ms in three runs, 16 threads 6.14 / 6.15 / 6.26 ms, 8 threads 6.83 ms -- waking a wide team costs more
+ * than its bandwidth returns.  CHOLMOD_API_THREADS overrides. */
+static int api_threads (void)
+{
+    const char *e = getenv ("CHOLMOD_API_THREADS") ;
+    if (e && atoi (e) > 0) return atoi (e) ;
+    const int nt = ssamd_host_threads () ;
+    return nt > 16 ? 16 : nt ;
+}
+
 static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
 {
     const Int *Ap = A->p, *Ai = A->i ;
     const Int ncol = (Int) A->ncol, nz = Ap [ncol] ;
-    const int nth = ssamd_host_threads () ;
+    const int nth = api_threads () ;
     uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t) A->nrow * 0xff51afd7ed558ccdull) ^ ((uint64_t) (A->stype + 2) << 56) ;
     uint64_t hp = 0, hi = 0, gp = 0, gi = 0 ;
 #pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp,gp)
@@ -418,7 +430,7 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         {
             const double *Ax = A->x ;
             const int64_t CH = (int64_t) 1 << 20 ;          /* 8 MB per push */
-            const int nth = ssamd_host_threads () ;
+            const int nth = api_threads () ;
             for (int64_t o = 0 ; o < cap && rc == CHOLMOD_HIP_OK ; o += CH)
             {
                 const int64_t cnt = (cap - o < CH) ? cap - o : CH ;

@@ -6,6 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import build_workload
 from suitesparse_amd import cholmod as ch
 w, m = sys.argv[1], int(sys.argv[2])
+if os.environ.get("PROBE_NODE"):        # pin the whole process (all its threads) to one NUMA node's cpus
+    txt = open("/sys/devices/system/node/node%s/cpulist" % os.environ["PROBE_NODE"]).read().strip()
+    cpus = []
+    for part in txt.split(","):
+        lo, hi = (int(v) for v in (part.split("-") + [part])[:2])
+        cpus += list(range(lo, hi + 1))
+    os.sched_setaffinity(0, cpus)
 n, Ap, Ai, Ax, stype, perm, name = build_workload(w, m)
 S = ch.Session(factor_on_device=True, ordering="default")
 A = S.sparse(n, Ap, Ai, Ax, stype)
