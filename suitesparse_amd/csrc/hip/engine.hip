@@ -495,6 +495,13 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, COMMA 4>, dim3 (g4), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
                 else TW_LAUNCH (k_update3<2 COMMA, COMMA 4>, dim3 (g4), dim3 (256), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             }
+            else if (L.half)
+            {
+                // two waves per tile (k_update3 <..., HALF>): the launches of 512 .. 10 240 tiles, schedule_dense.hip
+                const unsigned gh = 2u * (unsigned) ((L.grid + 7) / 8 * 8) ;
+                if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, COMMA 1 COMMA true>, dim3 (gh), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+                else TW_LAUNCH (k_update3<2 COMMA, COMMA 1 COMMA true>, dim3 (gh), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
+            }
             else if (L.aux >= 1024) TW_LAUNCH (k_update3<4 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             else TW_LAUNCH (k_update3<2 COMMA, >, dim3 (L.grid), dim3 (64), 0, st, P->d_gg + L.goff, L.ng, P->d_Lx, P->d_cb) ;
             break ;
@@ -1749,7 +1756,7 @@ int cholmod_hip_debug_schedule_hash (cholmod_hip_plan *P, uint64_t *out16)
     uint64_t h = H0 ;
     for (const Launch &L : S.launches)
     {
-        const i64 v [] = {L.kind, L.grid, L.ng, (i64) L.goff, L.stream, L.wait_ev, L.rec_ev, L.ar_g0, L.ar_gn, L.aux, L.leaf_T, L.leaf_pw, L.ndiag,
+        const i64 v [] = {L.kind, L.grid, L.ng, (i64) L.goff, L.stream, L.wait_ev, L.rec_ev, L.ar_g0, L.ar_gn, L.aux, L.leaf_T, L.leaf_pw, L.ndiag, L.half,
             L.xd.slab, L.xd.lda, L.xd.w, L.xd.mb, L.xd.R, L.xd.g, L.xd.r} ;
         h = fnv (h, v, sizeof (v)) ;
         const double d [] = {L.flops, L.bytes} ;

@@ -1841,11 +1841,16 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 // TW: the even columns of a phi-embedded complex panel (see update_tile): the row / column pairs a
 // lane loads ARE the (re, im) pairs, fragment parity = row parity, so the four real products of a
 // complex entry are acc [2 q + {0,1}][2 p + {0,1}][r] of one lane and are combined in place.
-template <int DEPTH, bool EDGE, int TW = 0>
-__device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB)
+// NQ = 2: the whole 64 x 64 tile; NQ = 1 (round 5): its left or right HALF, 64 rows x 32 columns starting at column cofs (0 or
+// 32) of the tile -- two waves share a tile, so a region of T tiles puts 2 T waves on the chip: the launches of 1 000 - 6 000
+// tiles (the top fronts of the mid-size problems) that fill the 2048 wave slots one and a bit or two and a bit times then
+// waste half a tile time at most instead of a whole one.  Three loads feed eight MFMAs instead of four feeding sixteen; the
+// entries are computed in the same order as in the whole tile: bit-identical results.
+template <int DEPTH, bool EDGE, int TW = 0, int NQ = 2>
+__device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB, int cofs = 0)
 {
     const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4 ;
-    const int row0 = I * 64, col0 = J * 64 ;
+    const int row0 = I * 64, col0 = J * 64 + cofs ;
     const int mrem = G.m - row0, nrem = G.n - col0 ;
     const i64 lda = G.lda ;
     const int K = G.k ;
@@ -1869,7 +1874,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         pa [q] = Lx + G.a_off + row0 + (i64) lk * lda ;
         pb [q] = Lx + G.b_off + col0 + (i64) lk * lda ;
     }
-    struct Frag { double a [4], b [4] ; } ;     // a [2 q + h] = A (row pair q, member h), likewise b
+    struct Frag { double a [4], b [2 * NQ] ; } ;     // a [2 q + h] = A (row pair q, member h), likewise b (NQ column pairs)
     // a full k-step (columns kk .. kk + 3 all below K)
     auto load = [&] (Frag &F, int kk)
     {
@@ -1880,14 +1885,17 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
             if constexpr (EDGE)
             {
                 F.a [2 * q] = pa [q][ko + ra [q][0]] ; F.a [2 * q + 1] = pa [q][ko + ra [q][1]] ;
-                F.b [2 * q] = pb [q][ko + rb [q][0]] ; F.b [2 * q + 1] = pb [q][ko + rb [q][1]] ;
+                if (q < NQ) { F.b [2 * q] = pb [q][ko + rb [q][0]] ; F.b [2 * q + 1] = pb [q][ko + rb [q][1]] ; }
             }
             else
             {
                 d2u va = *(const d2u *) (pa [q] + ko + ra [q][0]) ;
-                d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ;
                 F.a [2 * q] = va.x ; F.a [2 * q + 1] = va.y ;
-                F.b [2 * q] = vb.x ; F.b [2 * q + 1] = vb.y ;
+                if (q < NQ)
+                {
+                    d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ;
+                    F.b [2 * q] = vb.x ; F.b [2 * q + 1] = vb.y ;
+                }
             }
         }
     } ;
@@ -1900,33 +1908,33 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
 #pragma unroll
         for (int q = 0 ; q < 2 ; q++)
         {
-            double a0, a1, b0, b1 ;
+            double a0, a1, b0 = 0, b1 = 0 ;
             if constexpr (EDGE)
             {
                 a0 = pa [q][ko + ra [q][0]] ; a1 = pa [q][ko + ra [q][1]] ;
-                b0 = pb [q][ko + rb [q][0]] ; b1 = pb [q][ko + rb [q][1]] ;
+                if (q < NQ) { b0 = pb [q][ko + rb [q][0]] ; b1 = pb [q][ko + rb [q][1]] ; }
             }
             else
             {
                 d2u va = *(const d2u *) (pa [q] + ko + ra [q][0]) ;
-                d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ;
-                a0 = va.x ; a1 = va.y ; b0 = vb.x ; b1 = vb.y ;
+                a0 = va.x ; a1 = va.y ;
+                if (q < NQ) { d2u vb = *(const d2u *) (pb [q] + ko + rb [q][0]) ; b0 = vb.x ; b1 = vb.y ; }
             }
             F.a [2 * q] = live ? a0 : 0.0 ; F.a [2 * q + 1] = live ? a1 : 0.0 ;
-            F.b [2 * q] = live ? b0 : 0.0 ; F.b [2 * q + 1] = live ? b1 : 0.0 ;
+            if (q < NQ) { F.b [2 * q] = live ? b0 : 0.0 ; F.b [2 * q + 1] = live ? b1 : 0.0 ; }
         }
     } ;
-    d4 acc [4][4] ;
+    d4 acc [4][2 * NQ] ;
 #pragma unroll
     for (int a = 0 ; a < 4 ; a++)
 #pragma unroll
-        for (int b = 0 ; b < 4 ; b++) acc [a][b] = (d4) {0.0, 0.0, 0.0, 0.0} ;
+        for (int b = 0 ; b < 2 * NQ ; b++) acc [a][b] = (d4) {0.0, 0.0, 0.0, 0.0} ;
     auto compute = [&] (const Frag &F)
     {
 #pragma unroll
         for (int a = 0 ; a < 4 ; a++)
 #pragma unroll
-            for (int b = 0 ; b < 4 ; b++)
+            for (int b = 0 ; b < 2 * NQ ; b++)
                 acc [a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64 (F.b [b], F.a [a], acc [a][b], 0, 0, 0) ;
     } ;
     // Operand set d holds k-step s + d at the top of an iteration; the set consumed last is
@@ -1968,7 +1976,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
 #pragma unroll
         for (int q = 0 ; q < 2 ; q++)
 #pragma unroll
-            for (int p = 0 ; p < 2 ; p++)
+            for (int p = 0 ; p < NQ ; p++)
 #pragma unroll
                 for (int r = 0 ; r < 4 ; r++)
                 {
@@ -1983,12 +1991,13 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
     double *C = (G.c_in_cb ? CB : Lx) + G.c_off + row0 + colx<TW == 2> (col0, G.ldc) ;
     const bool diag = G.tri && I == J ;
 #pragma unroll
-    for (int b = 0 ; b < 4 ; b++)
+    for (int b = 0 ; b < 2 * NQ ; b++)
 #pragma unroll
         for (int r = 0 ; r < 4 ; r++)
         {
             if (TW == 2 && (b & 1)) continue ;          // (complex storage: the even twin columns only)
-            const int j = 32 * (b >> 1) + 2 * (lk + 4 * r) + (b & 1) ;
+            const int j = 32 * (b >> 1) + 2 * (lk + 4 * r) + (b & 1) ;      // column inside this wave's part of the tile
+            const int jd = j + cofs ;                                       // ... inside the tile (the diagonal test)
             double *Cj = C + colx<TW == 2> (j, G.ldc) ;
 #pragma unroll
             for (int q = 0 ; q < 2 ; q++)
@@ -1998,13 +2007,13 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
                 {
 #pragma unroll
                     for (int h = 0 ; h < 2 ; h++)
-                        if (i + h < mrem && j < nrem && (!diag || i + h >= j))
+                        if (i + h < mrem && j < nrem && (!diag || i + h >= jd))
                         {
                             if (G.assign) Cj [i + h] = -acc [2 * q + h][b][r] ;
                             else Cj [i + h] -= acc [2 * q + h][b][r] ;
                         }
                 }
-                else if (!diag || i + 1 >= j)
+                else if (!diag || i + 1 >= jd)
                 {
                     d2u v ;
                     if (G.assign) { v.x = -acc [2 * q][b][r] ; v.y = -acc [2 * q + 1][b][r] ; }
@@ -2013,7 +2022,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
                         v = *(const d2u *) (Cj + i) ;
                         v.x -= acc [2 * q][b][r] ; v.y -= acc [2 * q + 1][b][r] ;
                     }
-                    if (diag && i < j) Cj [i + 1] = v.y ;           // (the pair straddles the diagonal)
+                    if (diag && i < jd) Cj [i + 1] = v.y ;          // (the pair straddles the diagonal)
                     else *(d2u *) (Cj + i) = v ;
                 }
             }
@@ -2025,18 +2034,32 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
 // tile walk).  A retiring workgroup then frees a wave slot on EVERY SIMD of its CU at once: the
 // four-wave workgroups of the exchange stream (and of RCCL) find room beside the update, which
 // one-wave workgroups -- refilled SIMD by SIMD -- never leave them.
-template <int DEPTH, int TW = 0, int WPB = 1>
+// HALF (round 5; one tile per workgroup only): blocks b and b + 8 -- the same XCD, hence the same tile walk -- take the left and
+// the right 32 columns of tile ((b >> 4) << 3) | (b & 7) of the one-wave launch; the grid is twice that launch's, rounded up
+// to whole groups of eight.
+template <int DEPTH, int TW = 0, int WPB = 1, bool HALF = false>
 __global__ void __launch_bounds__(64 * WPB, 2) k_update3 (const GemmGroup *g, int ng, double *Lx, double *CB)
 {
     int vb = (int) blockIdx.x ;
+    int cofs = 0 ;
     if constexpr (WPB > 1) vb = ((vb >> 3) * WPB + (int) (threadIdx.x >> 6)) * 8 + (vb & 7) ;
+    if constexpr (HALF) { cofs = ((vb >> 3) & 1) * 32 ; vb = ((vb >> 4) << 3) | (vb & 7) ; }
     int gi = find_group (g, ng, vb, &GemmGroup::tile_start) ;
     GemmGroup G = g [gi] ;
     int I, J ;
     if (vb - G.tile_start >= G.nblk) return ;
     if (!decode_tile (G, vb - G.tile_start, I, J)) return ;
-    if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
-    else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
+    if constexpr (HALF)
+    {
+        if (G.n - J * 64 - cofs <= 0) return ;                          // (the last tile column is at most 32 wide)
+        if (G.m - I * 64 >= 64 && G.n - J * 64 - cofs >= 32) update_tile_w<DEPTH, false, TW, 1> (G, I, J, Lx, CB, cofs) ;
+        else update_tile_w<DEPTH, true, TW, 1> (G, I, J, Lx, CB, cofs) ;
+    }
+    else
+    {
+        if (G.m - I * 64 >= 64 && G.n - J * 64 >= 64) update_tile_w<DEPTH, false, TW> (G, I, J, Lx, CB) ;
+        else update_tile_w<DEPTH, true, TW> (G, I, J, Lx, CB) ;
+    }
 }
 
 // ---- trailing update that also factors the next diagonal block ------------------

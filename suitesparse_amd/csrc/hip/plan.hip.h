@@ -91,6 +91,7 @@ struct Launch {
     int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
     int leaf_pw = 0 ;               // K_SMALL: every front is a leaf of <= 32 rows and <= leaf_pw (4/8/12/16) columns: two per wave (k_leaf_pair)
     int ndiag = 0 ;                 // K_CHAINF: diagonal workgroups of the launch (they come first in the grid)
+    int half = 0 ;                  // K_UPD_W: two waves per 64 x 64 tile, 64 x 32 each (k_update3<..., HALF>): launches of 512 .. 10 240 tiles
 } ;
 
 #define HIPCHK(call) do { hipError_t e_ = (call) ; if (e_ != hipSuccess) { \
@@ -355,6 +356,6 @@ int build_host (cholmod_hip_plan *P) ;
 // schedule_dense.hip: the launches of the dense partial factorization of one batch of fronts
 void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
-    const char *assign_cb = nullptr, const i64 *win = nullptr, const i32 *child = nullptr) ;
+    const char *assign_cb = nullptr, const i64 *win = nullptr, const i32 *child = nullptr, bool allow_half = false) ;
 
 } // namespace sship

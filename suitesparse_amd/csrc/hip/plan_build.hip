@@ -752,7 +752,8 @@ struct PlanBuilder
             schedule_zero (ids, nf) ;
             schedule_extend_add (ids, nf, 0) ;
             schedule_dense (P->fr, ids, nf, S, P->flags, P->owner.data (), P->grp0.data (), P->grpn.data (),
-                P->rank, P->world, P->assign_cb.data (), P->win_off.data (), P->child.data ()) ;
+                P->rank, P->world, P->assign_cb.data (), P->win_off.data (), P->child.data (),
+                P->world == 1 && !P->force_shared) ;      // (half tiles: one GPU -- plans of several ranks run four tiles per workgroup)
             schedule_extend_add (ids, nf, 1) ;
         }
     }

@@ -83,7 +83,13 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
     auto launch = [&] ()
     {
-        if (flags & 8192)       // third generation: one wave per tile, no LDS (operand sets in flight: 3 / 2 / 4)
+        if (flags & 524288)     // (round 5) half tiles: two waves per 64 x 64 tile, 64 x 32 each; depth 4 (flag 32768) or 2
+        {
+            const unsigned g2 = 2u * (unsigned) ((grid + 7) / 8 * 8) ;
+            if (flags & 32768) hipLaunchKernelGGL ((k_update3<4, 0, 1, true>), dim3 (g2), dim3 (64), 0, 0, dg, 1, d, d) ;
+            else hipLaunchKernelGGL ((k_update3<2, 0, 1, true>), dim3 (g2), dim3 (64), 0, 0, dg, 1, d, d) ;
+        }
+        else if (flags & 8192)       // third generation: one wave per tile, no LDS (operand sets in flight: 3 / 2 / 4)
             hipLaunchKernelGGL ((k_update3<3>), dim3 (grid), dim3 (64), 0, 0, dg, 1, d, d) ;
         else if (flags & 16384)
             hipLaunchKernelGGL ((k_update3<2>), dim3 (grid), dim3 (64), 0, 0, dg, 1, d, d) ;
@@ -434,6 +440,8 @@ double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, 
             HIPCHK (hipMemcpy (dg, &G, sizeof (G), hipMemcpyHostToDevice)) ;
         }
         if (pass == 0) hipLaunchKernelGGL ((k_update2<SMALL, SMALL, BKK, 2, false>), dim3 (G.nblk), dim3 (256), 0, 0, dg, 1, d, d) ;
+        else if ((flags & 524288) && (flags & 32768)) hipLaunchKernelGGL ((k_update3<4, 0, 1, true>), dim3 (2 * ((G.nblk + 7) / 8 * 8)), dim3 (64), 0, 0, dg, 1, d, d) ;
+        else if (flags & 524288) hipLaunchKernelGGL ((k_update3<2, 0, 1, true>), dim3 (2 * ((G.nblk + 7) / 8 * 8)), dim3 (64), 0, 0, dg, 1, d, d) ;
         else if (flags & 16384) hipLaunchKernelGGL ((k_update3<2>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
         else if (flags & 32768) hipLaunchKernelGGL ((k_update3<4>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;
         else hipLaunchKernelGGL ((k_update3<3>), dim3 (G.nblk), dim3 (64), 0, 0, dg, 1, d, d) ;

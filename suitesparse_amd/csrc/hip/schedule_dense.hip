@@ -34,6 +34,7 @@ struct DenseScheduler
     const char *assign_cb ;         // front's contribution block is written (not updated) by its first outer update
     const i64 *win ;                // window of a distributed front (offset in the rank's L), -1 / nullptr: none
     const i32 *child ;              // the rank's child lists (pricing of the extend-add into a window)
+    const bool allow_half ;         // one GPU: launches of a few thousand tiles may run two waves per tile (below)
     // ---- derived once per batch
     // The real twin of a complex factor (phi embedding, host/complex.c): every row / column pair (2i, 2i+1) is (re, im) of
     // one complex row, the odd columns of a panel are the rotations of the even ones.  The update kernels then contract over
@@ -50,6 +51,17 @@ struct DenseScheduler
     // the four waves per tile of k_update2 fill the chip better.  CHOLMOD_HIP_UPD3_MIN_TILES overrides (0 = never).
     // (every knob is read per batch: tests and in-process A/B runs change them between plans)
     i64 w_min_tiles ;
+    // Round 5: HALF tiles -- two waves per 64 x 64 tile, 64 x 32 each (kernels.hip.h: update_tile_w, NQ = 1).  A launch of T tiles
+    // fills the chip's 2048 wave slots T / 2048 times; with one or two and a bit fillings the last one is mostly empty (a
+    // triangular 4 488^2 region at K = 1024, 2 556 tiles: 48 TFLOP/s), and below 2048 tiles the four-wave kernel was all there
+    // was (35 - 50).  Measured standalone (tools/upd3.py half, profiles/r05_upd3_half_tiles.json): half tiles win from ~500 to
+    // ~8 000 tiles at every K >= 256 (64.5 against 48.3 / 58.3 for whole tiles / four-wave tiles at 2 556 tiles, 45.8 against
+    // 32.2 / 41.1 at 780), whole tiles from ~12 000 on (operand traffic per flop is 1.5 x).  So: a one-wave-per-tile launch of
+    // fewer than w_half_max tiles runs in half tiles, and the regions of a flush go to it from w_half_min pooled tiles on
+    // instead of 2048.  CHOLMOD_HIP_UPD3_HALF_MAX=0: off (whole tiles from 2048 on, as in rounds 3-4).
+    i64 w_half_min, w_half_max ;
+    int w_min_k ;                   // shortest contraction a pooled region may have (CHOLMOD_HIP_UPD3_MIN_K)
+    i64 unfuse_tiles ;              // a chain update of this many tiles is not fused with the next dpotrf (CHOLMOD_HIP_UNFUSE_TILES)
     bool by_launch ;                // ... pooled over the regions of a launch (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only)
     bool one_region ;               // tuning (CHOLMOD_HIP_UPDW_ONE_REGION=1): every region of a k_update3 launch a launch of its own
     bool swz16 ;                    // tuning (CHOLMOD_HIP_SWZ16=1): 16 x 16 super-tiles for the one-wave-per-tile walk
@@ -68,9 +80,10 @@ struct DenseScheduler
     std::vector<Upd> step ;
 
     DenseScheduler (const std::vector<FrontD> &fr_, const i32 *ids_, int nf_, Schedule &S_, int flags_, const i32 *owner_,
-        const i32 *grp0_, const i32 *grpn_, int rank_, int world_, const char *assign_cb_, const i64 *win_, const i32 *child_)
+        const i32 *grp0_, const i32 *grpn_, int rank_, int world_, const char *assign_cb_, const i64 *win_, const i32 *child_,
+        bool allow_half_)
         : fr (fr_), ids (ids_), nf (nf_), S (S_), flags (flags_), owner (owner_), grp0 (grp0_), grpn (grpn_), rank (rank_),
-          world (world_), assign_cb (assign_cb_), win (win_), child (child_)
+          world (world_), assign_cb (assign_cb_), win (win_), child (child_), allow_half (allow_half_)
     {
         cx = (flags & CHOLMOD_HIP_CX_STORAGE) != 0 ;
         twin = (flags & CHOLMOD_HIP_PHI_TWIN) != 0 || cx ;
@@ -83,6 +96,12 @@ struct DenseScheduler
         }
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; w_min_tiles = e ? (i64) atoll (e) : (i64) 2048 ; }
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; by_launch = !(e && atoi (e) == 0) ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MAX") ; w_half_max = e ? (i64) atoll (e) : (i64) 10240 ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MIN") ; w_half_min = e ? (i64) atoll (e) : (i64) 512 ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_K") ; w_min_k = e ? atoi (e) : 256 ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UNFUSE_TILES") ; unfuse_tiles = e ? (i64) atoll (e) : w_min_tiles ; }
+        if (!allow_half || w_min_tiles <= 0) w_half_max = 0 ;
+        if (w_half_max <= 0 || w_half_min > w_min_tiles) w_half_min = w_min_tiles ;
         one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
         swz16 = getenv ("CHOLMOD_HIP_SWZ16") != nullptr ;
         xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
@@ -326,6 +345,7 @@ struct DenseScheduler
         {
             L.ng = (int) (S.gg.size () - L.goff) ;
             L.grid = (int) tiles ;
+            L.half = (kind == K_UPD_W && tiles < w_half_max) ? 1 : 0 ;
             if (L.ng) S.launches.push_back (L) ;
             L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
             tiles = 0 ;
@@ -360,11 +380,12 @@ struct DenseScheduler
             // their sum reaches the threshold.  Below K = 256 the update is bound by the read-modify-write of C and the two
             // kernels are on par.
             i64 pooled = 0 ;
-            if (by_launch) for (auto &G : small) if (G.k >= 256 || region_tiles (G) >= w_min_tiles) pooled += region_tiles (G) ;
+            if (by_launch) for (auto &G : small) if (G.k >= w_min_k || region_tiles (G) >= w_min_tiles) pooled += region_tiles (G) ;
             std::vector<GemmGroup> keep ;
             for (auto &G : small)
             {
-                const bool w = region_tiles (G) >= w_min_tiles || (by_launch && pooled >= w_min_tiles && G.k >= 256) ;
+                // (w_half_min == w_min_tiles unless half tiles are on: then the pooled regions go from 512 tiles on)
+                const bool w = region_tiles (G) >= w_min_tiles || (by_launch && pooled >= w_half_min && G.k >= w_min_k) ;
                 if (w) wav.push_back (G) ; else keep.push_back (G) ;
             }
             small.swap (keep) ;
@@ -504,7 +525,7 @@ struct DenseScheduler
                 if (is_shared (ids [x.q]) || x.cb || x.kk < 512 || f.nscol - x.t0 < NB || x.t1 - x.t0 < NB) continue ;
                 pooled += tri_tiles (f.nsrow - x.t0, x.t1 - x.t0) ;
             }
-        return pooled >= 2 * w_min_tiles ;
+        return pooled >= 2 * unfuse_tiles ;
     }
     void emit_step ()
     {
@@ -525,7 +546,7 @@ struct DenseScheduler
             if (ff && w_min_tiles > 0 && !use_big && !is_shared (fid))
             {
                 // a region big enough for k_update3 is not fused with the next dpotrf
-                if (tri_tiles (f.nsrow - c0, x.t1 - c0) >= w_min_tiles) ff = false ;
+                if (tri_tiles (f.nsrow - c0, x.t1 - c0) >= unfuse_tiles) ff = false ;
                 if (ff_unfuse_wide_k && x.kk >= 512) ff = false ;
             }
             if (ff) pf_done [x.q] = x.t0 ;
@@ -802,9 +823,9 @@ struct DenseScheduler
 
 void schedule_dense (const std::vector<FrontD> &fr, const i32 *ids, int nf,
     Schedule &S, int flags, const i32 *owner, const i32 *grp0, const i32 *grpn, int rank, int world,
-    const char *assign_cb, const i64 *win, const i32 *child)
+    const char *assign_cb, const i64 *win, const i32 *child, bool allow_half)
 {
-    DenseScheduler D (fr, ids, nf, S, flags, owner, grp0, grpn, rank, world, assign_cb, win, child) ;
+    DenseScheduler D (fr, ids, nf, S, flags, owner, grp0, grpn, rank, world, assign_cb, win, child, allow_half) ;
     D.run () ;
 }
 

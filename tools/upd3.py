@@ -53,6 +53,29 @@ elif mode == "tail":
             out["diff"][f"f{fl}_{m}x{n}x{k}_tri{tri}_asg{asg}"] = pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, fl)
     for k in (3432, 3433, 1349, 1348):
         out["TFLOPs"][f"u3_tri24k_K{k}"] = pr.cholmod_hip_bench_update_kernel(24576, 24576, k, 2, TRI | D4) / 1e12
+elif mode == "half":
+    # (round 5) half tiles -- two waves per 64 x 64 tile -- on the region sizes of the mid-size problems' top fronts:
+    # agreement with k_update2 on ragged / triangular / assign regions, then rate against the whole-tile form and k_update2
+    HALF = 524288
+    out = {"diff": {}, "TFLOPs": {}}
+    for fl in (HALF | D2, HALF | D4):
+        for (m, n, k, tri, asg) in ((64, 64, 64, 0, 0), (200, 130, 67, 0, 0), (333, 333, 129, 1, 0), (1000, 700, 512, 1, 1), (129, 65, 4, 0, 1),
+                                    (129, 33, 5, 0, 0), (129, 31, 7, 0, 1), (2049, 2049, 1030, 1, 0), (1056, 1056, 260, 1, 0), (4096, 4096, 256, 0, 0)):
+            out["diff"][f"f{fl}_{m}x{n}x{k}_tri{tri}_asg{asg}"] = pr.cholmod_hip_debug_update_diff(m, n, k, tri, asg, fl)
+    for k, dep in ((1024, D4), (512, D2), (256, D2)):
+        for msz in (7560, 6536, 5512, 4488, 3464, 2440, 1416):
+            it = max(2, int(2e11 / (msz * msz * k)))
+            tiles = ((msz + 63) // 64) * ((msz + 63) // 64 + 1) // 2
+            row = {"tiles": tiles}
+            for name, fl in (("update2", TRI), ("update3", TRI | dep), ("update3_half", TRI | dep | HALF)):
+                row[name] = pr.cholmod_hip_bench_update_kernel(msz, msz, k, it, fl) / 1e12
+            out["TFLOPs"][f"tri{msz}_K{k}"] = row
+    for (m, n, k) in ((7000, 1024, 1024), (7000, 512, 512), (4000, 2048, 512), (12000, 2048, 2048)):
+        row = {"tiles": ((m + 63) // 64) * ((n + 63) // 64)}
+        dep = D4 if k >= 1024 else D2
+        for name, fl in (("update2", 0), ("update3", dep), ("update3_half", dep | HALF)):
+            row[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, max(2, int(2e11 / (m * n * k))), fl) / 1e12
+        out["TFLOPs"][f"rect{m}x{n}_K{k}"] = row
 elif mode == "sustain":
     for it in (2, 12, 36):
         out[f"u3_tri48k_K4096_iters{it}"] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, it, TRI | D4) / 1e12
