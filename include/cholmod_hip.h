@@ -287,6 +287,9 @@ int cholmod_hip_factor_checks_local (cholmod_hip_plan *plan, double *out5) ;
  *  [13] seconds in assemble (memset + A scatter)
  *  [24] device seconds of the last cholmod_hip_solve (its kernels, without the
  *       copies of the right-hand side)
+ *  [25] bytes of the all-gathers of [18] (as segments sent)   [39] those of them the main stream waits for at once: the
+ *       near-row chunks of every block column and the far-row chunks of the last block column of an outer block (the other
+ *       far-row gathers run on the exchange stream beside the chain of the following block columns)
  *  [26] trailing-update launches that also factor the next diagonal block (k_update2f: the
  *       K < 512 updates of the panel chain; NOT counted in [6]-[8], [16], [23])
  *  [27] their seconds   [28] their flops   [29] their algorithmic bytes

@@ -116,9 +116,12 @@ struct XchgD {
     i64 slab ;      // offset in Lx of entry (b0, b0) of the front
     i32 lda ;       // nsrow
     i32 w ;         // columns of the block column
-    i32 mb ;        // rows below the diagonal block (nsrow - b0 - w)
-    i32 R ;         // rows per chunk (g R >= mb)
+    i32 mb ;        // NEAR rows: below the diagonal block, inside the outer block column (o1 - b0 - w)
+    i32 R ;         // near rows per chunk (g R >= mb)
     i32 g, r ;      // group size, this rank's index in the group
+    i32 fo ;        // FAR rows: first one, counted from the diagonal block's first row (o1 - b0) ...
+    i32 mf ;        // ... how many (nsrow - o1) ...
+    i32 Rf ;        // ... and per chunk (g Rf >= mf): the same chunks for every block column of the outer block
 } ;
 // k_win_move: one workgroup = one column x WIN_ROWS rows
 #define WIN_ROWS 8192
@@ -126,7 +129,7 @@ struct WinD { i64 store ; i64 win ; i32 ld ; i32 c0, c1 ; i32 r0 ; i32 nrows ; i
 // the 256-column chain (k_diag / k_rowsolve / k_chainf)
 #define DG_W 256
 #define RS_ROWS 64
-struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 m1 ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 off2 ; i32 m2 ; i32 pad ; } ;
+struct CfGroup { i64 l_off ; i32 lda ; i32 w ; i32 front ; i32 col0 ; i32 m1 ; i32 slot ; i32 fslot ; i32 dstart ; i32 bstart ; i32 off2 ; i32 m2 ; i32 off3 ; i32 m3 ; i32 pad ; } ;
 // triangular solves
 struct SolveTask { i32 front ; i32 c0, c1 ; i32 below ; } ;   // columns [c0,c1) of a supernode
 #define SOLVE_IB 64          /* diagonal blocks with an explicit inverse (k_diag_inv64) */

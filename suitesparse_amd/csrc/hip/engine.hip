@@ -66,7 +66,7 @@ static void free_device (cholmod_hip_plan *P)
     if (P->ar_done) (void) hipEventDestroy (P->ar_done) ;
     void *ptrs [] = {P->d_Ls, P->d_fr, P->d_supermap, P->d_child, P->d_relmap, P->d_info,
         P->d_lvl_list, P->d_Lx, P->d_cb, P->d_zg, P->d_eg, P->d_pg, P->d_tg, P->d_tu_cnt, P->d_cdesc, P->d_smd, P->d_sp01, P->d_gg, P->d_sm,
-        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_crel, P->d_relpairs, P->d_dinv, P->d_sv,
+        P->d_Sp, P->d_Si, P->d_Snz, P->d_Sx, P->d_amap, P->d_X, P->d_Y, P->d_perm, P->d_xchg, P->d_stage, P->d_ag, P->d_agf, P->d_Lx_full, P->d_fr_full, P->d_dg, P->d_rg, P->d_wg, P->d_cg, P->d_cflags, P->d_crel, P->d_relpairs, P->d_dinv, P->d_sv,
         P->d_inv_tasks, P->d_winv, P->d_solved, P->d_sv_acc, P->d_ticket, P->d_chk, P->d_chk_out, P->d_thin_tim, P->d_sb_tasks, P->d_sb_commit, P->d_first_fail, P->d_vsrc, P->d_vals} ;
     for (void *p : ptrs) if (p) (void) hipFree (p) ;
     for (auto e : P->evpool) (void) hipEventDestroy (e) ;
@@ -93,7 +93,7 @@ static int upload_plan (cholmod_hip_plan *P)
             P->jitter_state = seed * 0x9E3779B97F4A7C15ull + (unsigned long long) (P->rank + 1) * 0xD1B54A32D192ED03ull ;
         }
     }
-    P->test_drop_waits = TEST_ENV ("CHOLMOD_HIP_TEST_DROP_WAITS") != nullptr ;
+    { const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_DROP_WAITS") ; P->test_drop_waits = e ? std::max (atoi (e), 1) : 0 ; }
     if (const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_HANG_EXCHANGE")) (void) sscanf (e, "%d:%ld:%ld", &P->test_hang_rank, &P->test_hang_xchg, &P->test_hang_fact) ;
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
@@ -176,15 +176,18 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
     {
-        i64 mx = 1, mxg = 1 ;
+        i64 mx = 1, mxg = 1, mxf = 1 ;
         for (const Launch &L : P->sch.launches)
             if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG)
             {
-                mx = std::max (mx, ((i64) L.xd.w * L.xd.w + (i64) L.xd.R * L.xd.w) * L.xd.g) ;
+                mx = std::max (mx, ((i64) L.xd.w * L.xd.w + ((i64) L.xd.R + L.xd.Rf) * L.xd.w) * L.xd.g) ;
                 mxg = std::max (mxg, (i64) L.xd.R * L.xd.w * L.xd.g) ;
+                mxf = std::max (mxf, (i64) L.xd.Rf * L.xd.w * L.xd.g) ;
             }
         HIPCHK (hipMalloc ((void **) &P->d_stage, (size_t) mx * sizeof (double))) ;
         HIPCHK (hipMalloc ((void **) &P->d_ag, (size_t) mxg * sizeof (double))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_agf, (size_t) mxf * sizeof (double))) ;
+        P->agf_len = mxf ;
         P->stage_len = mx ; P->ag_len = mxg ;
     }
     double tu3 = pnow () ;
@@ -271,8 +274,10 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 #define TW_LAUNCH(KA, KB, ...) do { if (cx) hipLaunchKernelGGL ((KA 2 KB), __VA_ARGS__) ; else if (twin) hipLaunchKernelGGL ((KA 1 KB), __VA_ARGS__) ; \
                                     else hipLaunchKernelGGL ((KA 0 KB), __VA_ARGS__) ; } while (0)
     // (test hook CHOLMOD_HIP_TEST_DROP_WAITS=1: the cross-stream waits of the schedule are skipped -- the mutation the jitter
-    // test must catch, tests/test_gpu_scale.py::test_stream_jitter_catches_a_dropped_wait)
-    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS && !P->test_drop_waits) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
+    // test must catch, tests/test_gpu_scale.py::test_stream_jitter_catches_a_dropped_wait; =2: only the joins with the far-row
+    // gathers of the shared fronts, tests/test_dist.py)
+    const bool drop_wait = P->test_drop_waits == 1 || (P->test_drop_waits == 2 && L.kind == K_JOIN) ;
+    if (!serial && L.wait_ev >= 0 && L.kind != K_XCHG_RS && !drop_wait) HIPCHK (hipStreamWaitEvent (st, P->sync_ev [L.wait_ev], 0)) ;
     if (P->jitter_us > 0 && !serial)
     {
         // test hook CHOLMOD_HIP_TEST_JITTER=seed[:max_us]: ahead of one launch in three, its stream is held up for a random
@@ -353,6 +358,9 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 // stream behind the event of the update that completed the block column, while
                 // the main stream goes on with the rest of the trailing update; the main stream
                 // then waits (on the device) for the sum before it touches the block column.
+                // The all-gather of the far chunks (L.far, L.stream == 1) runs on the second stream
+                // behind the event of the block column's chain (waited for above, like any launch's);
+                // the main stream meets it at a K_JOIN ahead of the outer update.
                 // Host callback (gloo tests, --exchange callback): it only knows a sum
                 // all-reduce, so the reduce-scatter is an all-reduce of all segments and the
                 // all-gather a sum of buffers that are zero outside the sender's chunk.
@@ -374,7 +382,8 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     if (it == P->nccl_group.end ()) return CHOLMOD_HIP_INVALID ;
                     comm = it->second ;
                 }
-                const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w, chunk = (i64) X.R * X.w ;
+                const i64 seg = (i64) X.w * X.w + ((i64) X.R + X.Rf) * X.w, chunk = (i64) (L.far ? X.Rf : X.R) * X.w ;
+                double *agb = L.far ? P->d_agf : P->d_ag ;
                 const long long xseq = ++P->prog_xchg_enq ;
                 if (P->prog_dev) hipLaunchKernelGGL (k_mark, dim3 (1), dim3 (1), 0, cs, P->prog_dev, (P->prog_fact << 32) | xseq) ;
 #ifdef CHOLMOD_HIP_TEST_HOOKS
@@ -392,8 +401,9 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 {
                     if (total <= 0) return ;
                     // (one workgroup per column and part: k_xchg_move)
-                    const unsigned parts = mode == 0 ? (unsigned) X.g + 1 : mode == 3 ? (unsigned) X.g : mode == 1 ? 2u : 1u ;
-                    hipLaunchKernelGGL (k_xchg_move, dim3 ((unsigned) X.w * parts), dim3 (ahead && narrow_xs () ? 64 : 256), 0, cs, X, mode, P->d_Lx, P->d_stage, P->d_ag) ;
+                    const unsigned parts = mode == 0 ? 2u * (unsigned) X.g + 1 : (mode == 3 || mode == 5) ? (unsigned) X.g : mode == 1 ? 3u : 1u ;
+                    const bool narrow = (ahead || (L.stream == 1 && !serial)) && narrow_xs () ;
+                    hipLaunchKernelGGL (k_xchg_move, dim3 ((unsigned) X.w * parts), dim3 (narrow ? 64 : 256), 0, cs, X, mode, P->d_Lx, P->d_stage, agb) ;
                 } ;
                 if (rs)
                 {
@@ -416,15 +426,15 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                 }
                 else
                 {
-                    if (!R) HIPCHK (hipMemsetAsync (P->d_ag, 0, (size_t) (chunk * X.g) * sizeof (double), cs)) ;
-                    move (2, chunk) ;
-                    if (R) RCCLCHK (R->AllGather (P->d_ag + (i64) X.r * chunk, P->d_ag, (size_t) chunk, ncclDouble, comm, cs)) ;
+                    if (!R) HIPCHK (hipMemsetAsync (agb, 0, (size_t) (chunk * X.g) * sizeof (double), cs)) ;
+                    move (L.far ? 4 : 2, chunk) ;
+                    if (R) RCCLCHK (R->AllGather (agb + (i64) X.r * chunk, agb, (size_t) chunk, ncclDouble, comm, cs)) ;
                     else
                     {
                         HIPCHK (hipStreamSynchronize (cs)) ;
-                        if (P->ar_fn (P->d_ag, chunk * X.g, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+                        if (P->ar_fn (agb, chunk * X.g, L.ar_g0, L.ar_gn, P->ar_user) != 0) return CHOLMOD_HIP_GPU_PROBLEM ;
                     }
-                    move (3, chunk * X.g) ;
+                    move (L.far ? 5 : 3, chunk * X.g) ;
                 }
                 if (P->prog_dev) hipLaunchKernelGGL (k_mark, dim3 (1), dim3 (1), 0, cs, P->prog_dev + 1, (P->prog_fact << 32) | xseq) ;
                 if (ahead)
@@ -514,6 +524,30 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
     return CHOLMOD_HIP_OK ;
 }
 
+// what the plan exchanges per factorization (stats [17], [18], [25], [39]; a property of the launch list)
+static void exchange_volume (const cholmod_hip_plan *P, double *S)
+{
+    S [17] = S [18] = S [25] = S [39] = 0 ;
+    const size_t nl = P->sch.launches.size () ;
+    for (size_t q = 0 ; q < nl ; q++)
+    {
+        const Launch &L = P->sch.launches [q] ;
+        if (L.kind != K_XCHG_RS && L.kind != K_XCHG_AG) continue ;
+        S [17] += 1 ; S [18] += L.bytes ;
+        if (L.kind != K_XCHG_AG) continue ;
+        // an all-gather the main stream waits for at once: in line, or on the exchange stream with the join right behind it
+        S [25] += L.bytes ;
+        bool inl = L.stream == 0 ;
+        for (size_t p = q + 1 ; !inl && p < nl ; p++)
+        {
+            const Launch &N = P->sch.launches [p] ;
+            if (N.kind == K_JOIN) inl = true ;
+            else if (!(N.kind == K_XCHG_AG && N.stream == 1)) break ;
+        }
+        if (inl) S [39] += L.bytes ;
+    }
+}
+
 // Run the numeric factorization on the resident S.  Leaves Lx on the device.
 static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *minor)
 {
@@ -567,6 +601,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (P->d_stage) HIPCHK (hipMemsetAsync (P->d_stage, 0xFF, (size_t) P->stage_len * sizeof (double), st)) ;
         if (P->lx_local > P->lx_fronts) HIPCHK (hipMemsetAsync (P->d_Lx + P->lx_fronts, 0xFF, (size_t) (P->lx_local - P->lx_fronts) * sizeof (double), st)) ;
         if (P->d_ag) HIPCHK (hipMemsetAsync (P->d_ag, 0xFF, (size_t) P->ag_len * sizeof (double), st)) ;
+        if (P->d_agf) HIPCHK (hipMemsetAsync (P->d_agf, 0xFF, (size_t) P->agf_len * sizeof (double), st)) ;
     }
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (poison ? P->lx_fronts : P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
@@ -686,6 +721,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     S [4] = 8.0 * P->arena ;
     S [5] = 8.0 * P->xsize ;
     S [36] = 8.0 * P->lx_local ;
+    exchange_volume (P, S) ;
     for (size_t q = 0 ; q < nl ; q++)
     {
         const Launch &L = P->sch.launches [q] ;
@@ -693,7 +729,6 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (L.kind == K_UPD_W) { S [33] += 1 ; S [34] += L.flops ; S [35] += L.bytes ; }
         if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
         if (L.kind == K_TRSM_UPD) S [31] += 1 ;
-        if (L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) { S [17] += 1 ; S [18] += L.bytes ; }
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
@@ -998,7 +1033,7 @@ int cholmod_hip_progress (cholmod_hip_plan *P, int64_t *out)
             for (const Launch &L : P->sch.launches)
                 if ((L.kind == K_XCHG_RS || L.kind == K_XCHG_AG) && ++seq == out [5])
                 {
-                    out [7] = L.kind ; out [8] = L.ar_g0 ; out [9] = L.ar_gn ; out [10] = L.xd.w ; out [11] = L.xd.mb ;
+                    out [7] = L.kind ; out [8] = L.ar_g0 ; out [9] = L.ar_gn ; out [10] = L.xd.w ; out [11] = L.xd.mb + L.xd.mf ;
                     break ;
                 }
         }
@@ -1702,6 +1737,7 @@ int cholmod_hip_get_stats (cholmod_hip_plan *P, double *stats)
     P->stats [36] = 8.0 * P->lx_local ;
     P->stats [22] = P->nsplit ;
     P->stats [24] = P->solve_seconds ;
+    exchange_volume (P, P->stats) ;
     for (int q = 0 ; q < CHOLMOD_HIP_NSTATS ; q++) stats [q] = P->stats [q] ;
     return CHOLMOD_HIP_OK ;
 }
@@ -1757,7 +1793,7 @@ int cholmod_hip_debug_schedule_hash (cholmod_hip_plan *P, uint64_t *out16)
     for (const Launch &L : S.launches)
     {
         const i64 v [] = {L.kind, L.grid, L.ng, (i64) L.goff, L.stream, L.wait_ev, L.rec_ev, L.ar_g0, L.ar_gn, L.aux, L.leaf_T, L.leaf_pw, L.ndiag, L.half,
-            L.xd.slab, L.xd.lda, L.xd.w, L.xd.mb, L.xd.R, L.xd.g, L.xd.r} ;
+            L.xd.slab, L.xd.lda, L.xd.w, L.xd.mb, L.xd.R, L.xd.g, L.xd.r, L.xd.fo, L.xd.mf, L.xd.Rf, L.far} ;
         h = fnv (h, v, sizeof (v)) ;
         const double d [] = {L.flops, L.bytes} ;
         h = fnv (h, d, sizeof (d)) ;

@@ -2276,21 +2276,25 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
 // ---- multi-GPU: packing of a shared front's block column for the row-split exchange ----
 // A block column [b0, b0+w) of a front shared by g ranks holds per-rank partial sums in
 // its live rows (>= b0).  It is summed with ONE reduce-scatter whose segment q carries
-//     [ D : the w x w diagonal block (ld = w) | chunk q : R x w rows below it (ld = R) ]
-// (chunk q = rows b0 + w + q R ... of the front, zero-padded past nsrow): every rank
-// receives the summed diagonal block and the summed rows of ITS chunk, runs the panel
-// chain (dpotrf / dtrsm / K < 512 updates, reference t_cholmod_super_numeric.c:864-867,
-// :997-1002) on those rows only, and the solved chunks travel back with one all-gather
-// (XchgD::ag: g x R x w).  Same volume as the all-reduce it replaces; the dtrsm and the
-// narrow updates of the block column are no longer repeated by every rank of the group.
+//     [ D : the w x w diagonal block (ld = w) | near chunk q : R x w (ld = R) | far chunk q : Rf x w (ld = Rf) ]
+// NEAR rows = the rows below D inside the outer block column [b0 + w, o1): later block columns of the
+// outer block need them as an operand; FAR rows = [o1, nsrow), cut into the SAME g chunks for every block
+// column of the outer block (chunks zero-padded past their last row).  Every rank receives the summed
+// diagonal block and the summed rows of ITS two chunks, runs the panel chain (dpotrf / dtrsm / K < 512
+// updates, reference t_cholmod_super_numeric.c:864-867, :997-1002) on those rows only, and the solved
+// chunks travel back with two all-gathers: a small one of the near chunks, in line, and a large one of the
+// far chunks that nobody needs before the outer update (round 5: the updates between the block columns of
+// an outer block are chunk-local on the far rows), so it runs on the exchange stream beside the chain of the
+// following block columns.  Same volume as the all-reduce it replaces.
 // mode 0: Lx -> stage (all g segments: this rank's partial sums, D repeated per segment)
-// mode 1: segment r of stage -> Lx (summed D and own chunk)
-// mode 2: own chunk of Lx -> ag + r R w        mode 3: ag (all chunks but r) -> Lx
+// mode 1: segment r of stage -> Lx (summed D and own chunks)
+// mode 2: own near chunk of Lx -> ag + r R w        mode 3: ag (all near chunks but r) -> Lx
+// mode 4: own far chunk of Lx -> ag + r Rf w        mode 5: ag (all far chunks but r) -> Lx   (ag: the buffer of that gather)
 // (round 4: one workgroup = one column of the block column x one part -- the diagonal block or one row chunk; rows
 // stream contiguously, no division per element: the element-indexed first version moved ~1 TB/s, and a rank of 8 moves
 // 67 GB through these copies per factorization of Poisson 200^3)
-// grid: w * (g + 1) workgroups for modes 0 / 3 (part g = the diagonal block; mode 3 has none), w * 2 for mode 1 (D, own
-// chunk), w for mode 2.
+// grid: w * (2 g + 1) workgroups for mode 0 (part 2 g = the diagonal block), w * 3 for mode 1 (D, own chunks), w for
+// modes 2 / 4, w * g for modes 3 / 5.
 // test hook (CHOLMOD_HIP_TEST_JITTER): keeps its stream busy for about `ticks` ticks of the 100 MHz wall clock
 __global__ void k_spin (long long ticks)
 {
@@ -2324,16 +2328,25 @@ __device__ __forceinline__ void xm_copy (double *dst, const double *src, int n, 
 
 __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *Lx, double *stage, double *ag)
 {
-    const i64 seg = (i64) X.w * X.w + (i64) X.R * X.w ;
+    const i64 seg = (i64) X.w * X.w + ((i64) X.R + X.Rf) * X.w ;
     const int j = (int) blockIdx.x % X.w, part = (int) blockIdx.x / X.w ;
     double *S = Lx + X.slab + (i64) j * X.lda ;                   // column j of the block column, from the diagonal block's first row
-    const int tid = threadIdx.x ;
+    const int tid = threadIdx.x, nt = (int) blockDim.x ;
+    // chunk q of the near (far = false) or far rows: where it starts in the column, its rows that exist, its place in a segment
+    auto rows_of = [&] (bool far, int q, int &first, int &nr, int &R, i64 &sofs)
+    {
+        R = far ? X.Rf : X.R ;
+        first = (far ? X.fo : X.w) + q * R ;
+        nr = (far ? X.mf : X.mb) - q * R ;
+        sofs = (i64) X.w * X.w + (far ? (i64) X.R * X.w : 0) + (i64) j * R ;
+    } ;
+    int first, nr, R ; i64 sofs ;
     if (mode == 0)
     {
-        if (part == X.g)
+        if (part == 2 * X.g)
         {
             // the diagonal block's column j (lower part, zero above) into every segment
-            for (int i = tid ; i < X.w ; i += (int) blockDim.x)
+            for (int i = tid ; i < X.w ; i += nt)
             {
                 const double v = (i >= j) ? S [i] : 0.0 ;
                 for (int q = 0 ; q < X.g ; q++) stage [(i64) q * seg + (i64) j * X.w + i] = v ;
@@ -2341,40 +2354,37 @@ __global__ void __launch_bounds__(256) k_xchg_move (XchgD X, int mode, double *L
         }
         else
         {
-            const int q = part ;
-            const double *src = S + X.w + (i64) q * X.R ;
-            double *dst = stage + (i64) q * seg + (i64) X.w * X.w + (i64) j * X.R ;
-            const int nr = X.mb - q * X.R ;                      // rows of this chunk that exist
-            xm_copy (dst, src, X.R, nr, tid, (int) blockDim.x, true) ;
+            const int q = part % X.g ;
+            rows_of (part >= X.g, q, first, nr, R, sofs) ;
+            xm_copy (stage + (i64) q * seg + sofs, S + first, R, nr, tid, nt, true) ;
         }
     }
     else if (mode == 1)
     {
         const double *ps = stage + (i64) X.r * seg ;
-        if (part == 0) { for (int i = j + tid ; i < X.w ; i += (int) blockDim.x) S [i] = ps [(i64) j * X.w + i] ; }
+        if (part == 0) { for (int i = j + tid ; i < X.w ; i += nt) S [i] = ps [(i64) j * X.w + i] ; }
         else
         {
-            const double *src = ps + (i64) X.w * X.w + (i64) j * X.R ;
-            double *dst = S + X.w + (i64) X.r * X.R ;
-            const int nr = X.mb - X.r * X.R ;
-            for (int i = tid ; i < X.R && i < nr ; i += (int) blockDim.x) dst [i] = src [i] ;
+            rows_of (part == 2, X.r, first, nr, R, sofs) ;
+            const double *src = ps + sofs ;
+            double *dst = S + first ;
+            for (int i = tid ; i < R && i < nr ; i += nt) dst [i] = src [i] ;
         }
     }
-    else if (mode == 2)
+    else if (mode == 2 || mode == 4)
     {
-        const double *src = S + X.w + (i64) X.r * X.R ;
-        double *dst = ag + (i64) X.r * X.R * X.w + (i64) j * X.R ;
-        const int nr = X.mb - X.r * X.R ;
-        for (int i = tid ; i < X.R ; i += (int) blockDim.x) dst [i] = (i < nr) ? src [i] : 0.0 ;
+        rows_of (mode == 4, X.r, first, nr, R, sofs) ;
+        const double *src = S + first ;
+        double *dst = ag + (i64) X.r * R * X.w + (i64) j * R ;
+        for (int i = tid ; i < R ; i += nt) dst [i] = (i < nr) ? src [i] : 0.0 ;
     }
     else
     {
         const int q = part ;
         if (q == X.r || q >= X.g) return ;
-        const double *src = ag + (i64) q * X.R * X.w + (i64) j * X.R ;
-        double *dst = S + X.w + (i64) q * X.R ;
-        const int nr = X.mb - q * X.R ;
-        xm_copy (dst, src, X.R < nr ? X.R : nr, nr, tid, (int) blockDim.x, false) ;
+        rows_of (mode == 5, q, first, nr, R, sofs) ;
+        const double *src = ag + (i64) q * R * X.w + (i64) j * R ;
+        xm_copy (S + first, src, R < nr ? R : nr, nr, tid, nt, false) ;
     }
 }
 
@@ -2710,8 +2720,9 @@ __global__ void __launch_bounds__(256) k_rowsolve (const RsGroup *g, int ng, dou
 // flags [4 slot + j]: low byte = stages of row block j published (s <= j: its solved blocks of the panels
 // < s; j + 1: its diagonal block and the inverses as well), then bits 8.. = 1 + nvt, nvt = valid columns
 // of the sub-block so far (w when no pivot has failed).
-// rows below the sub-block: [w, w + m1) and, for a front shared between ranks (its block column dealt by row chunks), a
-// second range [off2, off2 + m2) -- the rest of the 512-wide diagonal block on every rank, then this rank's chunk
+// rows below the sub-block: [w, w + m1) and, for a front shared between ranks (its block column dealt by row chunks), two
+// more ranges [off2, off2 + m2) and [off3, off3 + m3) -- the rest of the 512-wide diagonal block on every rank, then this
+// rank's chunk of the near rows (inside the outer block column) and its chunk of the far rows
 __device__ __forceinline__ double ld_coh (const double *p) { return __hip_atomic_load (p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 __device__ __forceinline__ void st_coh (double *p, double v) { __hip_atomic_store (p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ; }
 // polls (s_sleep 4 + one coherent load, ~1.5 us each) before a hand-off counts as failed: ~6 s, far beyond any jitter
@@ -2742,9 +2753,10 @@ __global__ void __launch_bounds__(256) k_chainf (const CfGroup *g, int ng, int n
     int row0 = 64 * rb, rowend = w ;
     if (!isdiag)
     {
-        const int t = (int) blockIdx.x - ndiag_total - G.bstart, n1 = (G.m1 + 63) >> 6 ;
+        const int t = (int) blockIdx.x - ndiag_total - G.bstart, n1 = (G.m1 + 63) >> 6, n2 = (G.m2 + 63) >> 6 ;
         if (t < n1) { row0 = w + 64 * t ; rowend = w + G.m1 ; }
-        else { row0 = G.off2 + 64 * (t - n1) ; rowend = G.off2 + G.m2 ; }
+        else if (t < n1 + n2) { row0 = G.off2 + 64 * (t - n1) ; rowend = G.off2 + G.m2 ; }
+        else { row0 = G.off3 + 64 * (t - n1 - n2) ; rowend = G.off3 + G.m3 ; }
     }
     const int row = row0 + 16 * wave + lr ;
     const bool rok = row < rowend ;

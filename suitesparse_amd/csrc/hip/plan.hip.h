@@ -72,7 +72,8 @@ static inline i64 window_len (const FrontD &f, int ob) { return (i64) f.nsrow * 
 static inline int window_count (const FrontD &f, int ob) { return f.nscol > ob ? 2 : 1 ; }
 
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
-// the partial sums by row chunks before its panel chain, all-gather of the solved chunks after it
+// the partial sums by row chunks before its panel chain, all-gathers of the solved chunks after it (near rows in line,
+// far rows on the exchange stream, awaited by a K_JOIN ahead of the outer update)
 enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_CHAINF, K_NKIND } ;
 
 struct Launch {
@@ -85,7 +86,8 @@ struct Launch {
     int stream = 0 ;    // 0 = main, 1 = exchange stream (window open, pack, collective ahead of time)
     int wait_ev = -1 ;  // event this launch's stream waits for first
     int rec_ev = -1 ;   // event recorded on its stream right after it
-    XchgD xd = {0, 0, 0, 0, 0, 1, 0} ;     // K_XCHG_RS / K_XCHG_AG: the block column and its row chunks
+    XchgD xd = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0} ;     // K_XCHG_RS / K_XCHG_AG: the block column and its row chunks
+    int far = 0 ;                           // K_XCHG_AG: 0 = the near chunks (in line), 1 = the far chunks (exchange stream)
     int ar_g0 = 0, ar_gn = 1 ;              // ... exchanged over the ranks [ar_g0, ar_g0+ar_gn)
     int aux = 0 ;                   // K_TRSM: widest panel of the launch (LDS sizing)
     int leaf_T = 0 ;                // K_SMALL, leaf_pw: doubles of LDS per front (its panel columns, packed)
@@ -240,7 +242,7 @@ struct cholmod_hip_plan {
     // native exchange: communicator of the world and one per rank group of the plan
     // ((first << 16) | size -> communicator); stream-ordered ncclAllReduce calls
     int jitter_us = 0 ; unsigned long long jitter_state = 0 ;     // test hook CHOLMOD_HIP_TEST_JITTER (run_launch)
-    bool test_drop_waits = false ;          // test hook CHOLMOD_HIP_TEST_DROP_WAITS (read per plan, upload_plan)
+    int test_drop_waits = 0 ;          // test hook CHOLMOD_HIP_TEST_DROP_WAITS (read per plan, upload_plan)
     int test_hang_rank = -1 ; long test_hang_xchg = -1, test_hang_fact = 2 ;     // test hook CHOLMOD_HIP_TEST_HANG_EXCHANGE=rank:seq (bench.py's watchdog)
     bool upd3_wg4 = false ;             // k_update3 with four tiles per workgroup (CHOLMOD_HIP_UPD3_WG4)
     ncclComm_t nccl_world = nullptr ;
@@ -248,8 +250,9 @@ struct cholmod_hip_plan {
     hipEvent_t ar_done = nullptr ;          // all-reduce on the second stream finished
     double *d_xchg = nullptr ;
     double *d_stage = nullptr ;             // the g segments of a block column (reduce-scatter, in place)
-    double *d_ag = nullptr ;                // the g solved row chunks of a block column (all-gather, in place)
-    i64 stage_len = 0, ag_len = 0 ;
+    double *d_ag = nullptr ;                // the g solved near-row chunks of a block column (all-gather, in place)
+    double *d_agf = nullptr ;               // ... its far-row chunks (a gather of its own, on the exchange stream)
+    i64 stage_len = 0, ag_len = 0, agf_len = 0 ;
     // triangular solves: per level, the supernodes one workgroup handles whole
     // and the big ones walked in SOLVE_SB-column blocks by many workgroups (k_solve_*_blk)
     std::vector<SolveTask> sv_tasks ;       // [whole-supernode tasks by level | block tasks]

@@ -148,28 +148,34 @@ struct DenseScheduler
         return nt * (nt + 1) / 2 + (mt - nt) * nt ;
     }
     // The exchange of the block column [c0, c1) of shared front q: geometry of its row chunks (descriptors.hip.h: XchgD).
-    // This rank keeps the diagonal block and rows [own_lo, own_hi).
+    // This rank keeps the diagonal block, its chunk of the NEAR rows [c1, o1) -- the rest of the outer block column: the
+    // later block columns of the outer block need them as an operand -- and its chunk of the FAR rows [o1, nsrow), which are
+    // cut the same way for every block column of the outer block.
     XchgD xchg_of (int q, int c0) const
     {
         const FrontD &f = fr [ids [q]] ;
         int c1 = std::min (c0 + MB, f.nscol) ;
         int g = grpn [ids [q]], r = rank - grp0 [ids [q]] ;
         if (world == 1) { g = 1 ; r = 0 ; }                 // (single-rank self test of the exchange path)
-        int mb = f.nsrow - c1 ;
-        int R = mb > 0 ? (((mb + g - 1) / g) + 15) / 16 * 16 : 0 ;
-        return XchgD {psx_at (ids [q], c0) + c0 + (i64) c0 * f.nsrow, f.nsrow, c1 - c0, mb, R, g, r} ;
+        const int OBq = ob_of (f), o1 = std::min ((c0 / OBq) * OBq + OBq, (int) f.nscol) ;
+        auto chunk = [g] (int rows) { return rows > 0 ? (((rows + g - 1) / g) + 15) / 16 * 16 : 0 ; } ;
+        const int mb = o1 - c1, mf = f.nsrow - o1 ;
+        return XchgD {psx_at (ids [q], c0) + c0 + (i64) c0 * f.nsrow, f.nsrow, c1 - c0, mb, chunk (mb), g, r, o1 - c0, mf, chunk (mf)} ;
     }
     // rows of a shared front's block column (the one that holds column i0) this rank works on below a sub-block that ends
-    // at column b1: the rest of the 512-wide diagonal block (every member) and the rank's chunk of the rows below it
-    void chunk_rows (int q, int i0, int b1, int lo [2], int hi [2]) const
+    // at column b1: the rest of the 512-wide diagonal block (every member), the rank's chunk of the near rows and its chunk
+    // of the far rows
+    void chunk_rows (int q, int i0, int b1, int lo [3], int hi [3]) const
     {
         const FrontD &f = fr [ids [q]] ;
-        lo [0] = b1 ; hi [0] = f.nsrow ; lo [1] = 0 ; hi [1] = 0 ;
+        lo [0] = b1 ; hi [0] = f.nsrow ; lo [1] = hi [1] = lo [2] = hi [2] = 0 ;
         if (!is_shared (ids [q])) return ;
-        XchgD X = xchg_of (q, (i0 / MB) * MB) ;
-        int e1 = (i0 / MB) * MB + X.w ;
-        hi [0] = e1 ;
-        lo [1] = e1 + X.r * X.R ; hi [1] = std::min (lo [1] + X.R, (int) f.nsrow) ;
+        const int b0 = (i0 / MB) * MB ;
+        XchgD X = xchg_of (q, b0) ;
+        hi [0] = b0 + X.w ;
+        lo [1] = b0 + X.w + X.r * X.R ; hi [1] = std::min (lo [1] + X.R, b0 + X.w + X.mb) ;
+        lo [2] = b0 + X.fo + X.r * X.Rf ; hi [2] = std::min (lo [2] + X.Rf, (int) f.nsrow) ;
+        for (int p = 1 ; p < 3 ; p++) if (hi [p] < lo [p]) hi [p] = lo [p] ;
     }
     int record_last ()
     {
@@ -227,25 +233,43 @@ struct DenseScheduler
             small.push_back (G) ;
         }
     }
+    // rows [lo, hi) x columns [c0, c1) of a front's window, K = [kc, kc + kk): a rectangle below the diagonal
+    void add_rows_update (int fid, int lo, int hi, int c0, int c1, int kc, int kk)
+    {
+        if (hi <= lo || c1 <= c0 || kk <= 0) return ;
+        const FrontD &f = fr [fid] ;
+        GemmGroup G = blank_region (fid) ;
+        const i64 wpsx = psx_at (fid, kc) ;
+        G.a_off = wpsx + lo + co (kc, f.nsrow) ;
+        G.b_off = wpsx + c0 + co (kc, f.nsrow) ;
+        G.c_off = wpsx + lo + co (c0, f.nsrow) ;
+        G.lda = f.nsrow ; G.ldc = f.nsrow ;
+        G.m = hi - lo ; G.n = c1 - c0 ; G.k = kk ; G.tri = 0 ;
+        if (twin) twin_operands (G, (lo | c0), kc) ;
+        small.push_back (G) ;
+    }
     // a narrow update inside a block column of a shared front: its rows have been dealt to the ranks of the group
-    // (reduce-scatter by row chunks, emit_rs) -- the rows of the diagonal block (every rank) and this rank's chunk below
+    // (reduce-scatter by row chunks, emit_rs) -- the rows of the diagonal block (every rank) and this rank's chunks below
     void add_chunk_update (const Upd &x, int c0, bool ff)
     {
         const FrontD &f = fr [ids [x.q]] ;
-        XchgD X = xchg_of (x.q, (x.kc / MB) * MB) ;
-        int b1 = (x.kc / MB) * MB + X.w ;
-        add_update (f, ids [x.q], c0, x.kc, x.kk, b1 - c0, x.t1 - c0, false, false, ff) ;
-        int lo = b1 + X.r * X.R, hi = std::min (lo + X.R, (int) f.nsrow) ;
-        if (hi <= lo) return ;
-        GemmGroup G = blank_region (ids [x.q]) ;
-        const i64 wpsx = psx_at (ids [x.q], x.kc) ;
-        G.a_off = wpsx + lo + co (x.kc, f.nsrow) ;
-        G.b_off = wpsx + c0 + co (x.kc, f.nsrow) ;
-        G.c_off = wpsx + lo + co (c0, f.nsrow) ;
-        G.lda = f.nsrow ; G.ldc = f.nsrow ;
-        G.m = hi - lo ; G.n = x.t1 - c0 ; G.k = x.kk ; G.tri = 0 ;
-        if (twin) twin_operands (G, (lo | c0), x.kc) ;
-        small.push_back (G) ;
+        int lo [3], hi [3] ;
+        chunk_rows (x.q, x.kc, c0, lo, hi) ;
+        add_update (f, ids [x.q], c0, x.kc, x.kk, hi [0] - c0, x.t1 - c0, false, false, ff) ;
+        for (int p = 1 ; p < 3 ; p++) add_rows_update (ids [x.q], lo [p], hi [p], c0, x.t1, x.kc, x.kk) ;
+    }
+    // a wide update (K >= 512) between the block columns of an outer block of a shared front, columns [c0, c1): the near
+    // rows (down to the end of the outer block column; every member has them since the in-line all-gathers of the K
+    // columns) by tiles dealt over the group, the far rows CHUNK-LOCALLY -- every member the rows it has solved itself,
+    // so that nobody needs the others' far rows before the outer update (their all-gather runs beside the chain)
+    void add_wide_shared (const Upd &x, int c0, int c1)
+    {
+        const FrontD &f = fr [ids [x.q]] ;
+        const int fid = ids [x.q], OBq = ob_of (f), o1 = std::min ((x.kc / OBq) * OBq + OBq, (int) f.nscol) ;
+        add_update (f, fid, c0, x.kc, x.kk, o1 - c0, c1 - c0, false, true) ;
+        int lo [3], hi [3] ;
+        chunk_rows (x.q, x.kc, c0, lo, hi) ;
+        add_rows_update (fid, lo [2], hi [2], c0, c1, x.kc, x.kk) ;
     }
     // a distributed contribution block: this rank's block of columns, one region that starts on the diagonal; the first
     // outer block assigns (nothing else ever writes there)
@@ -401,19 +425,58 @@ struct DenseScheduler
     {
         Launch La {K_XCHG_RS, 0, 0, 0, 0, 0} ;
         La.xd = xchg_of (q, c0) ;
-        La.bytes = 8.0 * ((double) La.xd.w * La.xd.w + (double) La.xd.R * La.xd.w) * La.xd.g ;
+        La.bytes = 8.0 * ((double) La.xd.w * La.xd.w + ((double) La.xd.R + La.xd.Rf) * La.xd.w) * La.xd.g ;
         La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
         La.wait_ev = wait_ev ;
         S.launches.push_back (La) ;
     }
-    void emit_ag (int q, int c0)
+    // The solved chunks of block column c0 of shared front q back to everybody.  The near chunks in line: the next block
+    // column's updates need those rows as an operand.  The far chunks are needed by the outer update only (the updates
+    // between block columns are chunk-local there, add_wide_shared): their gather is put aside (`pending`) and issued on
+    // the exchange stream behind the block column's chain -- after the next block column's reduce-scatter, which the chain
+    // is waiting for -- so that the main stream runs the following block columns beside it and meets it at join_far_gathers.
+    // Without the exchange look-ahead (CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD): both in line.
+    struct FarGather { int q, c0, ev ; } ;
+    std::vector<FarGather> pending ;
+    int far_ev = -1 ;                   // event behind the last far gather issued on the exchange stream, not joined yet
+    Launch ag_launch (int q, int c0, int far) const
     {
         Launch La {K_XCHG_AG, 0, 0, 0, 0, 0} ;
         La.xd = xchg_of (q, c0) ;
-        if (La.xd.R == 0) return ;                          // nothing below the diagonal block
-        La.bytes = 8.0 * (double) La.xd.R * La.xd.w * La.xd.g ;
+        La.far = far ;
+        La.bytes = 8.0 * (double) (far ? La.xd.Rf : La.xd.R) * La.xd.w * La.xd.g ;
         La.ar_g0 = grp0 [ids [q]] ; La.ar_gn = grpn [ids [q]] ;
-        S.launches.push_back (La) ;
+        return La ;
+    }
+    void emit_ag (int q, int c0)
+    {
+        Launch Ln = ag_launch (q, c0, 0), Lf = ag_launch (q, c0, 1) ;
+        if (Ln.xd.R > 0) S.launches.push_back (Ln) ;
+        if (Lf.xd.Rf == 0) return ;                         // nothing below the outer block column
+        if (xla) pending.push_back (FarGather {q, c0, -1}) ;
+        else S.launches.push_back (Lf) ;
+    }
+    void issue_far_gathers ()
+    {
+        for (const FarGather &p : pending)
+        {
+            Launch Lf = ag_launch (p.q, p.c0, 1) ;
+            Lf.stream = 1 ; Lf.wait_ev = p.ev ;
+            S.launches.push_back (Lf) ;
+            far_ev = -2 ;
+        }
+        if (far_ev == -2) far_ev = record_last () ;
+        pending.clear () ;
+    }
+    // the main stream needs the far rows of every block column gathered so far: the outer update, the window's way home
+    void join_far_gathers ()
+    {
+        issue_far_gathers () ;
+        if (far_ev < 0) return ;
+        Launch Lj {K_JOIN, 0, 0, 0, 0, 0} ;
+        Lj.wait_ev = far_ev ;
+        S.launches.push_back (Lj) ;
+        far_ev = -1 ;
     }
     // Window of a distributed front.  open (mode 0): the block columns of [ca, cb) -- the owners' stored columns, zero
     // elsewhere (k_win_move), then the contributions of this rank's children to those columns (extend-add into the window):
@@ -476,17 +539,30 @@ struct DenseScheduler
     // front that is complete in its window goes into the owners' slabs
     void leave_sub_block (int i0, int W)
     {
+        const size_t np = pending.size () ;
         for (int q = 0 ; q < nf ; q++)
         {
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= i0 || !is_shared (ids [q])) continue ;
             int b0 = (i0 / MB) * MB ;
             if (i0 + W >= std::min (b0 + MB, (int) f.nscol)) emit_ag (q, b0) ;
-            if (windowed (ids [q]))
-            {
-                int OBq = ob_of (f), o0 = (i0 / OBq) * OBq, o1 = std::min (o0 + OBq, (int) f.nscol) ;
-                if (i0 + W >= o1) emit_win (q, 1, o0, o1, 0, -1) ;
-            }
+        }
+        if (pending.size () > np)
+        {
+            // (the event behind the chain of these block columns and their in-line gathers, on the main stream)
+            const int ev = record_last () ;
+            for (size_t p = np ; p < pending.size () ; p++) pending [p].ev = ev ;
+        }
+        bool closing = false ;
+        for (int q = 0 ; q < nf ; q++)
+        {
+            const FrontD &f = fr [ids [q]] ;
+            if (f.nscol <= i0 || !windowed (ids [q])) continue ;
+            int OBq = ob_of (f), o0 = (i0 / OBq) * OBq, o1 = std::min (o0 + OBq, (int) f.nscol) ;
+            if (i0 + W < o1) continue ;
+            if (!closing) join_far_gathers () ;
+            closing = true ;
+            emit_win (q, 1, o0, o1, 0, -1) ;
         }
     }
 
@@ -504,7 +580,8 @@ struct DenseScheduler
                 const FrontD &f = fr [ids [x.q]] ;
                 int tn = std::min (x.t0 + MB, x.t1) ;
                 if (x.cb && windowed (ids [x.q])) add_outer_slabs (f, ids [x.q], x.kc, x.kk, x.t0, tn) ;
-                else add_update (f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
+                else if (x.cb) add_update (f, ids [x.q], x.t0, x.kc, x.kk, f.nsrow - x.t0, tn - x.t0, false, true) ;
+                else add_wide_shared (x, x.t0, tn) ;
                 any_next = true ;
             }
         if (!any_next) return -2 ;
@@ -529,6 +606,7 @@ struct DenseScheduler
     }
     void emit_step ()
     {
+        for (const Upd &x : step) if (x.cb && is_shared (ids [x.q])) { join_far_gathers () ; break ; }
         const int ev_next = emit_next_columns_first () ;
         const bool any_next = ev_next != -2 ;
         const bool ff_unfuse_wide_k = unfuse_wide_k () ;
@@ -551,6 +629,7 @@ struct DenseScheduler
             }
             if (ff) pf_done [x.q] = x.t0 ;
             if (!x.wide && is_shared (fid) && x.t1 > c0) { add_chunk_update (x, c0, ff) ; continue ; }
+            if (x.wide && is_shared (fid) && !x.cb) { if (x.t1 > c0) add_wide_shared (x, c0, x.t1) ; continue ; }
             // the outer update of a distributed front: its in-front columns slab by slab on their owners
             if (x.cb && windowed (fid)) { if (x.t1 > c0) add_outer_slabs (f, fid, x.kc, x.kk, c0, x.t1) ; }
             else if (x.t1 > c0) add_update (f, fid, c0, x.kc, x.kk, f.nsrow - c0, x.t1 - c0, false, x.wide, ff) ;
@@ -577,6 +656,7 @@ struct DenseScheduler
                 emit_rs (x.q, x.t0, ev_next) ;
                 early [x.q] = x.t0 ;
             }
+        issue_far_gathers () ;
         step.clear () ;
     }
     // Trailing updates after the sub-block [i0, i0 + W) of every front that still has columns there (`skip [q]`: the step
@@ -660,16 +740,16 @@ struct DenseScheduler
             int b1 = std::min (i0 + SB, o1) ;
             int w = b1 - i0 ;
             int slot = (int) (S.cg.size () - Lc.goff) ;
-            int lo [2], hi [2] ;
+            int lo [3], hi [3] ;
             chunk_rows (q, i0, b1, lo, hi) ;
-            int m1 = hi [0] - b1, off2 = 0, m2 = 0 ;
-            if (is_shared (ids [q])) { off2 = lo [1] - i0 ; m2 = std::max (hi [1] - lo [1], 0) ; }
-            S.cg.push_back (CfGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, m1, slot, S.ncflags++, dblocks, bblocks, off2, m2, 0}) ;
+            const int m1 = hi [0] - b1, m2 = hi [1] - lo [1], m3 = hi [2] - lo [2] ;
+            S.cg.push_back (CfGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, m1, slot, S.ncflags++, dblocks, bblocks,
+                m2 ? lo [1] - i0 : 0, m2, m3 ? lo [2] - i0 : 0, m3, 0}) ;
             dblocks += (w + 63) / 64 ;
-            bblocks += (m1 + 63) / 64 + (m2 + 63) / 64 ;
+            bblocks += (m1 + 63) / 64 + (m2 + 63) / 64 + (m3 + 63) / 64 ;
             wmax = std::max (wmax, w) ;
-            Lc.flops += (double) w * w * w / 3.0 + (double) (m1 + m2) * w * w ;
-            Lc.bytes += 16.0 * (m1 + m2) * w ;
+            Lc.flops += (double) w * w * w / 3.0 + (double) (m1 + m2 + m3) * w * w ;
+            Lc.bytes += 16.0 * (m1 + m2 + m3) * w ;
         }
         Lc.ng = (int) (S.cg.size () - Lc.goff) ; Lc.grid = dblocks + bblocks ; Lc.ndiag = dblocks ; Lc.aux = wmax ;
         S.max_dinv_slots = std::max (S.max_dinv_slots, Lc.ng) ;
@@ -693,9 +773,9 @@ struct DenseScheduler
             int slot = (int) (S.dg.size () - Ld.goff) ;
             S.dg.push_back (DgGroup {psx_at (ids [q], i0) + i0 + (i64) i0 * f.nsrow, f.nsrow, w, ids [q], i0, slot, 0}) ;
             Ld.flops += (double) w * w * w / 3.0 ;
-            int lo [2], hi [2] ;
+            int lo [3], hi [3] ;
             chunk_rows (q, i0, b1, lo, hi) ;
-            for (int part = 0 ; part < 2 ; part++)
+            for (int part = 0 ; part < 3 ; part++)
             {
                 int m = hi [part] - lo [part] ;
                 if (m <= 0) continue ;
@@ -784,9 +864,9 @@ struct DenseScheduler
             const FrontD &f = fr [ids [q]] ;
             if (f.nscol <= i0 || fused [q]) continue ;
             int nb = std::min (NB, f.nscol - i0) ;
-            int lo [2], hi [2] ;
+            int lo [3], hi [3] ;
             chunk_rows (q, i0, i0 + nb, lo, hi) ;
-            for (int part = 0 ; part < 2 ; part++)
+            for (int part = 0 ; part < 3 ; part++)
             {
                 int m = hi [part] - lo [part] ;
                 if (m <= 0) continue ;
@@ -816,7 +896,11 @@ struct DenseScheduler
         }
     }
 
-    void run () { if (chain256) run_chain256 () ; else run_chain64 () ; }
+    void run ()
+    {
+        if (chain256) run_chain256 () ; else run_chain64 () ;
+        join_far_gathers () ;       // (nothing left by now: the last block column of a shared front ends with a join)
+    }
 } ;
 
 } // namespace

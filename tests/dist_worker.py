@@ -273,7 +273,8 @@ def main():
                    allreduce_group_sizes=sorted(cb.stats["by_size"]) if cb else [],
                    nsplit=int(S.hip_stats(Lf)[22]), window_opens=int(S.hip_stats(Lf)[37]),
                    window_opens_negative_base=int(S.hip_stats(Lf)[38]), L_bytes_rank=float(S.hip_stats(Lf)[36]),
-                   L_bytes_whole=float(S.hip_stats(Lf)[5]))
+                   L_bytes_whole=float(S.hip_stats(Lf)[5]),
+                   gather_MB=float(S.hip_stats(Lf)[25]) / 1e6, gather_inline_MB=float(S.hip_stats(Lf)[39]) / 1e6)
         if st_o == 0:
             # the rank's share of the factor invariants (its own part of L, no gathered copy) and the invariants
             # of the gathered factor: the shares must add up to them
