@@ -1089,6 +1089,8 @@ def main():
             line["exchange"] = {"backend": "rccl (engine-native, stream-ordered)",
                                 "allreduce_calls_per_factorization": int(stats[17]),
                                 "allreduce_GB_per_factorization": 1e-9 * stats[18],
+                                "all_gather_GB_per_factorization": 1e-9 * stats[25],
+                                "all_gather_GB_waited_for_where_issued": 1e-9 * stats[39],
                                 "self_test_share_as_world": int(os.environ.get("CHOLMOD_HIP_SHARE_AS_WORLD", "0")) if selftest else None}
         if allreduce is not None:
             nfac = max(args.steps + args.warmup + (0 if args.no_profile_pass else 1), 1)

@@ -82,6 +82,7 @@ def main():
             "exec_flops_this_rank": ps[1], "launches": int(ps[2]),
             "shared_fronts": int((owner < 0).sum()), "own_fronts": int((owner == r).sum()),
             "allreduce_calls": ncall, "allreduce_GB": 1e-9 * nbytes, "allreduce_GB_by_group_size": by_size,
+            "gather_GB": 1e-9 * ps[25], "gather_GB_waited_for_where_issued": 1e-9 * ps[39],
             "L_GB_this_rank": 1e-9 * ps[36], "L_GB_whole": 1e-9 * ps[5], "arena_GB_this_rank": 1e-9 * ps[4],
             "profiled_seconds": {"update_wave_tiles": ps[32], "update_wave_tiles_TF": 1e-12 * ps[34] / max(ps[32], 1e-30),
                                  "update64": ps[6], "update64_TF": 1e-12 * ps[8] / max(ps[6], 1e-30),
