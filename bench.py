@@ -161,8 +161,8 @@ def cpu_baseline(sample_m):
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r04zq_pmc_summary_poisson200_top48.json"}
 # counters of EVERY launch of one refactorization of the mid-size workloads, summed per kernel (tools/pmc_workload.sh: three
 # separate rocprofv3 --pmc passes; round-4 review, item 3) -- matched by the start of the workload name
-PMC_BY_KERNEL = {"poisson3d_100^3": "r05_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r05_pmc_by_kernel_box42r3.json",
-                 "poisson2d_1259^2": "r05_pmc_by_kernel_p2d1259.json"}
+PMC_BY_KERNEL = {"poisson3d_100^3": "r05h_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r05h_pmc_by_kernel_box42r3.json",
+                 "poisson2d_1259^2": "r05h_pmc_by_kernel_p2d1259.json"}
 CHAIN_KERNELS = ("k_update2f", "k_trsm_upd", "k_trsm_mfma", "k_potrf_mfma", "k_extend_add", "k_update2", "k_update3", "k_thin_front",
                  "k_leaf_pair")
 
@@ -562,10 +562,25 @@ def launch_ranks(n, backend):
             print(f"bench.py: --gpus {n} needs {n} visible HIP devices, this node shows {have} "
                   "(--dist-backend gloo lets the ranks share device 0, for tests)", file=sys.stderr)
             return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    # (a port below the ephemeral range: one the kernel hands out for "bind to 0" can be taken by any outgoing connection
+    # of the host between this probe and the rendezvous)
+    import random
+    port = None
+    for _ in range(200):
+        cand = random.randrange(20000, 32000)
+        s = socket.socket()
+        try:
+            s.bind(("127.0.0.1", cand))
+            port = cand
+        except OSError:
+            pass
+        finally:
+            s.close()
+        if port is not None:
+            break
+    if port is None:
+        print("bench.py: no free rendezvous port on 127.0.0.1", file=sys.stderr)
+        return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)

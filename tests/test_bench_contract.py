@@ -40,11 +40,8 @@ def test_bench_json_line_contract():
 def test_bench_two_ranks_over_gloo():
     """The N > 1 launch line of the driver (torch.distributed.run, one rank per GPU);
     on the 1-GPU box the two ranks share GPU 0 and exchange through gloo."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from ports import free_port
+    port = free_port()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "32", "--steps", "2", "--warmup", "1",
@@ -68,11 +65,8 @@ def test_bench_keeps_its_line_when_the_gathered_factor_does_not_fit():
     """A rank that has no room for the gathered factor (two ranks at the headline size hold 181.6 + 117 GB with 8 GB to
     spare): the line must still be printed -- without the residual, with the note and the distributed invariants.  Here rank 1
     is told that it has no room (test hook)."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from ports import free_port
+    port = free_port()
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),
                           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "24", "--steps", "1", "--warmup", "1",
@@ -109,11 +103,8 @@ def test_bench_watchdog_turns_a_hung_collective_into_an_error_line():
     on the device), rank 0 waits for it in the exchange.  The per-step deadline expires: rank 0 prints ONE JSON line with
     "error", the phase, the completed step's time and the exchange its device has entered and not left, and the job exits
     non-zero -- instead of sitting there until the driver's 1800 s kill."""
-    import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    from ports import free_port
+    port = free_port()
     env = dict(os.environ, SSAMD_TEST_HOOKS_LIB="1", CHOLMOD_HIP_TEST_HANG_EXCHANGE="1:3:3")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port),

@@ -19,12 +19,7 @@ from suitesparse_amd import generators as G
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+from ports import free_port as _free_port  # noqa: E402
 
 
 def _run_ranks(world, mode, case, timeout=600, extra_env=None):
