@@ -17,8 +17,7 @@ from suitesparse_amd import cholmod as ch
 from suitesparse_amd import generators as G
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
+sys.path.insert(0, os.path.join(ROOT, "tests"))     # (tools/dist_soak.py imports this module as tests.test_dist)
 from ports import free_port as _free_port  # noqa: E402
 
 

@@ -11,6 +11,8 @@ JIT = len(sys.argv) > 1 and sys.argv[1] == "jitter"        # random hold-ups of 
 for it in range(12):
     for world, case in ((4, "p3d_32"), (3, "p3d_48"), (2, "dense_1400")):
         ex = dict(env, CHOLMOD_HIP_UPD3_MIN_TILES="1" if it % 2 else "2048")
+        # every third round: outer blocks of four block columns, so that far-row gathers ride the exchange stream beside the chain
+        if it % 3 == 1: ex.update(T.WIDE_OUTER)
         if JIT: ex["CHOLMOD_HIP_TEST_JITTER"] = f"{100 + it}:{500 if it % 3 else 3000}"
         res = T._run_ranks(world, "gpu", case, extra_env=ex)
         for r in res:
