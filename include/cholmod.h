@@ -39,7 +39,10 @@
  *  - the supernode partition is the CPU one on both paths (no devBuffSize splits);
  *  - an unsymmetric A (stype 0: factorize A*A' + beta*I) is served by forming tril (A*A') on
  *    the host and taking the symmetric path (real A; a column subset fset: NOT_INSTALLED);
- *  - update/downdate, Bset solves and every simplicial form of L, complex triplets and
+ *  - cholmod_l_solve2 with a sparse right-hand side (Bset) reads the columns the reference's supernodal -> simplicial
+ *    conversion would produce in place (same pattern, same reach, same Xset order) and leaves L supernodal
+ *    (host/subset_solve.c; the reference leaves it simplicial, Cholesky/cholmod_solve.c:1158-1180);
+ *  - update/downdate and every simplicial form of L, complex triplets and
  *    complex Matrix Market files: CHOLMOD_NOT_INSTALLED / CHOLMOD_INVALID.
  */
 #ifndef CHOLMOD_AMD_H
@@ -245,6 +248,7 @@ typedef struct cholmod_factor_struct
     int hip_is_twin ;           /* this factor IS the real twin of a complex factor (its owner's cx_twin): 1 = the
                                  * full twin (x: 4 xsize doubles), 2 = engine-only, complex storage (px = 2 x the
                                  * complex px; CHOLMOD_HIP_CX_STORAGE) */
+    void *bset_work ;           /* cholmod_l_solve2 with Bset: column -> supernode, flags (2n + 1 integers, built by the first call) */
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

@@ -107,7 +107,8 @@ class Factor(C.Structure):
                 ("dtype", C.c_int), ("useGPU", C.c_int),
                 ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
                 ("cx_twin", C.c_void_p), ("hip_apat_hash", C.c_uint64), ("hip_apat_nnz", C.c_size_t),
-                ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64), ("hip_is_twin", C.c_int)]
+                ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64), ("hip_is_twin", C.c_int),
+                ("bset_work", C.c_void_p)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare
@@ -221,6 +222,7 @@ def lib(hooks=None):
     sig("cholmod_l_factorize", C.c_int, [sp, fc, cm])
     sig("cholmod_l_factorize_p", C.c_int, [sp, C.POINTER(dbl * 2), vp, sz, fc, cm])
     sig("cholmod_l_solve", dn, [C.c_int, fc, dn, cm])
+    sig("cholmod_l_solve2", C.c_int, [C.c_int, fc, dn, sp, C.POINTER(dn), C.POINTER(sp), C.POINTER(dn), C.POINTER(dn), cm])
     sig("cholmod_l_rcond", dbl, [fc, cm])
     sig("cholmod_l_change_factor", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fc, cm])
     sig("cholmod_l_etree", C.c_int, [sp, vp, cm])
@@ -445,6 +447,47 @@ class Session:
         out = self.dense_to_numpy(X)
         self.free_dense(X)
         return out
+
+    def solve_subset(self, Lf, b, bset, sys=SYS_A, handles=None):
+        """cholmod_l_solve2 with a sparse right-hand side: b (length n, only its entries at the indices `bset` are
+        read).  Returns (x, xset): x of length n -- defined at the indices xset only, NaN elsewhere when the handles
+        are fresh -- and xset in the order the library produced it.  `handles`: a dict kept by the caller between calls
+        (the X / Xset / Y workspaces of the reference's interface); free with free_subset_handles."""
+        h = handles if handles is not None else {}
+        n = int(Lf.contents.n)
+        B = self.dense(b)
+        bset = np.ascontiguousarray(bset, dtype=np.int64)
+        Bs = self.L.cholmod_l_allocate_sparse(n, 1, max(len(bset), 1), 0, 1, 0, PATTERN, C.byref(self.cm))
+        _view(Bs.contents.p, 2, C.c_int64, np.int64)[:] = [0, len(bset)]
+        if len(bset):
+            _view(Bs.contents.i, len(bset), C.c_int64, np.int64)[:] = bset
+        X = h.get("X") or C.POINTER(Dense)()
+        Xs = h.get("Xset") or C.POINTER(Sparse)()
+        Y = h.get("Y") or C.POINTER(Dense)()
+        E = C.POINTER(Dense)()
+        fresh = not bool(X)
+        ok = self.L.cholmod_l_solve2(sys, Lf, B, Bs, C.byref(X), C.byref(Xs), C.byref(Y), C.byref(E), C.byref(self.cm))
+        self.free_dense(B)
+        self.free_sparse(Bs)
+        h.update(X=X, Xset=Xs, Y=Y)
+        try:
+            if not ok:
+                raise RuntimeError(f"cholmod_l_solve2 (Bset) failed, status {self.cm.status}")
+            k = int(_view(Xs.contents.p, 2, C.c_int64, np.int64)[1])
+            xset = _view(Xs.contents.i, max(k, 1), C.c_int64, np.int64)[:k].copy()
+            xall = self.dense_to_numpy(X)
+            x = np.full(n, np.nan, dtype=xall.dtype) if fresh else xall.copy()
+            x[xset] = xall[xset]
+            return x, xset
+        finally:
+            if handles is None:
+                self.free_subset_handles(h)
+
+    def free_subset_handles(self, h):
+        for k, fr in (("X", self.free_dense), ("Y", self.free_dense), ("Xset", self.free_sparse)):
+            if h.get(k):
+                fr(h[k])
+            h.pop(k, None)
 
     def hip_stats(self, Lf):
         s = (C.c_double * CHOLMOD_HIP_NSTATS)()

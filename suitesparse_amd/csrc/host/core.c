@@ -904,6 +904,7 @@ int cholmod_l_free_factor (cholmod_factor **LH, cholmod_common *Common)
     cholmod_l_free (n, sizeof (Int), L->Perm, Common) ;
     cholmod_l_free (n, sizeof (Int), L->ColCount, Common) ;
     if (L->IPerm) cholmod_l_free (n, sizeof (Int), L->IPerm, Common) ;
+    if (L->bset_work) cholmod_l_free (2 * n + 1, sizeof (Int), L->bset_work, Common) ;
     if (L->super) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->super, Common) ;
     if (L->pi) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->pi, Common) ;
     if (L->px) cholmod_l_free (L->nsuper + 1, sizeof (Int), L->px, Common) ;

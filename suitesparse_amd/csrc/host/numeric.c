@@ -771,11 +771,16 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
     RETURN_IF_NULL (L, FALSE) ;
     RETURN_IF_NULL (B, FALSE) ;
     RETURN_IF_NULL (X_Handle, FALSE) ;
-    (void) Xset_Handle ; (void) Y_Handle ; (void) E_Handle ;
-    if (Bset) { ERROR (CHOLMOD_NOT_INSTALLED, "sparse right-hand-side subsets not built") ; return FALSE ; }
+    (void) E_Handle ;
     if (sys < CHOLMOD_A || sys > CHOLMOD_Pt) { ERROR (CHOLMOD_INVALID, "invalid system") ; return FALSE ; }
     if (B->xtype < CHOLMOD_REAL || B->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "B must be numeric") ; return FALSE ; }
     if (B->d < L->n || B->nrow != L->n) { ERROR (CHOLMOD_INVALID, "dimensions of L and B do not match") ; return FALSE ; }
+    if (Bset)
+    {
+        /* (reference cholmod_solve.c:1081-1094) */
+        if (B->ncol != 1) { ERROR (CHOLMOD_INVALID, "Bset requires a single right-hand side") ; return FALSE ; }
+        if (L->xtype != B->xtype) { ERROR (CHOLMOD_INVALID, "Bset requires xtype of L and B to match") ; return FALSE ; }
+    }
     Common->status = CHOLMOD_OK ;
     Int n = (Int) L->n, nrhs = (Int) B->ncol ;
     const int Lcomplex = (L->xtype == CHOLMOD_COMPLEX) ;
@@ -793,6 +798,8 @@ int cholmod_l_solve2 (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_spar
         if (!X) return FALSE ;
         *X_Handle = X ;
     }
+    /* a sparse right-hand side: the entries of X on the pattern Bset reaches, subset_solve.c */
+    if (Bset) return ssamd_solve_subset (sys, L, B, Bset, X, Xset_Handle, Y_Handle, Common) ;
     const Int *Perm = L->Perm ;
     double re, im ;
     if (sys == CHOLMOD_P || sys == CHOLMOD_Pt || sys == CHOLMOD_D)
