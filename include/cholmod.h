@@ -38,7 +38,7 @@
  *    reference's silent degradation to the CPU path;
  *  - the supernode partition is the CPU one on both paths (no devBuffSize splits);
  *  - an unsymmetric A (stype 0: factorize A*A' + beta*I) is served by forming tril (A*A') on
- *    the host and taking the symmetric path (real A; a column subset fset: NOT_INSTALLED);
+ *    the host and taking the symmetric path (real A; a column subset fset: A(:,f)*A(:,f)', the columns cut out first);
  *  - cholmod_l_solve2 with a sparse right-hand side (Bset) reads the columns the reference's supernodal -> simplicial
  *    conversion would produce in place (same pattern, same reach, same Xset order) and leaves L supernodal
  *    (host/subset_solve.c; the reference leaves it simplicial, Cholesky/cholmod_solve.c:1158-1180);

@@ -647,16 +647,18 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
 {
     RETURN_IF_NULL_COMMON (NULL) ;
     RETURN_IF_NULL (A, NULL) ;
-    (void) fset ; (void) fsize ;
     Common->status = CHOLMOD_OK ;
     const int timing = getenv ("CHOLMOD_ANALYZE_TIMING") != NULL ;
     double tt [8] ; tt [0] = ssamd_now () ;
     if (A->stype == 0)
     {
-        /* unsymmetric A: analyse A*A' (cholmod_analyze.c:402-418 orders and counts A(:,f)*A(:,f)').  Here its pattern is formed
-         * (core.c: ssamd_aat) and analysed as the symmetric matrix it is; a column subset f is not built. */
-        if (fset) { ERROR (CHOLMOD_NOT_INSTALLED, "analysis of A(:,f)*A(:,f)' (fset) not built") ; return NULL ; }
-        cholmod_sparse *C = ssamd_aat (A, NULL, 0, TRUE, Common) ;
+        /* unsymmetric A: analyse A*A', or A(:,f)*A(:,f)' for a column subset f (cholmod_analyze.c:402-418 orders and counts
+         * it).  Here its pattern is formed (core.c: ssamd_column_subset, ssamd_aat) and analysed as the symmetric matrix
+         * it is. */
+        cholmod_sparse *Af = fset ? ssamd_column_subset (A, fset, fsize, 0, Common) : NULL ;
+        if (fset && !Af) return NULL ;
+        cholmod_sparse *C = ssamd_aat (Af ? Af : A, NULL, 0, TRUE, Common) ;
+        if (Af) cholmod_l_free_sparse (&Af, Common) ;
         if (!C) return NULL ;
         cholmod_factor *LC = cholmod_l_analyze_p2 (for_whom, C, UserPerm, NULL, 0, Common) ;
         cholmod_l_free_sparse (&C, Common) ;

@@ -587,6 +587,45 @@ cholmod_sparse *cholmod_l_ptranspose (cholmod_sparse *A, int values, SuiteSparse
     return ssamd_sym_permute (A, values, Perm, !(A->stype > 0), Common) ;
 }
 
+/* A (:, f): the columns fset [0 .. fsize-1] of A, in that order (values = 0: pattern only).  The reference hands fset to its
+ * transposes and its A*A' assembly (CHOLMOD/Cholesky/cholmod_analyze.c:402-418, cholmod_factorize.c:197-224: F = A(p,f)');
+ * here the subset is cut out once and A(:,f)*A(:,f)' formed from it.  An index outside 0 .. ncol-1 or listed twice is
+ * CHOLMOD_INVALID, as in the reference's subset check (Core/cholmod_transpose.c:520-560). */
+cholmod_sparse *ssamd_column_subset (cholmod_sparse *A, const SuiteSparse_long *fset, size_t fsize, int values, cholmod_common *Common)
+{
+    const Int ncol = (Int) A->ncol ;
+    const Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
+    const double *Ax = A->x ;
+    char *seen = cholmod_l_calloc (ncol > 0 ? ncol : 1, 1, Common) ;
+    if (!seen) return NULL ;
+    Int nz = 0 ;
+    int ok = TRUE ;
+    for (size_t k = 0 ; k < fsize && ok ; k++)
+    {
+        const Int j = fset [k] ;
+        if (j < 0 || j >= ncol || seen [j]) { ok = FALSE ; break ; }
+        seen [j] = 1 ;
+        nz += A->packed ? Ap [j+1] - Ap [j] : Anz [j] ;
+    }
+    cholmod_l_free (ncol > 0 ? ncol : 1, 1, seen, Common) ;
+    if (!ok) { ERROR (CHOLMOD_INVALID, "invalid fset") ; return NULL ; }
+    const int av = values && A->xtype == CHOLMOD_REAL && Ax ;
+    cholmod_sparse *S = cholmod_l_allocate_sparse (A->nrow, fsize, nz, A->sorted, TRUE, 0, av ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+    if (!S) return NULL ;
+    Int *Sp = S->p, *Si = S->i ;
+    double *Sx = S->x ;
+    Int dst = 0 ;
+    for (size_t k = 0 ; k < fsize ; k++)
+    {
+        const Int j = fset [k] ;
+        Sp [k] = dst ;
+        Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
+        for ( ; p < pend ; p++) { Si [dst] = Ai [p] ; if (av) Sx [dst] = Ax [p] ; dst++ ; }
+    }
+    Sp [fsize] = dst ;
+    return S ;
+}
+
 /* C = A * F as a symmetric matrix, one triangle stored (lower: stype -1, else upper: stype 1), columns sorted; F = A' (or
  * A(:,f)') is taken if given, else formed.  values = 0: pattern only.  Real matrices.
  *

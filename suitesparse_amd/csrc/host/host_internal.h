@@ -36,6 +36,7 @@ typedef SuiteSparse_long Int ;
 int ssamd_host_threads (void) ;
 int ssamd_host_threads_uncapped (void) ;
 cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int lower, cholmod_common *Common) ;
+cholmod_sparse *ssamd_column_subset (cholmod_sparse *A, const SuiteSparse_long *fset, size_t fsize, int values, cholmod_common *Common) ;
 cholmod_sparse *ssamd_sym_permute (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,
     cholmod_common *Common) ;
 cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSparse_long *Perm, int upper_out,

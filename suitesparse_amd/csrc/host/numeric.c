@@ -386,7 +386,6 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     RETURN_IF_NULL_COMMON (FALSE) ;
     RETURN_IF_NULL (A, FALSE) ;
     RETURN_IF_NULL (L, FALSE) ;
-    (void) fsize ;
     if (A->xtype < CHOLMOD_REAL || A->xtype > CHOLMOD_ZOMPLEX) { ERROR (CHOLMOD_INVALID, "A must be numeric") ; return FALSE ; }
     if (A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "A and L dimensions do not match") ; return FALSE ; }
     if (!L->is_super) { ERROR (CHOLMOD_NOT_INSTALLED, "simplicial factorization not built") ; return FALSE ; }
@@ -394,10 +393,12 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     {
         /* factorize A*A' + beta*I (cholmod_factorize.c:197-224: S = A(p,f), F = S', super_numeric (S, F, beta)): tril (A*A')
          * is formed on the host and takes the symmetric branch below -- permutation, upload and, from the second call with
-         * the same pattern on, the values-only path included.  A(:,f)*A(:,f)' (fset) is not built. */
-        if (fset) { ERROR (CHOLMOD_NOT_INSTALLED, "factorization of A(:,f)*A(:,f)' (fset) not built") ; return FALSE ; }
+         * the same pattern on, the values-only path included.  A column subset f: A(:,f)*A(:,f)', the columns cut out first. */
         if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*A' not built") ; return FALSE ; }
-        cholmod_sparse *C = ssamd_aat (A, NULL, 1, TRUE, Common) ;
+        cholmod_sparse *Af = fset ? ssamd_column_subset (A, fset, fsize, 1, Common) : NULL ;
+        if (fset && !Af) return FALSE ;
+        cholmod_sparse *C = ssamd_aat (Af ? Af : A, NULL, 1, TRUE, Common) ;
+        if (Af) cholmod_l_free_sparse (&Af, Common) ;
         if (!C) return FALSE ;
         int okc = cholmod_l_factorize_p (C, beta, NULL, 0, L, Common) ;
         cholmod_l_free_sparse (&C, Common) ;

@@ -2,7 +2,7 @@
 (CHOLMOD/Cholesky/cholmod_factorize.c:197-224, CHOLMOD/Supernodal/t_cholmod_super_numeric.c:223-237, :385-418).  This build forms
 tril (A*A') on the host (csrc/host/core.c: ssamd_aat) and takes the symmetric path; the factor is the same.  Checked against numpy on
 the dense product: L*L' = P (A*A' + beta*I) P', the solve, a second factorization with new values, the expert entry point
-cholmod_l_super_numeric (S, F, beta, L), and what is not built (a column subset fset).  CPU path here, GPU path marked gpu."""
+cholmod_l_super_numeric (S, F, beta, L), and a column subset fset (A(:,f)*A(:,f)').  CPU path here, GPU path marked gpu."""
 import ctypes as C
 
 import numpy as np
@@ -77,10 +77,23 @@ def _run(use_gpu):
     assert np.linalg.norm(Ld3 - Ld2) <= 1e-13 * np.linalg.norm(Ld2)
     S.cm.error_handler = ch.ERRFUNC(0)
     assert S.L.cholmod_l_super_numeric(Sp, None, C.byref(b2), Lf, C.byref(S.cm)) == 0 and S.cm.status == ch.INVALID      # F is required
-    # a column subset is not built, and says so
-    fset = np.arange(10, dtype=np.int64)
-    assert S.L.cholmod_l_factorize_p(A, C.byref(b2), fset.ctypes.data, 10, Lf, C.byref(S.cm)) == 0 and S.cm.status == ch.NOT_INSTALLED
-    assert not S.L.cholmod_l_analyze_p(A, None, fset.ctypes.data, 10, C.byref(S.cm)) and S.cm.status == ch.NOT_INSTALLED
+    # a column subset f: A(:,f)*A(:,f)' + beta*I (cholmod_analyze.c:402-418, cholmod_factorize.c:197-224), in the order given
+    fset = np.ascontiguousarray(rng.permutation(n)[:50], dtype=np.int64)
+    Lf2 = S.L.cholmod_l_analyze_p(A, None, fset.ctypes.data, len(fset), C.byref(S.cm))
+    assert Lf2 and S.cm.status == ch.OK
+    assert S.L.cholmod_l_factorize_p(A, C.byref(b2), fset.ctypes.data, len(fset), Lf2, C.byref(S.cm)) == 1 and S.cm.status == ch.OK
+    fv2 = ch.FactorView(Lf2)
+    Mf = M[:, fset]
+    Cf = (Mf @ Mf.T).toarray() + beta * np.eye(m)
+    Lf2d = _dense_L(fv2)
+    P2 = fv2.Perm
+    assert np.linalg.norm(Lf2d @ Lf2d.T - Cf[np.ix_(P2, P2)]) <= 1e-13 * np.linalg.norm(Cf)
+    # an index listed twice, or outside the columns of A: CHOLMOD_INVALID
+    bad = np.array([3, 7, 3], dtype=np.int64)
+    assert S.L.cholmod_l_factorize_p(A, C.byref(b2), bad.ctypes.data, 3, Lf2, C.byref(S.cm)) == 0 and S.cm.status == ch.INVALID
+    bad = np.array([3, n], dtype=np.int64)
+    assert not S.L.cholmod_l_analyze_p(A, None, bad.ctypes.data, 2, C.byref(S.cm)) and S.cm.status == ch.INVALID
+    S.free_factor(Lf2)
     for X in (Sp, Fp, A, A2):
         S.free_sparse(X)
     S.free_factor(Lf)
