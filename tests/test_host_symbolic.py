@@ -176,13 +176,18 @@ def test_invalid_arguments():
     with pytest.raises(RuntimeError):
         S.analyze(A, np.zeros(n, dtype=np.int64))       # not a permutation
     assert S.cm.status == ch.INVALID
-    # an unsymmetric matrix is analysed as A*A' (round 5, tests/test_aat.py); what is not built is a column subset
+    # an unsymmetric matrix is analysed as A*A', with a column subset as A(:,f)*A(:,f)' (round 5, tests/test_aat.py);
+    # a subset that lists a column twice is invalid
     A0 = S.sparse(n, Ap, Ai, Ax, 0)
     L0 = S.analyze(A0)
     assert L0 and S.cm.status == ch.OK and L0.contents.n == n
     S.free_factor(L0)
     fset = np.arange(3, dtype=np.int64)
-    assert not S.L.cholmod_l_analyze_p(A0, None, fset.ctypes.data, 3, C.byref(S.cm)) and S.cm.status == ch.NOT_INSTALLED
+    L1 = S.L.cholmod_l_analyze_p(A0, None, fset.ctypes.data, 3, C.byref(S.cm))
+    assert L1 and S.cm.status == ch.OK and L1.contents.n == n
+    S.free_factor(L1)
+    fset = np.array([1, 2, 1], dtype=np.int64)
+    assert not S.L.cholmod_l_analyze_p(A0, None, fset.ctypes.data, 3, C.byref(S.cm)) and S.cm.status == ch.INVALID
     S.free_sparse(A)
     S.free_sparse(A0)
     assert S.cm.malloc_count == 0
