@@ -64,6 +64,7 @@ struct DenseScheduler
     i64 unfuse_tiles ;              // a chain update of this many tiles is not fused with the next dpotrf (CHOLMOD_HIP_UNFUSE_TILES)
     bool by_launch ;                // ... pooled over the regions of a launch (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only)
     bool one_region ;               // tuning (CHOLMOD_HIP_UPDW_ONE_REGION=1): every region of a k_update3 launch a launch of its own
+    i64 w_alone_tiles ;             // a region of this many tiles is a k_update3 launch of its own (CHOLMOD_HIP_UPDW_ALONE_TILES; 0: never)
     bool swz16 ;                    // tuning (CHOLMOD_HIP_SWZ16=1): 16 x 16 super-tiles for the one-wave-per-tile walk
     bool xla ;                      // exchange look-ahead (several ranks)
     bool chain256 = false ;         // the 256-column chain instead of the 64-column one
@@ -103,6 +104,7 @@ struct DenseScheduler
         if (!allow_half || w_min_tiles <= 0) w_half_max = 0 ;
         if (w_half_max <= 0 || w_half_min > w_min_tiles) w_half_min = w_min_tiles ;
         one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
+        { const char *e = getenv ("CHOLMOD_HIP_UPDW_ALONE_TILES") ; w_alone_tiles = e ? (i64) atoll (e) : (i64) 32768 ; }
         swz16 = getenv ("CHOLMOD_HIP_SWZ16") != nullptr ;
         xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
         balance_cb = !use_big && !getenv ("CHOLMOD_HIP_NO_CB_BALANCE") ;
@@ -374,9 +376,17 @@ struct DenseScheduler
             L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
             tiles = 0 ;
         } ;
+        bool alone = false ;        // the launch holds a region that keeps it to itself
         for (auto &G : v)
         {
-            if (one_region && kind == K_UPD_W && S.gg.size () > L.goff) close_launch () ;
+            // A big region gets a launch of its own (w_alone_tiles = 32 768; measured at 200^3, tools/lp_by_k.py / lp_regions.py:
+            // the outer update of a top front as ONE launch -- the trapezoid of its in-front columns and the square of its
+            // contribution block -- runs at 66 - 69 TFLOP/s, the same two regions as two launches at 72.6 - 74.6 each; the step
+            // 7188 -> 7069 ms, un-profiled, same box: profiles/r05_ab_updw_alone.log).  Why one launch is slower is not
+            // understood; launch boundaries cost nothing at these sizes.
+            const bool big_one = kind == K_UPD_W && w_alone_tiles > 0 && region_tiles (G) >= w_alone_tiles ;
+            if ((one_region || big_one || alone) && kind == K_UPD_W && S.gg.size () > L.goff) close_launch () ;
+            alone = big_one ;
             const i64 mine = place_region (G, T, kind == K_UPD_W, tiles) ;
             if (mine == 0) continue ;
             const i64 cnt = G.ntiles ;

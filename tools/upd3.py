@@ -7,6 +7,7 @@
   sustain     the same launch for 0.3 / 1.6 / 4.8 s (is the rate inside a long factorization a power effect?)
   offset      the operands 0 / 60 / 150 / 240 GB into one allocation (does it matter where a front lives?)
   rounds      triangular regions of 6k .. 48k rows at K = 4096 / 1024: rate against the number of rounds of 2048 tiles
+  trap        tall trapezoids (the in-front part of a top front's outer update) against the square of its contribution block
 usage: python tools/upd3.py [mode]      prints one JSON line"""
 import ctypes as C
 import json
@@ -76,6 +77,18 @@ elif mode == "half":
         for name, fl in (("update2", 0), ("update3", dep), ("update3_half", dep | HALF)):
             row[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, max(2, int(2e11 / (m * n * k))), fl) / 1e12
         out["TFLOPs"][f"rect{m}x{n}_K{k}"] = row
+elif mode == "trap":
+    # (round 5) the outer update of a top front = a tall trapezoid (the in-front columns right of the outer block) + the square of
+    # the contribution block: in the 200^3 factorization the launches with a NARROW trapezoid run at 66-69 TFLOP/s, the launches
+    # of one square region at 74-75 (tools/lp_by_k.py).  The trapezoid alone, as a rectangle, and the square, same K:
+    for name, (m, n, k, it, fl) in {
+            "trap_42397x2797": (42397, 2797, 4096, 2, TRI | D4 | ODD), "rect_42397x2797": (42397, 2797, 4096, 2, D4 | ODD),
+            "trap_46493x6893": (46493, 6893, 4096, 1, TRI | D4 | ODD), "trap_58705x18705": (58705, 18705, 4096, 1, TRI | D4 | ODD),
+            "tri_39600": (39600, 39600, 4096, 1, TRI | D4 | ODD), "trap_42397x2797_noswz": (42397, 2797, 4096, 2, TRI | D4 | ODD | NOSWZ),
+            "trap_42397x2797_swz16": (42397, 2797, 4096, 2, TRI | D4 | ODD | SWZ16),
+            "trap_42397x2797_even": (42397, 2797, 4096, 2, TRI | D4), "trap_42368x2816_even": (42368, 2816, 4096, 2, TRI | D4),
+            "trap_42397x512": (42397, 512, 4096, 4, TRI | D4 | ODD), "trap_42397x1024": (42397, 1024, 4096, 4, TRI | D4 | ODD)}.items():
+        out[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
 elif mode == "sustain":
     for it in (2, 12, 36):
         out[f"u3_tri48k_K4096_iters{it}"] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, it, TRI | D4) / 1e12
