@@ -158,7 +158,7 @@ def cpu_baseline(sample_m):
                       f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas}, host cores {cores}"}
 
 
-PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r04zq_pmc_summary_poisson200_top48.json"}
+PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r05j_pmc_summary_poisson200_top48.json"}
 # counters of EVERY launch of one refactorization of the mid-size workloads, summed per kernel (tools/pmc_workload.sh: three
 # separate rocprofv3 --pmc passes; round-4 review, item 3) -- matched by the start of the workload name
 PMC_BY_KERNEL = {"poisson3d_100^3": "r05h_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r05h_pmc_by_kernel_box42r3.json",
