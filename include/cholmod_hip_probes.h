@@ -15,6 +15,8 @@ extern "C" {
  * Returns achieved flop/s, or a negative CHOLMOD_HIP_* code. */
 double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k,
     int iters, int flags) ;
+/* the outer update of a top front, trapezoid + square, as one launch or as two (tools/upd3.py pair) */
+double cholmod_hip_bench_update_pair (int64_t m1, int64_t n1, int64_t m2, int64_t k, int64_t ld, int iters, int mode) ;
 
 /* Issue-bound v_mfma_f64_16x16x4_f64 loop without memory traffic: the measured
  * fp64 matrix-core ceiling (flop/s) printed next to the 78.6 TFLOP/s spec. */

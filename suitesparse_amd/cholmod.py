@@ -154,7 +154,7 @@ HIP_SYMBOLS = [
 
 PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
 PROBE_SYMBOLS = [
-    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
+    "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_update_pair", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
     "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_probe_cu_mask", "cholmod_hip_probe_overlap", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
 ]
@@ -294,6 +294,7 @@ def probes():
     vp, i64, dbl = C.c_void_p, C.c_int64, C.c_double
     for name, res, args in (
             ("cholmod_hip_bench_update_kernel", dbl, [i64, i64, i64, C.c_int, C.c_int]),
+            ("cholmod_hip_bench_update_pair", dbl, [i64, i64, i64, i64, i64, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mfma_peak", dbl, [C.c_int, C.c_int]),
             ("cholmod_hip_bench_mfma_peak2", dbl, [C.c_int, C.c_int, C.c_int, C.c_int]),
             ("cholmod_hip_bench_mixed", dbl, [C.c_int, C.c_int, C.c_int]),

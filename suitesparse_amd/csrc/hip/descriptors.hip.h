@@ -103,6 +103,8 @@ struct RelPair { i32 d ; i32 a ; i64 off ; } ;
 #ifndef EA_TW
 #define EA_TW 8           // (16: 4.5 / 15.8 / 1.08 ms of extend-add at the nd24k stand-in / Poisson 100^3 / 2D 1259^2; 8: 3.9 / 14.5 / 0.96; 4: 3.7 / 14.4 / 1.05; 32: 5.6 / 16.0 / 1.48)
 #endif
+// doubles every device array that holds panels of L ends with: k_update3's partial tiles read up to 63 rows past a column's end
+#define UPD3_LX_PAD 64
 // inner panel width (k_potrf_mfma, k_trsm_mfma) and the leading dimension of its LDS copy
 #define PF_NB 64
 #define PF2_LD 64

@@ -172,7 +172,7 @@ static int upload_plan (cholmod_hip_plan *P)
     HIPCHK (hipMalloc ((void **) &P->d_first_fail, sizeof (int))) ;
     // test hook: behave as if the reservation of L failed (degradation tests)
     if (TEST_ENV ("CHOLMOD_HIP_TEST_FAIL_ALLOC")) return CHOLMOD_HIP_OUT_OF_MEMORY ;
-    HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P->d_Lx, (std::max<i64> (P->lx_local, 1) + UPD3_LX_PAD) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_cb, std::max<i64> (P->arena, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P->d_xchg, 3 * (size_t) P->world * sizeof (double))) ;
     {
@@ -579,7 +579,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     {
         // (the gather went through the host and released the rank's own array: cholmod_hip_gather_factor)
         if (P->d_Lx_full) { (void) hipFree (P->d_Lx_full) ; P->d_Lx_full = nullptr ; }
-        HIPCHK (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double))) ;
+        HIPCHK (hipMalloc ((void **) &P->d_Lx, (std::max<i64> (P->lx_local, 1) + UPD3_LX_PAD) * sizeof (double))) ;
     }
     if (!P->d_cb)
     {
@@ -1082,7 +1082,7 @@ int cholmod_hip_gather_factor (cholmod_hip_plan *P)
     bool staged = false ;
     auto restore_own = [&] () -> bool       // the rank's own array back from the host copy
     {
-        if (hipMalloc ((void **) &P->d_Lx, std::max<i64> (P->lx_local, 1) * sizeof (double)) == hipSuccess
+        if (hipMalloc ((void **) &P->d_Lx, (std::max<i64> (P->lx_local, 1) + UPD3_LX_PAD) * sizeof (double)) == hipSuccess
             && hipMemcpy (P->d_Lx, own_host.get (), (size_t) P->lx_local * sizeof (double), hipMemcpyHostToDevice) == hipSuccess) return true ;
         (void) hipGetLastError () ;
         fprintf (stderr, "cholmod_hip_gather_factor: rank %d lost its part of the factor\n", P->rank) ;
@@ -1857,7 +1857,7 @@ int cholmod_hip_dense_partial_factor (double *F, int64_t nsrow, int64_t nscol, i
         P.sync_ev.push_back (ev) ;
     }
     i64 ncb = nsrow - nscol ;
-    HIPCHK (hipMalloc ((void **) &P.d_Lx, nsrow * nscol * sizeof (double))) ;
+    HIPCHK (hipMalloc ((void **) &P.d_Lx, (nsrow * nscol + UPD3_LX_PAD) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P.d_cb, std::max<i64> (ncb * ncb, 1) * sizeof (double))) ;
     HIPCHK (hipMalloc ((void **) &P.d_info, sizeof (i32))) ;
     HIPCHK (hipMemset (P.d_info, 0, sizeof (i32))) ;

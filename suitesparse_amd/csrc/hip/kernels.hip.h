@@ -1836,8 +1836,8 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 //     k_update2 (64 + 64 rows per 64 x 64 tile), no ds_write / ds_read / s_barrier at all;
 //   * DEPTH operand sets are in flight (3: the loads of a k-step are issued three steps,
 //     i.e. >= 3000 cycles, before their MFMAs), two waves per SIMD cover the rest.
-// Partial tiles (EDGE) use 8-byte loads with clamped rows; a K that is no multiple of 4 ends
-// with one masked k-step in either path.
+// Partial tiles (EDGE) mask their stores (and, with UPD3_CLAMP_LOADS, use 8-byte loads with clamped rows); a K that is no
+// multiple of 4 ends with one masked k-step in either path.
 // TW: the even columns of a phi-embedded complex panel (see update_tile): the row / column pairs a
 // lane loads ARE the (re, im) pairs, fragment parity = row parity, so the four real products of a
 // complex entry are acc [2 q + {0,1}][2 p + {0,1}][r] of one lane and are combined in place.
@@ -1846,6 +1846,14 @@ __global__ void __launch_bounds__(256, MINW) k_update2 (const GemmGroup *g, int 
 // tiles (the top fronts of the mid-size problems) that fill the 2048 wave slots one and a bit or two and a bit times then
 // waste half a tile time at most instead of a whole one.  Three loads feed eight MFMAs instead of four feeding sixteen; the
 // entries are computed in the same order as in the whole tile: bit-identical results.
+// Partial tiles load like whole ones (round 5): a lane's rows past the edge of the region are rows of the same panel further
+// down, or -- below the front's last row -- the first rows of its next column, of the next front, or the UPD3_LX_PAD doubles
+// every allocation of L ends with; what they feed are accumulators of rows / columns the epilogue never stores.  With the
+// clamped 8-byte loads of rounds 3-4 (UPD3_CLAMP_LOADS = 1) a partial tile took twice the time of a whole one, and the tiles
+// behind it in the launch lost the lockstep their L2 reuse depends on (schedule_dense.hip: flush_kind).
+#ifndef UPD3_CLAMP_LOADS
+#define UPD3_CLAMP_LOADS 0
+#endif
 template <int DEPTH, bool EDGE, int TW = 0, int NQ = 2>
 __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J, double *Lx, double *CB, int cofs = 0)
 {
@@ -1862,7 +1870,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
     {
         ra [q][0] = 32 * q + 2 * lr ; ra [q][1] = ra [q][0] + 1 ;
         rb [q][0] = 32 * q + 2 * lr ; rb [q][1] = rb [q][0] + 1 ;
-        if constexpr (EDGE)
+        if constexpr (EDGE && UPD3_CLAMP_LOADS)
         {
 #pragma unroll
             for (int h = 0 ; h < 2 ; h++)
@@ -1882,7 +1890,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
 #pragma unroll
         for (int q = 0 ; q < 2 ; q++)
         {
-            if constexpr (EDGE)
+            if constexpr (EDGE && UPD3_CLAMP_LOADS)
             {
                 F.a [2 * q] = pa [q][ko + ra [q][0]] ; F.a [2 * q + 1] = pa [q][ko + ra [q][1]] ;
                 if (q < NQ) { F.b [2 * q] = pb [q][ko + rb [q][0]] ; F.b [2 * q + 1] = pb [q][ko + rb [q][1]] ; }
@@ -1909,7 +1917,7 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
         for (int q = 0 ; q < 2 ; q++)
         {
             double a0, a1, b0 = 0, b1 = 0 ;
-            if constexpr (EDGE)
+            if constexpr (EDGE && UPD3_CLAMP_LOADS)
             {
                 a0 = pa [q][ko + ra [q][0]] ; a1 = pa [q][ko + ra [q][1]] ;
                 if (q < NQ) { b0 = pb [q][ko + rb [q][0]] ; b1 = pb [q][ko + rb [q][1]] ; }

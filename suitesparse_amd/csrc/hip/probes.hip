@@ -128,6 +128,75 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     return 2.0 * entries * k * iters / (ms * 1e-3) ;
 }
 
+/* (round 5) The outer update of a top front as the engine issues it: the trapezoid of the in-front columns right of the outer
+ * block (rows [0, m1) x columns [0, n1) of the panel rows, triangular) and the square of the contribution block (the last m2
+ * rows, triangular), both contracting the same K columns of ONE panel of leading dimension ld >= m1.
+ * mode 0: one launch, trapezoid first (the engine until the end of round 5); 1: two launches; 2: one launch, square first;
+ * 3: one launch, the square's blocks padded to start at a multiple of 2048 * 8 blocks.  Returns flop/s over both regions. */
+double cholmod_hip_bench_update_pair (int64_t m1, int64_t n1, int64_t m2, int64_t k, int64_t ld, int iters, int mode)
+{
+    if (m1 <= 0 || n1 <= 0 || m2 <= 0 || m2 > m1 || n1 > m1 || k <= 0 || ld < m1 || iters <= 0) return CHOLMOD_HIP_INVALID ;
+    if (!probe_device ()) return CHOLMOD_HIP_NO_DEVICE ;
+    const i64 a_off = 1 ;                                       // (8-byte aligned only, as a packed front)
+    const i64 c1_off = a_off + ld * k + 1 ;                     // C of the trapezoid: m1 x n1, ldc = ld (it lives in the front)
+    const i64 c2_off = c1_off + ld * n1 + 1 ;                   // C of the square: m2 x m2
+    const i64 total = c2_off + m2 * m2 ;
+    double *d = nullptr ;
+    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    hipLaunchKernelGGL (k_fill_random, dim3 (4096), dim3 (256), 0, 0, d, total) ;
+    if (hipDeviceSynchronize () != hipSuccess) { (void) hipFree (d) ; return CHOLMOD_HIP_GPU_PROBLEM ; }
+    auto region = [&] (i64 rows0, i64 m, i64 n, i64 c_off, i64 ldc)
+    {
+        GemmGroup G ;
+        memset (&G, 0, sizeof (G)) ;
+        G.a_off = a_off + rows0 ; G.b_off = G.a_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) ldc ;
+        G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = 1 ; G.tile_mul = 1 ;
+        G.mt = (i32) ((m + 63) / 64) ; G.nt = (i32) ((n + 63) / 64) ;
+        G.ntiles = (i32) ((i64) G.nt * (G.nt + 1) / 2 + (i64) (G.mt - G.nt) * G.nt) ;
+        G.nblk = (G.ntiles + 63) / 64 * 64 ;
+        G.swz = 1 ;
+        return G ;
+    } ;
+    GemmGroup T = region (0, m1, n1, c1_off, ld), Q = region (m1 - m2, m2, m2, c2_off, m2) ;
+    GemmGroup two [2] ;
+    if (mode == 2) { two [0] = Q ; two [1] = T ; } else { two [0] = T ; two [1] = Q ; }
+    two [0].tile_start = 0 ;
+    two [1].tile_start = (two [0].nblk + 7) / 8 * 8 ;
+    if (mode == 3) two [1].tile_start = (two [0].nblk + 16383) / 16384 * 16384 ;
+    const int grid2 = two [1].tile_start + two [1].nblk ;
+    GemmGroup sep [2] = {T, Q} ;
+    sep [0].tile_start = sep [1].tile_start = 0 ;
+    GemmGroup *dg = nullptr ;
+    (void) hipMalloc ((void **) &dg, 4 * sizeof (GemmGroup)) ;
+    (void) hipMemcpy (dg, two, 2 * sizeof (GemmGroup), hipMemcpyHostToDevice) ;
+    (void) hipMemcpy (dg + 2, sep, 2 * sizeof (GemmGroup), hipMemcpyHostToDevice) ;
+    auto launch = [&] ()
+    {
+        if (mode == 1)
+        {
+            hipLaunchKernelGGL ((k_update3<4>), dim3 (sep [0].nblk), dim3 (64), 0, 0, dg + 2, 1, d, d) ;
+            hipLaunchKernelGGL ((k_update3<4>), dim3 (sep [1].nblk), dim3 (64), 0, 0, dg + 3, 1, d, d) ;
+        }
+        else hipLaunchKernelGGL ((k_update3<4>), dim3 (grid2), dim3 (64), 0, 0, dg, 2, d, d) ;
+    } ;
+    hipEvent_t e0, e1 ;
+    (void) hipEventCreate (&e0) ; (void) hipEventCreate (&e1) ;
+    launch () ;
+    (void) hipDeviceSynchronize () ;
+    (void) hipEventRecord (e0, 0) ;
+    for (int it = 0 ; it < iters ; it++) launch () ;
+    (void) hipEventRecord (e1, 0) ;
+    (void) hipEventSynchronize (e1) ;
+    float ms = 0 ;
+    (void) hipEventElapsedTime (&ms, e0, e1) ;
+    hipError_t err = hipGetLastError () ;
+    (void) hipFree (d) ; (void) hipFree (dg) ;
+    (void) hipEventDestroy (e0) ; (void) hipEventDestroy (e1) ;
+    if (err != hipSuccess || ms <= 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+    const double entries = (double) n1 * (n1 + 1) / 2 + (double) (m1 - n1) * n1 + (double) m2 * (m2 + 1) / 2 ;
+    return 2.0 * entries * k * iters / (ms * 1e-3) ;
+}
+
 /* mixed MFMA+VALU issue test: returns seconds; flops are computed by the caller */
 double cholmod_hip_bench_mixed (int blocks_per_cu, int it_mfma, int it_valu)
 {
@@ -529,6 +598,9 @@ __global__ void k_where_am_i (long long *out, long long spin_ticks)
         unsigned xcc = __builtin_amdgcn_s_getreg ((31 << 11) | 20) ;    // HW_REG_XCC_ID
         out [blockIdx.x] = ((long long) xcc << 32) | hw ;
     }
+    // (spin_ticks < 0: uneven durations, 1 .. 4 times |spin_ticks| by a hash of the block index -- does the block -> XCD
+    // assignment stay blockIdx % 8 when workgroups retire out of order?  tools/xcd_map.py)
+    if (spin_ticks < 0) spin_ticks = -spin_ticks * (1 + (long long) (((unsigned) blockIdx.x * 2654435761u) >> 30)) ;
     long long t0 = __builtin_amdgcn_s_memrealtime () ;
     while (__builtin_amdgcn_s_memrealtime () - t0 < spin_ticks) __builtin_amdgcn_s_sleep (8) ;
 }

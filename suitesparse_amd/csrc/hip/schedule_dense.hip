@@ -13,6 +13,7 @@
 // column being factored lives in a window on every member, is summed by a reduce-scatter by row chunks before its chain and
 // gathered after it (emit_rs / emit_ag), the next one opened and summed ahead of time beside the rest of the outer update.
 #include "plan.hip.h"
+#include <algorithm>
 
 namespace sship {
 namespace {
@@ -64,6 +65,7 @@ struct DenseScheduler
     i64 unfuse_tiles ;              // a chain update of this many tiles is not fused with the next dpotrf (CHOLMOD_HIP_UNFUSE_TILES)
     bool by_launch ;                // ... pooled over the regions of a launch (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only)
     bool one_region ;               // tuning (CHOLMOD_HIP_UPDW_ONE_REGION=1): every region of a k_update3 launch a launch of its own
+    bool w_squares_first ;          // tuning (CHOLMOD_HIP_UPDW_SQUARES_FIRST=1): square regions ahead of trapezoids in a k_update3 launch
     i64 w_alone_tiles ;             // a region of this many tiles is a k_update3 launch of its own (CHOLMOD_HIP_UPDW_ALONE_TILES; 0: never)
     bool swz16 ;                    // tuning (CHOLMOD_HIP_SWZ16=1): 16 x 16 super-tiles for the one-wave-per-tile walk
     bool xla ;                      // exchange look-ahead (several ranks)
@@ -104,7 +106,8 @@ struct DenseScheduler
         if (!allow_half || w_min_tiles <= 0) w_half_max = 0 ;
         if (w_half_max <= 0 || w_half_min > w_min_tiles) w_half_min = w_min_tiles ;
         one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
-        { const char *e = getenv ("CHOLMOD_HIP_UPDW_ALONE_TILES") ; w_alone_tiles = e ? (i64) atoll (e) : (i64) 32768 ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UPDW_SQUARES_FIRST") ; w_squares_first = e && atoi (e) != 0 ; }
+        { const char *e = getenv ("CHOLMOD_HIP_UPDW_ALONE_TILES") ; w_alone_tiles = e ? (i64) atoll (e) : (i64) 0 ; }
         swz16 = getenv ("CHOLMOD_HIP_SWZ16") != nullptr ;
         xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
         balance_cb = !use_big && !getenv ("CHOLMOD_HIP_NO_CB_BALANCE") ;
@@ -376,14 +379,22 @@ struct DenseScheduler
             L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
             tiles = 0 ;
         } ;
+        // One wave per tile keeps its L2 reuse only while the waves of a super-tile run in step: a launch starts all its
+        // waves at once, tiles of equal K take equal time, so round after round of 2048 tiles starts together -- until slower
+        // tiles scatter the starts, after which every wave streams its operands alone (twice the bytes per second at the
+        // memory side, 66 instead of 74 TFLOP/s, for the REST of the launch: tools/upd3.py pair).
+        // The slow tiles were the partial ones of a trapezoid's ragged last tile column (clamped 8-byte loads, twice the
+        // time); since they load like whole tiles (kernels.hip.h: UPD3_CLAMP_LOADS) the order of the regions in a launch no
+        // longer matters (squares first: +-0.3 %, opt-in).
+        if (kind == K_UPD_W && w_squares_first)
+            std::stable_partition (v.begin (), v.end (), [] (const GemmGroup &G) { return G.tri && G.m == G.n ; }) ;
         bool alone = false ;        // the launch holds a region that keeps it to itself
         for (auto &G : v)
         {
-            // A big region gets a launch of its own (w_alone_tiles = 32 768; measured at 200^3, tools/lp_by_k.py / lp_regions.py:
-            // the outer update of a top front as ONE launch -- the trapezoid of its in-front columns and the square of its
-            // contribution block -- runs at 66 - 69 TFLOP/s, the same two regions as two launches at 72.6 - 74.6 each; the step
-            // 7188 -> 7069 ms, un-profiled, same box: profiles/r05_ab_updw_alone.log).  Why one launch is slower is not
-            // understood; launch boundaries cost nothing at these sizes.
+            // tuning (CHOLMOD_HIP_UPDW_ALONE_TILES=t): a region of >= t tiles gets a launch of its own.  It was the default for a
+            // day (t = 32 768: the outer update of a top front ran at 66 - 69 TFLOP/s as one launch of trapezoid + square, at
+            // 72.6 - 74.6 as two; 200^3 7188 -> 7069 ms) -- until the cause turned out to be the slow partial tiles (above);
+            // with those fixed the one launch is as fast and saves its tail: 6953 against 6967 ms (profiles/r05_ab_updw_alone.log).
             const bool big_one = kind == K_UPD_W && w_alone_tiles > 0 && region_tiles (G) >= w_alone_tiles ;
             if ((one_region || big_one || alone) && kind == K_UPD_W && S.gg.size () > L.goff) close_launch () ;
             alone = big_one ;

@@ -8,6 +8,7 @@
   offset      the operands 0 / 60 / 150 / 240 GB into one allocation (does it matter where a front lives?)
   rounds      triangular regions of 6k .. 48k rows at K = 4096 / 1024: rate against the number of rounds of 2048 tiles
   trap        tall trapezoids (the in-front part of a top front's outer update) against the square of its contribution block
+  pair        a top front's outer update (trapezoid + square on one panel) as one launch, as two, and re-ordered
 usage: python tools/upd3.py [mode]      prints one JSON line"""
 import ctypes as C
 import json
@@ -89,6 +90,14 @@ elif mode == "trap":
             "trap_42397x2797_even": (42397, 2797, 4096, 2, TRI | D4), "trap_42368x2816_even": (42368, 2816, 4096, 2, TRI | D4),
             "trap_42397x512": (42397, 512, 4096, 4, TRI | D4 | ODD), "trap_42397x1024": (42397, 1024, 4096, 4, TRI | D4 | ODD)}.items():
         out[name] = pr.cholmod_hip_bench_update_kernel(m, n, k, it, fl) / 1e12
+elif mode == "pair":
+    # (round 5) the outer update of a top front of the 200^3 factorization -- trapezoid 42696 x 2896 and square 39800^2 on one
+    # panel of ld 50888, K = 4096 -- as ONE launch (the engine before the split: 67 TFLOP/s there), as two launches (what ships),
+    # as one launch with the square first, and with the square's blocks starting at a multiple of 16 384
+    for name, (m1, n1, m2, k, ld) in {"front_50888_ob1": (42696, 2896, 39800, 4096, 50888), "front_50888_ob0": (46792, 6992, 39800, 4096, 50888),
+                                      "front_62801_ob4": (42321, 2321, 40000, 4096, 62801), "mid_100cubed": (11000, 1024, 9900, 4096, 14000)}.items():
+        out[name] = {mname: pr.cholmod_hip_bench_update_pair(m1, n1, m2, k, ld, 2, md) / 1e12
+                     for mname, md in (("one_launch", 0), ("two_launches", 1), ("one_launch_square_first", 2), ("one_launch_square_at_16384", 3))}
 elif mode == "sustain":
     for it in (2, 12, 36):
         out[f"u3_tri48k_K4096_iters{it}"] = pr.cholmod_hip_bench_update_kernel(49152, 49152, 4096, it, TRI | D4) / 1e12
