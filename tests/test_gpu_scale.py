@@ -324,9 +324,10 @@ def test_wave_tile_update_kernel_everywhere_and_nowhere(monkeypatch, min_tiles):
 
 
 def test_big_update_regions_in_launches_of_their_own(monkeypatch):
-    """Round 5: a region of >= 32 768 tiles is a k_update3 launch of its own (schedule_dense.hip: w_alone_tiles; the outer update
-    of a top front as one launch of two regions ran 7 % below the two launches).  With the threshold at 64 tiles and every
-    region through k_update3 the split happens on every level of the test problems; against the oracle, more launches."""
+    """Round 5, tuning knob CHOLMOD_HIP_UPDW_ALONE_TILES (schedule_dense.hip: w_alone_tiles): a region of that many tiles is a
+    k_update3 launch of its own -- the default for a day, until the partial tiles that made the combined launch slow were fixed
+    in the kernel.  With the threshold at 64 tiles and every region through k_update3 the split happens on every level of the
+    test problems; against the oracle, more launches."""
     n, Ap, Ai, Ax, perm, O, mask = _oracle("p3d_64_nd")
     launches = {}
     for alone in ("0", "64"):
