@@ -70,6 +70,7 @@ def run_once(S, n, Ap, Ai, Ax, stype, perm, b):
     ch._view(a.i, nz, C.c_int64, np.int64)[:] = Ai
     ch._view(a.x, nz, C.c_double, np.float64)[:] = Ax
     stage, res, Lf, B, X = "analyze", None, None, None, None
+    X2, Y2, E2, Xs = C.POINTER(ch.Dense)(), C.POINTER(ch.Dense)(), C.POINTER(ch.Dense)(), C.POINTER(ch.Sparse)()
     try:
         if perm is None:
             Lf = S.L.cholmod_l_analyze(A, cm)
@@ -94,8 +95,37 @@ def run_once(S, n, Ap, Ai, Ax, stype, perm, b):
             return stage, None
         x = ch._view(X.contents.x, n, C.c_double, np.float64).copy()
         res = float(np.linalg.norm(G.sym_matvec(n, Ap, Ai, Ax, stype, x) - b) / np.linalg.norm(b))
+        # ... and the solve with a sparse right-hand side (Bset): IPerm, the column -> supernode map, Xset, Y and X are
+        # allocated on the way, each of them may fail
+        stage = "subset"
+        Bs = S.L.cholmod_l_allocate_sparse(n, 1, 2, 0, 1, 0, ch.PATTERN, cm)
+        if not Bs:
+            return stage, None
+        try:
+            ch._view(Bs.contents.p, 2, C.c_int64, np.int64)[:] = [0, 2]
+            ch._view(Bs.contents.i, 2, C.c_int64, np.int64)[:] = [0, n // 2]
+            b2 = np.zeros(n); b2[[0, n // 2]] = [1.0, -2.0]
+            ch._view(B.contents.x, n, C.c_double, np.float64)[:] = b2
+            ok = S.L.cholmod_l_solve2(ch.SYS_A, Lf, B, Bs, C.byref(X2), C.byref(Xs), C.byref(Y2), C.byref(E2), cm)
+            if not ok:
+                return stage, None
+            k = int(ch._view(Xs.contents.p, 2, C.c_int64, np.int64)[1])
+            xset = ch._view(Xs.contents.i, k, C.c_int64, np.int64).copy()
+            x2 = ch._view(X2.contents.x, n, C.c_double, np.float64).copy()
+            # (X is defined on Xset only: compared with a full solve of the same right-hand side)
+            Xf = S.L.cholmod_l_solve(ch.SYS_A, Lf, B, cm)
+            if not Xf:
+                return stage, None
+            xf = ch._view(Xf.contents.x, n, C.c_double, np.float64).copy()
+            S.free_dense(Xf)
+            assert np.allclose(x2[xset], xf[xset], rtol=1e-11, atol=1e-13)
+        finally:
+            S.free_sparse(Bs)
         return "done", res
     finally:
+        for h, fr in ((X2, S.free_dense), (Y2, S.free_dense), (Xs, S.free_sparse)):
+            if h:
+                fr(h)
         if X:
             S.free_dense(X)
         if B:
@@ -135,7 +165,7 @@ def test_every_host_allocation_may_fail_cpu_path(case, golden_dir):
                 assert stage == "done" and res < 1e-11, (k, stage, res)
                 done = True
             k += 1
-    assert k > 20 and {"analyze", "factorize", "solve"} <= stages, (k, stages)
+    assert k > 20 and {"analyze", "factorize", "solve", "subset"} <= stages, (k, stages)
     S.finish()
 
 
