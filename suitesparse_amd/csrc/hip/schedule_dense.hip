@@ -61,12 +61,10 @@ struct DenseScheduler
     // fewer than w_half_max tiles runs in half tiles, and the regions of a flush go to it from w_half_min pooled tiles on
     // instead of 2048.  CHOLMOD_HIP_UPD3_HALF_MAX=0: off (whole tiles from 2048 on, as in rounds 3-4).
     i64 w_half_min, w_half_max ;
-    int w_min_k ;                   // shortest contraction a pooled region may have (CHOLMOD_HIP_UPD3_MIN_K)
-    i64 unfuse_tiles ;              // a chain update of this many tiles is not fused with the next dpotrf (CHOLMOD_HIP_UNFUSE_TILES)
+    int w_min_k ;                   // shortest contraction a pooled region may have
+    i64 unfuse_tiles ;              // a chain update of this many tiles is not fused with the next dpotrf
     bool by_launch ;                // ... pooled over the regions of a launch (CHOLMOD_HIP_UPD3_BY_LAUNCH=0: by region only)
     bool one_region ;               // tuning (CHOLMOD_HIP_UPDW_ONE_REGION=1): every region of a k_update3 launch a launch of its own
-    bool w_squares_first ;          // tuning (CHOLMOD_HIP_UPDW_SQUARES_FIRST=1): square regions ahead of trapezoids in a k_update3 launch
-    i64 w_alone_tiles ;             // a region of this many tiles is a k_update3 launch of its own (CHOLMOD_HIP_UPDW_ALONE_TILES; 0: never)
     bool swz16 ;                    // tuning (CHOLMOD_HIP_SWZ16=1): 16 x 16 super-tiles for the one-wave-per-tile walk
     bool xla ;                      // exchange look-ahead (several ranks)
     bool chain256 = false ;         // the 256-column chain instead of the 64-column one
@@ -100,14 +98,12 @@ struct DenseScheduler
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; w_min_tiles = e ? (i64) atoll (e) : (i64) 2048 ; }
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; by_launch = !(e && atoi (e) == 0) ; }
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MAX") ; w_half_max = e ? (i64) atoll (e) : (i64) 10240 ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MIN") ; w_half_min = e ? (i64) atoll (e) : (i64) 512 ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_K") ; w_min_k = e ? atoi (e) : 256 ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UNFUSE_TILES") ; unfuse_tiles = e ? (i64) atoll (e) : w_min_tiles ; }
+        // (measured flat within the noise and fixed: pooled regions from 256 / 512 / 1024 tiles on, shortest pooled contraction
+        // 256 / 128 / 64, chain updates un-fused from 2048 ... 256 tiles on -- profiles/r05_ab_upd3_half_knobs.log)
+        w_half_min = 512 ; w_min_k = 256 ; unfuse_tiles = w_min_tiles ;
         if (!allow_half || w_min_tiles <= 0) w_half_max = 0 ;
         if (w_half_max <= 0 || w_half_min > w_min_tiles) w_half_min = w_min_tiles ;
         one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
-        { const char *e = getenv ("CHOLMOD_HIP_UPDW_SQUARES_FIRST") ; w_squares_first = e && atoi (e) != 0 ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UPDW_ALONE_TILES") ; w_alone_tiles = e ? (i64) atoll (e) : (i64) 0 ; }
         swz16 = getenv ("CHOLMOD_HIP_SWZ16") != nullptr ;
         xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
         balance_cb = !use_big && !getenv ("CHOLMOD_HIP_NO_CB_BALANCE") ;
@@ -379,25 +375,12 @@ struct DenseScheduler
             L = Launch {L.kind, 0, 0, S.gg.size (), 0, 0} ;
             tiles = 0 ;
         } ;
-        // One wave per tile keeps its L2 reuse only while the waves of a super-tile run in step: a launch starts all its
-        // waves at once, tiles of equal K take equal time, so round after round of 2048 tiles starts together -- until slower
-        // tiles scatter the starts, after which every wave streams its operands alone (twice the bytes per second at the
-        // memory side, 66 instead of 74 TFLOP/s, for the REST of the launch: tools/upd3.py pair).
-        // The slow tiles were the partial ones of a trapezoid's ragged last tile column (clamped 8-byte loads, twice the
-        // time); since they load like whole tiles (kernels.hip.h: UPD3_CLAMP_LOADS) the order of the regions in a launch no
-        // longer matters (squares first: +-0.3 %, opt-in).
-        if (kind == K_UPD_W && w_squares_first)
-            std::stable_partition (v.begin (), v.end (), [] (const GemmGroup &G) { return G.tri && G.m == G.n ; }) ;
-        bool alone = false ;        // the launch holds a region that keeps it to itself
+        // (One wave per tile keeps its L2 reuse only while the waves of a super-tile run in step -- DESIGN section 9 item 3: what
+        // broke the step were the partial tiles' slow loads, fixed in the kernel; re-ordering the regions of a launch, squares
+        // ahead of trapezoids, or giving the big ones launches of their own then measured +-0.3 % and is not done.)
         for (auto &G : v)
         {
-            // tuning (CHOLMOD_HIP_UPDW_ALONE_TILES=t): a region of >= t tiles gets a launch of its own.  It was the default for a
-            // day (t = 32 768: the outer update of a top front ran at 66 - 69 TFLOP/s as one launch of trapezoid + square, at
-            // 72.6 - 74.6 as two; 200^3 7188 -> 7069 ms) -- until the cause turned out to be the slow partial tiles (above);
-            // with those fixed the one launch is as fast and saves its tail: 6953 against 6967 ms (profiles/r05_ab_updw_alone.log).
-            const bool big_one = kind == K_UPD_W && w_alone_tiles > 0 && region_tiles (G) >= w_alone_tiles ;
-            if ((one_region || big_one || alone) && kind == K_UPD_W && S.gg.size () > L.goff) close_launch () ;
-            alone = big_one ;
+            if (one_region && kind == K_UPD_W && S.gg.size () > L.goff) close_launch () ;
             const i64 mine = place_region (G, T, kind == K_UPD_W, tiles) ;
             if (mine == 0) continue ;
             const i64 cnt = G.ntiles ;

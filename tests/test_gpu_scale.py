@@ -323,30 +323,6 @@ def test_wave_tile_update_kernel_everywhere_and_nowhere(monkeypatch, min_tiles):
     S.finish()
 
 
-def test_big_update_regions_in_launches_of_their_own(monkeypatch):
-    """Round 5, tuning knob CHOLMOD_HIP_UPDW_ALONE_TILES (schedule_dense.hip: w_alone_tiles): a region of that many tiles is a
-    k_update3 launch of its own -- the default for a day, until the partial tiles that made the combined launch slow were fixed
-    in the kernel.  With the threshold at 64 tiles and every region through k_update3 the split happens on every level of the
-    test problems; against the oracle, more launches."""
-    n, Ap, Ai, Ax, perm, O, mask = _oracle("p3d_64_nd")
-    launches = {}
-    for alone in ("0", "64"):
-        monkeypatch.setenv("CHOLMOD_HIP_UPD3_MIN_TILES", "16")
-        monkeypatch.setenv("CHOLMOD_HIP_UPDW_ALONE_TILES", alone)
-        S = ch.Session()
-        A = S.sparse(n, Ap, Ai, Ax, -1)
-        Lf = S.analyze(A, perm)
-        assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
-        launches[alone] = S.hip_stats(Lf)[33]
-        fv = ch.FactorView(Lf)
-        assert np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask]) < TOL_L
-        S.free_factor(Lf)
-        S.free_sparse(A)
-        S.finish()
-    assert launches["64"] > launches["0"] > 0, launches
-    _compare("box42_r3_nd")
-
-
 def test_dense_front_with_ragged_sizes_through_wave_tiles(monkeypatch):
     """A dense front whose sizes are multiples of nothing (2 717 rows, 1 333 eliminated columns:
     partial last tiles in both directions, a last outer block of 53 columns -> K = 53), every
