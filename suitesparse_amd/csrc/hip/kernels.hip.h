@@ -2011,18 +2011,10 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
             for (int q = 0 ; q < 2 ; q++)
             {
                 const int i = 32 * q + 2 * lr ;
-                if constexpr (EDGE)
+                // the row pair (i, i + 1) of column j, both rows inside the region
+                auto store_pair = [&] ()
                 {
-#pragma unroll
-                    for (int h = 0 ; h < 2 ; h++)
-                        if (i + h < mrem && j < nrem && (!diag || i + h >= jd))
-                        {
-                            if (G.assign) Cj [i + h] = -acc [2 * q + h][b][r] ;
-                            else Cj [i + h] -= acc [2 * q + h][b][r] ;
-                        }
-                }
-                else if (!diag || i + 1 >= jd)
-                {
+                    if (diag && i + 1 < jd) return ;
                     d2u v ;
                     if (G.assign) { v.x = -acc [2 * q][b][r] ; v.y = -acc [2 * q + 1][b][r] ; }
                     else
@@ -2032,7 +2024,22 @@ __device__ __forceinline__ void update_tile_w (const GemmGroup &G, int I, int J,
                     }
                     if (diag && i < jd) Cj [i + 1] = v.y ;          // (the pair straddles the diagonal)
                     else *(d2u *) (Cj + i) = v ;
+                } ;
+                if constexpr (EDGE)
+                {
+                    // (a partial tile stores like a whole one wherever the pair and the column exist: its masked scalar stores made
+                    // it slower than its neighbours at short K, and tiles of unequal length cost the launch its lockstep)
+                    if (j < nrem)
+                    {
+                        if (i + 1 < mrem) store_pair () ;
+                        else if (i < mrem && (!diag || i >= jd))
+                        {
+                            if (G.assign) Cj [i] = -acc [2 * q][b][r] ;
+                            else Cj [i] -= acc [2 * q][b][r] ;
+                        }
+                    }
                 }
+                else store_pair () ;
             }
         }
 }
