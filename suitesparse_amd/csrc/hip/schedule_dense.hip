@@ -13,7 +13,6 @@
 // column being factored lives in a window on every member, is summed by a reduce-scatter by row chunks before its chain and
 // gathered after it (emit_rs / emit_ag), the next one opened and summed ahead of time beside the rest of the outer update.
 #include "plan.hip.h"
-#include <algorithm>
 
 namespace sship {
 namespace {
