@@ -147,7 +147,8 @@ def cpu_baseline(sample_m):
         return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {err}"}
     top = max(pts, key=lambda q: q["GFLOPs"])
     one = next((q for q in pts if q["threads"] == 1), None)
-    return {"value": top["GFLOPs"], "unit": "GFLOP/s", "cores": top["threads"], "kind": "port",
+    return {"value": top["GFLOPs"], "unit": "GFLOP/s", "cores": top["threads"], "host_cores": cores, "kind": "port",
+            "sample_short": f"poisson3d {sample_m}^3 ND, whole factorization, {top['seconds_best']:.1f} s",
             "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
             "by_threads": pts,
             "speedup_over_one_thread": (top["GFLOPs"] / one["GFLOPs"]) if one else None,
@@ -589,6 +590,134 @@ def launch_ranks(n, backend):
     return subprocess.call(cmd, env=env)
 
 
+LINE_LIMIT = 4096       # bytes of the ONE stdout line (round-5 review: a 25.9 KB line left the driver's record unparsed)
+
+
+def _r(x, sig=6):
+    """A number at `sig` significant digits (None / non-finite -> None): the line carries numbers, not 17-digit reprs."""
+    if x is None or isinstance(x, (bool, str)):
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    x = float(x)
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{sig}g}")
+
+
+def compact_line(full):
+    """The ONE line the driver parses, built from the full record: numbers only, no prose, <= LINE_LIMIT bytes.  The full
+    record (counter tables, per-class times, sweeps, notes) goes to bench_detail.json and to stderr."""
+    g = full.get
+    line = {k: g(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                              "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _r(g("value"), 12), _r(g("ms_per_step"), 12)
+    cfg = g("config") or {}
+    line["config"] = {k: _r(cfg.get(k), 12 if k == "fl" else 7) for k in ("workload", "n", "fl", "executed_flops", "nsuper", "Lx_GB", "launches_per_step")
+                      if k in cfg}
+    line["config"]["parallelism"] = ("1 GPU" if g("n_gpus") == 1 else f"{g('n_gpus')} GPUs, etree subtrees + column slabs of shared fronts")
+    for k in ("pct_fp64_mfma_peak_per_gpu", "ms_per_step_resident", "ms_per_step_api", "value_api", "residual_2norm",
+              "measured_fp64_mfma_ceiling_TFLOPs"):
+        if g(k) is not None:
+            line[k] = _r(g(k))
+    rf = g("roofline")
+    if rf:
+        mu = rf.get("mfma_utilisation")
+        if isinstance(mu, dict):
+            mu = mu.get("mfma_pipe_utilisation", mu.get("mfma_utilisation"))
+        ach = _r(rf["achieved"], 8)
+        line["roofline"] = {"bound": rf["bound"], "achieved": ach, "peak": rf["peak"], "unit": rf["unit"],
+                            "frac": (ach / rf["peak"]) if ach is not None else None, "traffic": _r(rf.get("traffic")),
+                            "traffic_over_algorithmic": _r(rf.get("traffic_over_algorithmic"), 4),
+                            "mfma_utilisation": _r(mu, 4), "kernel": (rf.get("kernel") or "").split(" ")[0],
+                            "launches": rf.get("launches"), "avg_launch_ms": _r(rf.get("avg_launch_ms"))}
+    else:
+        line["roofline"] = None
+    cb = g("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "host_cores": cb.get("host_cores"), "kind": cb.get("kind"),
+                                "sample": (cb.get("sample_short") or (cb.get("sample") or "")[:60])}
+        if cb.get("by_threads"):
+            line["cpu_baseline"]["by_threads"] = {str(q["threads"]): _r(q["GFLOPs"], 4) for q in cb["by_threads"]}
+    else:
+        line["cpu_baseline"] = None
+    hs = g("host_seconds")
+    if hs:
+        line["host_seconds"] = {k: _r(v, 4) for k, v in hs.items()}
+    for key in ("factor_checks", "factor_checks_distributed"):
+        fc = g(key)
+        if fc:
+            line[key] = {k: _r(fc.get(k), 4) for k in ("logdet_rel_err", "trace_rel_err", "upper_nonzeros", "nonfinite",
+                                                       "nonpositive_diag", "solve_device_ms", "ranks_that_could_not_check")
+                         if fc.get(k) is not None}
+    sec = []
+    for s in g("secondary") or []:
+        if "error" in s:
+            sec.append({"workload": s.get("workload", "")[:40], "error": str(s["error"])[:80]})
+            continue
+        if "complex" in s:          # the complex line: times only
+            sec.append({"workload": s["workload"].split(" ")[0], "ms_per_step": _r(s["complex"]["ms_per_step"]),
+                        "TFLOPs_on_4fl": _r(s["complex"].get("TFLOPs_on_4fl")), "complex_over_real_time": _r(s.get("complex_over_real_time"), 4),
+                        "residual_2norm": _r(s["complex"].get("residual_2norm"), 3)})
+            continue
+        r2 = s.get("roofline") or {}
+        o = {"workload": s["workload"].split(" ")[0], "value": _r(s.get("value")), "ms_per_step": _r(s.get("ms_per_step")),
+             "ms_per_step_resident": _r(s.get("ms_per_step_resident")), "pct_fp64_mfma_peak": _r(s.get("pct_fp64_mfma_peak"), 4),
+             "pct_fp64_mfma_peak_resident": _r(s.get("pct_fp64_mfma_peak_resident"), 4),
+             "roofline_frac": _r(r2.get("frac"), 4), "critical_path_ratio": _r(s.get("ms_per_step_over_critical_path"), 4),
+             "residual_2norm": _r(s.get("residual_2norm"), 3)}
+        if s.get("hbm_roofline"):
+            o["hbm_roofline_frac"] = _r(s["hbm_roofline"].get("frac"), 4)
+        sec.append(o)
+    if sec:
+        line["secondary"] = sec
+    ex = g("exchange")
+    if ex:
+        line["exchange"] = {k: _r(v, 5) for k, v in ex.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
+    for k in ("truncated", "error", "residual_2norm_note"):
+        if g(k):
+            line[k] = str(g(k))[:160]
+    line["detail"] = "bench_detail.json"
+    txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    # (should anything above ever grow past the limit, the optional parts go first: the contract keys never do)
+    for drop in ("secondary", "host_seconds", "factor_checks", "factor_checks_distributed", "exchange"):
+        if len(txt) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(txt) <= LINE_LIMIT, len(txt)
+    return txt
+
+
+def emit(full, out_fd):
+    """Full record -> bench_detail.json (beside bench.py, and under gpurun_out/ when that exists) and stderr; the compact
+    line -> stdout."""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (np.integer,)):
+            return int(o)
+        if isinstance(o, (float, np.floating)):
+            o = float(o)
+            return o if (o == o and abs(o) != float("inf")) else None
+        return o
+    full = clean(full)
+    detail = json.dumps(full, allow_nan=False, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+    sys.stderr.write("[bench detail] " + json.dumps(full, allow_nan=False) + "\n")
+    sys.stderr.flush()
+    os.write(out_fd, (compact_line(full) + "\n").encode())
+
+
 METRIC = "GFLOP/s supernodal Cholesky factor (Common->fl / t_factorize)"
 
 
@@ -667,9 +796,13 @@ class Watchdog:
             # the timed region is complete: the measurement goes out, marked as cut short
             line = dict(self.fallback, truncated=why + " -- sections after the timed region are missing from this line")
             rc = 0
-        txt = json.dumps(line)
+        txt = json.dumps(line, default=str)
         if self.rank == 0:
-            os.write(self.out_fd, (txt + "\n").encode())
+            try:
+                os.write(self.out_fd, (compact_line(line) + "\n").encode())
+            except Exception:
+                os.write(self.out_fd, (json.dumps({k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "error", "phase")},
+                                                  default=str)[:LINE_LIMIT] + "\n").encode())
         else:
             time.sleep(8.0)             # rank 0's line first
         sys.stderr.write(f"[bench watchdog rank {self.rank}] {txt}\n")
@@ -1118,7 +1251,7 @@ def main():
             already = wd.done
             wd.done = True
         if not already:
-            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            emit(line, real_stdout)
     wd.finish()
     if dist is not None:
         dist.destroy_process_group()

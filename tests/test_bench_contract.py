@@ -17,10 +17,12 @@ def test_bench_json_line_contract():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, out.stdout
+    assert len(lines[0]) < 4096, len(lines[0])          # (round-5 review: a 25.9 KB line left the driver's record unparsed)
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
+    assert os.path.exists(os.path.join(ROOT, "bench_detail.json"))
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "GFLOP/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["value"] > 0 and abs(d["value"] - d["config"]["fl"] / d["ms_per_step"] / 1e6) < 1e-6 * d["value"]
