@@ -678,6 +678,17 @@ def compact_line(full):
     for k in ("truncated", "error", "residual_2norm_note"):
         if g(k):
             line[k] = str(g(k))[:160]
+    if g("error"):      # the watchdog's line: where the run stood (small: nothing after the timed region exists)
+        for k in ("phase", "rank", "steps_completed", "last_completed_step_ms", "seconds_since_start"):
+            if k in full:
+                line[k] = _r(g(k)) if not isinstance(g(k), str) else g(k)[:160]
+        if g("completed_step_ms"):
+            line["completed_step_ms"] = [_r(v, 5) for v in g("completed_step_ms")[-8:]]
+        if g("progress"):
+            line["progress"] = g("progress")
+        for k in ("roofline", "cpu_baseline"):
+            if line.get(k) is None:
+                line.pop(k, None)
     line["detail"] = "bench_detail.json"
     txt = json.dumps(line, allow_nan=False, separators=(",", ":"))
     # (should anything above ever grow past the limit, the optional parts go first: the contract keys never do)

@@ -194,6 +194,8 @@ typedef struct cholmod_common_struct
     int hip_cpu_fallback ;
     int prefer_zomplex ;            /* X of cholmod_l_solve: zomplex instead of complex
                                      * (reference cholmod_core.h, Cholesky/cholmod_solve.c:1112) */
+    int prefer_binary ;             /* cholmod_l_read_*: a symmetric pattern-only file keeps all-one values instead of
+                                     * diagonal = 1 + degree, off-diagonal = -1 (cholmod_core.h:545-560) */
 } cholmod_common ;
 
 typedef struct cholmod_sparse_struct
@@ -291,7 +293,15 @@ int cholmod_l_free_dense (cholmod_dense **X, cholmod_common *Common) ;
 int cholmod_l_free_factor (cholmod_factor **L, cholmod_common *Common) ;
 
 /* ---- Check / IO ------------------------------------------------------------ */
+/* Check/cholmod_read.c (cholmod_check.h:251-330): triplet ("coordinate") and dense ("array") files, Matrix Market banner
+ * optional, real / complex / pattern */
+#define CHOLMOD_SPARSE 1            /* *mtype of cholmod_l_read_matrix (cholmod_core.h:300-303) */
+#define CHOLMOD_DENSE 3
+#define CHOLMOD_TRIPLET 4
 cholmod_sparse *cholmod_l_read_sparse (FILE *f, cholmod_common *Common) ;
+cholmod_triplet *cholmod_l_read_triplet (FILE *f, cholmod_common *Common) ;
+cholmod_dense *cholmod_l_read_dense (FILE *f, cholmod_common *Common) ;
+void *cholmod_l_read_matrix (FILE *f, int prefer, int *mtype, cholmod_common *Common) ;
 int cholmod_l_check_factor (cholmod_factor *L, cholmod_common *Common) ;
 int cholmod_l_check_sparse (cholmod_sparse *A, cholmod_common *Common) ;
 int cholmod_l_gpu_stats (cholmod_common *Common) ;

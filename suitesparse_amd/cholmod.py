@@ -76,7 +76,7 @@ class Common(C.Structure):
         ("hip_factor_on_device", C.c_int), ("hip_flags", C.c_int), ("hip_profile", C.c_int),
         ("hip_rank", C.c_int), ("hip_world", C.c_int),
         ("hip_allreduce", C.c_void_p), ("hip_allreduce_user", C.c_void_p),
-        ("hip_cpu_fallback", C.c_int), ("prefer_zomplex", C.c_int),
+        ("hip_cpu_fallback", C.c_int), ("prefer_zomplex", C.c_int), ("prefer_binary", C.c_int),
     ]
 
 
@@ -85,6 +85,12 @@ class Sparse(C.Structure):
                 ("p", C.c_void_p), ("i", C.c_void_p), ("nz", C.c_void_p), ("x", C.c_void_p),
                 ("z", C.c_void_p), ("stype", C.c_int), ("itype", C.c_int), ("xtype", C.c_int),
                 ("dtype", C.c_int), ("sorted", C.c_int), ("packed", C.c_int)]
+
+
+class Triplet(C.Structure):
+    _fields_ = [("nrow", C.c_size_t), ("ncol", C.c_size_t), ("nzmax", C.c_size_t), ("nnz", C.c_size_t),
+                ("i", C.c_void_p), ("j", C.c_void_p), ("x", C.c_void_p), ("z", C.c_void_p),
+                ("stype", C.c_int), ("itype", C.c_int), ("xtype", C.c_int), ("dtype", C.c_int)]
 
 
 class Dense(C.Structure):
@@ -120,7 +126,7 @@ API_SYMBOLS = [
     "cholmod_l_allocate_triplet", "cholmod_l_free_triplet", "cholmod_l_triplet_to_sparse",
     "cholmod_l_allocate_dense", "cholmod_l_zeros", "cholmod_l_ones", "cholmod_l_copy_dense",
     "cholmod_l_free_dense", "cholmod_l_free_factor",
-    "cholmod_l_read_sparse", "cholmod_l_check_factor", "cholmod_l_check_sparse",
+    "cholmod_l_read_sparse", "cholmod_l_read_triplet", "cholmod_l_read_dense", "cholmod_l_read_matrix", "cholmod_l_check_factor", "cholmod_l_check_sparse",
     "cholmod_gpu_memorysize", "cholmod_gpu_probe", "cholmod_gpu_deallocate", "cholmod_gpu_end", "cholmod_gpu_allocate",
     "cholmod_l_gpu_stats", "cholmod_l_sdmult", "cholmod_l_norm_dense", "cholmod_l_norm_sparse",
     "cholmod_l_analyze", "cholmod_l_analyze_p", "cholmod_l_analyze_p2",
@@ -240,6 +246,10 @@ def lib(hooks=None):
     sig("cholmod_l_hip_stats", C.c_int, [fc, C.POINTER(dbl * CHOLMOD_HIP_NSTATS), cm])
     sig("cholmod_l_refactorize_resident", C.c_int, [C.POINTER(dbl * 2), fc, cm])
     sig("cholmod_l_read_sparse", sp, [vp, cm])
+    sig("cholmod_l_read_dense", dn, [vp, cm])
+    sig("cholmod_l_read_triplet", vp, [vp, cm])
+    sig("cholmod_l_free_triplet", C.c_int, [C.POINTER(vp), cm])
+    sig("cholmod_l_read_matrix", vp, [vp, C.c_int, C.POINTER(C.c_int), cm])
     # engine shim
     sig("cholmod_hip_probe", C.c_int, [])
     sig("cholmod_hip_set_device", C.c_int, [C.c_int])

@@ -454,8 +454,9 @@ cholmod_sparse *ssamd_sym_permute_src (cholmod_sparse *A, int values, SuiteSpars
                 Int q ;
 #pragma omp atomic capture
                 q = cursor [col]++ ;
-                /* (source position, moved to the other triangle = transposed) */
-                Ci [q] = row ; src [q] = (p << 1) | (row != r) ;
+                /* (source position, moved to the other triangle = transposed; the unpermuted transpose of the reference
+                 * conjugates the diagonal too, the permuted one does not: Core/t_cholmod_transpose.c:199-215, :268-277) */
+                Ci [q] = row ; src [q] = (p << 1) | (row != r || (!Pinv && r == c && upper_in != upper_out)) ;
             }
         }
         /* pass 3: every column sorted by (row, source position), values gathered */
@@ -762,9 +763,9 @@ cholmod_triplet *cholmod_l_allocate_triplet (size_t nrow, size_t ncol, size_t nz
     int stype, int xtype, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (NULL) ;
-    if (xtype != CHOLMOD_PATTERN && xtype != CHOLMOD_REAL)
+    if (xtype != CHOLMOD_PATTERN && xtype != CHOLMOD_REAL && xtype != CHOLMOD_COMPLEX)
     {
-        ERROR (CHOLMOD_INVALID, "xtype invalid") ;
+        ERROR (CHOLMOD_INVALID, "xtype invalid") ;      /* (zomplex triplets: not built -- the reader returns complex) */
         return NULL ;
     }
     Common->status = CHOLMOD_OK ;
@@ -775,7 +776,7 @@ cholmod_triplet *cholmod_l_allocate_triplet (size_t nrow, size_t ncol, size_t nz
     T->stype = stype ; T->itype = CHOLMOD_LONG ; T->xtype = xtype ; T->dtype = CHOLMOD_DOUBLE ;
     T->i = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
     T->j = cholmod_l_malloc (nzmax, sizeof (Int), Common) ;
-    if (xtype == CHOLMOD_REAL) T->x = cholmod_l_malloc (nzmax, sizeof (double), Common) ;
+    if (xtype != CHOLMOD_PATTERN) T->x = cholmod_l_malloc (nzmax, SSAMD_XENT (xtype) * sizeof (double), Common) ;
     if (Common->status < CHOLMOD_OK) { cholmod_l_free_triplet (&T, Common) ; return NULL ; }
     return T ;
 }
@@ -787,7 +788,7 @@ int cholmod_l_free_triplet (cholmod_triplet **TH, cholmod_common *Common)
     cholmod_triplet *T = *TH ;
     cholmod_l_free (T->nzmax, sizeof (Int), T->i, Common) ;
     cholmod_l_free (T->nzmax, sizeof (Int), T->j, Common) ;
-    if (T->x) cholmod_l_free (T->nzmax, sizeof (double), T->x, Common) ;
+    if (T->x) cholmod_l_free (T->nzmax, SSAMD_XENT (T->xtype) * sizeof (double), T->x, Common) ;
     cholmod_l_free (1, sizeof (cholmod_triplet), T, Common) ;
     *TH = NULL ;
     return TRUE ;
@@ -795,7 +796,8 @@ int cholmod_l_free_triplet (cholmod_triplet **TH, cholmod_common *Common)
 
 /* Duplicates are summed; for stype != 0 entries in the ignored triangle are
  * transposed into the stored one (reference Core/cholmod_triplet.c:266-270:
- * "entries in the wrong triangle are transposed").  Output columns sorted. */
+ * "entries in the wrong triangle are transposed" -- the value moves as it is, complex ones
+ * are not conjugated: t_cholmod_triplet.c:62-100).  Output columns sorted. */
 cholmod_sparse *cholmod_l_triplet_to_sparse (cholmod_triplet *T, size_t nzmax,
     cholmod_common *Common)
 {
@@ -838,11 +840,12 @@ cholmod_sparse *cholmod_l_triplet_to_sparse (cholmod_triplet *T, size_t nzmax,
     }
     size_t cap = (size_t) nd > nzmax ? (size_t) nd : nzmax ;
     cholmod_sparse *A = cholmod_l_allocate_sparse (nrow, ncol, cap, TRUE, TRUE, T->stype,
-        T->xtype == CHOLMOD_REAL ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+        T->xtype, Common) ;
     if (A)
     {
         Int *Ap = A->p, *Ai = A->i ;
         double *Ax = A->x ;
+        const int cx = (T->xtype == CHOLMOD_COMPLEX) ;
         Int dst = -1 ;
         for (Int j = 0 ; j <= ncol ; j++) Ap [j] = 0 ;
         for (Int q = 0 ; q < nz ; q++)
@@ -853,10 +856,12 @@ cholmod_sparse *cholmod_l_triplet_to_sparse (cholmod_triplet *T, size_t nzmax,
             {
                 dst++ ;
                 Ai [dst] = r ;
-                if (Ax) Ax [dst] = 0 ;
+                if (Ax && !cx) Ax [dst] = 0 ;
+                if (Ax && cx) Ax [2*dst] = Ax [2*dst+1] = 0 ;
                 Ap [c+1]++ ;
             }
-            if (Ax) Ax [dst] += Tx [k] ;
+            if (Ax && !cx) Ax [dst] += Tx [k] ;
+            if (Ax && cx) { Ax [2*dst] += Tx [2*k] ; Ax [2*dst+1] += Tx [2*k+1] ; }
         }
         for (Int j = 0 ; j < ncol ; j++) Ap [j+1] += Ap [j] ;
     }

@@ -5,90 +5,275 @@
 #include "host_internal.h"
 #include <ctype.h>
 
-/* ---- reader (format: reference Check/cholmod_read.c:14-110) ------------------------- */
+/* ---- reader (format: reference Check/cholmod_read.c:9-140) ---------------------------
+ * One pass over the lines of the file: '%' lines are comments (the first one may be the
+ * Matrix Market banner), blank lines are skipped, the first data line is the header
+ * (2 numbers: a dense "array"; 3 or 4: triplets, the 4th the stype), every later data line
+ * one entry whose token count gives the type (coordinate 2 pattern / 3 real / 4 complex;
+ * array 1 real / 2 complex). */
 
-static int next_data_line (FILE *f, char *buf, size_t cap, char *mm_sym)
+#define RD_LINE 1030            /* the reference's MAXLINE (cholmod_read.c:154) + slack */
+enum { RD_GENERAL = 0, RD_LOWER = -1, RD_UPPER = 1, RD_SKEW = -2, RD_CSYM = -3, RD_UNKNOWN = 999 } ;
+
+typedef struct
 {
-    while (fgets (buf, (int) cap, f))
+    int have_banner ;       /* %%MatrixMarket seen on the first line */
+    int array ;             /* banner says "array" (dense) */
+    int stype ;             /* RD_* */
+    double h [4] ;          /* header numbers */
+    int nh ;
+} rd_head ;
+
+static int rd_blank (const char *p)
+{
+    if (*p == '%') return TRUE ;
+    while (*p) { if (!isspace ((unsigned char) *p)) return FALSE ; p++ ; }
+    return TRUE ;
+}
+
+/* values at or beyond 1e308 stand for +-Inf in these files (cholmod_read.c:173-185) */
+static double rd_value (double x) { return (x >= 1e308 || x <= -1e308) ? 2 * x : x ; }
+
+static int rd_header (FILE *f, char *buf, rd_head *H)
+{
+    int first = TRUE ;
+    memset (H, 0, sizeof (*H)) ;
+    H->stype = RD_UNKNOWN ;
+    while (fgets (buf, RD_LINE, f))
     {
-        char *p = buf ;
-        while (*p && isspace ((unsigned char) *p)) p++ ;
-        if (*p == '\0') continue ;
-        if (*p == '%')
+        if (first && strncasecmp (buf, "%%MatrixMarket", 14) == 0)
         {
-            if (mm_sym && strncasecmp (p, "%%MatrixMarket", 14) == 0)
-            {
-                /* %%MatrixMarket matrix <fmt> <type> <storage> */
-                char w [5][64] = {{0}} ;
-                sscanf (p, "%63s %63s %63s %63s %63s", w [0], w [1], w [2], w [3], w [4]) ;
-                char c0 = (char) tolower ((unsigned char) w [4][0]) ;
-                char c1 = (char) tolower ((unsigned char) w [4][1]) ;
-                *mm_sym = (c0 == 's' && c1 == 'k') ? 'k' : c0 ;
-            }
+            /* %%MatrixMarket matrix <fmt> <type> <storage>: first letters only */
+            char w [5][64] = {{0}} ;
+            if (sscanf (buf, "%63s %63s %63s %63s %63s", w [0], w [1], w [2], w [3], w [4]) < 5) return FALSE ;
+            int fmt = tolower ((unsigned char) w [2][0]), typ = tolower ((unsigned char) w [3][0]) ;
+            int s0 = tolower ((unsigned char) w [4][0]), s1 = tolower ((unsigned char) w [4][1]) ;
+            if (tolower ((unsigned char) w [1][0]) != 'm' || (fmt != 'c' && fmt != 'a')) return FALSE ;
+            if (typ != 'r' && typ != 'c' && typ != 'p' && typ != 'i') return FALSE ;
+            H->have_banner = TRUE ;
+            H->array = (fmt == 'a') ;
+            if (s0 == 'g') H->stype = RD_GENERAL ;
+            else if (s0 == 's' && s1 == 'k') H->stype = RD_SKEW ;
+            else if (s0 == 's') H->stype = (typ == 'c') ? RD_CSYM : RD_LOWER ;
+            else if (s0 == 'h') H->stype = RD_LOWER ;
+            else return FALSE ;
+            first = FALSE ;
             continue ;
         }
+        first = FALSE ;
+        if (rd_blank (buf)) continue ;
+        H->h [0] = H->h [1] = -1 ;
+        H->nh = sscanf (buf, "%lg %lg %lg %lg", &H->h [0], &H->h [1], &H->h [2], &H->h [3]) ;
+        if (H->nh < 2 || H->nh > 4 || H->h [0] < 0 || H->h [1] < 0 || H->h [0] > 9.2e18 || H->h [1] > 9.2e18) return FALSE ;
+        if (H->nh == 2 && !H->have_banner) { H->array = TRUE ; H->stype = RD_GENERAL ; }
+        if (H->nh == 2 && !H->array) return FALSE ;
+        if (H->nh >= 3 && !H->have_banner) H->array = FALSE ;
+        if (H->nh >= 3 && H->h [2] < 0) return FALSE ;
+        if (H->nh == 4) H->stype = H->h [3] < 0 ? RD_LOWER : H->h [3] > 0 ? RD_UPPER : RD_GENERAL ;
+        if (H->h [0] != H->h [1]) H->stype = RD_GENERAL ;         /* rectangular: unsymmetric */
         return TRUE ;
     }
     return FALSE ;
 }
 
-/* Returns a real sparse matrix; symmetric inputs come back upper-stored when
- * Common->prefer_upper (the default), as the reference (cholmod_read.c:1135-1190). */
-cholmod_sparse *cholmod_l_read_sparse (FILE *f, cholmod_common *Common)
+static cholmod_triplet *rd_triplets (FILE *f, char *buf, const rd_head *H, int prefer_unsym, cholmod_common *Common)
+{
+    size_t nrow = (size_t) H->h [0], ncol = (size_t) H->h [1], nnz = (size_t) H->h [2] ;
+    int stype = H->stype ;
+    if (nrow == 0 || ncol == 0 || nnz == 0) return cholmod_l_allocate_triplet (nrow, ncol, 0, 0, CHOLMOD_REAL, Common) ;
+    const int unknown = (stype == RD_UNKNOWN), skew = (stype == RD_SKEW), csym = (stype == RD_CSYM) ;
+    /* skew-symmetric and complex symmetric files come back with both triangles (stype 0); so does everything when the
+     * caller prefers unsymmetric, and an unknown stype may turn out to be (cholmod_read.c:531-545) */
+    size_t extra = (stype < RD_LOWER || unknown || (prefer_unsym && stype != RD_GENERAL)) ? nnz : 0 ;
+    if (extra) stype = unknown ? RD_UNKNOWN : RD_GENERAL ;
+    if (nnz > (size_t) 1 << 60 || nrow > (size_t) 1 << 60 || ncol > (size_t) 1 << 60)
+    { ERROR (CHOLMOD_TOO_LARGE, "problem too large") ; return NULL ; }
+    cholmod_triplet *T = NULL ;
+    Int *Ti = NULL, *Tj = NULL ;
+    double *Tx = NULL ;
+    int xtype = CHOLMOD_PATTERN, ntok = 0, lower_only = TRUE, upper_only = TRUE, one_based = TRUE ;
+    Int imax = 0, jmax = 0 ;
+    for (size_t k = 0 ; k < nnz ; k++)
+    {
+        double a = -1, b = -1, x = 0, z = 0 ;
+        int nt = 0 ;
+        for ( ; ; )
+        {
+            if (!fgets (buf, RD_LINE, f))
+            {
+                cholmod_l_free_triplet (&T, Common) ;
+                ERROR (CHOLMOD_INVALID, "premature EOF") ;
+                return NULL ;
+            }
+            if (rd_blank (buf)) continue ;
+            nt = sscanf (buf, "%lg %lg %lg %lg", &a, &b, &x, &z) ;
+            break ;
+        }
+        if (nt == EOF) nt = 0 ;
+        if (k == 0)
+        {
+            if (nt < 2 || nt > 4) { ERROR (CHOLMOD_INVALID, "invalid format") ; return NULL ; }
+            ntok = nt ;
+            xtype = nt == 2 ? CHOLMOD_PATTERN : nt == 3 ? CHOLMOD_REAL : CHOLMOD_COMPLEX ;
+            T = cholmod_l_allocate_triplet (nrow, ncol, nnz + extra, stype == RD_UNKNOWN ? 0 : stype,
+                xtype == CHOLMOD_PATTERN ? CHOLMOD_REAL : xtype, Common) ;
+            if (!T) return NULL ;
+            Ti = T->i ; Tj = T->j ; Tx = T->x ;
+        }
+        if (nt != ntok || a < 0 || b < 0 || a > 9.2e18 || b > 9.2e18)
+        {
+            cholmod_l_free_triplet (&T, Common) ;
+            ERROR (CHOLMOD_INVALID, "invalid matrix file") ;
+            return NULL ;
+        }
+        Int i = (Int) a, j = (Int) b ;
+        Ti [k] = i ; Tj [k] = j ;
+        if (i < j) lower_only = FALSE ;
+        if (i > j) upper_only = FALSE ;
+        if (xtype == CHOLMOD_REAL) Tx [k] = rd_value (x) ;
+        else if (xtype == CHOLMOD_COMPLEX) { Tx [2*k] = rd_value (x) ; Tx [2*k+1] = rd_value (z) ; }
+        if (i == 0 || j == 0) one_based = FALSE ;
+        if (i > imax) imax = i ;
+        if (j > jmax) jmax = j ;
+    }
+    if (one_based) for (size_t k = 0 ; k < nnz ; k++) { Ti [k]-- ; Tj [k]-- ; }
+    if (one_based ? (imax > (Int) nrow || jmax > (Int) ncol) : (imax >= (Int) nrow || jmax >= (Int) ncol))
+    {
+        cholmod_l_free_triplet (&T, Common) ;
+        ERROR (CHOLMOD_INVALID, "indices out of range") ;
+        return NULL ;
+    }
+    if (unknown)
+    {
+        /* only one triangle present: symmetric with that triangle stored (a diagonal matrix: upper); else unsymmetric */
+        if (lower_only && !upper_only) { stype = RD_LOWER ; }
+        else if (upper_only) { stype = RD_UPPER ; }
+        else { stype = RD_GENERAL ; extra = 0 ; }
+        if (prefer_unsym && stype != RD_GENERAL) stype = RD_GENERAL ; else if (stype != RD_GENERAL) extra = 0 ;
+        if (stype == RD_GENERAL && !prefer_unsym) extra = 0 ;
+    }
+    if (extra > 0)
+    {
+        size_t p = nnz ;
+        for (size_t k = 0 ; k < nnz ; k++)
+        {
+            if (Ti [k] == Tj [k]) continue ;
+            Ti [p] = Tj [k] ; Tj [p] = Ti [k] ;
+            if (xtype == CHOLMOD_REAL) Tx [p] = skew ? -Tx [k] : Tx [k] ;
+            else if (xtype == CHOLMOD_COMPLEX)
+            {
+                Tx [2*p]   = skew ? -Tx [2*k] : Tx [2*k] ;
+                Tx [2*p+1] = csym ? Tx [2*k+1] : -Tx [2*k+1] ;      /* skew: -(x); Hermitian: conj (x) */
+            }
+            p++ ;
+        }
+        nnz = p ;
+    }
+    T->nnz = nnz ;
+    T->stype = stype ;
+    if (xtype == CHOLMOD_PATTERN)
+    {
+        if (stype == RD_GENERAL || Common->prefer_binary)
+        {
+            for (size_t k = 0 ; k < nnz ; k++) Tx [k] = 1 ;
+        }
+        else
+        {
+            /* a symmetric pattern becomes positive definite: diagonal = 1 + degree, off-diagonals -1 (:819-857) */
+            Int *deg = cholmod_l_calloc (nrow + 1, sizeof (Int), Common) ;
+            if (!deg) { cholmod_l_free_triplet (&T, Common) ; return NULL ; }
+            for (size_t k = 0 ; k < nnz ; k++)
+                if ((stype < 0 && Ti [k] > Tj [k]) || (stype > 0 && Ti [k] < Tj [k])) { deg [Ti [k]]++ ; deg [Tj [k]]++ ; }
+            for (size_t k = 0 ; k < nnz ; k++) Tx [k] = (Ti [k] == Tj [k]) ? (double) (1 + deg [Ti [k]]) : -1.0 ;
+            cholmod_l_free (nrow + 1, sizeof (Int), deg, Common) ;
+        }
+    }
+    return T ;
+}
+
+/* Matrix Market "array": column-major, one entry per line; symmetric / Hermitian / skew files hold the lower triangle
+ * (skew: strictly lower) and come back full (cholmod_read.c:128-150, :880-1060). */
+static cholmod_dense *rd_dense (FILE *f, char *buf, const rd_head *H, cholmod_common *Common)
+{
+    size_t nrow = (size_t) H->h [0], ncol = (size_t) H->h [1] ;
+    int stype = H->stype ;
+    if (nrow == 0 || ncol == 0) return cholmod_l_zeros (nrow, ncol, CHOLMOD_REAL, Common) ;
+    cholmod_dense *X = NULL ;
+    double *Xx = NULL ;
+    int ntok = 0, xtype = CHOLMOD_REAL, firstent = TRUE ;
+    for (size_t j = 0 ; j < ncol ; j++)
+    {
+        size_t i0 = stype == RD_GENERAL ? 0 : stype == RD_SKEW ? j + 1 : j ;
+        for (size_t i = i0 ; i < nrow ; i++)
+        {
+            double x = 0, z = 0 ;
+            int nt = 0 ;
+            for ( ; ; )
+            {
+                if (!fgets (buf, RD_LINE, f))
+                {
+                    cholmod_l_free_dense (&X, Common) ;
+                    ERROR (CHOLMOD_INVALID, "premature EOF") ;
+                    return NULL ;
+                }
+                if (rd_blank (buf)) continue ;
+                nt = sscanf (buf, "%lg %lg", &x, &z) ;
+                break ;
+            }
+            if (nt == EOF) nt = 0 ;
+            if (firstent)
+            {
+                if (nt < 1 || nt > 2) { ERROR (CHOLMOD_INVALID, "invalid matrix file") ; return NULL ; }
+                ntok = nt ;
+                xtype = nt == 2 ? CHOLMOD_COMPLEX : CHOLMOD_REAL ;
+                X = cholmod_l_zeros (nrow, ncol, xtype, Common) ;
+                if (!X) return NULL ;
+                Xx = X->x ;
+                firstent = FALSE ;
+            }
+            if (nt != ntok)
+            {
+                cholmod_l_free_dense (&X, Common) ;
+                ERROR (CHOLMOD_INVALID, "invalid matrix file") ;
+                return NULL ;
+            }
+            x = rd_value (x) ; z = rd_value (z) ;
+            size_t p = i + j * nrow, q = j + i * nrow ;
+            if (xtype == CHOLMOD_REAL)
+            {
+                Xx [p] = x ;
+                if (p != q && stype == RD_LOWER) Xx [q] = x ;
+                if (p != q && stype == RD_SKEW) Xx [q] = -x ;
+            }
+            else
+            {
+                Xx [2*p] = x ; Xx [2*p+1] = z ;
+                if (p != q && stype == RD_LOWER) { Xx [2*q] = x ; Xx [2*q+1] = -z ; }      /* Hermitian */
+                if (p != q && stype == RD_SKEW) { Xx [2*q] = -x ; Xx [2*q+1] = -z ; }
+                if (p != q && stype == RD_CSYM) { Xx [2*q] = x ; Xx [2*q+1] = z ; }
+            }
+        }
+    }
+    return X ;
+}
+
+cholmod_triplet *cholmod_l_read_triplet (FILE *f, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (NULL) ;
     RETURN_IF_NULL (f, NULL) ;
     Common->status = CHOLMOD_OK ;
-    char buf [1024] ;
-    char mm = 0 ;
-    if (!next_data_line (f, buf, sizeof buf, &mm)) { ERROR (CHOLMOD_INVALID, "premature EOF") ; return NULL ; }
-    double h [4] = {0, 0, 0, 0} ;
-    int nh = sscanf (buf, "%lg %lg %lg %lg", &h [0], &h [1], &h [2], &h [3]) ;
-    if (nh < 3) { ERROR (CHOLMOD_INVALID, "invalid header (dense 'array' files are not built)") ; return NULL ; }
-    Int nrow = (Int) h [0], ncol = (Int) h [1], nnz = (Int) h [2] ;
-    int stype_known = 0, stype = 0 ;
-    if (nh >= 4) { stype = (int) h [3] ; stype_known = 1 ; }
-    else if (mm) { stype = (mm == 's' || mm == 'h') ? -1 : 0 ; stype_known = 1 ; }
-    if (nrow < 0 || ncol < 0 || nnz < 0) { ERROR (CHOLMOD_INVALID, "invalid header") ; return NULL ; }
-    cholmod_triplet *T = cholmod_l_allocate_triplet (nrow, ncol, nnz, 0, CHOLMOD_REAL, Common) ;
+    char buf [RD_LINE + 2] ;
+    rd_head H ;
+    if (!rd_header (f, buf, &H) || H.array) { ERROR (CHOLMOD_INVALID, "invalid format") ; return NULL ; }
+    return rd_triplets (f, buf, &H, FALSE, Common) ;
+}
+
+/* Symmetric inputs come back upper-stored when Common->prefer_upper (the default), as the
+ * reference (cholmod_read.c:1135-1190). */
+cholmod_sparse *cholmod_l_read_sparse (FILE *f, cholmod_common *Common)
+{
+    cholmod_triplet *T = cholmod_l_read_triplet (f, Common) ;
     if (!T) return NULL ;
-    Int *Ti = T->i, *Tj = T->j ;
-    double *Tx = T->x ;
-    int one_based = TRUE, pattern = FALSE ;
-    Int k ;
-    for (k = 0 ; k < nnz ; k++)
-    {
-        if (!next_data_line (f, buf, sizeof buf, NULL)) { ERROR (CHOLMOD_INVALID, "premature EOF") ; break ; }
-        double a = 0, b = 0, v = 1, w = 0 ;
-        int nt = sscanf (buf, "%lg %lg %lg %lg", &a, &b, &v, &w) ;
-        if (nt < 2) { ERROR (CHOLMOD_INVALID, "invalid matrix file") ; break ; }
-        if (nt >= 4) { ERROR (CHOLMOD_NOT_INSTALLED, "complex matrices not built") ; break ; }
-        if (nt == 2) { pattern = TRUE ; v = 1 ; }
-        Ti [k] = (Int) a ; Tj [k] = (Int) b ; Tx [k] = v ;
-        if (Ti [k] == 0 || Tj [k] == 0) one_based = FALSE ;
-    }
-    if (k < nnz) { cholmod_l_free_triplet (&T, Common) ; return NULL ; }
-    T->nnz = nnz ;
-    if (one_based) for (k = 0 ; k < nnz ; k++) { Ti [k]-- ; Tj [k]-- ; }
-    if (!stype_known)
-    {
-        int lo = FALSE, up = FALSE ;
-        for (k = 0 ; k < nnz ; k++) { if (Ti [k] > Tj [k]) lo = TRUE ; if (Ti [k] < Tj [k]) up = TRUE ; }
-        stype = (nrow != ncol || (lo && up)) ? 0 : (up ? 1 : -1) ;
-    }
-    if (mm == 'k') stype = 0 ;      /* skew-symmetric: returned unsymmetric in the reference */
-    T->stype = stype ;
-    if (pattern && stype != 0)
-    {
-        /* symmetric pattern: diagonal = degree+1, off-diagonals -1 (reader notes :106-110) */
-        Int *deg = cholmod_l_calloc (nrow + 1, sizeof (Int), Common) ;
-        if (deg)
-        {
-            for (k = 0 ; k < nnz ; k++) if (Ti [k] != Tj [k]) { deg [Ti [k]]++ ; deg [Tj [k]]++ ; }
-            for (k = 0 ; k < nnz ; k++) Tx [k] = (Ti [k] == Tj [k]) ? (double) (deg [Ti [k]] + 1) : -1.0 ;
-            cholmod_l_free (nrow + 1, sizeof (Int), deg, Common) ;
-        }
-    }
     cholmod_sparse *A = cholmod_l_triplet_to_sparse (T, 0, Common) ;
     cholmod_l_free_triplet (&T, Common) ;
     if (A && A->stype < 0 && Common->prefer_upper)
@@ -97,6 +282,48 @@ cholmod_sparse *cholmod_l_read_sparse (FILE *f, cholmod_common *Common)
         cholmod_l_free_sparse (&A, Common) ;
         A = A2 ;
     }
+    return A ;
+}
+
+cholmod_dense *cholmod_l_read_dense (FILE *f, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (f, NULL) ;
+    Common->status = CHOLMOD_OK ;
+    char buf [RD_LINE + 2] ;
+    rd_head H ;
+    if (!rd_header (f, buf, &H) || !H.array) { ERROR (CHOLMOD_INVALID, "invalid format") ; return NULL ; }
+    return rd_dense (f, buf, &H, Common) ;
+}
+
+/* Either kind (cholmod_read.c:1236-1330): *mtype says what came back.  prefer: 0 as stored (triplet), 1 sparse with
+ * both triangles of a symmetric file (stype 0), 2 sparse, symmetric files stored symmetric. */
+void *cholmod_l_read_matrix (FILE *f, int prefer, int *mtype, cholmod_common *Common)
+{
+    RETURN_IF_NULL_COMMON (NULL) ;
+    RETURN_IF_NULL (f, NULL) ;
+    RETURN_IF_NULL (mtype, NULL) ;
+    Common->status = CHOLMOD_OK ;
+    char buf [RD_LINE + 2] ;
+    rd_head H ;
+    if (!rd_header (f, buf, &H)) { ERROR (CHOLMOD_INVALID, "invalid format") ; return NULL ; }
+    if (H.array)
+    {
+        *mtype = CHOLMOD_DENSE ;
+        return rd_dense (f, buf, &H, Common) ;
+    }
+    cholmod_triplet *T = rd_triplets (f, buf, &H, prefer == 1, Common) ;
+    *mtype = CHOLMOD_TRIPLET ;
+    if (prefer == 0 || !T) return T ;
+    cholmod_sparse *A = cholmod_l_triplet_to_sparse (T, 0, Common) ;
+    cholmod_l_free_triplet (&T, Common) ;
+    if (A && prefer == 2 && A->stype < 0)
+    {
+        cholmod_sparse *A2 = cholmod_l_ptranspose (A, 2, NULL, NULL, 0, Common) ;
+        cholmod_l_free_sparse (&A, Common) ;
+        A = A2 ;
+    }
+    *mtype = CHOLMOD_SPARSE ;
     return A ;
 }
 

@@ -162,6 +162,7 @@ def test_bench_exchange_selftest_at_100_cubed_over_rccl():
 
 
 @pytest.mark.gpu
+@pytest.mark.slow
 @pytest.mark.parametrize("grid,extra", [(200, {"CHOLMOD_HIP_NO_CB_PASSTHROUGH": "1"}), (160, {})])
 def test_bench_exchange_selftest_at_the_headline_size_over_rccl(grid, extra):
     """The same self test at the metric's own configuration (Poisson 200^3, 8 M dof, L = 181.6 GB): CHOLMOD_HIP_SHARE_AS_WORLD=8

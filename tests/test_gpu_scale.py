@@ -175,7 +175,7 @@ def test_poisson100_full_size_properties(golden_dir):
     S.finish()
 
 
-@pytest.mark.parametrize("ob4096_rows", [None, 10000])
+@pytest.mark.parametrize("ob4096_rows", [pytest.param(None, marks=pytest.mark.slow), 10000])
 def test_dense_partial_factor_16500_rows(monkeypatch, ob4096_rows):
     """One dense front of 16 500 rows, 8 300 eliminated columns (outer block columns
     2048 wide by default, 4096 wide -- two full ones and a remainder -- when
