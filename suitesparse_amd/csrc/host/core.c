@@ -610,18 +610,26 @@ cholmod_sparse *ssamd_column_subset (cholmod_sparse *A, const SuiteSparse_long *
     }
     cholmod_l_free (ncol > 0 ? ncol : 1, 1, seen, Common) ;
     if (!ok) { ERROR (CHOLMOD_INVALID, "invalid fset") ; return NULL ; }
-    const int av = values && A->xtype == CHOLMOD_REAL && Ax ;
-    cholmod_sparse *S = cholmod_l_allocate_sparse (A->nrow, fsize, nz, A->sorted, TRUE, 0, av ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+    const int av = values && A->xtype != CHOLMOD_PATTERN && Ax ;
+    cholmod_sparse *S = cholmod_l_allocate_sparse (A->nrow, fsize, nz, A->sorted, TRUE, 0, av ? A->xtype : CHOLMOD_PATTERN, Common) ;
     if (!S) return NULL ;
     Int *Sp = S->p, *Si = S->i ;
-    double *Sx = S->x ;
+    double *Sx = S->x, *Sz = S->z ;
+    const double *Az = A->z ;
+    const int cx = av && A->xtype == CHOLMOD_COMPLEX, zx = av && A->xtype == CHOLMOD_ZOMPLEX ;
     Int dst = 0 ;
     for (size_t k = 0 ; k < fsize ; k++)
     {
         const Int j = fset [k] ;
         Sp [k] = dst ;
         Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
-        for ( ; p < pend ; p++) { Si [dst] = Ai [p] ; if (av) Sx [dst] = Ax [p] ; dst++ ; }
+        for ( ; p < pend ; p++)
+        {
+            Si [dst] = Ai [p] ;
+            if (cx) { Sx [2*dst] = Ax [2*p] ; Sx [2*dst+1] = Ax [2*p+1] ; }
+            else if (av) { Sx [dst] = Ax [p] ; if (zx) Sz [dst] = Az [p] ; }
+            dst++ ;
+        }
     }
     Sp [fsize] = dst ;
     return S ;
@@ -637,12 +645,12 @@ cholmod_sparse *ssamd_column_subset (cholmod_sparse *A, const SuiteSparse_long *
  * Reference for the product itself: CHOLMOD/Core/cholmod_aat.c. */
 cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int lower, cholmod_common *Common)
 {
-    if (A->xtype != CHOLMOD_REAL && values) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*A' not built") ; return NULL ; }
     const Int m = (Int) A->nrow, ncol = (Int) A->ncol ;
     cholmod_sparse *Fown = NULL ;
+    if (F && values && F->xtype != A->xtype) { ERROR (CHOLMOD_INVALID, "A and F must have the same xtype") ; return NULL ; }
     if (!F)
     {
-        Fown = cholmod_l_ptranspose (A, values ? 1 : 0, NULL, NULL, 0, Common) ;
+        Fown = cholmod_l_ptranspose (A, values ? (A->xtype == CHOLMOD_REAL ? 1 : 2) : 0, NULL, NULL, 0, Common) ;
         if (!Fown) return NULL ;
         F = Fown ;
     }
@@ -653,11 +661,13 @@ cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int
         return NULL ;
     }
     const Int *Ap = A->p, *Ai = A->i, *Anz = A->nz, *Fp = F->p, *Fi = F->i, *Fnz = F->nz ;
-    const double *Ax = A->x, *Fx = F->x ;
+    const double *Ax = A->x, *Fx = F->x, *Az = A->z, *Fz = F->z ;
     const int av = values && Ax && Fx ;
+    const int cx = av && A->xtype == CHOLMOD_COMPLEX, zx = av && A->xtype == CHOLMOD_ZOMPLEX ;
+    const size_t we = (cx || zx) ? 2 : 1 ;
     Int *mark = cholmod_l_malloc (m > 0 ? m : 1, sizeof (Int), Common) ;
     Int *Cp = cholmod_l_malloc (m + 1, sizeof (Int), Common) ;
-    double *w = av ? cholmod_l_calloc (m > 0 ? m : 1, sizeof (double), Common) : NULL ;
+    double *w = av ? cholmod_l_calloc (m > 0 ? m : 1, we * sizeof (double), Common) : NULL ;
     cholmod_sparse *C = NULL ;
     int ok = mark && Cp && (!av || w) ;
     if (ok)
@@ -682,7 +692,8 @@ cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int
             }
         }
         Cp [m] = nz ;
-        C = cholmod_l_allocate_sparse (m, m, nz, TRUE, TRUE, lower ? -1 : 1, av ? CHOLMOD_REAL : CHOLMOD_PATTERN, Common) ;
+        C = cholmod_l_allocate_sparse (m, m, nz, TRUE, TRUE, lower ? -1 : 1,
+            !av ? CHOLMOD_PATTERN : (cx || zx) ? CHOLMOD_COMPLEX : CHOLMOD_REAL, Common) ;
         ok = (C != NULL) ;
     }
     if (ok)
@@ -698,14 +709,21 @@ cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int
             for ( ; p < pend ; p++)
             {
                 Int k = Fi [p] ;
-                const double fkj = av ? Fx [p] : 0.0 ;
+                const double fkj = !av ? 0.0 : cx ? Fx [2*p] : Fx [p] ;
+                const double fkjz = cx ? Fx [2*p+1] : zx ? Fz [p] : 0.0 ;
                 Int q = Ap [k], qend = A->packed ? Ap [k+1] : q + Anz [k] ;
                 for ( ; q < qend ; q++)
                 {
                     Int i = Ai [q] ;
                     if (lower ? i < j : i > j) continue ;
                     if (mark [i] != j) { mark [i] = j ; Ci [dst++] = i ; }
-                    if (av) w [i] += Ax [q] * fkj ;
+                    if (cx || zx)
+                    {
+                        const double ar = cx ? Ax [2*q] : Ax [q], ai = cx ? Ax [2*q+1] : Az [q] ;
+                        w [2*i] += ar * fkj - ai * fkjz ;
+                        w [2*i+1] += ar * fkjz + ai * fkj ;
+                    }
+                    else if (av) w [i] += Ax [q] * fkj ;
                 }
             }
             /* sort the column (short lists: insertion sort; long ones: by a counting pass over the marks would need O(m)) */
@@ -741,12 +759,18 @@ cholmod_sparse *ssamd_aat (cholmod_sparse *A, cholmod_sparse *F, int values, int
                     while (b >= 0 && col [b] > v) { col [b + 1] = col [b] ; b-- ; }
                     col [b + 1] = v ;
                 }
-            if (av) for (Int a = 0 ; a < len ; a++) { Cx [Cp [j] + a] = w [col [a]] ; w [col [a]] = 0.0 ; }
+            if (cx || zx)
+                for (Int a = 0 ; a < len ; a++)
+                {
+                    Cx [2 * (Cp [j] + a)] = w [2 * col [a]] ; Cx [2 * (Cp [j] + a) + 1] = w [2 * col [a] + 1] ;
+                    w [2 * col [a]] = w [2 * col [a] + 1] = 0.0 ;
+                }
+            else if (av) for (Int a = 0 ; a < len ; a++) { Cx [Cp [j] + a] = w [col [a]] ; w [col [a]] = 0.0 ; }
         }
     }
     if (mark) cholmod_l_free (m > 0 ? m : 1, sizeof (Int), mark, Common) ;
     if (Cp) cholmod_l_free (m + 1, sizeof (Int), Cp, Common) ;
-    if (w) cholmod_l_free (m > 0 ? m : 1, sizeof (double), w, Common) ;
+    if (w) cholmod_l_free (m > 0 ? m : 1, we * sizeof (double), w, Common) ;
     if (Fown) cholmod_l_free_sparse (&Fown, Common) ;
     if (!ok && C) cholmod_l_free_sparse (&C, Common) ;
     return ok ? C : NULL ;

@@ -211,7 +211,7 @@ int cholmod_l_super_numeric (cholmod_sparse *A, cholmod_sparse *F, double beta [
          * column of A*F on the fly): tril (A*F) is formed on the host (core.c: ssamd_aat) and factorized as the symmetric
          * matrix it is */
         if (!F) { ERROR (CHOLMOD_INVALID, "F is required for the unsymmetric case") ; return FALSE ; }
-        if (A->xtype != CHOLMOD_REAL || F->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*F not built") ; return FALSE ; }
+        if (F->xtype != A->xtype) { ERROR (CHOLMOD_INVALID, "A and F must have the same xtype") ; return FALSE ; }
         if (A->nrow != L->n) { ERROR (CHOLMOD_INVALID, "invalid dimensions") ; return FALSE ; }
         cholmod_sparse *C = ssamd_aat (A, F, 1, TRUE, Common) ;
         if (!C) return FALSE ;
@@ -394,7 +394,6 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         /* factorize A*A' + beta*I (cholmod_factorize.c:197-224: S = A(p,f), F = S', super_numeric (S, F, beta)): tril (A*A')
          * is formed on the host and takes the symmetric branch below -- permutation, upload and, from the second call with
          * the same pattern on, the values-only path included.  A column subset f: A(:,f)*A(:,f)', the columns cut out first. */
-        if (A->xtype != CHOLMOD_REAL) { ERROR (CHOLMOD_NOT_INSTALLED, "complex A*A' not built") ; return FALSE ; }
         cholmod_sparse *Af = fset ? ssamd_column_subset (A, fset, fsize, 1, Common) : NULL ;
         if (fset && !Af) return FALSE ;
         cholmod_sparse *C = ssamd_aat (Af ? Af : A, NULL, 1, TRUE, Common) ;
