@@ -204,9 +204,12 @@ def test_reference_matrix_hip_path(d, f, relax, postorder):
 
 # ---- the matrices that are not positive definite, once more: quick_return_if_not_posdef (the failing supernode is not
 # refactorized up to the failing column, t_cholmod_super_numeric.c:905-925), and the rank-deficient rectangular files with
-# beta = 0 (A*A' singular: 1_0 is a 1-by-0 matrix, 3_2 has more rows than columns)
+# beta = 0 where A*A' is EXACTLY singular (1_0 is a 1-by-0 matrix, a2 is 200-by-200 with no entry: a zero pivot in any
+# arithmetic).  3_2 (3-by-2, rank 2) is not in the list: its third pivot is rounding noise around zero -- LAPACK's dpotrf
+# gets +5.5e-17, the oracle's loop a non-positive value, the HIP kernels a positive one -- so whether it "is" positive
+# definite is decided by the summation order, not by the algorithm
 SINGULAR = [("tcov", f, None) for f in ("2lo.tri", "2up.tri", "3singular", "c3singular", "z3singular", "cha", "cha.mtx")] + \
-           [("demo", "n5", None), ("tcov", "1_0", 0.0), ("tcov", "3_2", 0.0), ("tcov", "a2", 0.0)]
+           [("demo", "n5", None), ("tcov", "1_0", 0.0), ("tcov", "a2", 0.0)]
 SING_PARAMS = [(d, f, b, q, p) for d, f, b in SINGULAR for q in (False, True) for p in (0, 1)]
 SING_IDS = [f"{d}/{f}-beta{b}-quick{int(q)}-post{p}" for d, f, b, q, p in SING_PARAMS]
 
