@@ -16,6 +16,9 @@
  * Product code: nothing here uses oracle/ (which is test infrastructure). */
 #include "host_internal.h"
 #include <dlfcn.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <pthread.h>
 #include <time.h>
 #include <errno.h>
@@ -34,35 +37,18 @@ typedef void (*dtrsm_fn) (const char *, const char *, const char *, const char *
 typedef void (*dpotrf_fn) (const char *, const int *, double *, const int *, int *) ;
 
 typedef void (*set_threads_fn) (int) ;
+typedef int (*get_threads_fn0) (void) ;
+static pthread_mutex_t g_blas_threads_lock = PTHREAD_MUTEX_INITIALIZER ;
 static struct
 {
     int tried ;
     void *handle ;
     dgemm_fn gemm ; dsyrk_fn syrk ; dtrsm_fn trsm ; dpotrf_fn potrf ;
-    set_threads_fn set_threads ;    /* openblas_set_num_threads / MKL_Set_Num_Threads / bli_thread_set_num_threads, or NULL */
+    set_threads_fn set_threads ;    /* openblas_set_num_threads / MKL_Set_Num_Threads, or NULL */
+    get_threads_fn0 get_threads ;   /* openblas_get_num_threads / MKL_Get_Max_Threads, or NULL */
     int max_threads, cur_threads ;
-    double grain ;                  /* flops of a dense call per BLAS thread */
     char name [256] ;
 } g_blas ;
-
-/* Threads for ONE dense call, by its flop count.  The left-looking loop issues its BLAS calls one after the other, and
- * almost all of them are tiny (Poisson 100^3 under AMD: 97 % of 601 338 updates have <= 16 columns): a threaded
- * BLAS that wakes 64 threads for each of them spends its time in the wake-up, not in the arithmetic -- rounds 3-4 measured
- * 36 GFLOP/s at 64 threads against 216 at 16.  So a call gets one thread per ~128 Mflop, at most what the caller allows
- * (OMP_NUM_THREADS): small calls run on the calling thread, the few big ones (which hold the flops) on all of them, and
- * more threads never cost.  Without a thread-control entry point in the bound library the BLAS decides for itself. */
-static void blas_threads_for (double flops)
-{
-    if (!g_blas.set_threads) return ;
-    /* (one thread per 128 Mflop -- a few milliseconds of dgemm per thread.  Poisson 100^3 on 2 x EPYC 9575F with scipy's
-     * OpenBLAS, GFLOP/s at 16 / 32 / 64 threads: 542 / 286 / 149 with 4 Mflop per thread, 466 / 304 / 179 with 32, 480 / 330 /
-     * 221 with 128; rounds 3-4, every call on all threads: 216 at 16, 36 at 64.  What is left of the drop beyond 16 threads
-     * is the BLAS's own scaling on the few top fronts.) */
-    const double grain = g_blas.grain ;          /* (CHOLMOD_CPU_MFLOP_PER_THREAD, read when the BLAS is bound) */
-    int t = flops < grain ? 1 : (int) (flops / grain) + 1 ;
-    if (t > g_blas.max_threads) t = g_blas.max_threads ;
-    if (t != g_blas.cur_threads) { g_blas.set_threads (t) ; g_blas.cur_threads = t ; }
-}
 
 static void *sym2 (void *h, const char *prefix, const char *name)
 {
@@ -118,13 +104,14 @@ static int try_blas (const char *path, const char *prefix)
         return 0 ;
     }
     g_blas.gemm = g ; g_blas.syrk = s ; g_blas.trsm = t ; g_blas.potrf = p ;
-    /* per-call thread control, where the library offers it (blas_threads_for) */
+    /* thread control, where the library offers it as (int) -> void / (void) -> int: the factorization runs the BLAS on one
+     * thread per call and restores the entry setting (ssamd_cpu_super_numeric).  BLIS's bli_thread_set_num_threads takes a
+     * dim_t and is left alone: such a library keeps its own threading and the loop stays on one OpenMP thread. */
     g_blas.set_threads = (set_threads_fn) sym2 (h, prefix, "openblas_set_num_threads") ;
-    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "openblas_set_num_threads") ;
-    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "MKL_Set_Num_Threads") ;
-    if (!g_blas.set_threads) g_blas.set_threads = (set_threads_fn) dlsym (h, "bli_thread_set_num_threads") ;
+    g_blas.get_threads = (get_threads_fn0) sym2 (h, prefix, "openblas_get_num_threads") ;
+    if (!g_blas.set_threads) { g_blas.set_threads = (set_threads_fn) dlsym (h, "openblas_set_num_threads") ; g_blas.get_threads = (get_threads_fn0) dlsym (h, "openblas_get_num_threads") ; }
+    if (!g_blas.set_threads) { g_blas.set_threads = (set_threads_fn) dlsym (h, "MKL_Set_Num_Threads") ; g_blas.get_threads = (get_threads_fn0) dlsym (h, "MKL_Get_Max_Threads") ; }
     g_blas.max_threads = ssamd_host_threads_uncapped () ;
-    { const char *ge = getenv ("CHOLMOD_CPU_MFLOP_PER_THREAD") ; g_blas.grain = (ge && atof (ge) > 0) ? 1e6 * atof (ge) : 128e6 ; }
     g_blas.cur_threads = -1 ;
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;
     g_blas.handle = h ;         /* (last: everything above is in place when a reader sees the handle) */
@@ -275,198 +262,703 @@ static double now_s (void)
 
 /* ---- numeric factorization --------------------------------------------------------- */
 
-/* A: lower-stored permuted matrix (packed or not, sorted or not).  L: supernodal
- * symbolic or numeric factor with L->x allocated (xsize doubles).  Returns TRUE
- * (also when not positive definite: status / L->minor tell), FALSE on failure. */
+/* Where the threads come from (round 6; the round-5 review's "honest CPU baseline", and the advisor's note on the BLAS thread
+ * count): the bound BLAS runs ONE thread per call for the whole factorization -- its entry setting is read first and put back
+ * on return -- and every thread of parallelism is an OpenMP thread of this file:
+ *   phase A  independent subtrees of the supernodal elimination tree, one thread each (the reference's left-looking loop on
+ *            the subtree's supernodes, private workspace), heaviest first.  A descendant that has finished inside its subtree
+ *            and still has rows above it is parked and handed to its first ancestor in the top part afterwards, subtree by
+ *            subtree in index order, so the summation order does not depend on the schedule of the threads;
+ *   phase B  the top part (the few supernodes that hold most of the flops), one supernode after the other, each by tiles:
+ *            the updates from its pending descendants by 256 x 256 target tiles (a thread owns a tile and pulls every
+ *            descendant's share of it: disjoint targets, no atomics), the panel by a blocked right-looking factorization
+ *            (diagonal block on one thread, the rows below and the trailing tiles on all of them).
+ * A threaded BLAS asked for 64 threads on each of a few hundred thousand small calls was 6 x slower than at 16 (rounds 3-4);
+ * sized per call by its flops (round 5) it still lost beyond 16 threads to its own dpotrf / dsyrk on the top fronts.  With
+ * one thread (OMP_NUM_THREADS = 1, or no thread control in the bound library) the loop below is the reference's, in order. */
+
+typedef int (*get_threads_fn) (void) ;
+
+typedef struct
+{
+    /* the factor and the matrix */
+    Int n, nsuper ;
+    const Int *Super, *Lpi, *Lpx, *Ls ;
+    const Int *Ap, *Ai, *Anz ;
+    const double *Ax ;
+    double *Lx ;
+    int packed ;
+    double beta ;
+    int quick ;
+    int have_blas ;
+    /* shared state of the left-looking loop */
+    Int *col2s, *cursor, *link, *pending ;
+    int32_t *owner ;            /* subtree of a supernode, -1 = top part */
+} cpu_ctx ;
+
+typedef struct
+{
+    int32_t *where ;            /* position of a global row in the current supernode (n entries) */
+    Int *relpos ;               /* maxesize + 1 */
+    double *C ;                 /* update scratch */
+    double t_syrk, t_gemm, t_potrf, t_trsm, t_asm ;
+    size_t n_syrk, n_gemm, n_potrf, n_trsm ;
+} cpu_ws ;
+
+static void assemble_columns (const cpu_ctx *X, const int32_t *where, Int s, Int c0, Int c1)
+{
+    const Int k1 = X->Super [s], psi = X->Lpi [s], nsrow = X->Lpi [s+1] - psi ;
+    double *Fs = X->Lx + X->Lpx [s] ;
+    for (Int k = k1 + c0 ; k < k1 + c1 ; k++)
+    {
+        double *col = Fs + (k - k1) * nsrow ;
+        memset (col, 0, (size_t) nsrow * sizeof (double)) ;
+        /* A(:, k), lower part, into the supernode (entries outside the symbolic pattern are dropped,
+         * t_cholmod_super_numeric.c:377-378) */
+        Int p = X->Ap [k], pend = X->packed ? X->Ap [k+1] : p + X->Anz [k] ;
+        for ( ; p < pend ; p++)
+        {
+            Int i = X->Ai [p] ;
+            if (i < k) continue ;
+            Int r = where [i] ;
+            if (r >= 0 && r < nsrow && X->Ls [psi + r] == i) col [r] = X->Ax [p] ;
+        }
+        col [k - k1] += X->beta ;
+    }
+}
+
+/* One supernode as the reference's loop builds it (t_cholmod_super_numeric.c:279-1048), on the calling thread: assemble,
+ * pull one dense update per pending descendant, factor the diagonal block, solve the rows below.  pass 1 only after a
+ * failed pivot: the same again, to factor the columns before that pivot (the "repeat supernode", :883-968; the pending
+ * lists are advanced by the caller once the supernode is done).  Returns the number of good columns, *info = LAPACK's. */
+static Int factor_supernode_seq (const cpu_ctx *X, cpu_ws *W, Int s, Int *info_out)
+{
+    const Int k1 = X->Super [s], k2 = X->Super [s+1], nscol = k2 - k1 ;
+    const Int psi = X->Lpi [s], nsrow = X->Lpi [s+1] - psi ;
+    const Int *Ls = X->Ls, *Lpi = X->Lpi, *Lpx = X->Lpx, *Super = X->Super ;
+    double *Lx = X->Lx, *Fs = Lx + Lpx [s], *C = W->C ;
+    int32_t *where = W->where ;
+    Int *relpos = W->relpos ;
+    double t0 ;
+    for (Int r = 0 ; r < nsrow ; r++) where [Ls [psi + r]] = (int32_t) r ;
+    Int good = nscol, info_first = 0 ;
+    for (int pass = 0 ; pass < 2 ; pass++)
+    {
+        t0 = now_s () ;
+        assemble_columns (X, where, s, 0, nscol) ;
+        W->t_asm += now_s () - t0 ;
+        for (Int d = X->pending [s] ; d != EMPTY ; d = X->link [d])
+        {
+            const Int dk = Super [d+1] - Super [d] ;                /* columns of d */
+            const Int dpi = Lpi [d], drows = Lpi [d+1] - dpi ;
+            const Int q1 = X->cursor [d] ;                          /* first row of d inside s */
+            Int q2 = q1 ;
+            while (q2 < drows && Ls [dpi + q2] < k2) q2++ ;
+            const Int n1 = q2 - q1, n2 = drows - q1 ;               /* rows inside s / from there down */
+            const double *Ld = Lx + Lpx [d] + q1 ;                  /* ld = drows */
+            for (Int r = 0 ; r < n2 ; r++) relpos [r] = where [Ls [dpi + q1 + r]] ;
+            if (X->have_blas)
+            {
+                const double one = 1.0, zero = 0.0 ;
+                int in1 = (int) n1, idk = (int) dk, ild = (int) drows, ildc = (int) n2, in3 = (int) (n2 - n1) ;
+                t0 = now_s () ;
+                g_blas.syrk ("L", "N", &in1, &idk, &one, Ld, &ild, &zero, C, &ildc) ;
+                W->t_syrk += now_s () - t0 ; W->n_syrk++ ;
+                if (in3 > 0)
+                {
+                    t0 = now_s () ;
+                    g_blas.gemm ("N", "C", &in3, &in1, &idk, &one, Ld + n1, &ild, Ld, &ild, &zero, C + n1, &ildc) ;
+                    W->t_gemm += now_s () - t0 ; W->n_gemm++ ;
+                }
+                for (Int j = 0 ; j < n1 ; j++)
+                {
+                    double *dst = Fs + relpos [j] * nsrow ;
+                    const double *cj = C + j * n2 ;
+                    for (Int i = j ; i < n2 ; i++) dst [relpos [i]] -= cj [i] ;
+                }
+            }
+            else
+            {
+                /* built-in: the scratch receives 0 - L_d L_d' (lower trapezoid) */
+                t0 = now_s () ;
+                for (Int j = 0 ; j < n1 ; j++) memset (C + j * n2 + j, 0, (size_t) (n2 - j) * sizeof (double)) ;
+                k_gemm_nt (n2, n1, dk, Ld, drows, Ld, drows, C, n2, 1) ;
+                W->t_syrk += now_s () - t0 ; W->n_syrk++ ;
+                for (Int j = 0 ; j < n1 ; j++)
+                {
+                    double *dst = Fs + relpos [j] * nsrow ;
+                    const double *cj = C + j * n2 ;
+                    for (Int i = j ; i < n2 ; i++) dst [relpos [i]] += cj [i] ;
+                }
+            }
+        }
+        /* diagonal block: the first `good` columns */
+        Int info = 0 ;
+        t0 = now_s () ;
+        if (X->have_blas)
+        {
+            int in = (int) good, ild = (int) nsrow, iinfo = 0 ;
+            g_blas.potrf ("L", &in, Fs, &ild, &iinfo) ;
+            info = iinfo ;
+        }
+        else info = k_potrf (good, Fs, nsrow) ;
+        W->t_potrf += now_s () - t0 ; W->n_potrf++ ;
+        if (info > 0 && pass == 0)
+        {
+            info_first = info ;
+            good = (info == 1 || X->quick) ? 0 : info - 1 ;
+            if (good > 0) continue ;                /* redo with the leading columns only */
+        }
+        break ;
+    }
+    if (good > 0 && nsrow > good)
+    {
+        /* rows below the factored block (after a failed pivot that includes the remaining rows of the diagonal block, as
+         * in the reference) */
+        t0 = now_s () ;
+        if (X->have_blas)
+        {
+            const double one = 1.0 ;
+            int im = (int) (nsrow - good), in = (int) good, ild = (int) nsrow ;
+            g_blas.trsm ("R", "L", "C", "N", &im, &in, &one, Fs, &ild, Fs + good, &ild) ;
+        }
+        else k_trsm (nsrow - good, good, Fs, nsrow, Fs + good, nsrow) ;
+        W->t_trsm += now_s () - t0 ; W->n_trsm++ ;
+    }
+    *info_out = info_first ;
+    return good ;
+}
+
+/* s is done: its descendants move on to the supernode of their next row, s itself becomes a pending descendant of the
+ * supernode of its first row below.  A target outside the subtree `own` (phase A) is not touched: the descendant is
+ * parked on the subtree's list (*park_head / *park_tail, linked through link []) and handed over after the phase. */
+static void advance_descendants (const cpu_ctx *X, Int s, int32_t own, Int *park_head, Int *park_tail)
+{
+    const Int *Ls = X->Ls, *Lpi = X->Lpi ;
+    const Int k2 = X->Super [s+1], nscol = k2 - X->Super [s] ;
+    Int d = X->pending [s] ;
+    X->pending [s] = EMPTY ;
+    X->cursor [s] = nscol ;
+    /* (s last: the reference pushes it after its descendants, so it is the first one its parent pulls) */
+    for (int self = 0 ; self < 2 ; self++)
+    {
+        for ( ; d != EMPTY ; )
+        {
+            Int dnext = self ? EMPTY : X->link [d] ;
+            const Int dpi = Lpi [d], drows = Lpi [d+1] - dpi ;
+            Int q2 = X->cursor [d] ;
+            while (q2 < drows && Ls [dpi + q2] < k2) q2++ ;
+            X->cursor [d] = q2 ;
+            if (q2 < drows)
+            {
+                Int t = X->col2s [Ls [dpi + q2]] ;
+                if (own >= 0 && X->owner [t] != own)
+                {
+                    X->link [d] = EMPTY ;
+                    if (*park_tail == EMPTY) *park_head = d ; else X->link [*park_tail] = d ;
+                    *park_tail = d ;
+                }
+                else { X->link [d] = X->pending [t] ; X->pending [t] = d ; }
+            }
+            d = dnext ;
+        }
+        d = s ;
+    }
+}
+
+/* binary max-heap of supernodes keyed by w [] (the subtree weights) */
+static void heap_push (Int *heap, Int *hn, const double *w, Int v)
+{
+    Int c = (*hn)++ ;
+    heap [c] = v ;
+    while (c > 0 && w [heap [(c - 1) / 2]] < w [heap [c]])
+    {
+        Int t = heap [c] ; heap [c] = heap [(c - 1) / 2] ; heap [(c - 1) / 2] = t ;
+        c = (c - 1) / 2 ;
+    }
+}
+
+static void heap_pop (Int *heap, Int *hn, const double *w)
+{
+    heap [0] = heap [--(*hn)] ;
+    for (Int c = 0 ; ; )
+    {
+        Int l = 2 * c + 1, m = c ;
+        if (l < *hn && w [heap [l]] > w [heap [m]]) m = l ;
+        if (l + 1 < *hn && w [heap [l + 1]] > w [heap [m]]) m = l + 1 ;
+        if (m == c) break ;
+        Int t = heap [c] ; heap [c] = heap [m] ; heap [m] = t ;
+        c = m ;
+    }
+}
+
+/* ---- phase B: one top supernode by tiles -------------------------------------------------------------------------------- */
+
+#define CPU_TILE 256
+
+typedef struct { Int d, q1, n1, n2 ; int32_t jlo, jhi, ihi ; } cpu_upd ;     /* a pending descendant and the target positions it spans */
+
+/* first r in [lo, hi) with where [Ls [base + r]] >= key (the positions of d's rows inside s increase with r) */
+static Int lower_bound_pos (const int32_t *where, const Int *Ls, Int base, Int lo, Int hi, int32_t key)
+{
+    while (lo < hi)
+    {
+        Int mid = lo + (hi - lo) / 2 ;
+        if (where [Ls [base + mid]] < key) lo = mid + 1 ; else hi = mid ;
+    }
+    return lo ;
+}
+
+static Int factor_supernode_tiled (const cpu_ctx *X, cpu_ws *WS, int nth, Int s, cpu_upd *U, Int *info_out)
+{
+    const Int k1 = X->Super [s], k2 = X->Super [s+1], nscol = k2 - k1 ;
+    const Int psi = X->Lpi [s], nsrow = X->Lpi [s+1] - psi ;
+    const Int *Ls = X->Ls, *Lpi = X->Lpi, *Lpx = X->Lpx, *Super = X->Super ;
+    double *Lx = X->Lx, *Fs = Lx + Lpx [s] ;
+    int32_t *where = WS [0].where ;
+    double t0 = now_s () ;
+#pragma omp parallel for schedule(static) num_threads(nth)
+    for (Int r = 0 ; r < nsrow ; r++) where [Ls [psi + r]] = (int32_t) r ;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(nth)
+    for (Int c = 0 ; c < nscol ; c++) assemble_columns (X, where, s, c, c + 1) ;
+    WS [0].t_asm += now_s () - t0 ;
+    /* the pending descendants, as an array */
+    Int nu = 0 ;
+    for (Int d = X->pending [s] ; d != EMPTY ; d = X->link [d])
+    {
+        const Int dpi = Lpi [d], drows = Lpi [d+1] - dpi, q1 = X->cursor [d] ;
+        Int q2 = q1 ;
+        while (q2 < drows && Ls [dpi + q2] < k2) q2++ ;
+        cpu_upd u ;
+        u.d = d ; u.q1 = q1 ; u.n1 = q2 - q1 ; u.n2 = drows - q1 ;
+        u.jlo = where [Ls [dpi + q1]] ; u.jhi = where [Ls [dpi + q2 - 1]] ; u.ihi = where [Ls [dpi + drows - 1]] ;
+        if (u.n1 > 0) U [nu++] = u ;
+    }
+    /* updates, by target tiles of the lower trapezoid: tile (rb, cb) = rows [rb T, rb T + T) x columns [cb T, cb T + T) */
+    const Int T = CPU_TILE ;
+    const Int ncb = (nscol + T - 1) / T, nrb = (nsrow + T - 1) / T ;
+    t0 = now_s () ;
+    if (nu > 0)
+    {
+#pragma omp parallel num_threads(nth)
+        {
+            int me = 0 ;
+#ifdef _OPENMP
+            me = omp_get_thread_num () ;
+#endif
+            cpu_ws *W = WS + me ;
+            double *C = W->C ;
+            /* (tiles of a column block from the bottom up would not matter: every tile is independent) */
+#pragma omp for schedule(dynamic, 1) collapse(2)
+            for (Int cb = 0 ; cb < ncb ; cb++)
+                for (Int rb = 0 ; rb < nrb ; rb++)
+                {
+                    if (rb < cb) continue ;
+                    const int32_t c0 = (int32_t) (cb * T), c1 = (int32_t) ((cb + 1) * T < nscol ? (cb + 1) * T : nscol) ;
+                    const int32_t r0 = (int32_t) (rb * T), r1 = (int32_t) ((rb + 1) * T < nsrow ? (rb + 1) * T : nsrow) ;
+                    for (Int q = 0 ; q < nu ; q++)
+                    {
+                        const cpu_upd *u = U + q ;
+                        if (u->jhi < c0 || u->jlo >= c1 || u->ihi < r0) continue ;
+                        const Int d = u->d, dpi = Lpi [d], drows = Lpi [d+1] - dpi, dk = Super [d+1] - Super [d] ;
+                        const Int base = dpi ;
+                        /* rows of d that land in the tile's columns / rows */
+                        const Int j0 = lower_bound_pos (where, Ls, base, u->q1, u->q1 + u->n1, c0) ;
+                        const Int j1 = lower_bound_pos (where, Ls, base, j0, u->q1 + u->n1, c1) ;
+                        if (j1 <= j0) continue ;
+                        Int i0 = lower_bound_pos (where, Ls, base, u->q1, u->q1 + u->n2, r0) ;
+                        const Int i1 = lower_bound_pos (where, Ls, base, i0, u->q1 + u->n2, r1) ;
+                        if (i0 < j0) i0 = j0 ;          /* only the lower trapezoid of the update: i >= j */
+                        if (i1 <= i0) continue ;
+                        const Int M = i1 - i0, N = j1 - j0 ;
+                        const double *Ai_ = Lx + Lpx [d] + i0, *Aj_ = Lx + Lpx [d] + j0 ;     /* ld = drows */
+                        if (X->have_blas)
+                        {
+                            const double one = 1.0, zero = 0.0 ;
+                            int im = (int) M, in = (int) N, ik = (int) dk, ild = (int) drows ;
+                            g_blas.gemm ("N", "C", &im, &in, &ik, &one, Ai_, &ild, Aj_, &ild, &zero, C, &im) ;
+                            for (Int jj = 0 ; jj < N ; jj++)
+                            {
+                                double *dst = Fs + (Int) where [Ls [base + j0 + jj]] * nsrow ;
+                                const double *cj = C + jj * M ;
+                                Int ii = (j0 + jj > i0) ? j0 + jj - i0 : 0 ;
+                                for ( ; ii < M ; ii++) dst [where [Ls [base + i0 + ii]]] -= cj [ii] ;
+                            }
+                        }
+                        else
+                        {
+                            memset (C, 0, (size_t) M * (size_t) N * sizeof (double)) ;
+                            k_gemm_nt (M, N, dk, Ai_, drows, Aj_, drows, C, M, 0) ;
+                            for (Int jj = 0 ; jj < N ; jj++)
+                            {
+                                double *dst = Fs + (Int) where [Ls [base + j0 + jj]] * nsrow ;
+                                const double *cj = C + jj * M ;
+                                Int ii = (j0 + jj > i0) ? j0 + jj - i0 : 0 ;
+                                for ( ; ii < M ; ii++) dst [where [Ls [base + i0 + ii]]] += cj [ii] ;
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    WS [0].t_gemm += now_s () - t0 ; WS [0].n_gemm += (size_t) nu ;
+    /* the panel: blocked right-looking, block columns of T */
+    Int info = 0 ;
+    for (Int b0 = 0 ; b0 < nscol && info == 0 ; b0 += T)
+    {
+        const Int kb = (nscol - b0 < T) ? nscol - b0 : T ;
+        double *D = Fs + b0 + b0 * nsrow ;
+        t0 = now_s () ;
+        if (X->have_blas)
+        {
+            int in = (int) kb, ild = (int) nsrow, iinfo = 0 ;
+            g_blas.potrf ("L", &in, D, &ild, &iinfo) ;
+            info = iinfo ;
+        }
+        else info = k_potrf (kb, D, nsrow) ;
+        WS [0].t_potrf += now_s () - t0 ; WS [0].n_potrf++ ;
+        if (info > 0) { info += b0 ; break ; }
+        const Int below = nsrow - (b0 + kb) ;
+        if (below <= 0) continue ;
+        t0 = now_s () ;
+        const Int nchunk = (below + T - 1) / T ;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nth)
+        for (Int c = 0 ; c < nchunk ; c++)
+        {
+            const Int r0 = b0 + kb + c * T, m = (nsrow - r0 < T) ? nsrow - r0 : T ;
+            if (X->have_blas)
+            {
+                const double one = 1.0 ;
+                int im = (int) m, in = (int) kb, ild = (int) nsrow ;
+                g_blas.trsm ("R", "L", "C", "N", &im, &in, &one, D, &ild, Fs + r0 + b0 * nsrow, &ild) ;
+            }
+            else k_trsm (m, kb, D, nsrow, Fs + r0 + b0 * nsrow, nsrow) ;
+        }
+        WS [0].t_trsm += now_s () - t0 ; WS [0].n_trsm++ ;
+        /* trailing tiles of the supernode's own columns: (rb, cb) on the grid of T starting at b0 + kb */
+        const Int e0 = b0 + kb ;
+        const Int tcb = (nscol - e0 + T - 1) / T, trb = (nsrow - e0 + T - 1) / T ;
+        if (tcb <= 0) continue ;
+        t0 = now_s () ;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2) num_threads(nth)
+        for (Int cb = 0 ; cb < tcb ; cb++)
+            for (Int rb = 0 ; rb < trb ; rb++)
+            {
+                if (rb < cb) continue ;
+                const Int c0 = e0 + cb * T, cn = (nscol - c0 < T) ? nscol - c0 : T ;
+                const Int r0 = e0 + rb * T, rn = (nsrow - r0 < T) ? nsrow - r0 : T ;
+                const double *Ar = Fs + r0 + b0 * nsrow, *Ac = Fs + c0 + b0 * nsrow ;
+                double *Ct = Fs + r0 + c0 * nsrow ;
+                if (X->have_blas)
+                {
+                    const double one = 1.0, mone = -1.0 ;
+                    int im = (int) rn, in = (int) cn, ik = (int) kb, ild = (int) nsrow ;
+                    if (rb == cb)
+                    {
+                        /* a diagonal tile: its square part by dsyrk (the strictly upper triangle of the diagonal block
+                         * keeps its zeros), rows past the square -- the last column block may be short -- by dgemm */
+                        g_blas.syrk ("L", "N", &in, &ik, &mone, Ac, &ild, &one, Ct, &ild) ;
+                        if (rn > cn)
+                        {
+                            int ir = (int) (rn - cn) ;
+                            g_blas.gemm ("N", "C", &ir, &in, &ik, &mone, Ar + cn, &ild, Ac, &ild, &one, Ct + cn, &ild) ;
+                        }
+                    }
+                    else g_blas.gemm ("N", "C", &im, &in, &ik, &mone, Ar, &ild, Ac, &ild, &one, Ct, &ild) ;
+                }
+                else k_gemm_nt (rn, cn, kb, Ar, nsrow, Ac, nsrow, Ct, nsrow, rb == cb) ;
+            }
+        WS [0].t_syrk += now_s () - t0 ; WS [0].n_syrk++ ;
+    }
+    *info_out = info ;
+    return info > 0 ? -1 : nscol ;
+}
+
 int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common)
 {
     bind_blas_once () ;
-    const int have_blas = g_blas.handle != NULL ;
+    cpu_ctx X ;
+    memset (&X, 0, sizeof (X)) ;
+    X.have_blas = g_blas.handle != NULL ;
     const Int n = (Int) L->n, nsuper = (Int) L->nsuper ;
-    const Int *Super = L->super, *Lpi = L->pi, *Lpx = L->px, *Ls = L->s ;
-    const Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
-    const double *Ax = A->x ;
-    double *Lx = L->x ;
-    const int packed = A->packed ;
+    X.n = n ; X.nsuper = nsuper ;
+    X.Super = L->super ; X.Lpi = L->pi ; X.Lpx = L->px ; X.Ls = L->s ;
+    X.Ap = A->p ; X.Ai = A->i ; X.Anz = A->nz ; X.Ax = A->x ; X.Lx = L->x ;
+    X.packed = A->packed ; X.beta = beta ; X.quick = Common->quick_return_if_not_posdef ;
+    const Int *Super = X.Super, *Lpi = X.Lpi, *Lpx = X.Lpx, *Ls = X.Ls ;
+    double *Lx = X.Lx ;
 
-    /* workspace: position of a global row in the current supernode; the supernode
-     * of every column; per descendant the cursor into its row list and the link
-     * of the pending list it currently sits on */
-    Int *where = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
-    Int *col2s = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
-    Int *cursor = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
-    Int *link = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
-    Int *pending = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
-    Int *relpos = cholmod_l_malloc (L->maxesize + 1, sizeof (Int), Common) ;
-    double *C = cholmod_l_malloc (L->maxcsize > 0 ? L->maxcsize : 1, sizeof (double), Common) ;
-    int ok = where && col2s && cursor && link && pending && relpos && C ;
-    Int sfail = EMPTY, info_fail = 0 ;
-    double t_syrk = 0, t_gemm = 0, t_potrf = 0, t_trsm = 0, t_asm = 0 ;
-    size_t n_syrk = 0, n_gemm = 0, n_potrf = 0, n_trsm = 0 ;
+    /* threads: OpenMP's, all in this file; the BLAS one per call (its entry setting restored on return).  A bound library
+     * without a thread-control entry point keeps its own threading and this loop stays on one thread. */
+    int nth = ssamd_host_threads_uncapped () ;
+    { const char *e = getenv ("CHOLMOD_CPU_SUBTREES") ; if (e && !strcmp (e, "0")) nth = 1 ; }
+    if (X.have_blas && !g_blas.set_threads) nth = 1 ;
+    if (n >= ((Int) 1 << 31) - 1) nth = 1 ;
+    if (nsuper < 2) nth = 1 ;
+    int blas_entry_threads = -1 ;
+    if (X.have_blas && g_blas.set_threads)
+    {
+        pthread_mutex_lock (&g_blas_threads_lock) ;         /* (one factorization at a time changes the BLAS's global count) */
+        blas_entry_threads = g_blas.get_threads ? g_blas.get_threads () : g_blas.max_threads ;
+        if (nth > 1) g_blas.set_threads (1) ;
+    }
+
+    cpu_ws *WS = cholmod_l_calloc ((size_t) nth, sizeof (cpu_ws), Common) ;
+    X.col2s = cholmod_l_malloc (n > 0 ? n : 1, sizeof (Int), Common) ;
+    X.cursor = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    X.link = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    X.pending = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+    X.owner = cholmod_l_malloc (nsuper + 1, sizeof (int32_t), Common) ;
+    int ok = WS && X.col2s && X.cursor && X.link && X.pending && X.owner ;
+    Int *sparent = NULL, *order = NULL, *sub_ptr = NULL, *sub_list = NULL, *park = NULL ;
+    double *wsub = NULL ;
+    cpu_upd *U = NULL ;
+    Int nsub = 0, ntop = 0 ;
+    size_t csizeA = 1, csize0 = 1 ;
     if (ok)
     {
         for (Int s = 0 ; s < nsuper ; s++)
         {
-            for (Int k = Super [s] ; k < Super [s+1] ; k++) col2s [k] = s ;
-            pending [s] = EMPTY ; link [s] = EMPTY ; cursor [s] = 0 ;
+            for (Int k = Super [s] ; k < Super [s+1] ; k++) X.col2s [k] = s ;
+            X.pending [s] = EMPTY ; X.link [s] = EMPTY ; X.cursor [s] = 0 ; X.owner [s] = -1 ;
         }
-        for (Int i = 0 ; i < n ; i++) where [i] = EMPTY ;
     }
-    for (Int s = 0 ; ok && s < nsuper ; s++)
+    if (ok && nth > 1)
     {
-        const Int k1 = Super [s], k2 = Super [s+1], nscol = k2 - k1 ;
-        const Int psi = Lpi [s], nsrow = Lpi [s+1] - psi, psx = Lpx [s] ;
-        double *Fs = Lx + psx ;
-        double t0 ;
-        for (Int r = 0 ; r < nsrow ; r++) where [Ls [psi + r]] = r ;
-        Int good = nscol ;
-        /* pass 0: the supernode as the reference builds it; pass 1 only after a
-         * failed pivot: the same again, to factor the columns before that pivot
-         * (the reference's "repeat supernode", t_cholmod_super_numeric.c:883-968;
-         * the pending lists are only advanced once the supernode is done) */
-        for (int pass = 0 ; pass < 2 ; pass++)
+        /* the cut: subtree weights (flops of a supernode's own columns, sum_j (rows below and including j)^2); the heaviest
+         * subtree is opened -- its root joins the top part, its children become subtrees -- until there are 4 subtrees per
+         * thread or none is heavier than 1 / (2 threads) of the whole */
+        sparent = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        wsub = cholmod_l_malloc (nsuper + 1, sizeof (double), Common) ;
+        order = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        sub_ptr = cholmod_l_malloc (nsuper + 2, sizeof (Int), Common) ;
+        sub_list = cholmod_l_malloc (nsuper + 1, sizeof (Int), Common) ;
+        ok = sparent && wsub && order && sub_ptr && sub_list ;
+        if (ok)
         {
-            t0 = now_s () ;
-            memset (Fs, 0, (size_t) nsrow * (size_t) nscol * sizeof (double)) ;
-            /* A(:, k1:k2-1), lower part, into the supernode (entries outside the
-             * symbolic pattern are dropped, t_cholmod_super_numeric.c:377-378) */
-            for (Int k = k1 ; k < k2 ; k++)
+            double total = 0 ;
+            for (Int s = 0 ; s < nsuper ; s++)
             {
-                Int p = Ap [k], pend = packed ? Ap [k+1] : p + Anz [k] ;
-                double *col = Fs + (k - k1) * nsrow ;
-                for ( ; p < pend ; p++)
-                {
-                    Int i = Ai [p] ;
-                    if (i < k) continue ;
-                    Int r = where [i] ;
-                    if (r >= 0 && r < nsrow && Ls [psi + r] == i) col [r] = Ax [p] ;
-                }
-                col [k - k1] += beta ;
+                const Int nscol = Super [s+1] - Super [s], nsrow = Lpi [s+1] - Lpi [s] ;
+                sparent [s] = (nsrow > nscol) ? X.col2s [Ls [Lpi [s] + nscol]] : EMPTY ;
+                double w = 0, r = (double) nsrow ;
+                for (Int j = 0 ; j < nscol ; j++, r -= 1.0) w += r * r ;
+                wsub [s] = w ;
             }
-            t_asm += now_s () - t0 ;
-            /* updates from the descendants waiting on s */
-            for (Int d = pending [s] ; d != EMPTY ; d = link [d])
+            for (Int s = 0 ; s < nsuper ; s++) { if (sparent [s] != EMPTY) wsub [sparent [s]] += wsub [s] ; else total += wsub [s] ; }
+            /* children lists (head / next through order [] and sub_list [] as scratch) */
+            Int *chead = sub_ptr, *cnext = sub_list ;
+            for (Int s = 0 ; s < nsuper ; s++) chead [s] = EMPTY ;
+            for (Int s = nsuper - 1 ; s >= 0 ; s--) if (sparent [s] != EMPTY) { cnext [s] = chead [sparent [s]] ; chead [sparent [s]] = s ; }
+            /* candidate roots in a simple binary max-heap keyed by wsub */
+            Int *heap = order, hn = 0 ;
+            for (Int s = 0 ; s < nsuper ; s++) if (sparent [s] == EMPTY) heap_push (heap, &hn, wsub, s) ;
+            const double heavy = total / (2.0 * (double) nth) ;
+            /* (a supernode in the top part runs by tiles: worth it only for one that is big by itself) */
+            while (hn > 0 && (hn < 4 * (Int) nth || wsub [heap [0]] > heavy))
             {
-                const Int dk = Super [d+1] - Super [d] ;               /* columns of d */
-                const Int dpi = Lpi [d], drows = Lpi [d+1] - dpi ;
-                const Int q1 = cursor [d] ;                             /* first row of d inside s */
-                Int q2 = q1 ;
-                while (q2 < drows && Ls [dpi + q2] < k2) q2++ ;
-                const Int n1 = q2 - q1, n2 = drows - q1 ;               /* rows inside s / from there down */
-                const double *Ld = Lx + Lpx [d] + q1 ;                  /* ld = drows */
-                for (Int r = 0 ; r < n2 ; r++) relpos [r] = where [Ls [dpi + q1 + r]] ;
-                if (have_blas)
-                {
-                    const double one = 1.0, zero = 0.0 ;
-                    int in1 = (int) n1, idk = (int) dk, ild = (int) drows, ildc = (int) n2, in3 = (int) (n2 - n1) ;
-                    t0 = now_s () ;
-                    blas_threads_for ((double) n1 * (double) n2 * (double) dk * 2.0) ;     /* (syrk + gemm of this descendant) */
-                    g_blas.syrk ("L", "N", &in1, &idk, &one, Ld, &ild, &zero, C, &ildc) ;
-                    t_syrk += now_s () - t0 ; n_syrk++ ;
-                    if (in3 > 0)
-                    {
-                        t0 = now_s () ;
-                        g_blas.gemm ("N", "C", &in3, &in1, &idk, &one, Ld + n1, &ild, Ld, &ild, &zero, C + n1, &ildc) ;
-                        t_gemm += now_s () - t0 ; n_gemm++ ;
-                    }
-                    for (Int j = 0 ; j < n1 ; j++)
-                    {
-                        double *dst = Fs + relpos [j] * nsrow ;
-                        const double *cj = C + j * n2 ;
-                        for (Int i = j ; i < n2 ; i++) dst [relpos [i]] -= cj [i] ;
-                    }
-                }
-                else
-                {
-                    /* built-in: the scratch receives 0 - L_d L_d' (lower trapezoid) */
-                    t0 = now_s () ;
-                    for (Int j = 0 ; j < n1 ; j++) memset (C + j * n2 + j, 0, (size_t) (n2 - j) * sizeof (double)) ;
-                    k_gemm_nt (n2, n1, dk, Ld, drows, Ld, drows, C, n2, 1) ;
-                    t_syrk += now_s () - t0 ; n_syrk++ ;
-                    for (Int j = 0 ; j < n1 ; j++)
-                    {
-                        double *dst = Fs + relpos [j] * nsrow ;
-                        const double *cj = C + j * n2 ;
-                        for (Int i = j ; i < n2 ; i++) dst [relpos [i]] += cj [i] ;
-                    }
-                }
+                const Int t = heap [0] ;
+                if (chead [t] == EMPTY) break ;                     /* the heaviest subtree is a leaf */
+                heap_pop (heap, &hn, wsub) ;
+                X.owner [t] = -2 ;                                  /* top part */
+                for (Int c = chead [t] ; c != EMPTY ; c = cnext [c]) heap_push (heap, &hn, wsub, c) ;
             }
-            /* diagonal block: the first `good` columns */
+            /* subtree roots in index order = subtree ids; members inherit top-down (parents have higher indices) */
+            /* subtree ids in index order of the roots; the members inherit top-down (a parent has the higher index) */
+            nsub = hn ;
+            for (Int q = 0 ; q < hn ; q++) X.owner [heap [q]] = -3 ;
+            {
+                int32_t id = 0 ;
+                for (Int s = 0 ; s < nsuper ; s++) if (X.owner [s] == -3) X.owner [s] = id++ ;
+            }
+            for (Int s = nsuper - 1 ; s >= 0 ; s--)
+            {
+                if (X.owner [s] == -2) X.owner [s] = -1 ;                       /* top part */
+                else if (X.owner [s] < 0) X.owner [s] = X.owner [sparent [s]] ;  /* a member: its parent is final and not in the top part */
+            }
+            /* member lists per subtree, ascending; the top part's list */
+            for (Int q = 0 ; q <= nsub + 1 ; q++) sub_ptr [q] = 0 ;
+            for (Int s = 0 ; s < nsuper ; s++) sub_ptr [(X.owner [s] < 0 ? nsub : X.owner [s]) + 1]++ ;
+            for (Int q = 0 ; q <= nsub ; q++) sub_ptr [q+1] += sub_ptr [q] ;
+            {
+                Int *fill = order ;
+                for (Int q = 0 ; q <= nsub ; q++) fill [q] = sub_ptr [q] ;
+                for (Int s = 0 ; s < nsuper ; s++) sub_list [fill [X.owner [s] < 0 ? nsub : X.owner [s]]++] = s ;
+            }
+            ntop = sub_ptr [nsub + 1] - sub_ptr [nsub] ;
+            /* scratch of a subtree thread: the largest panel below the cut bounds every update there (n1 <= nscol, n2 <= nsrow) */
+            for (Int s = 0 ; s < nsuper ; s++)
+                if (X.owner [s] >= 0)
+                {
+                    size_t e = (size_t) (Lpi [s+1] - Lpi [s]) * (size_t) (Super [s+1] - Super [s]) ;
+                    if (e > csizeA) csizeA = e ;
+                }
+            /* (... and a top supernode below the tiling threshold, 4 tiles' worth of panel, runs the same loop on thread 0) */
+            if (csizeA < (size_t) 4 * CPU_TILE * CPU_TILE) csizeA = (size_t) 4 * CPU_TILE * CPU_TILE ;
+        }
+    }
+    if (ok && nth == 1) csize0 = L->maxcsize > 0 ? L->maxcsize : 1 ;
+    if (ok)
+    {
+        for (int t = 0 ; t < nth && ok ; t++)
+        {
+            WS [t].where = cholmod_l_malloc (n > 0 ? n : 1, sizeof (int32_t), Common) ;
+            WS [t].relpos = cholmod_l_malloc (L->maxesize + 1, sizeof (Int), Common) ;
+            WS [t].C = cholmod_l_malloc (nth == 1 ? csize0 : csizeA, sizeof (double), Common) ;
+            ok = WS [t].where && WS [t].relpos && WS [t].C ;
+        }
+    }
+    if (ok && nth > 1)
+    {
+        park = cholmod_l_malloc (2 * (size_t) (nsub > 0 ? nsub : 1), sizeof (Int), Common) ;
+        U = cholmod_l_malloc ((size_t) nsuper + 1, sizeof (cpu_upd), Common) ;
+        ok = park && U ;
+    }
+    Int sfail = EMPTY, info_fail = 0 ;
+    if (ok && nth == 1)
+    {
+        for (Int i = 0 ; i < n ; i++) WS [0].where [i] = -1 ;
+        for (Int s = 0 ; s < nsuper ; s++)
+        {
             Int info = 0 ;
-            t0 = now_s () ;
-            if (have_blas)
-            {
-                int in = (int) good, ild = (int) nsrow, iinfo = 0 ;
-                blas_threads_for ((double) good * (double) good * (double) good / 3.0) ;
-                g_blas.potrf ("L", &in, Fs, &ild, &iinfo) ;
-                info = iinfo ;
-            }
-            else info = k_potrf (good, Fs, nsrow) ;
-            t_potrf += now_s () - t0 ; n_potrf++ ;
-            if (info > 0 && pass == 0)
+            Int good = factor_supernode_seq (&X, WS, s, &info) ;
+            if (info > 0)
             {
                 sfail = s ; info_fail = info ;
-                good = (info == 1 || Common->quick_return_if_not_posdef) ? 0 : info - 1 ;
-                if (good > 0) continue ;                /* redo with the leading columns only */
+                const Int nsrow = Lpi [s+1] - Lpi [s], nscol = Super [s+1] - Super [s] ;
+                memset (Lx + Lpx [s] + good * nsrow, 0, (size_t) nsrow * (size_t) (nscol - good) * sizeof (double)) ;
+                break ;
             }
-            break ;
-        }
-        if (good > 0 && nsrow > good)
-        {
-            /* rows below the factored block (after a failed pivot that includes the
-             * remaining rows of the diagonal block, as in the reference) */
-            t0 = now_s () ;
-            if (have_blas)
-            {
-                const double one = 1.0 ;
-                int im = (int) (nsrow - good), in = (int) good, ild = (int) nsrow ;
-                blas_threads_for ((double) (nsrow - good) * (double) good * (double) good) ;
-                g_blas.trsm ("R", "L", "C", "N", &im, &in, &one, Fs, &ild, Fs + good, &ild) ;
-            }
-            else k_trsm (nsrow - good, good, Fs, nsrow, Fs + good, nsrow) ;
-            t_trsm += now_s () - t0 ; n_trsm++ ;
-        }
-        if (sfail != EMPTY)
-        {
-            /* zero the columns from the failed pivot on, and every later supernode */
-            memset (Fs + good * nsrow, 0, (size_t) nsrow * (size_t) (nscol - good) * sizeof (double)) ;
-            if (Lpx [s+1] < (Int) L->xsize)
-                memset (Lx + Lpx [s+1], 0, (size_t) ((Int) L->xsize - Lpx [s+1]) * sizeof (double)) ;
-            break ;
-        }
-        /* the descendants move on to the supernode of their next row, if any */
-        for (Int d = pending [s] ; d != EMPTY ; )
-        {
-            Int dnext = link [d] ;
-            const Int dpi = Lpi [d], drows = Lpi [d+1] - dpi ;
-            Int q2 = cursor [d] ;
-            while (q2 < drows && Ls [dpi + q2] < k2) q2++ ;
-            cursor [d] = q2 ;
-            if (q2 < drows)
-            {
-                Int t = col2s [Ls [dpi + q2]] ;
-                link [d] = pending [t] ; pending [t] = d ;
-            }
-            d = dnext ;
-        }
-        pending [s] = EMPTY ;
-        /* s becomes a pending descendant of the supernode of its first row below */
-        cursor [s] = nscol ;
-        if (nsrow > nscol)
-        {
-            Int t = col2s [Ls [psi + nscol]] ;
-            link [s] = pending [t] ; pending [t] = s ;
+            advance_descendants (&X, s, -1, NULL, NULL) ;
         }
     }
-    if (where) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), where, Common) ;
-    if (col2s) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), col2s, Common) ;
-    if (cursor) cholmod_l_free (nsuper + 1, sizeof (Int), cursor, Common) ;
-    if (link) cholmod_l_free (nsuper + 1, sizeof (Int), link, Common) ;
-    if (pending) cholmod_l_free (nsuper + 1, sizeof (Int), pending, Common) ;
-    if (relpos) cholmod_l_free (L->maxesize + 1, sizeof (Int), relpos, Common) ;
-    if (C) cholmod_l_free (L->maxcsize > 0 ? L->maxcsize : 1, sizeof (double), C, Common) ;
+    else if (ok)
+    {
+        /* ---- phase A: the subtrees, heaviest first ---- */
+        Int *sfail_sub = order ;            /* per subtree: failing supernode or EMPTY (order [] is free again) */
+        Int *info_sub = sparent ;           /* per subtree: its info (sparent [] is not needed any more) */
+        Int *by_weight = cholmod_l_malloc ((size_t) (nsub > 0 ? nsub : 1), sizeof (Int), Common) ;
+        ok = by_weight != NULL ;
+        if (ok)
+        {
+            for (Int q = 0 ; q < nsub ; q++) { by_weight [q] = q ; sfail_sub [q] = EMPTY ; park [2*q] = park [2*q+1] = EMPTY ; }
+            /* roots' weights: the last member of a subtree's list is its root */
+            for (Int a = 1 ; a < nsub ; a++)
+            {
+                Int v = by_weight [a], b = a - 1 ;
+                double wv = wsub [sub_list [sub_ptr [v+1] - 1]] ;
+                while (b >= 0 && wsub [sub_list [sub_ptr [by_weight [b] + 1] - 1]] < wv) { by_weight [b+1] = by_weight [b] ; b-- ; }
+                by_weight [b+1] = v ;
+            }
+#pragma omp parallel num_threads(nth)
+            {
+                int me = 0 ;
+#ifdef _OPENMP
+                me = omp_get_thread_num () ;
+#endif
+                cpu_ws *W = WS + me ;
+                for (Int i = 0 ; i < n ; i++) W->where [i] = -1 ;
+#pragma omp for schedule(dynamic, 1)
+                for (Int qq = 0 ; qq < nsub ; qq++)
+                {
+                    const Int q = by_weight [qq] ;
+                    for (Int p = sub_ptr [q] ; p < sub_ptr [q+1] ; p++)
+                    {
+                        const Int s = sub_list [p] ;
+                        Int info = 0 ;
+                        Int good = factor_supernode_seq (&X, W, s, &info) ;
+                        if (info > 0)
+                        {
+                            sfail_sub [q] = s ; info_sub [q] = info ;
+                            const Int nsrow = Lpi [s+1] - Lpi [s], nscol = Super [s+1] - Super [s] ;
+                            memset (Lx + Lpx [s] + good * nsrow, 0, (size_t) nsrow * (size_t) (nscol - good) * sizeof (double)) ;
+                            break ;
+                        }
+                        advance_descendants (&X, s, (int32_t) q, &park [2*q], &park [2*q+1]) ;
+                    }
+                }
+            }
+            for (Int q = 0 ; q < nsub ; q++)
+                if (sfail_sub [q] != EMPTY && (sfail == EMPTY || sfail_sub [q] < sfail)) { sfail = sfail_sub [q] ; info_fail = info_sub [q] ; }
+            /* the parked descendants go to their first ancestor in the top part, subtree by subtree */
+            for (Int q = 0 ; q < nsub ; q++)
+                for (Int d = park [2*q] ; d != EMPTY ; )
+                {
+                    Int dnext = X.link [d] ;
+                    Int t = X.col2s [Ls [Lpi [d] + X.cursor [d]]] ;
+                    X.link [d] = X.pending [t] ; X.pending [t] = d ;
+                    d = dnext ;
+                }
+            cholmod_l_free ((size_t) (nsub > 0 ? nsub : 1), sizeof (Int), by_weight, Common) ;
+            /* ---- phase B: the top part in index order (everything below a top supernode is complete); a failure below
+             * ends it at the first failing index: what lies beyond is zeroed anyway ---- */
+            for (Int p = sub_ptr [nsub] ; p < sub_ptr [nsub + 1] ; p++)
+            {
+                const Int s = sub_list [p] ;
+                if (sfail != EMPTY && s > sfail) break ;
+                const Int nscol = Super [s+1] - Super [s], nsrow = Lpi [s+1] - Lpi [s] ;
+                Int info = 0, good ;
+                const int tiled = (nscol >= 2 * CPU_TILE || (double) nsrow * (double) nscol >= 4.0 * CPU_TILE * CPU_TILE) ;
+                if (tiled)
+                {
+                    good = factor_supernode_tiled (&X, WS, nth, s, U, &info) ;
+                    if (info > 0)
+                    {
+                        /* the repeat-supernode protocol, in order, on one thread (rare: a scratch of the panel's size) */
+                        cpu_ws W1 = WS [0] ;
+                        W1.C = cholmod_l_malloc ((size_t) nsrow * (size_t) nscol, sizeof (double), Common) ;
+                        if (!W1.C) { ok = FALSE ; break ; }
+                        good = factor_supernode_seq (&X, &W1, s, &info) ;
+                        cholmod_l_free ((size_t) nsrow * (size_t) nscol, sizeof (double), W1.C, Common) ;
+                    }
+                }
+                else good = factor_supernode_seq (&X, WS, s, &info) ;
+                if (info > 0)
+                {
+                    sfail = s ; info_fail = info ;
+                    memset (Lx + Lpx [s] + good * nsrow, 0, (size_t) nsrow * (size_t) (nscol - good) * sizeof (double)) ;
+                    break ;
+                }
+                advance_descendants (&X, s, -1, NULL, NULL) ;
+            }
+        }
+    }
+    if (ok && sfail != EMPTY && Lpx [sfail+1] < (Int) L->xsize)
+        memset (Lx + Lpx [sfail+1], 0, (size_t) ((Int) L->xsize - Lpx [sfail+1]) * sizeof (double)) ;     /* every later supernode */
+    if (blas_entry_threads >= 0)
+    {
+        if (nth > 1 && blas_entry_threads > 0) g_blas.set_threads (blas_entry_threads) ;
+        pthread_mutex_unlock (&g_blas_threads_lock) ;
+    }
+    double t_syrk = 0, t_gemm = 0, t_potrf = 0, t_trsm = 0, t_asm = 0 ;
+    size_t n_syrk = 0, n_gemm = 0, n_potrf = 0, n_trsm = 0 ;
+    if (WS)
+    {
+        for (int t = 0 ; t < nth ; t++)
+        {
+            t_syrk += WS [t].t_syrk ; t_gemm += WS [t].t_gemm ; t_potrf += WS [t].t_potrf ; t_trsm += WS [t].t_trsm ; t_asm += WS [t].t_asm ;
+            n_syrk += WS [t].n_syrk ; n_gemm += WS [t].n_gemm ; n_potrf += WS [t].n_potrf ; n_trsm += WS [t].n_trsm ;
+            if (WS [t].where) cholmod_l_free (n > 0 ? n : 1, sizeof (int32_t), WS [t].where, Common) ;
+            if (WS [t].relpos) cholmod_l_free (L->maxesize + 1, sizeof (Int), WS [t].relpos, Common) ;
+            if (WS [t].C) cholmod_l_free (nth == 1 ? csize0 : csizeA, sizeof (double), WS [t].C, Common) ;
+        }
+        cholmod_l_free ((size_t) nth, sizeof (cpu_ws), WS, Common) ;
+    }
+    if (X.col2s) cholmod_l_free (n > 0 ? n : 1, sizeof (Int), X.col2s, Common) ;
+    if (X.cursor) cholmod_l_free (nsuper + 1, sizeof (Int), X.cursor, Common) ;
+    if (X.link) cholmod_l_free (nsuper + 1, sizeof (Int), X.link, Common) ;
+    if (X.pending) cholmod_l_free (nsuper + 1, sizeof (Int), X.pending, Common) ;
+    if (X.owner) cholmod_l_free (nsuper + 1, sizeof (int32_t), X.owner, Common) ;
+    if (sparent) cholmod_l_free (nsuper + 1, sizeof (Int), sparent, Common) ;
+    if (wsub) cholmod_l_free (nsuper + 1, sizeof (double), wsub, Common) ;
+    if (order) cholmod_l_free (nsuper + 1, sizeof (Int), order, Common) ;
+    if (sub_ptr) cholmod_l_free (nsuper + 2, sizeof (Int), sub_ptr, Common) ;
+    if (sub_list) cholmod_l_free (nsuper + 1, sizeof (Int), sub_list, Common) ;
+    if (park) cholmod_l_free (2 * (size_t) (nsub > 0 ? nsub : 1), sizeof (Int), park, Common) ;
+    if (U) cholmod_l_free ((size_t) nsuper + 1, sizeof (cpu_upd), U, Common) ;
+    (void) ntop ;
     if (!ok) return FALSE ;
-    /* the reference's counters (cholmod_core.h:1004-1024) */
+    /* the reference's counters (cholmod_core.h:1004-1024; with several threads: summed over the threads) */
     Common->cholmod_cpu_syrk_time = t_syrk ; Common->cholmod_cpu_gemm_time = t_gemm ;
     Common->cholmod_cpu_potrf_time = t_potrf ; Common->cholmod_cpu_trsm_time = t_trsm ;
     Common->cholmod_cpu_syrk_calls = n_syrk ; Common->cholmod_cpu_gemm_calls = n_gemm ;

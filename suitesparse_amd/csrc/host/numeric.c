@@ -10,6 +10,11 @@
  * CHOLMOD/Supernodal/cholmod_super_numeric.c, cholmod_super_solve.c;
  * CHOLMOD/GPU/cholmod_gpu.c. */
 #include "host_internal.h"
+#ifdef _OPENMP
+#include <omp.h>
+#else
+static int omp_get_thread_num (void) { return 0 ; }
+#endif
 #include <time.h>
 
 /* ---- GPU entry points (reference CHOLMOD/GPU/cholmod_gpu.c:71-486) ---------------- */
@@ -164,7 +169,11 @@ static int finish_numeric (int rc, int64_t minor, cholmod_factor *L, cholmod_com
     const int was_symbolic = (L->xtype == CHOLMOD_PATTERN && !L->x) ;
     if (rc < 0)
     {
-        if (was_symbolic) back_to_symbolic (L) ;
+        /* the device copy is void whatever L was on entry (run_factorize clears it first): a numeric L keeps the values
+         * it has on the host, if it has them (the reference leaves the old values of a numeric L in place); otherwise L is
+         * symbolic again -- never a "numeric" L whose device factor is a zeroed or partial one */
+        if (was_symbolic || !(L->x && L->hip_host_valid)) back_to_symbolic (L) ;
+        else L->hip_on_device = FALSE ;
         return map_hip_status (rc, Common, "HIP factorization failed") ;
     }
     L->xtype = CHOLMOD_REAL ;
@@ -341,15 +350,13 @@ static int api_threads (void)
     return nt > 16 ? 16 : nt ;
 }
 
-static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
+typedef struct { uint64_t hp, gp, hi, gi ; } pat_sums ;
+
+/* the column pointers j0 .. j1-1 / the row indices p0 .. p1-1 into the four sums (order-independent: any split will do) */
+static void pattern_hash_p (const Int *Ap, Int j0, Int j1, pat_sums *S)
 {
-    const Int *Ap = A->p, *Ai = A->i ;
-    const Int ncol = (Int) A->ncol, nz = Ap [ncol] ;
-    const int nth = api_threads () ;
-    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t) A->nrow * 0xff51afd7ed558ccdull) ^ ((uint64_t) (A->stype + 2) << 56) ;
-    uint64_t hp = 0, hi = 0, gp = 0, gi = 0 ;
-#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp,gp)
-    for (Int j = 0 ; j <= ncol ; j++)
+    uint64_t hp = 0, gp = 0 ;
+    for (Int j = j0 ; j < j1 ; j++)
     {
         uint64_t x = (uint64_t) Ap [j] + 0x9E3779B97F4A7C15ull * (uint64_t) (j + 1) ;
         x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
@@ -358,8 +365,13 @@ static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
         y ^= y >> 33 ; y *= 0xff51afd7ed558ccdull ; y ^= y >> 33 ; y *= 0xc4ceb9fe1a85ec53ull ; y ^= y >> 33 ;
         gp += y ;
     }
-#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hi,gi)
-    for (Int p = 0 ; p < nz ; p++)
+    S->hp += hp ; S->gp += gp ;
+}
+
+static void pattern_hash_i (const Int *Ai, Int p0, Int p1, pat_sums *S)
+{
+    uint64_t hi = 0, gi = 0 ;
+    for (Int p = p0 ; p < p1 ; p++)
     {
         uint64_t x = (uint64_t) Ai [p] + 0xD1B54A32D192ED03ull * (uint64_t) (p + 1) ;
         x ^= x >> 30 ; x *= 0xbf58476d1ce4e5b9ull ; x ^= x >> 27 ; x *= 0x94d049bb133111ebull ; x ^= x >> 31 ;
@@ -368,13 +380,45 @@ static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
         y ^= y >> 33 ; y *= 0xff51afd7ed558ccdull ; y ^= y >> 33 ; y *= 0xc4ceb9fe1a85ec53ull ; y ^= y >> 33 ;
         gi += y ;
     }
+    S->hi += hi ; S->gi += gi ;
+}
+
+static uint64_t pattern_hash_fold (cholmod_sparse *A, const pat_sums *S, uint64_t *second)
+{
+    const Int ncol = (Int) A->ncol, nz = ((Int *) A->p) [ncol] ;
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ((uint64_t) A->nrow * 0xff51afd7ed558ccdull) ^ ((uint64_t) (A->stype + 2) << 56) ;
     if (second)
     {
-        uint64_t g = gp ^ ((gi << 23) | (gi >> 41)) ^ ((uint64_t) nz * 0x9FB21C651E98DF25ull) ;
+        uint64_t g = S->gp ^ ((S->gi << 23) | (S->gi >> 41)) ^ ((uint64_t) nz * 0x9FB21C651E98DF25ull) ;
         g ^= g >> 32 ; g *= 0xd6e8feb86659fd93ull ; g ^= g >> 32 ;
         *second = g ^ ((uint64_t) ncol << 17) ;
     }
-    return h ^ hp ^ (hi * 0x2545F4914F6CDD1Dull) ;
+    return h ^ S->hp ^ (S->hi * 0x2545F4914F6CDD1Dull) ;
+}
+
+static uint64_t pattern_hash (cholmod_sparse *A, uint64_t *second)
+{
+    const Int *Ap = A->p, *Ai = A->i ;
+    const Int ncol = (Int) A->ncol, nz = Ap [ncol] ;
+    const int nth = api_threads () ;
+    uint64_t hp = 0, hi = 0, gp = 0, gi = 0 ;
+    const Int PIECE = (Int) 1 << 16 ;
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hp,gp)
+    for (Int j = 0 ; j <= ncol ; j += PIECE)
+    {
+        pat_sums T = {0, 0, 0, 0} ;
+        pattern_hash_p (Ap, j, (j + PIECE < ncol + 1) ? j + PIECE : ncol + 1, &T) ;
+        hp += T.hp ; gp += T.gp ;
+    }
+#pragma omp parallel for schedule(static) num_threads(nth) reduction(+:hi,gi)
+    for (Int p = 0 ; p < nz ; p += PIECE)
+    {
+        pat_sums T = {0, 0, 0, 0} ;
+        pattern_hash_i (Ai, p, (p + PIECE < nz) ? p + PIECE : nz, &T) ;
+        hi += T.hi ; gi += T.gi ;
+    }
+    pat_sums S = {hp, gp, hi, gi} ;
+    return pattern_hash_fold (A, &S, second) ;
 }
 
 /* reference: Cholesky/cholmod_factorize.c:97-300, supernodal symmetric branch
@@ -426,11 +470,91 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         const int timing = getenv ("CHOLMOD_API_TIMING") != NULL ;
         double tq0 = timing ? api_now () : 0, tq1 = 0, tq2 = 0 ;
         int rc = cholmod_hip_values_staging (plan, &stage, &cap) ;
-        if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz)
+        const int nth = api_threads () ;
+        static int overlap = -1 ;
+        if (overlap < 0) { const char *e = getenv ("CHOLMOD_API_OVERLAP") ; overlap = (e && !strcmp (e, "0")) ? 0 : 1 ; }
+        if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz && nth >= 2 && overlap)
+        {
+            /* Round 6: nothing but the DMA itself stands between the call and the factorization.  Thread 0 pushes every chunk
+             * as soon as the others have staged it, commits and ENQUEUES THE FACTORIZATION AT ONCE; the other threads stage
+             * the chunks (A->x into the pinned buffer) and then take the pattern hash while the device already works.  The
+             * proof that the resident S and its value map fit A therefore arrives after the fact: should it fail -- another
+             * pattern with the same number of entries -- what the device computed is discarded and the call takes the long
+             * way (permutation, full upload, factorization), which rebuilds S, map and factor from scratch.  (Round 5: stage
+             * 1.0 ms, then the hash 1.25 ms, then the factorization: 2.7 ms on top of the nd24k stand-in's 27.9 ms step.) */
+            const double *Ax = A->x ;
+            const Int *Ap = A->p, *Ai = A->i ;
+            const Int ncol = (Int) A->ncol ;
+            const int64_t CH = (int64_t) 1 << 20 ;          /* 8 MB per push */
+            const int64_t PIECE = 32768 ;                   /* 256 KB per staging turn */
+            const int64_t nchunk = (cap + CH - 1) / CH ;
+            const int64_t npiece = (cap + PIECE - 1) / PIECE ;
+            const int64_t HP = (int64_t) 1 << 16 ;          /* entries per hash turn */
+            const int64_t nhp = ((int64_t) ncol + 1 + HP - 1) / HP, nhi = ((int64_t) annz + HP - 1) / HP ;
+            int64_t *chunk_done = cholmod_l_calloc ((size_t) (nchunk > 0 ? nchunk : 1), sizeof (int64_t), Common) ;
+            if (!chunk_done) return FALSE ;
+            int64_t next_piece = 0, next_hash = 0 ;
+            pat_sums tot = {0, 0, 0, 0} ;
+            int64_t minor = (int64_t) L->n ;
+            int rcf = CHOLMOD_HIP_OK, rcp = CHOLMOD_HIP_OK ;
+#pragma omp parallel num_threads(nth)
+            {
+                if (omp_get_thread_num () == 0)
+                {
+                    for (int64_t c = 0 ; c < nchunk && rcp == CHOLMOD_HIP_OK ; c++)
+                    {
+                        const int64_t o = c * CH, cnt = (cap - o < CH) ? cap - o : CH ;
+                        const int64_t need = (cnt + PIECE - 1) / PIECE ;
+                        while (__atomic_load_n (&chunk_done [c], __ATOMIC_ACQUIRE) < need) { /* (a few microseconds) */ }
+                        rcp = cholmod_hip_values_push (plan, o, cnt) ;
+                    }
+                    if (timing) tq1 = api_now () ;
+                    if (rcp == CHOLMOD_HIP_OK && cholmod_hip_values_commit (plan, 1) == CHOLMOD_HIP_OK)
+                        rcf = cholmod_hip_factorize_resident (plan, beta ? beta [0] : 0.0, Common->quick_return_if_not_posdef, &minor) ;
+                    else
+                    {
+                        (void) cholmod_hip_values_commit (plan, 0) ;
+                        rcp = CHOLMOD_HIP_INVALID ;
+                    }
+                }
+                else
+                {
+                    for ( ; ; )
+                    {
+                        const int64_t k = __atomic_fetch_add (&next_piece, 1, __ATOMIC_RELAXED) ;
+                        if (k >= npiece) break ;
+                        const int64_t q = k * PIECE, len = (cap - q < PIECE) ? cap - q : PIECE ;
+                        memcpy (stage + q, Ax + q, (size_t) len * sizeof (double)) ;
+                        __atomic_fetch_add (&chunk_done [q / CH], 1, __ATOMIC_RELEASE) ;
+                    }
+                    pat_sums mine = {0, 0, 0, 0} ;
+                    for ( ; ; )
+                    {
+                        const int64_t k = __atomic_fetch_add (&next_hash, 1, __ATOMIC_RELAXED) ;
+                        if (k >= nhp + nhi) break ;
+                        if (k < nhp) pattern_hash_p (Ap, (Int) (k * HP), (Int) (((k + 1) * HP < ncol + 1) ? (k + 1) * HP : ncol + 1), &mine) ;
+                        else pattern_hash_i (Ai, (Int) ((k - nhp) * HP), (Int) (((k - nhp + 1) * HP < (int64_t) annz) ? (k - nhp + 1) * HP : (int64_t) annz), &mine) ;
+                    }
+#pragma omp critical (ssamd_pattern_hash)
+                    { tot.hp += mine.hp ; tot.gp += mine.gp ; tot.hi += mine.hi ; tot.gi += mine.gi ; }
+                }
+            }
+            cholmod_l_free ((size_t) (nchunk > 0 ? nchunk : 1), sizeof (int64_t), chunk_done, Common) ;
+            hash = pattern_hash_fold (A, &tot, &hash2) ;
+            hashed = TRUE ;
+            if (timing) tq2 = api_now () ;
+            if (rcp == CHOLMOD_HIP_OK && L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2)
+            {
+                if (timing) fprintf (stderr, "cholmod_l_factorize (values only, overlapped): last push at %.3f ms, factorization + hash done at %.3f ms\n",
+                    1e3 * (tq1 - tq0), 1e3 * (tq2 - tq0)) ;
+                return finish_numeric (rcf, minor, L, Common) ;
+            }
+            /* (another pattern after all: the device's S, map and factor are void; the long way rebuilds all three) */
+        }
+        else if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz)
         {
             const double *Ax = A->x ;
             const int64_t CH = (int64_t) 1 << 20 ;          /* 8 MB per push */
-            const int nth = api_threads () ;
             for (int64_t o = 0 ; o < cap && rc == CHOLMOD_HIP_OK ; o += CH)
             {
                 const int64_t cnt = (cap - o < CH) ? cap - o : CH ;

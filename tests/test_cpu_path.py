@@ -137,6 +137,75 @@ def test_cpu_not_posdef_protocol_matches_oracle(quick):
     S.finish()
 
 
+PAR_CHECK = r'''
+import sys, os, ctypes
+import numpy as np
+sys.path.insert(0, ".")
+from oracle.oracle import OracleFactor, bind_blas
+from suitesparse_amd import cholmod as ch, generators as G
+m = int(os.environ["GRID"])
+n, Ap, Ai, Ax = G.poisson3d(m)
+perm = G.geometric_nd(m, m, m, 4)
+bind_blas()
+O = OracleFactor(n, Ap, Ai, -1, perm=perm, postorder=True)
+mask = O.lower_mask()
+lib = os.environ.get("CHOLMOD_BLAS_LIBRARY", "none")
+getter = None
+if lib != "none":
+    path, prefix = lib.split(":")
+    B = ctypes.CDLL(path)
+    getter = getattr(B, prefix + "openblas_get_num_threads")
+    # the caller's setting must survive the factorization (not above the library's own maximum, OMP_NUM_THREADS at its load)
+    want = min(2, int(os.environ.get("OMP_NUM_THREADS", "1")))
+    getattr(B, prefix + "openblas_set_num_threads")(want)
+S = ch.Session(use_gpu=0)
+# a failing pivot deep in a subtree (phase A), in a supernode of the top part (phase B: the root), and none at all
+sup = O.super
+nsc = np.diff(sup)
+cases = [None, int(sup[O.nsuper // 3] + min(2, nsc[O.nsuper // 3] - 1)), int(sup[O.nsuper - 1] + nsc[O.nsuper - 1] // 2)]
+for kbad in cases:
+    vals = Ax.copy()
+    if kbad is not None:
+        vals[Ap[int(O.Perm[kbad])]] = -7.0
+    st = O.factorize(vals)
+    A = S.sparse(n, Ap, Ai, vals, -1)
+    Lf = S.analyze(A, perm)
+    assert S.factorize(A, Lf) == 1
+    fv = ch.FactorView(Lf)
+    assert S.cm.status == (ch.NOT_POSDEF if st == 1 else ch.OK) and fv.minor == O.minor, (kbad, S.cm.status, fv.minor, O.minor)
+    assert np.array_equal(fv.x[mask] != 0, (O.x != 0)[mask]), kbad
+    err = np.linalg.norm((fv.x - O.x)[mask]) / np.linalg.norm(O.x[mask])
+    assert err < 1e-12, (kbad, err)
+    assert np.all(fv.x[~mask] == 0)
+    if kbad is None:
+        b = G.demo_rhs(n)
+        x = S.solve(Lf, b)
+        assert np.linalg.norm(G.sym_matvec(n, Ap, Ai, vals, -1, x) - b) / np.linalg.norm(b) < 1e-11
+        assert S.cm.cholmod_cpu_potrf_calls >= fv.nsuper
+    S.free_factor(Lf); S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+if getter is not None:
+    assert getter() == want, getter()
+S.finish()
+print("ok")
+'''
+
+
+@pytest.mark.parametrize("blas", ["builtin", "dlopen"])
+@pytest.mark.parametrize("threads,grid", [(1, 24), (8, 24), (8, 40), (3, 32)])
+def test_cpu_path_on_several_threads(blas, threads, grid):
+    """Round 6: independent subtrees on one thread each, the top supernodes by tiles (cpu_numeric.c), the BLAS on one
+    thread per call and its entry thread count restored.  Poisson 40^3 has a 1 600-column root and supernodes beyond the
+    tiling threshold; against the oracle, with a failing pivot in a subtree, one in the root, and none."""
+    lib = "none" if blas == "builtin" else _scipy_blas()
+    if lib is None:
+        pytest.skip("no LP64 BLAS with LAPACK found for dlopen")
+    if blas == "builtin" and grid > 32:
+        pytest.skip("the built-in kernels are for plumbing, not for 40^3")
+    out = _run_child(PAR_CHECK, {"CHOLMOD_BLAS_LIBRARY": lib, "GRID": str(grid), "OMP_NUM_THREADS": str(threads)})
+    assert out.strip().endswith("ok")
+
+
 def test_env_default_is_cpu_like_the_reference(monkeypatch):
     """Common->useGPU == -1 (cholmod_l_start): CHOLMOD_USE_GPU unset selects the CPU
     (CHOLMOD/Supernodal/cholmod_super_symbolic.c:286-291), =1 the GPU."""

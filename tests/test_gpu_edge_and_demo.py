@@ -386,8 +386,38 @@ def test_factorize_again_with_new_values_and_with_a_new_pattern(stype):
     assert O2.factorize(Ax2, Ap=Ap2, Ai=Ai2) == 0
     fv = ch.FactorView(Lf)
     assert np.linalg.norm((fv.x - O2.x)[mask]) / np.linalg.norm(O2.x[mask]) < 1e-12
+    # another pattern with the SAME number of entries (one row index moved): the values-only path starts the factorization
+    # before the pattern hash is in (round 6) -- the hash must then void what the device computed and the call must take
+    # the long way; twice, so that the second call goes through the values-only path of the NEW pattern
+    Ai3 = Ai2.copy()
+    cols2 = np.repeat(np.arange(n), np.diff(Ap2))
+    moved = False
+    for q in range(len(Ai3) - 1, 0, -1):
+        j = cols2[q]
+        lo = Ai3[q - 1] if cols2[q - 1] == j else -1
+        cand = Ai3[q] - 1 if stype < 0 else Ai3[q] + 1
+        # keep the column sorted, off the diagonal, inside the stored triangle and away from its neighbours
+        if stype < 0 and cand > j and cand > lo and Ai3[q] != j:
+            Ai3[q] = cand ; moved = True ; break
+        if stype > 0 and cand < j and Ai3[q] != j and (q + 1 == len(Ai3) or cols2[q + 1] != j or Ai3[q + 1] > cand):
+            Ai3[q] = cand ; moved = True ; break
+    assert moved
+    A3 = S.sparse(n, Ap2, Ai3, Ax2, stype)
+    for _ in range(2):
+        h_before = Lf.contents.hip_apat_hash
+        assert S.factorize(A3, Lf) == 1 and S.cm.status == ch.OK
+        assert O2.factorize(Ax2, Ap=Ap2, Ai=Ai3) == 0
+        fv = ch.FactorView(Lf)
+        assert np.linalg.norm((fv.x - O2.x)[mask]) / np.linalg.norm(O2.x[mask]) < 1e-12
+    assert Lf.contents.hip_apat_hash == h_before            # (second call: same pattern, values only)
+    # ... and back to the previous pattern, again with the same count
+    assert S.factorize(A2, Lf) == 1 and S.cm.status == ch.OK
+    assert O2.factorize(Ax2, Ap=Ap2, Ai=Ai2) == 0
+    fv = ch.FactorView(Lf)
+    assert np.linalg.norm((fv.x - O2.x)[mask]) / np.linalg.norm(O2.x[mask]) < 1e-12
     S.free_factor(Lf)
     S.free_sparse(A)
     S.free_sparse(A2)
+    S.free_sparse(A3)
     assert S.cm.malloc_count == 0
     S.finish()
