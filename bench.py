@@ -65,98 +65,81 @@ def _scipy_openblas():
 
 
 CPU_CHILD = r"""
-import json, os, sys, time
+import ctypes, json, os, sys, time
 sys.path.insert(0, os.environ["BENCH_ROOT"])
 from suitesparse_amd import cholmod as ch, generators as G
-import ctypes as C
 m = int(os.environ["BENCH_CPU_M"])
-# BENCH_CPU_PIN=1 (off by default): the threads of this process (OpenMP team, the BLAS's own pool -- they inherit the mask) on
-# the first T physical cores of NUMA node 0.  Measured in round 5 on the 2 x 64-core EPYC 9575F box, Poisson 100^3: pinned
-# 315 / 294 / 111 GFLOP/s at 16 / 32 / 64 threads against 480 / 330 / 221 un-pinned -- sixteen threads spread over all the
-# CCDs have more L3 and memory channels than sixteen neighbours, and the bound OpenBLAS (scipy's pthread build) loses
-# beyond 16 threads either way: its dpotrf / dsyrk on the top fronts, not this loop, is what does not scale.
-pinned = None
-try:
-    T = int(os.environ.get("OMP_NUM_THREADS", "0"))
-    if T > 0 and os.environ.get("BENCH_CPU_PIN", "0") != "0":
-        txt = open("/sys/devices/system/node/node0/cpulist").read().strip()
-        first = txt.split(",")[0]                      # (the first range = the physical cores; later ranges are their SMT siblings)
-        lo, hi = (int(v) for v in (first.split("-") + [first])[:2])
-        cpus = list(range(lo, hi + 1))[:T]
-        if len(cpus) == T:
-            os.sched_setaffinity(0, cpus)
-            pinned = "cpus %d-%d of NUMA node 0" % (cpus[0], cpus[-1])
-except Exception:
-    pinned = None
+counts = [int(v) for v in os.environ["BENCH_CPU_COUNTS"].split(",")]
+budget = float(os.environ.get("BENCH_CPU_BUDGET_S", "30"))
+gomp = ctypes.CDLL("libgomp.so.1")
 n, Ap, Ai, Ax = G.poisson3d(m)
 perm = G.geometric_nd(m, m, m, 4)
 S = ch.Session(use_gpu=0)
 A = S.sparse(n, Ap, Ai, Ax, -1)
 Lf = S.analyze(A, perm)
-secs = []
-for _ in range(int(os.environ.get("BENCH_CPU_REPS", "2"))):
+# one untimed factorization on all threads: the first touch of L->x (10.5 GB at 100^3) is page faults, not arithmetic
+t0 = time.perf_counter()
+ok = S.factorize(A, Lf)
+first = time.perf_counter() - t0
+assert ok == 1 and S.cm.status == 0
+pts, spent = [], 0.0
+for t in sorted(counts, reverse=True):          # widest first: should the budget run out, the narrow points are the ones missing
+    if spent > budget:
+        break
+    gomp.omp_set_num_threads(t)
     t0 = time.perf_counter()
     ok = S.factorize(A, Lf)
-    secs.append(time.perf_counter() - t0)
+    dt = time.perf_counter() - t0
     assert ok == 1 and S.cm.status == 0
-S.L.ssamd_cpu_blas_name.restype = C.c_char_p
-print(json.dumps({"fl": S.cm.fl, "seconds": secs, "blas": S.L.ssamd_cpu_blas_name().decode(),
-                  "threads": int(os.environ.get("OMP_NUM_THREADS", "0")) or os.cpu_count(), "pinned": pinned}))
+    spent += dt
+    pts.append({"threads": t, "seconds": dt})
+S.L.ssamd_cpu_blas_name.restype = ctypes.c_char_p
+print(json.dumps({"fl": S.cm.fl, "points": pts, "first_seconds": first, "blas": S.L.ssamd_cpu_blas_name().decode()}))
 """
 
 
 def cpu_baseline(sample_m):
-    """The build's own CPU supernodal path (Common->useGPU = 0: suitesparse_amd/csrc/host/cpu_numeric.c,
-    the reference's left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU
-    supernodal path") timed on the host cores on a bounded sample of the same workload family, in
-    child processes (the BLAS binding and its thread pool are per process).  Not the oracle: nothing
-    under oracle/ is timed.  The sample is BASELINE configs[1] itself (Poisson 100^3, fl = 6.3e12: about half a minute
-    per factorization) at 16, 32 and 64 threads; `value` is the best of them and `cores` the thread count that gave it,
-    every point is in `by_threads`.  (Rounds 3-4 used 56^3 and saw 64 threads 6 x slower than 16: the threaded BLAS woke
-    every thread for each of the several hundred thousand tiny updates; host/cpu_numeric.c now sizes the thread count
-    of every dense call by its flops.)"""
+    """The build's own CPU supernodal path (Common->useGPU = 0: suitesparse_amd/csrc/host/cpu_numeric.c, the reference's
+    left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU supernodal path") timed on the host
+    cores on a bounded sample of the same workload family, in ONE child process (the BLAS binding is per process).  Not the
+    oracle: nothing under oracle/ is timed.  The sample is BASELINE configs[1] itself (Poisson 100^3, fl = 6.3e12); after
+    one untimed factorization (first touch of L->x) the child times one factorization per thread count -- 8, 16, 32, 64, 128
+    and every hardware thread of the box, widest first, until 30 s are spent; `value` is the best, `cores` the thread count
+    that gave it, `host_cores` what the box has.  Round 6: the path runs independent subtrees on one thread each and the top
+    supernodes by tiles, the BLAS on one thread per call (rounds 3-5: a threaded BLAS under a serial loop, best at 16
+    threads and slower beyond)."""
     import subprocess
+    cores = os.cpu_count() or 1
     base = dict(os.environ, BENCH_ROOT=ROOT, BENCH_CPU_M=str(sample_m))
     if "CHOLMOD_BLAS_LIBRARY" not in base:
         b = _scipy_openblas()
         if b:
             base["CHOLMOD_BLAS_LIBRARY"] = b
-    cores = os.cpu_count() or 1
-    big = sample_m >= 80            # (a BASELINE-size sample: tens of seconds per factorization)
     if "OMP_NUM_THREADS" in os.environ:
         counts = [int(os.environ["OMP_NUM_THREADS"])]
-    elif big:
-        counts = sorted({min(cores, 8), min(cores, 16), min(cores, 32), min(cores, 64)})      # up to one socket's cores (EPYC 9575F: 64)
     else:
-        counts = sorted({1, min(cores, 16), min(cores, 64)})
-    base["BENCH_CPU_REPS"] = os.environ.get("BENCH_CPU_REPS", "1" if big else "2")
-    pts, blas, fl, err = [], None, None, None
-    for t in counts:
-        env = dict(base, OMP_NUM_THREADS=str(t), OPENBLAS_NUM_THREADS=str(t), MKL_NUM_THREADS=str(t))
-        try:
-            out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=900)
-            r = json.loads(out.stdout.strip().splitlines()[-1])
-        except Exception as e:      # report, never fail the bench line
-            err = repr(e)
-            continue
-        blas, fl = r["blas"], r["fl"]
-        best = min(r["seconds"])
-        pts.append({"threads": t, "GFLOPs": r["fl"] / best / 1e9, "seconds_best": best, "seconds_first": r["seconds"][0],
-                    "pinned": r.get("pinned")})
-    if not pts:
-        return {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port", "sample": f"failed: {err}"}
+        counts = sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)})
+    base["BENCH_CPU_COUNTS"] = ",".join(str(c) for c in counts)
+    env = dict(base, OMP_NUM_THREADS=str(max(counts)), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", OMP_PROC_BIND="false")
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=900)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:      # report, never fail the bench line
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "host_cores": cores, "kind": "port", "sample": f"failed: {e!r}"[:200]}
+    leg = time.perf_counter() - t0
+    fl, blas = r["fl"], r["blas"]
+    pts = sorted(({"threads": q["threads"], "GFLOPs": fl / q["seconds"] / 1e9, "seconds_best": q["seconds"]} for q in r["points"]),
+                 key=lambda q: q["threads"])
     top = max(pts, key=lambda q: q["GFLOPs"])
-    one = next((q for q in pts if q["threads"] == 1), None)
     return {"value": top["GFLOPs"], "unit": "GFLOP/s", "cores": top["threads"], "host_cores": cores, "kind": "port",
             "sample_short": f"poisson3d {sample_m}^3 ND, whole factorization, {top['seconds_best']:.1f} s",
             "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
-            "by_threads": pts,
-            "speedup_over_one_thread": (top["GFLOPs"] / one["GFLOPs"]) if one else None,
+            "by_threads": pts, "first_factorization_seconds": r["first_seconds"], "leg_seconds": leg,
             "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)),
             "sample": f"poisson3d {sample_m}^3 geometric ND" + (" (BASELINE configs[1], the whole factorization)" if sample_m == 100 else "")
-                      + f", best of {base['BENCH_CPU_REPS']} factorization(s) per thread count "
-                      f"({', '.join(str(q['threads']) for q in pts)} threads; every dense call gets one BLAS thread per ~128 Mflop, at most that many), "
-                      f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas}, host cores {cores}"}
+                      + f", one factorization per thread count ({', '.join(str(q['threads']) for q in pts)}) after one untimed, "
+                      f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas} (one thread per call), host cores {cores}"}
 
 
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r05k_pmc_summary_poisson200_top48.json"}

@@ -221,6 +221,14 @@ int cholmod_hip_refresh_values (cholmod_hip_plan *plan, const double *values, in
 int cholmod_hip_values_staging (cholmod_hip_plan *plan, double **host_buffer, int64_t *nvalues) ;
 int cholmod_hip_values_push (cholmod_hip_plan *plan, int64_t offset, int64_t count) ;
 int cholmod_hip_values_commit (cholmod_hip_plan *plan, int commit) ;
+/* Round 6: the same upload in the order the factorization needs the values, chunk by chunk, so that a batch of fronts
+ * waits for its own entries only (cholmod_l_factorize drives it from three kinds of host threads; engine.hip has the
+ * protocol).  cholmod_hip_values_gather_index: *index = where staged position k comes from in the caller's value array, or
+ * NULL when this plan has no batch order (several ranks, no assembly map yet) -- then staging / push / commit above apply;
+ * *count = staged positions (the entries of the resident S), *chunk_len = positions per chunk. */
+int cholmod_hip_values_gather_index (cholmod_hip_plan *plan, const int64_t **index, int64_t *chunk_len, int64_t *count) ;
+int cholmod_hip_values_begin (cholmod_hip_plan *plan) ;
+int cholmod_hip_values_push_chunk (cholmod_hip_plan *plan, int64_t chunk) ;
 
 /* Copy the device-resident packed Lx (xsize doubles) to the host. */
 int cholmod_hip_download_factor (cholmod_hip_plan *plan, double *Lx_host) ;

@@ -145,7 +145,7 @@ HIP_SYMBOLS = [
     "cholmod_hip_probe", "cholmod_hip_memorysize", "cholmod_hip_set_device", "cholmod_hip_device_count",
     "cholmod_hip_plan_create", "cholmod_hip_plan_destroy", "cholmod_hip_factorize",
     "cholmod_hip_plan_create_dist", "cholmod_hip_set_allreduce", "cholmod_hip_get_partition",
-    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_diag_minmax", "cholmod_hip_values_staging", "cholmod_hip_values_push", "cholmod_hip_values_commit", "cholmod_hip_debug_routing",
+    "cholmod_hip_get_groups", "cholmod_hip_get_batches", "cholmod_hip_progress_enable", "cholmod_hip_progress", "cholmod_hip_debug_schedule_hash", "cholmod_hip_diag_minmax", "cholmod_hip_values_staging", "cholmod_hip_values_push", "cholmod_hip_values_commit", "cholmod_hip_values_gather_index", "cholmod_hip_values_begin", "cholmod_hip_values_push_chunk", "cholmod_hip_debug_routing",
     "cholmod_hip_gather_factor",
     "cholmod_hip_upload_matrix", "cholmod_hip_factorize_resident",
     "cholmod_hip_set_value_map", "cholmod_hip_refresh_values",
@@ -162,7 +162,7 @@ PROBES_PATH = os.path.join(_HERE, "lib", "libcholmod_amd_probes.so")
 PROBE_SYMBOLS = [
     "cholmod_hip_bench_update_kernel", "cholmod_hip_bench_update_pair", "cholmod_hip_bench_mfma_peak", "cholmod_hip_bench_mfma_peak2",
     "cholmod_hip_bench_mixed", "cholmod_hip_debug_potrf_cycles", "cholmod_hip_debug_panel_cycles",
-    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_probe_cu_mask", "cholmod_hip_probe_overlap", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles",
+    "cholmod_hip_debug_latency", "cholmod_hip_bench_mfma_ceiling", "cholmod_hip_probe_cu_mask", "cholmod_hip_probe_overlap", "cholmod_hip_debug_update_diff", "cholmod_hip_debug_diag_cycles", "cholmod_hip_bench_handoff",
 ]
 
 _probes = None

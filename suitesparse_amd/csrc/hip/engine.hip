@@ -3,6 +3,7 @@
 // the triangular solves, and the extern "C" shim declared in include/cholmod_hip.h.  One process drives one GPU.
 #include "kernels.hip.h"
 #include "plan.hip.h"
+#include <thread>
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -57,6 +58,9 @@ static void free_device (cholmod_hip_plan *P)
     if (P->prog_dev) { (void) hipHostFree (P->prog_dev) ; P->prog_dev = nullptr ; }
     if (P->h_vals) { (void) hipHostFree (P->h_vals) ; P->h_vals = nullptr ; }
     if (P->values_ev) { (void) hipEventDestroy (P->values_ev) ; P->values_ev = nullptr ; }
+    for (auto e : P->chunk_ev) (void) hipEventDestroy (e) ;
+    P->chunk_ev.clear () ;
+    if (P->d_vorder) { (void) hipFree (P->d_vorder) ; P->d_vorder = nullptr ; }
     if (RcclApi *R = (P->nccl_world ? rccl_api () : nullptr))
     {
         for (auto &g : P->nccl_group) (void) R->CommDestroy (g.second) ;
@@ -97,16 +101,15 @@ static int upload_plan (cholmod_hip_plan *P)
     if (const char *e = TEST_ENV ("CHOLMOD_HIP_TEST_HANG_EXCHANGE")) (void) sscanf (e, "%d:%ld:%ld", &P->test_hang_rank, &P->test_hang_xchg, &P->test_hang_fact) ;
     // several ranks: k_update3 with four tiles per workgroup, so that the exchange stream's (and RCCL's) four-wave workgroups
     // find room beside a trailing update (rocprofv3, rank 0 of 8 at 200^3: k_win_move 959 -> 94 ms in all, longest launch
-    // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  CHOLMOD_HIP_UPD3_WG4=0 / 1 forces either form.
+    // 79 -> 1.2 ms; the update itself 2351 -> 2378 ms).  (its knob, measured both ways in round 4, is gone.)
     P->upd3_wg4 = P->world > 1 || P->force_shared ;
-    if (const char *e = getenv ("CHOLMOD_HIP_UPD3_WG4")) P->upd3_wg4 = atoi (e) != 0 ;
     {
         // The exchange stream runs BESIDE the rest of a trailing update (look-ahead: window open, extend-add, pack, the
         // collective): its small workgroups must get the wave slots the update's tiles free up, ahead of the update's own
         // remaining tiles -- at default priority rocprofv3 shows k_win_move stretched over the whole 78 ms of the update it
-        // was meant to hide behind (round 4).  CHOLMOD_HIP_NO_STREAM_PRIORITY=1: as before.
+        // was meant to hide behind (round 4).  
         int least = 0, greatest = 0 ;
-        if (!getenv ("CHOLMOD_HIP_NO_STREAM_PRIORITY") && hipDeviceGetStreamPriorityRange (&least, &greatest) == hipSuccess && greatest != least)
+        if (hipDeviceGetStreamPriorityRange (&least, &greatest) == hipSuccess && greatest != least)
             HIPCHK (hipStreamCreateWithPriority (&P->stream2, hipStreamDefault, greatest)) ;
         else HIPCHK (hipStreamCreate (&P->stream2)) ;
     }
@@ -231,25 +234,10 @@ static int raise_lds_limits ()
     return CHOLMOD_HIP_OK ;
 }
 
-// waves per SIMD the one-wave thin-front kernel is compiled for, by size class (<= 32 / 48 / 64
-// rows); CHOLMOD_HIP_THIN_MINW = "a" or "a,b,c" overrides (3 .. 6)
-static int thin_minw (int cls)
-{
-    static int v [3] = {4, 4, 3} ;      // (measured on the 2D 1259^2 problem: 6 everywhere 1.044 ms, 4 / 4 / 3 1.004 ms)
-    static const bool init = [] ()
-    {
-        if (const char *e = getenv ("CHOLMOD_HIP_THIN_MINW"))
-        {
-            int a = 0, b = 0, c = 0 ;
-            int k = sscanf (e, "%d,%d,%d", &a, &b, &c) ;
-            if (k == 1) b = c = a ;
-            if (k == 1 || k == 3) { int w [3] = {a, b, c} ; for (int q = 0 ; q < 3 ; q++) if (w [q] >= 3 && w [q] <= 6) v [q] = w [q] ; }
-        }
-        return true ;
-    } () ;
-    (void) init ;
-    return v [cls] ;
-}
+// waves per SIMD the one-wave thin-front kernel is compiled for, by size class (<= 32 / 48 / 64 rows): 4 / 4 / 3
+// (measured on the 2D 1259^2 problem in round 2: 6 everywhere 1.044 ms, 4 / 4 / 3 1.004 ms; the knob and the other
+// instantiations are gone)
+static int thin_minw (int cls) { return cls == 2 ? 3 : 4 ; }
 
 // CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS=1 (tuning): the kernels of the exchange stream (window open, extend-add into the window,
 // pack) as ONE-wave workgroups.  Beside a trailing update whose one-wave tiles refill every register-file slot as it frees
@@ -325,12 +313,11 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
 #define LEAF_LAUNCH(PW_, MINW_) \
                     hipLaunchKernelGGL ((k_leaf_pair<PW_, MINW_>), dim3 ((L.grid + 1) / 2), dim3 (64), (size_t) (2 * L.leaf_T + 128) * sizeof (double), st, \
                         P->d_sm + L.goff, L.grid, P->d_smd + L.goff, P->d_sp01 + 2 * L.goff, P->d_Sx, P->d_amap, P->cur_beta, P->d_Lx, P->d_cb, P->d_info, L.leaf_T)
-                    static const int lw = [] () { const char *e = getenv ("CHOLMOD_HIP_LEAF_MINW") ; int w = e ? atoi (e) : 4 ; return (w == 2 || w == 3 || w == 5 || w == 6) ? w : 4 ; } () ;
 #define LEAF_PW(MINW_) \
                     { if (L.leaf_pw <= 4) LEAF_LAUNCH (4, MINW_) ; else if (L.leaf_pw <= 8) LEAF_LAUNCH (8, MINW_) ; \
                       else if (L.leaf_pw <= 12) LEAF_LAUNCH (12, MINW_) ; else LEAF_LAUNCH (16, MINW_) ; }
                     // (measured on the 2D 1259^2 leaf level: 4 waves per SIMD 0.112 ms, 5: 0.191, 6: 0.245)
-                    if (lw == 2) LEAF_PW (2) else if (lw == 3) LEAF_PW (3) else if (lw == 5) LEAF_PW (5) else if (lw == 6) LEAF_PW (6) else LEAF_PW (4)
+                    LEAF_PW (4)
 #undef LEAF_PW
 #undef LEAF_LAUNCH
                 }
@@ -342,9 +329,7 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
                     // allow) by size class -- the LDS of the wider classes caps the occupancy
                     // anyway (9.6 / 16.9 KB per front), and 80 registers spill
                     const int w = thin_minw (L.aux <= 32 ? 0 : L.aux <= 48 ? 1 : 2) ;
-                    if (w == 6) THIN_LAUNCH (1, false, 6) ;
-                    else if (w == 5) THIN_LAUNCH (1, false, 5) ;
-                    else if (w == 3) THIN_LAUNCH (1, false, 3) ;
+                    if (w == 3) THIN_LAUNCH (1, false, 3) ;
                     else THIN_LAUNCH (1, false, 4) ;
                 }
 #undef THIN_LAUNCH
@@ -549,29 +534,36 @@ static void exchange_volume (const cholmod_hip_plan *P, double *S)
 }
 
 // Run the numeric factorization on the resident S.  Leaves Lx on the device.
-static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *minor)
+/* the chunks 0 .. need-1 into S and L, on the main stream, as soon as each has been pushed and copied */
+static int apply_value_chunks (cholmod_hip_plan *P, long need)
+{
+    while (P->chunks_applied < need)
+    {
+        const long c = P->chunks_applied ;
+        for (long spin = 0 ; ; spin++)
+        {
+            const long have = P->chunks_pushed.load (std::memory_order_acquire) ;
+            if (have < 0) return CHOLMOD_HIP_GPU_PROBLEM ;
+            if (have > c) break ;
+            if ((spin & 1023) == 1023) std::this_thread::yield () ;
+        }
+        HIPCHK (hipStreamWaitEvent (P->stream, P->chunk_ev [c], 0)) ;
+        const i64 k0 = c * P->chunk_len, k1 = std::min<i64> (k0 + P->chunk_len, P->s_cur_nz) ;
+        hipLaunchKernelGGL (k_values_chunk, dim3 ((unsigned) ((k1 - k0 + 255) / 256)), dim3 (256), 0, P->stream,
+            k0, k1, P->d_vorder, P->d_vals, P->d_amap, P->d_Sx, P->d_Lx) ;
+        P->chunks_applied = c + 1 ;
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+/* What a factorization enqueues before it touches a value: the start event, (re)allocation of what a gather released, the
+ * clearing of L and of the per-factorization counters.  cholmod_hip_values_begin calls it ahead of time, so that the
+ * clearing runs beside the upload of the values. */
+static int factorize_prologue (cholmod_hip_plan *P)
 {
     hipStream_t st = P->stream ;
-    if (!P->d_Sp) return CHOLMOD_HIP_INVALID ;
-    bool prof = P->profiling ;
-    static const bool host_timing = getenv ("CHOLMOD_HIP_HOST_TIMING") != nullptr ;
-    auto now = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
-    double th0 = now () ;
-    P->cur_beta = beta ;
-    P->cur_mapped = P->amap_valid ? 1 : 0 ;     // thin fronts: A through the map the first assembly recorded
-    size_t nl = P->sch.launches.size () ;
-    if (prof)
-    {
-        while (P->evpool.size () < 2 * (nl + 1))
-        {
-            hipEvent_t e ; HIPCHK (hipEventCreate (&e)) ; P->evpool.push_back (e) ;
-        }
-    }
     P->winv_valid = false ;                 // the diagonal-block inverses follow the factor
     HIPCHK (hipEventRecord (P->ev0, st)) ;
-    int poisoned = CHOLMOD_HIP_OK ;
-    bool building_map = false ;
-    if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
     // Lx := 0 (several ranks: the rank's own fronts -- its d_Lx holds nothing else); the complete
     // factor a gather may have left in d_Lx_full is stale from here on
     P->full_valid = false ;
@@ -607,14 +599,55 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;
     HIPCHK (hipMemsetAsync (P->d_tu_cnt, 0, std::max<size_t> (P->sch.tg.size (), 1) * sizeof (i32), st)) ;
     if (P->d_cflags) HIPCHK (hipMemsetAsync (P->d_cflags, 0, (4 * (size_t) P->sch.ncflags + 4) * sizeof (int), st)) ;
-    if (P->values_pending)
+    return CHOLMOD_HIP_OK ;
+}
+
+static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *minor)
+{
+    hipStream_t st = P->stream ;
+    if (!P->d_Sp) return CHOLMOD_HIP_INVALID ;
+    bool prof = P->profiling ;
+    static const bool host_timing = getenv ("CHOLMOD_HIP_HOST_TIMING") != nullptr ;
+    auto now = [] () { return std::chrono::duration<double> (std::chrono::steady_clock::now ().time_since_epoch ()).count () ; } ;
+    double th0 = now () ;
+    P->cur_beta = beta ;
+    P->cur_mapped = P->amap_valid ? 1 : 0 ;     // thin fronts: A through the map the first assembly recorded
+    size_t nl = P->sch.launches.size () ;
+    if (prof)
+    {
+        while (P->evpool.size () < 2 * (nl + 1))
+        {
+            hipEvent_t e ; HIPCHK (hipEventCreate (&e)) ; P->evpool.push_back (e) ;
+        }
+    }
+    int poisoned = CHOLMOD_HIP_OK ;
+    bool building_map = false ;
+    if (prof) HIPCHK (hipEventRecord (P->evpool [0], st)) ;
+    if (!P->prologue_done)
+    {
+        const int rp = factorize_prologue (P) ;
+        if (rp != CHOLMOD_HIP_OK) return rp ;
+    }
+    P->prologue_done = false ;
+    const bool chunked = P->values_chunked ;
+    P->values_chunked = false ;
+    if (chunked)
+    {
+        // (cholmod_hip_values_begin: the values arrive chunk by chunk in batch order; the diagonal shift first, every chunk
+        // is added into the cleared L right before the first launch of the first batch that needs it)
+        if (beta != 0.0 && P->n > 0)
+            hipLaunchKernelGGL (k_add_beta<false>, dim3 ((unsigned) ((P->n + 255) / 256)), dim3 (256), 0, st,
+                P->n, P->d_supermap, P->d_fr, P->d_Lx, beta) ;
+    }
+    if (!chunked && P->values_pending)
     {
         // (cholmod_hip_values_commit: the new values of S arrive on the exchange stream; everything above -- the clearing of
         // L -- ran beside their upload, the assembly is the first to read them)
         HIPCHK (hipStreamWaitEvent (st, P->values_ev, 0)) ;
         P->values_pending = false ;
     }
-    if (P->n > 0 && P->amap_valid)
+    if (chunked) { }
+    else if (P->n > 0 && P->amap_valid)
     {
         // the resident S was assembled before: stream it through its map
         if (P->s_nz > 0)
@@ -647,6 +680,11 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
     {
         const Launch &L = P->sch.launches [q] ;
         P->prog_launch = (long long) q + 1 ;
+        if (chunked)
+        {
+            const int rv = apply_value_chunks (P, P->launch_need_chunks [q]) ;
+            if (rv != CHOLMOD_HIP_OK) return rv ;
+        }
         if (prof && poisoned == CHOLMOD_HIP_OK) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1)], st)) ;
         if (poisoned != CHOLMOD_HIP_OK)
         {
@@ -667,6 +705,12 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
             continue ;
         }
         if (prof) HIPCHK (hipEventRecord (P->evpool [2 * (q + 1) + 1], st)) ;
+    }
+    if (chunked)
+    {
+        // (whatever the schedule did not ask for -- nothing, normally -- so that the resident S is complete)
+        const int rv = apply_value_chunks (P, P->nchunks) ;
+        if (rv != CHOLMOD_HIP_OK) return rv ;
     }
     if (poisoned == CHOLMOD_HIP_OK && hipGetLastError () != hipSuccess) poisoned = CHOLMOD_HIP_GPU_PROBLEM ;
     if (poisoned != CHOLMOD_HIP_OK && P->world == 1) return poisoned ;
@@ -1353,6 +1397,8 @@ int cholmod_hip_upload_matrix (cholmod_hip_plan *P, const int64_t *Sp, const int
     P->amap_valid = false ;         // a new pattern may have come with the new values
     P->s_cur_nz = nz ;
     P->vsrc_nz = 0 ;                // ... and the value map of the previous one is void
+    P->h_vgather.clear () ; P->values_chunked = false ;
+    if (!Snz && P->world == 1) P->h_Sp.assign (Sp, Sp + n + 1) ; else P->h_Sp.clear () ;
     return CHOLMOD_HIP_OK ;
 }
 
@@ -1366,6 +1412,146 @@ int cholmod_hip_set_value_map (cholmod_hip_plan *P, const int64_t *src, int64_t 
     HIPCHK (hipMalloc ((void **) &P->d_vals, std::max<i64> (nvalues, 1) * sizeof (double))) ;
     if (snz) HIPCHK (hipMemcpy (P->d_vsrc, src, snz * sizeof (i64), hipMemcpyHostToDevice)) ;
     P->vsrc_nz = snz ; P->vals_n = nvalues ;
+    // the same map in the order the factorization asks for the values: entries of S sorted by the LAUNCH that needs them
+    // first -- a thin front's entries by its own launch (the thin-front kernels read their columns of S themselves), a
+    // generic front's by the first launch of its batch behind the thin ones (k_values_chunk has then put them into L) --
+    // and by source position inside such a class.  One rank, packed S.
+    P->h_vgather.clear () ; P->batch_entries_end.clear () ; P->launch_need_chunks.clear () ;
+    if (P->d_vorder) { (void) hipFree (P->d_vorder) ; P->d_vorder = nullptr ; }
+    static const bool chunked_off = getenv ("CHOLMOD_HIP_VALUES_IN_BATCH_ORDER") && !strcmp (getenv ("CHOLMOD_HIP_VALUES_IN_BATCH_ORDER"), "0") ;
+    if (!chunked_off && P->world == 1 && !(P->flags & CHOLMOD_HIP_CX_STORAGE) && (i64) P->h_Sp.size () == P->n + 1 && snz > 0 && snz <= nvalues
+        && !P->batch_launch0.empty () && !P->force_shared)
+    {
+        const size_t nb = P->batch_launch0.size (), nl = P->sch.launches.size () ;
+        // need [sf]: the launch before which front sf's entries must have been applied
+        std::vector<i32> need ((size_t) std::max<i64> (P->nsuper, 1), -1) ;
+        std::vector<i32> generic_launch (nb, 0) ;
+        bool okn = true ;
+        for (size_t b = 0 ; b < nb ; b++)
+        {
+            const size_t q0 = P->batch_launch0 [b], q1 = (b + 1 < nb) ? P->batch_launch0 [b + 1] : nl ;
+            size_t q = q0 ;
+            for ( ; q < q1 && P->sch.launches [q].kind == K_SMALL ; q++)
+            {
+                const Launch &Lq = P->sch.launches [q] ;
+                for (size_t e = Lq.goff ; e < Lq.goff + (size_t) Lq.ng ; e++) need [P->sch.sm [e]] = (i32) q ;
+            }
+            generic_launch [b] = (i32) std::min (q, q1 > 0 ? q1 - 1 : 0) ;
+        }
+        for (i64 sf = 0 ; sf < P->nsuper && okn ; sf++)
+        {
+            const i32 b = P->batch_of [sf] ;
+            if (b < 0 || (size_t) b >= nb) { okn = false ; break ; }
+            if (need [sf] < 0) need [sf] = generic_launch [b] ;
+        }
+        if (okn && nl > 0)
+        {
+            // buckets by need, filled in source order on a few threads: the caller's staging copy (stage [k] = values
+            // [index [k]]) then walks its value array front to back once per class -- sequential reads with gaps -- and the
+            // scatter to S's order is left to the device, where it costs nothing.  (S's own order made that copy a random
+            // gather: 1.7 ms for the 4.75 M entries of the 2D stand-in against 0.4 ms for a plain copy.)
+            std::vector<i64> order ((size_t) snz) ;
+            P->h_vgather.resize ((size_t) snz) ;
+            std::vector<i64> cnt (nl + 1, 0) ;
+            {
+                std::vector<i32> needq ((size_t) snz) ;
+                std::vector<i64> inv ((size_t) nvalues, -1) ;
+                const int T = (int) std::max<i64> (1, std::min<i64> (8, snz / 200000)) ;
+                auto par = [&] (auto fn) {
+                    std::vector<std::thread> th ;
+                    for (int t = 1 ; t < T ; t++) th.emplace_back (fn, t) ;
+                    fn (0) ;
+                    for (auto &x : th) x.join () ;
+                } ;
+                par ([&] (int t) {
+                    const i64 s0 = P->nsuper * t / T, s1 = P->nsuper * (t + 1) / T ;
+                    for (i64 sf = s0 ; sf < s1 ; sf++)
+                        for (i64 q = P->h_Sp [P->super [sf]] ; q < P->h_Sp [P->super [sf + 1]] ; q++) { needq [q] = need [sf] ; inv [src [q]] = q ; }
+                }) ;
+                std::vector<std::vector<i64>> tcnt (T, std::vector<i64> (nl, 0)) ;
+                par ([&] (int t) {
+                    const i64 a0 = nvalues * t / T, a1 = nvalues * (t + 1) / T ;
+                    for (i64 a = a0 ; a < a1 ; a++) if (inv [a] >= 0) tcnt [t][needq [inv [a]]]++ ;
+                }) ;
+                for (size_t q = 0 ; q < nl ; q++)
+                {
+                    i64 off = cnt [q] ;
+                    for (int t = 0 ; t < T ; t++) { const i64 c = tcnt [t][q] ; tcnt [t][q] = off ; off += c ; }
+                    cnt [q + 1] = off ;
+                }
+                par ([&] (int t) {
+                    const i64 a0 = nvalues * t / T, a1 = nvalues * (t + 1) / T ;
+                    for (i64 a = a0 ; a < a1 ; a++)
+                    {
+                        const i64 q = inv [a] ;
+                        if (q < 0) continue ;
+                        const i64 k = tcnt [t][needq [q]]++ ;
+                        order [k] = q ; P->h_vgather [k] = a ;
+                    }
+                }) ;
+            }
+            HIPCHK (hipMalloc ((void **) &P->d_vorder, (size_t) snz * sizeof (i64))) ;
+            HIPCHK (hipMemcpy (P->d_vorder, order.data (), (size_t) snz * sizeof (i64), hipMemcpyHostToDevice)) ;
+            P->nchunks = (long) ((snz + P->chunk_len - 1) / P->chunk_len) ;
+            // chunks a launch needs = those that hold the entries of every class up to its own
+            P->launch_need_chunks.assign (nl + 1, (i32) P->nchunks) ;
+            for (size_t q = 0 ; q < nl ; q++) P->launch_need_chunks [q] = (i32) ((cnt [q + 1] + P->chunk_len - 1) / P->chunk_len) ;
+            while ((long) P->chunk_ev.size () < P->nchunks)
+            {
+                hipEvent_t e ; HIPCHK (hipEventCreateWithFlags (&e, hipEventDisableTiming)) ; P->chunk_ev.push_back (e) ;
+            }
+        }
+    }
+    return CHOLMOD_HIP_OK ;
+}
+
+/* Round 6 -- the value upload in the order the factorization needs it.  cholmod_hip_values_gather_index: where staged
+ * position k comes from in the caller's value array (NULL: no batch order for this plan -- use staging / push / commit as
+ * before) and the chunk length.  The caller then runs three roles on threads of its own:
+ *   * cholmod_hip_values_begin (plan): the clearing of L is enqueued at once (it runs beside the upload), the chunk
+ *     counters are reset; then cholmod_hip_factorize_resident, whose launch loop waits -- host side for the push, device
+ *     side for the copy -- only for the chunks the next batch needs, applies them (k_values_chunk) and goes on;
+ *   * staging: host_buffer [k] = values [index [k]], chunk by chunk;
+ *   * cholmod_hip_values_push_chunk (plan, c) for c = 0, 1, ... as chunks are staged (one thread, in order);
+ *     cholmod_hip_values_push_chunk (plan, -1) if the staging failed: the waiting factorization returns an error.
+ * Nothing of this touches the resident S before the factorization applies it, chunk by chunk. */
+int cholmod_hip_values_gather_index (cholmod_hip_plan *P, const int64_t **index, int64_t *chunk_len, int64_t *count)
+{
+    if (!P || !index || !chunk_len || !count) return CHOLMOD_HIP_INVALID ;
+    const bool ok = !P->h_vgather.empty () && (i64) P->h_vgather.size () == P->s_cur_nz && P->vsrc_nz == P->s_cur_nz
+        && P->amap_valid && P->d_vorder && P->launch_need_chunks.size () == P->sch.launches.size () + 1 ;
+    *index = ok ? P->h_vgather.data () : nullptr ;
+    *chunk_len = P->chunk_len ;
+    *count = P->s_cur_nz ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_values_begin (cholmod_hip_plan *P)
+{
+    if (!P || !P->h_vals || P->h_vgather.empty () || !P->amap_valid) return CHOLMOD_HIP_INVALID ;
+    P->chunks_pushed.store (0) ;
+    P->chunks_applied = 0 ;
+    P->values_chunked = true ;
+    P->values_pending = false ;
+    const int rc = factorize_prologue (P) ;
+    if (rc != CHOLMOD_HIP_OK) { P->values_chunked = false ; return rc ; }
+    P->prologue_done = true ;
+    return CHOLMOD_HIP_OK ;
+}
+
+int cholmod_hip_values_push_chunk (cholmod_hip_plan *P, int64_t c)
+{
+    if (!P || !P->h_vals) return CHOLMOD_HIP_INVALID ;
+    if (c < 0 || c >= P->nchunks) { P->chunks_pushed.store (-1) ; return CHOLMOD_HIP_INVALID ; }
+    const i64 k0 = c * P->chunk_len, k1 = std::min<i64> (k0 + P->chunk_len, P->s_cur_nz) ;
+    if (hipMemcpyAsync (P->d_vals + k0, P->h_vals + k0, (size_t) (k1 - k0) * sizeof (double), hipMemcpyHostToDevice, P->stream2) != hipSuccess
+        || hipEventRecord (P->chunk_ev [c], P->stream2) != hipSuccess)
+    {
+        (void) hipGetLastError () ;
+        P->chunks_pushed.store (-1) ;
+        return CHOLMOD_HIP_GPU_PROBLEM ;
+    }
+    P->chunks_pushed.store ((long) c + 1, std::memory_order_release) ;
     return CHOLMOD_HIP_OK ;
 }
 

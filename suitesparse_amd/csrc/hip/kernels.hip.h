@@ -180,6 +180,21 @@ __global__ void __launch_bounds__(256) k_gather_values (i64 nz, const i64 *src, 
     if (q < nz) Sx [q] = values [src [q]] ;
 }
 
+// One chunk of a value upload in batch order (round 6): staged entry k belongs to entry order [k] of S; it refreshes the
+// resident S (the thin-front kernels read their columns from there) and, where the entry has a place in L's generic
+// fronts, lands there.  "+=" into the cleared L: k_add_beta has run before, no two entries of S share a target.
+__global__ void __launch_bounds__(256) k_values_chunk (i64 k0, i64 k1, const i64 *order, const double *staged, const i64 *amap,
+    double *Sx, double *Lx)
+{
+    i64 k = k0 + blockIdx.x * (i64) 256 + threadIdx.x ;
+    if (k >= k1) return ;
+    const i64 q = order [k] ;
+    const double v = staged [k] ;
+    Sx [q] = v ;
+    const i64 m = amap [q] ;
+    if (m >= 0) Lx [m] += v ;
+}
+
 // Lx(k,k) += beta for the columns this rank's k_assemble owns (after k_assemble_mapped)
 template <bool CX>
 __global__ void __launch_bounds__(256) k_add_beta (i64 n, const i32 *supermap, const FrontD *fr, double *Lx, double beta)

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>      // types only: the library itself is bound with dlopen (cholmod_hip_rccl_attach)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 #include <new>
 #include <queue>
 #include <vector>
+#include <atomic>
 #include <chrono>
 
 // Test hooks (CHOLMOD_HIP_TEST_*: stream jitter, poisoned arena, dropped waits, injected failures, a hung exchange) exist
@@ -332,6 +334,19 @@ struct cholmod_hip_plan {
     i64 vsrc_nz = 0, vals_n = 0, s_cur_nz = 0 ;
     double *h_vals = nullptr ; i64 h_vals_n = 0 ;           // pinned staging of the value upload (cholmod_hip_values_staging)
     hipEvent_t values_ev = nullptr ; bool values_pending = false ;     // ... and the event behind its gather into S
+    // round 6: the same upload in the order the factorization needs it -- the entries of S sorted by the batch of their
+    // column's front (cholmod_hip_set_value_map), staged / pushed / applied chunk by chunk; a batch waits for its own chunks only
+    std::vector<i64> h_Sp ;                         // host copy of S's column pointers (cholmod_hip_upload_matrix)
+    std::vector<int64_t> h_vgather ;                    // staged position -> position in the caller's value array
+    i64 *d_vorder = nullptr ;                       // staged position -> entry of S
+    std::vector<i64> batch_entries_end ;            // staged entries of the batches 0 .. b
+    std::vector<size_t> batch_launch0 ;             // first launch of batch b (build_host)
+    std::vector<i32> launch_need_chunks ;           // chunks that must have been applied before launch q
+    std::vector<hipEvent_t> chunk_ev ;
+    i64 chunk_len = (i64) 1 << 20 ;                 // entries per chunk (8 MB)
+    long nchunks = 0, chunks_applied = 0 ;
+    std::atomic<long> chunks_pushed {0} ;           // ... by the caller's pushing thread (-1: it failed)
+    bool values_chunked = false, prologue_done = false ;
     int cur_mapped = 0 ;
     i64 *d_amap = nullptr ; bool amap_valid = false ;    // S entry -> index in Lx (or -1), built by the first assembly of a resident S
     // solve workspace

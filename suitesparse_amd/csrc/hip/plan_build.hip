@@ -247,7 +247,6 @@ struct PlanBuilder
         // (1 / (6 world): with 1 / (4 world) two subtrees of 6 % each stayed atomic at four ranks on Poisson 200^3 and left
         // one rank 7.7 % above the mean; now within 1.2 %)
         double thr_div = 6.0 ;
-        if (const char *e = getenv ("CHOLMOD_HIP_SHARE_DIV")) if (atof (e) >= 1.0) thr_div = atof (e) ;
         const double thr = total / (thr_div * share_world) ;
         std::vector<char> shared (nsuper, 0) ;
         std::vector<double> load (share_world, 0.0) ;
@@ -645,11 +644,21 @@ struct PlanBuilder
         for (int c = 0 ; c < NCLS ; c++)
         {
             if (bucket [c].empty ()) continue ;
-            Launch Ls_ {K_SMALL, (int) bucket [c].size (), (int) bucket [c].size (), S.sm.size (), 0, 0} ;
+            // (round 6) a class of very many fronts -- the leaves of a 2D / circuit problem: 65 136 in one launch at the
+            // G3_circuit stand-in -- goes out as four launches over consecutive fronts: run from a resident S they cost
+            // three launch latencies; fed by cholmod_l_factorize from host memory, each waits for its own quarter of the
+            // values only (the upload travels in the order of the launches, engine.hip: cholmod_hip_set_value_map)
+            const size_t nb_ = bucket [c].size () ;
+            const int parts = (P->world == 1 && nb_ >= 16384) ? 4 : 1 ;
+            for (int part = 0 ; part < parts ; part++)
+            {
+            const size_t b0_ = nb_ * part / parts, b1_ = nb_ * (part + 1) / parts ;
+            Launch Ls_ {K_SMALL, (int) (b1_ - b0_), (int) (b1_ - b0_), S.sm.size (), 0, 0} ;
             int mx = 0, mxc = 0, mxt = 0 ;
             bool leaves = !(P->flags & CHOLMOD_HIP_NO_LEAF_PAIRS) && !(P->flags & CHOLMOD_HIP_CX_STORAGE) ;
-            for (i32 sid : bucket [c])
+            for (size_t bi = b0_ ; bi < b1_ ; bi++)
             {
+                const i32 sid = bucket [c][bi] ;
                 FrontD &f = P->fr [sid] ;
                 if (f.assemble == 1) f.assemble = 2 ;
                 mx = std::max (mx, f.nsrow) ;
@@ -669,6 +678,7 @@ struct PlanBuilder
             Ls_.aux = mx ;                              // widest member: LDS sizing, waves per front
             if (leaves && mx <= 32 && mxc <= 16) { Ls_.leaf_pw = (mxc + 3) / 4 * 4 ; Ls_.leaf_T = (mxt + 31) / 32 * 32 ; }
             S.launches.push_back (Ls_) ;
+            }
         }
     }
     // zero-fill of the contribution blocks that need it.  Contribution blocks of unshared fronts are never zero-filled: their
@@ -710,7 +720,7 @@ struct PlanBuilder
         // stand-in and Poisson 100^3 like 4, the 2D problem 8)
         int tw = EA_TW ;
         for (int q = 0 ; q < nf ; q++)
-            if (P->fr [ids [q]].child_end != P->fr [ids [q]].child_begin && P->fr [ids [q]].nsrow >= 2048) tw = getenv ("CHOLMOD_HIP_EA_TW_BIG") ? atoi (getenv ("CHOLMOD_HIP_EA_TW_BIG")) : 4 ;
+            if (P->fr [ids [q]].child_end != P->fr [ids [q]].child_begin && P->fr [ids [q]].nsrow >= 2048) tw = 4 ;
         Le.aux = tw ;
         for (int q = 0 ; q < nf ; q++)
         {
@@ -740,8 +750,10 @@ struct PlanBuilder
     {
         Schedule &S = P->sch ;
         std::vector<i32> mine_ids, gen ;
+        P->batch_launch0.clear () ;
         for (const auto &bt : batches)
         {
+            P->batch_launch0.push_back (S.launches.size ()) ;      // (the batch's first launch: what its values must have arrived for)
             mine_ids.clear () ; gen.clear () ;
             for (i32 sf : bt) if (mine (sf)) mine_ids.push_back (sf) ;
             if (mine_ids.empty ()) continue ;

@@ -704,6 +704,86 @@ __global__ void __launch_bounds__(256) k_mfma_ceiling (double *out, long long *s
 }
 
 
+// Hand-off latency between two workgroups (round 6): block `prod` writes a payload of `ndbl` doubles and raises a flag,
+// block `cons` waits for the flag, reads the payload, checks it and raises the flag back; `rounds` ping-pongs, wall clock
+// per one-way hand-off out of thread 0 of the producer.  Every other block of the launch leaves at once, so that with
+// block -> XCD = blockIdx % 8 (tools/xcd_map.py) the pair (0, 8) shares an XCD's L2 and the pair (0, 1) does not.
+// MODE 0: payload and flags by relaxed AGENT-scope atomics (global_store / global_load sc1: what k_chainf does);
+// MODE 1: payload by WORKGROUP-scope atomics (sc0: past the L1, served by the XCD's L2), flags agent scope;
+// MODE 2: payload by plain stores / loads behind an L1 invalidate (buffer_inv sc0... emitted by a workgroup-scope acquire
+//         fence in threadgroup-split-safe code), flags workgroup scope -- only meaningful inside one XCD.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_handoff (double *payload, int *flags, int prod, int cons, int ndbl, int rounds,
+    long long *ticks, int *bad)
+{
+    const int b = (int) blockIdx.x, tid = threadIdx.x ;
+    if (b != prod && b != cons) return ;
+    __shared__ int s_v ;
+    int errors = 0 ;
+    long long w0 = 0 ;
+    if (b == prod && tid == 0) w0 = wall_clock64 () ;
+    for (int r = 1 ; r <= rounds ; r++)
+    {
+        // (a wait that ran out ends the probe for both sides: flags [48], agent scope; no second full wait)
+        if (tid == 0) s_v = (errors & 2) ? 1 : __hip_atomic_load (flags + 48, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+        __syncthreads () ;
+        if (s_v) break ;
+        __syncthreads () ;
+        if (b == prod)
+        {
+            for (int e = tid ; e < ndbl ; e += 256)
+            {
+                const double v = (double) (r * 4096 + e) ;
+                if (MODE == 0) __hip_atomic_store (payload + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+                else if (MODE == 1) __hip_atomic_store (payload + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+                else payload [e] = v ;
+            }
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
+            __syncthreads () ;
+            if (tid == 0)
+            {
+                if (MODE == 2) __hip_atomic_store (flags, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+                else __hip_atomic_store (flags, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+                // wait for the echo
+                int n = 0 ;
+                while ((MODE == 2 ? __hip_atomic_load (flags + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                  : __hip_atomic_load (flags + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r)
+                    if (++n > (1 << 18)) { errors |= 2 ; break ; }
+            }
+            __syncthreads () ;
+        }
+        else
+        {
+            if (tid == 0)
+            {
+                int n = 0 ;
+                while ((MODE == 2 ? __hip_atomic_load (flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                  : __hip_atomic_load (flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r)
+                    if (++n > (1 << 18)) { errors |= 2 ; break ; }
+            }
+            __syncthreads () ;
+            if (MODE == 2) __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "workgroup") ;
+            for (int e = tid ; e < ndbl ; e += 256)
+            {
+                double v ;
+                if (MODE == 0) v = __hip_atomic_load (payload + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+                else if (MODE == 1) v = __hip_atomic_load (payload + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+                else v = ((volatile double *) payload) [e] ;
+                if (v != (double) (r * 4096 + e)) errors |= 1 ;
+            }
+            __syncthreads () ;
+            if (tid == 0)
+            {
+                if (MODE == 2) __hip_atomic_store (flags + 32, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP) ;
+                else __hip_atomic_store (flags + 32, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+            }
+        }
+    }
+    if (b == prod && tid == 0) ticks [0] = wall_clock64 () - w0 ;
+    if (errors & 2) __hip_atomic_store (flags + 48, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ;
+    if (errors) atomicOr (bad, errors) ;
+}
+
 // full-mantissa pseudo-random fill in [-0.5, 0.5) (splitmix64 of the index)
 __global__ void __launch_bounds__(256) k_fill_random (double *x, i64 n)
 {

@@ -676,4 +676,27 @@ int cholmod_hip_probe_overlap (const uint32_t *mask_a, const uint32_t *mask_b, i
     return CHOLMOD_HIP_OK ;
 }
 
+/* one-way hand-off time in microseconds between blocks `prod` and `cons` of one launch (k_handoff), or -1; *bad: bit 0 = a
+ * payload word arrived stale, bit 1 = a wait ran out */
+double cholmod_hip_bench_handoff (int mode, int prod, int cons, int ndbl, int rounds, int *bad)
+{
+    double *payload = nullptr ; int *flags = nullptr, *dbad = nullptr ; long long *ticks = nullptr ;
+    if (hipMalloc ((void **) &payload, (size_t) std::max (ndbl, 1) * sizeof (double)) != hipSuccess) return -1 ;
+    if (hipMalloc ((void **) &flags, 64 * sizeof (int)) != hipSuccess) return -1 ;
+    if (hipMalloc ((void **) &dbad, sizeof (int)) != hipSuccess) return -1 ;
+    if (hipMalloc ((void **) &ticks, sizeof (long long)) != hipSuccess) return -1 ;
+    (void) hipMemset (flags, 0, 64 * sizeof (int)) ; (void) hipMemset (dbad, 0, sizeof (int)) ; (void) hipMemset (payload, 0, (size_t) std::max (ndbl, 1) * sizeof (double)) ;
+    const int grid = std::max (prod, cons) + 1 ;
+    if (mode == 0) hipLaunchKernelGGL (k_handoff<0>, dim3 (grid), dim3 (256), 0, 0, payload, flags, prod, cons, ndbl, rounds, ticks, dbad) ;
+    else if (mode == 1) hipLaunchKernelGGL (k_handoff<1>, dim3 (grid), dim3 (256), 0, 0, payload, flags, prod, cons, ndbl, rounds, ticks, dbad) ;
+    else hipLaunchKernelGGL (k_handoff<2>, dim3 (grid), dim3 (256), 0, 0, payload, flags, prod, cons, ndbl, rounds, ticks, dbad) ;
+    long long t = 0 ; int hb = 0 ;
+    bool ok = hipDeviceSynchronize () == hipSuccess && hipMemcpy (&t, ticks, sizeof (t), hipMemcpyDeviceToHost) == hipSuccess
+        && hipMemcpy (&hb, dbad, sizeof (hb), hipMemcpyDeviceToHost) == hipSuccess ;
+    (void) hipFree (payload) ; (void) hipFree (flags) ; (void) hipFree (dbad) ; (void) hipFree (ticks) ;
+    if (bad) *bad = hb ;
+    if (!ok) return -1 ;
+    return (double) t / 100.0 / (2.0 * rounds) ;        // (s_memrealtime: 100 MHz)
+}
+
 } // extern "C"

@@ -95,15 +95,15 @@ struct DenseScheduler
             maxrows = std::max (maxrows, fr [ids [q]].nsrow) ;
         }
         { const char *e = getenv ("CHOLMOD_HIP_UPD3_MIN_TILES") ; w_min_tiles = e ? (i64) atoll (e) : (i64) 2048 ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UPD3_BY_LAUNCH") ; by_launch = !(e && atoi (e) == 0) ; }
-        { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MAX") ; w_half_max = e ? (i64) atoll (e) : (i64) 10240 ; }
+        by_launch = true ;
+        { const char *e = getenv ("CHOLMOD_HIP_UPD3_HALF_MAX") ; w_half_max = e ? (i64) atoll (e) : (i64) 10240 ; }      // (=0: whole tiles only, kept for the schedule fingerprints that cover that form)
         // (measured flat within the noise and fixed: pooled regions from 256 / 512 / 1024 tiles on, shortest pooled contraction
         // 256 / 128 / 64, chain updates un-fused from 2048 ... 256 tiles on -- profiles/r05_ab_upd3_half_knobs.log)
         w_half_min = 512 ; w_min_k = 256 ; unfuse_tiles = w_min_tiles ;
         if (!allow_half || w_min_tiles <= 0) w_half_max = 0 ;
         if (w_half_max <= 0 || w_half_min > w_min_tiles) w_half_min = w_min_tiles ;
-        one_region = getenv ("CHOLMOD_HIP_UPDW_ONE_REGION") != nullptr ;
-        swz16 = getenv ("CHOLMOD_HIP_SWZ16") != nullptr ;
+        one_region = false ;
+        swz16 = false ;
         xla = !(flags & CHOLMOD_HIP_NO_EXCHANGE_LOOKAHEAD) ;
         balance_cb = !use_big && !getenv ("CHOLMOD_HIP_NO_CB_BALANCE") ;
         early.assign (nf, -1) ; early_open.assign (nf, -1) ; pf_done.assign (nf, -1) ;
@@ -703,8 +703,7 @@ struct DenseScheduler
         {
             bool any_shared = false ;
             for (int q = 0 ; q < nf ; q++) if (is_shared (ids [q])) any_shared = true ;
-            const char *e1 = getenv ("CHOLMOD_HIP_CHAINF_MIN_COLS"), *e2 = getenv ("CHOLMOD_HIP_CHAINF_MAX_ROWS") ;
-            chain256 = !any_shared && maxnscol >= (e1 ? atoi (e1) : 192) && maxrows <= (e2 ? atoi (e2) : 16384) ;
+            chain256 = !any_shared && maxnscol >= 192 && maxrows <= 16384 ;
         }
         // A batch that holds a front shared between ranks takes the fused 256-column chain by default: the chain of a shared
         // front is the part of a rank's work that does not shrink with the number of ranks, and its 64-column form has no

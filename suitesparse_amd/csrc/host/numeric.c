@@ -473,7 +473,98 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         const int nth = api_threads () ;
         static int overlap = -1 ;
         if (overlap < 0) { const char *e = getenv ("CHOLMOD_API_OVERLAP") ; overlap = (e && !strcmp (e, "0")) ? 0 : 1 ; }
-        if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz && nth >= 2 && overlap)
+        const int64_t *gidx = NULL ;
+        int64_t glen = 0, gcount = 0 ;
+        if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz && nth >= 3 && overlap
+            && cholmod_hip_values_gather_index (plan, &gidx, &glen, &gcount) == CHOLMOD_HIP_OK && gidx && glen > 0 && gcount <= cap
+            && cholmod_hip_values_begin (plan) == CHOLMOD_HIP_OK)
+        {
+            /* Round 6, second step: the values in the order the factorization needs them.  The entries of S are staged
+             * sorted by the batch of their front (stage [k] = A->x [index [k]]: the permutation to S's order, formerly a
+             * gather kernel on the device, happens in the staging copy) and pushed chunk by chunk; the factorization --
+             * already enqueueing on thread 0, its clearing of L first -- waits before every batch for that batch's chunks
+             * only.  Thread 0: the factorization; thread 1: pushes chunks as they are complete; the others: stage, then
+             * take the pattern hash.  The hash is checked after the fact, as below. */
+            const double *Ax = A->x ;
+            const Int *Ap = A->p, *Ai = A->i ;
+            const Int ncol = (Int) A->ncol ;
+            const int64_t snz = gcount ;                    /* (one staged value per entry of S) */
+            const int64_t CH = glen, PIECE = 16384 ;        /* (glen is a multiple of PIECE: 2^20) */
+            const int64_t nchunk = (snz + CH - 1) / CH, npiece = (snz + PIECE - 1) / PIECE ;
+            const int64_t HP = (int64_t) 1 << 16 ;
+            const int64_t nhp = ((int64_t) ncol + 1 + HP - 1) / HP, nhi = ((int64_t) annz + HP - 1) / HP ;
+            int64_t *chunk_done = cholmod_l_calloc ((size_t) (nchunk > 0 ? nchunk : 1), sizeof (int64_t), Common) ;
+            int64_t next_piece = 0, next_hash = 0 ;
+            pat_sums tot = {0, 0, 0, 0} ;
+            int64_t minor = (int64_t) L->n ;
+            int rcf = CHOLMOD_HIP_OK ;
+            if (!chunk_done)
+            {
+                /* (the prologue is enqueued and a factorization is expected to follow: let it fail cleanly) */
+                (void) cholmod_hip_values_push_chunk (plan, -1) ;
+                (void) cholmod_hip_factorize_resident (plan, 0.0, 0, &minor) ;
+                return finish_numeric (CHOLMOD_HIP_OUT_OF_MEMORY, minor, L, Common) ;
+            }
+#pragma omp parallel num_threads(nth)
+            {
+                const int me = omp_get_thread_num (), team = omp_get_num_threads () ;
+                /* (a team smaller than asked for -- a thread limit, a call from inside a parallel region -- must not leave
+                 * the factorization waiting for chunks nobody pushes: thread 0 then stages and pushes everything first) */
+                const int stager = (team >= 3) ? (me >= 2) : (me == 0), pusher = (team >= 3) ? (me == 1) : (me == 0) ;
+                if (stager)
+                    for ( ; ; )
+                    {
+                        const int64_t k = __atomic_fetch_add (&next_piece, 1, __ATOMIC_RELAXED) ;
+                        if (k >= npiece) break ;
+                        const int64_t q0 = k * PIECE, q1 = (q0 + PIECE < snz) ? q0 + PIECE : snz ;
+                        for (int64_t q = q0 ; q < q1 ; q++)
+                        {
+                            /* (the index rises inside a batch: mostly the next cache lines, the prefetch covers the gaps) */
+                            if (q + 24 < q1) __builtin_prefetch (Ax + gidx [q + 24], 0, 0) ;
+                            stage [q] = Ax [gidx [q]] ;
+                        }
+                        __atomic_fetch_add (&chunk_done [q0 / CH], 1, __ATOMIC_RELEASE) ;
+                    }
+                if (pusher)
+                {
+                    for (int64_t c = 0 ; c < nchunk ; c++)
+                    {
+                        const int64_t o = c * CH, cnt = (snz - o < CH) ? snz - o : CH ;
+                        const int64_t need = (cnt + PIECE - 1) / PIECE ;
+                        while (__atomic_load_n (&chunk_done [c], __ATOMIC_ACQUIRE) < need) { /* (microseconds) */ }
+                        if (cholmod_hip_values_push_chunk (plan, c) != CHOLMOD_HIP_OK) break ;
+                    }
+                    if (timing) tq1 = api_now () ;
+                }
+                if (me == 0)
+                    rcf = cholmod_hip_factorize_resident (plan, beta ? beta [0] : 0.0, Common->quick_return_if_not_posdef, &minor) ;
+                if (me >= 1 || team == 1)
+                {
+                    pat_sums mine = {0, 0, 0, 0} ;
+                    for ( ; ; )
+                    {
+                        const int64_t k = __atomic_fetch_add (&next_hash, 1, __ATOMIC_RELAXED) ;
+                        if (k >= nhp + nhi) break ;
+                        if (k < nhp) pattern_hash_p (Ap, (Int) (k * HP), (Int) (((k + 1) * HP < ncol + 1) ? (k + 1) * HP : ncol + 1), &mine) ;
+                        else pattern_hash_i (Ai, (Int) ((k - nhp) * HP), (Int) (((k - nhp + 1) * HP < (int64_t) annz) ? (k - nhp + 1) * HP : (int64_t) annz), &mine) ;
+                    }
+#pragma omp critical (ssamd_pattern_hash)
+                    { tot.hp += mine.hp ; tot.gp += mine.gp ; tot.hi += mine.hi ; tot.gi += mine.gi ; }
+                }
+            }
+            cholmod_l_free ((size_t) (nchunk > 0 ? nchunk : 1), sizeof (int64_t), chunk_done, Common) ;
+            hash = pattern_hash_fold (A, &tot, &hash2) ;
+            hashed = TRUE ;
+            if (timing) tq2 = api_now () ;
+            if (L->hip_apat_hash == hash && L->hip_apat_hash2 == hash2)
+            {
+                if (timing) fprintf (stderr, "cholmod_l_factorize (values only, in batch order): last push at %.3f ms, factorization + hash done at %.3f ms\n",
+                    1e3 * (tq1 - tq0), 1e3 * (tq2 - tq0)) ;
+                return finish_numeric (rcf, minor, L, Common) ;
+            }
+            /* (another pattern after all: the device's S, map and factor are void; the long way rebuilds all three) */
+        }
+        else if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz && nth >= 2 && overlap)
         {
             /* Round 6: nothing but the DMA itself stands between the call and the factorization.  Thread 0 pushes every chunk
              * as soon as the others have staged it, commits and ENQUEUES THE FACTORIZATION AT ONCE; the other threads stage
@@ -580,6 +671,8 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         }
         L->hip_apat_valid = FALSE ;         /* no usable map after all: the long way */
     }
+    const int ltiming = getenv ("CHOLMOD_API_TIMING") != NULL ;
+    double tl0 = ltiming ? api_now () : 0, tl1 = 0, tl2 = 0, tl3 = 0 ;
     if (vmap_ok && !hashed) hash = pattern_hash (A, &hash2) ;
     cholmod_sparse *S = NULL ;
     Int *src = NULL ;
@@ -598,7 +691,9 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     }
     if (!S) return FALSE ;
     L->hip_apat_valid = FALSE ;
+    if (ltiming) tl1 = api_now () ;
     int ok = cholmod_l_super_numeric (S, NULL, beta ? beta : zero, L, Common) ;
+    if (ltiming) tl2 = api_now () ;
     /* the engine now holds S: tell it where S's values come from in A */
     if (ok && L->hip_plan && L->hip_on_device && A->xtype == CHOLMOD_REAL && A->packed && Common->hip_world <= 1
         && (S == A || src))
@@ -623,6 +718,12 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
     }
     if (src) cholmod_l_free (((Int *) S->p) [S->ncol] > 0 ? ((Int *) S->p) [S->ncol] : 1, sizeof (Int), src, Common) ;
     if (S != A) cholmod_l_free_sparse (&S, Common) ;
+    if (ltiming)
+    {
+        tl3 = api_now () ;
+        fprintf (stderr, "cholmod_l_factorize (long way): hash + permutation %.3f s, plan + upload + factorization %.3f s, value map %.3f s\n",
+            tl1 - tl0, tl2 - tl1, tl3 - tl2) ;
+    }
     return ok ;
 }
 
