@@ -77,7 +77,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             return
-        if case in ("p3d_64", "p3d_48", "p3d_32_notposdef_root"):
+        if case in ("p3d_64", "p3d_32_notposdef_root") or (case == "p3d_48" and world >= 8):
             bind_blas()                 # (the oracle's dense kernels through a BLAS: 64^3 in seconds instead of minutes)
         if case == "p3d_20":
             n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)

@@ -558,7 +558,7 @@ def test_distributed_slab_widths(own_w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env,flags", [({"CHOLMOD_HIP_SHARED_CHAIN64": "1"}, 0), ({"CHOLMOD_HIP_NO_CHAINF": "1"}, 8192),
+@pytest.mark.parametrize("env,flags", [({"CHOLMOD_HIP_SHARED_CHAIN64": "1"}, 0), pytest.param({"CHOLMOD_HIP_NO_CHAINF": "1"}, 8192, marks=pytest.mark.slow),
                                        pytest.param({"CHOLMOD_HIP_NARROW_EXCHANGE_KERNELS": "1"}, 0, marks=pytest.mark.slow),
                                        ({"CHOLMOD_HIP_NO_CB_PASSTHROUGH": "1"}, 0),
                                        pytest.param({"CHOLMOD_HIP_NO_CB_PASSTHROUGH": "1", "CHOLMOD_HIP_NO_CB_BALANCE": "1"}, 256,
@@ -654,7 +654,7 @@ def test_native_exchange_both_orders_and_subgroups(flags):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,native", [(3, True), (4, True), (2, False)])
+@pytest.mark.parametrize("world,native", [pytest.param(3, True, marks=pytest.mark.slow), (4, True), (2, False)])
 def test_distributed_with_wave_tile_kernel_on_dealt_tiles(world, native):
     """The update kernel an 8-GPU run of the headline spends its time in (k_update3, one wave per tile) on
     the tiles of shared fronts that are DEALT over the ranks of a group (GemmGroup.tile_mul / tile_add):
