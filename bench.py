@@ -301,7 +301,7 @@ def roofline_of(S, Lf, wname, world):
 
 KIND_NAMES = {0: "zero", 1: "extend_add", 2: "potrf", 3: "trsm", 4: "update128", 5: "update64", 7: "reduce_scatter", 8: "thin",
               9: "update+potrf", 10: "trsm+upd+potrf", 11: "all_gather", 12: "update_w", 13: "diag256", 14: "rowsolve",
-              15: "window", 16: "chain256f", 17: "trsm+upd128+potrf"}
+              15: "window", 16: "chain256f"}
 SM_MAX = 136            # rows up to which a front runs in the thin-front kernel (descriptors.hip.h)
 UPD3_STANDALONE_TFLOPS = 75.0    # k_update3 on a 16 384^2 x 4096 region (printed live as measured_update_kernel_*)
 
@@ -342,12 +342,9 @@ def critical_path(S, Lf, lp, ms_step):
     def floor(k):
         q = (kinds == k) & (msl > 0)
         return float(msl[q].min()) if q.any() else 0.0
-    f_tu, f_tr, f_uf, f_pf, f_thin, f_t2 = floor(10), floor(3), floor(9), floor(2), floor(8), floor(17)
-    # one step of the chain: (trsm+upd+potrf) then (trsm, update+potrf) per 128 columns -- round 6: the second pair is one launch
-    # (trsm + K = 128 update + potrf) on every other even step; without the fusions potrf + trsm + update
-    if f_tu > 0 and f_t2 > 0:
-        step_floor = (f_tu + min(f_t2, f_tr + f_uf if f_uf > 0 else f_t2)) / 2.0
-    elif f_tu > 0 and f_uf > 0:
+    f_tu, f_tr, f_uf, f_pf, f_thin = floor(10), floor(3), floor(9), floor(2), floor(8)
+    # one step of the chain: (trsm+upd+potrf) then (trsm, update+potrf) per 128 columns; without the fusions potrf + trsm + update
+    if f_tu > 0 and f_uf > 0:
         step_floor = (f_tu + f_tr + f_uf) / 2.0
     else:
         step_floor = f_pf + f_tr + floor(5)
@@ -378,7 +375,7 @@ def critical_path(S, Lf, lp, ms_step):
     for k in set(kinds.tolist()):
         q = kinds == k
         fk = floor(k)
-        if k in upd_kinds or k in (2, 3, 10, 13, 14, 16, 17):
+        if k in upd_kinds or k in (2, 3, 10, 13, 14, 16):
             roof = lp["flops"][q] / (UPD3_STANDALONE_TFLOPS * 1e12) * 1e3
         else:
             roof = lp["bytes"][q] / 8e12 * 1e3

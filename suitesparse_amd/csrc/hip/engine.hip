@@ -225,7 +225,6 @@ static int raise_lds_limits ()
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_mfma<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
-    HIPCHK (hipFuncSetAttribute ((const void *) k_trsm_upd2, hipFuncAttributeMaxDynamicSharedMemorySize, (int) trsm_upd2_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_rowsolve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) rowsolve_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_chainf, hipFuncAttributeMaxDynamicSharedMemorySize, (int) chainf_lds_bytes ())) ;
     HIPCHK (hipFuncSetAttribute ((const void *) k_thin_front<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)) ;
@@ -464,11 +463,6 @@ static int run_launch (cholmod_hip_plan *P, const Launch &L, bool serial)
         case K_TRSM_UPD:
             { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
             CX_LAUNCH (k_trsm_upd, dim3 (L.grid), dim3 (256), trsm_upd_lds_bytes (), st,
-                P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, P->d_tu_cnt + L.goff) ;
-            break ;
-        case K_TRSM_UPD2:
-            { int rl = raise_lds_limits () ; if (rl != CHOLMOD_HIP_OK) return rl ; }
-            hipLaunchKernelGGL (k_trsm_upd2, dim3 (L.grid), dim3 (256), trsm_upd2_lds_bytes (), st,
                 P->d_tg + L.goff, L.ng, P->d_Lx, P->d_info, P->d_tu_cnt + L.goff) ;
             break ;
         case K_UPD_BIG:
@@ -778,7 +772,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
         if (L.kind == K_UPD_SMALL) { S [7] += 1 ; S [8] += L.flops ; S [16] += L.bytes ; }
         if (L.kind == K_UPD_W) { S [33] += 1 ; S [34] += L.flops ; S [35] += L.bytes ; }
         if (L.kind == K_UPD_PF) { S [26] += 1 ; S [28] += L.flops ; S [29] += L.bytes ; }
-        if (L.kind == K_TRSM_UPD || L.kind == K_TRSM_UPD2) S [31] += 1 ;
+        if (L.kind == K_TRSM_UPD) S [31] += 1 ;
         if (L.kind == K_SMALL) { S [20] += L.bytes ; S [21] += L.ng ; }
         S [22] = P->nsplit ;
         if (L.kind == K_UPD_BIG) { S [15] += L.flops ; }
@@ -813,7 +807,7 @@ static int run_factorize (cholmod_hip_plan *P, double beta, int quick, i64 *mino
                 case K_ROWSOLVE: S [12] += sec ; break ;
                 case K_SMALL: S [19] += sec ; break ;
                 case K_TRSM: S [12] += sec ; break ;
-                case K_TRSM_UPD: case K_TRSM_UPD2: S [30] += sec ; break ;
+                case K_TRSM_UPD: S [30] += sec ; break ;
             }
         }
     }

@@ -2303,233 +2303,6 @@ __global__ void __launch_bounds__(256) k_trsm_upd (const TrGroup *g, int ng, dou
     pf_store<CX> (A, lda, T, PF_NB, fail, lane, wave) ;
 }
 
-// ---- the even steps of the panel chain with p = 2 in ONE launch (round 6) ------------------------------------------------
-// Recursive doubling at the second block e + 1 of a pair: the reference's dtrsm of the rows below L (e+1, e+1), then the
-// K = 128 update of the next TWO 64-column blocks with the pair (e, e + 1), then the dpotrf of the first of them -- until
-// round 5 two launches (k_trsm_mfma, then k_update2f: 9-13 + 23 us at their floors).  Here every workgroup owns 64 rows
-// below the pair for the whole step, as in k_trsm_upd:
-//   * it solves its rows X_b (columns of block e + 1; the columns of block e were solved one step earlier and are only
-//     loaded) and, redundantly, the rows of the two target blocks T0 = [t0, t0 + 64), T1 = [t0 + 64, t0 + 128) -- the
-//     B operands of its two tiles: no hand-off between workgroups, the price is two more 64 x 64 x 64 solves;
-//   * tile column 0: -X_T0 (K = 128, k-major) goes to LDS, C (rows, T0 columns) -= X_b X_T0' out of registers; then the
-//     same LDS region takes -X_T1 for tile column 1.  Workgroup 0 (rows T0) has the tile (T0, T0): it keeps it in LDS and
-//     eliminates it (pf_eliminate) -- the next diagonal block; workgroup 1 (rows T1) stores only the lower triangle of
-//     its tile (T1, T1);
-//   * the rows T0 and T1 of block e + 1 are read unsolved by everybody and solved in place by their owners: the same
-//     write-after-read hazard as in k_trsm_upd, closed the same way -- whoever draws the last ticket stores them.
-// Conditions (scheduler): both blocks of the pair and both target blocks are full and lie in one outer block column, the
-// front is not shared, a real plan.  TrGroup: l_off = L (e+1, e+1), b_off = row t0 of block e + 1's columns, m = rows from
-// t0 on, col0 = first column of block e + 1.  LDS: -L11 (32 KB) + inverses (8 KB) + 128 x TU_LDX (80 KB).
-__host__ __device__ inline size_t trsm_upd2_lds_bytes ()
-{
-    return (size_t) (64 * 64 + 4 * 256 + 128 * TU_LDX) * sizeof (double) ;
-}
-__global__ void __launch_bounds__(256) k_trsm_upd2 (const TrGroup *g, int ng, double *Lx, i32 *info, i32 *cnt)
-{
-    extern __shared__ __attribute__((aligned(16))) double tu2_lds [] ;
-    double *Ls = tu2_lds ;                          // [64][64]  -L11 k-major; later the next diagonal block
-    double *Wd = Ls + 64 * 64 ;                     // [4][16][16] inverses of the 16 x 16 diagonal blocks
-    double *Xt = Wd + 4 * 256 ;                     // [128][TU_LDX]  -X_T k-major (k = 0..63: block e, 64..127: block e + 1)
-    __shared__ int s_fail, s_last ;
-    __builtin_amdgcn_s_setprio (3) ;
-    const int gi = find_group (g, ng, (int) blockIdx.x, &TrGroup::blk_start) ;
-    const TrGroup G = g [gi] ;
-    const i64 lda = G.lda ;
-    const int ldl = 64 ;
-    const double *L11 = Lx + G.l_off ;
-    const int inf = info [G.front] ;
-    int nvalid = 64 ;
-    if (inf != 0)
-    {
-        nvalid = inf - 1 - G.col0 ;
-        if (nvalid < 0) nvalid = 0 ;
-        if (nvalid > 64) nvalid = 64 ;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6 ;
-    const int lr = lane & 15, lk = lane >> 4 ;
-    const int blk = (int) blockIdx.x - G.blk_start ;
-    const int row = blk * TRM_ROWS + wave * 16 + lr ;
-    const bool rok = row < G.m ;
-    double *B = Lx + G.b_off ;                                  // rows from t0 on, columns of block e + 1
-    const double *Bp = B - 64 * lda ;                           // the same rows, columns of block e (solved)
-    double *C0 = B + 64 * lda, *C1 = B + 128 * lda ;            // ... the two target blocks
-    const int brow = rok ? row : G.m - 1 ;
-    const int t0row = wave * 16 + lr, t1row = 64 + wave * 16 + lr ;
-    d4 bj [4], bt0 [4], bt1 [4] ;
-    {
-        const int j = tid & 63 ;
-        double tmp [16] ;
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++) tmp [q] = L11 [j + (i64) ((tid >> 6) + 4 * q) * lda] ;
-#pragma unroll
-        for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
-            {
-                const i64 c = (i64) (16 * jj + lk + 4 * r) * lda ;
-                bj [jj][r] = B [brow + c] ;
-                bt0 [jj][r] = B [t0row + c] ;
-                bt1 [jj][r] = B [t1row + c] ;
-            }
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++)
-        {
-            const int k = (tid >> 6) + 4 * q ;
-            double v = (j == k) ? 1.0 : 0.0 ;
-            if (j < nvalid && k < j) v = -tmp [q] ;
-            if (j < nvalid && k == j) v = tmp [q] ;
-            Ls [k * ldl + j] = v ;
-        }
-    }
-    if (tid == 0) s_fail = -1 ;
-    __syncthreads () ;
-    auto tick = [] (int) {} ;
-    trsm_diag_inverses (Ls, ldl, Wd, 4, lane, wave, tick) ;
-    const int nwg = (G.m + TRM_ROWS - 1) / TRM_ROWS ;
-    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory") ;
-    __syncthreads () ;
-    // (every load of the unsolved rows T0 / T1 of this workgroup has arrived: the ticket)
-    if (tid == 0) s_last = (nwg == 1 || __hip_atomic_fetch_add (cnt + gi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) ? 1 : 0 ;
-    d4 xr [4], xt [4] ;
-    trsm_solve_rows<false> (bj, 4, Ls, ldl, Wd, lane, nvalid, rok && blk >= 2, 64, B, brow, lda, tick, xr) ;
-    // the operands of the own rows for block e (solved one step ago), in the accumulator = A-operand layout
-    d4 pj [4], c0 [4], c1 [4] ;
-#pragma unroll
-    for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-        for (int r = 0 ; r < 4 ; r++)
-        {
-            const i64 c = (i64) (16 * jj + lk + 4 * r) * lda ;
-            pj [jj][r] = Bp [brow + c] ;
-            c0 [jj][r] = C0 [brow + c] ;
-            c1 [jj][r] = C1 [brow + c] ;
-        }
-    // ---- tile column 0: -X_T0, K = 128
-    if (blk == 0)
-    {
-#pragma unroll
-        for (int j = 0 ; j < 4 ; j++) xt [j] = xr [j] ;
-    }
-    else trsm_solve_rows<false> (bt0, 4, Ls, ldl, Wd, lane, nvalid, false, 64, B, t0row, lda, tick, xt) ;
-    {
-        const int j = tid & 63 ;
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++)
-        {
-            const int k = (tid >> 6) + 4 * q ;
-            Xt [k * TU_LDX + j] = -Bp [j + (i64) k * lda] ;
-        }
-#pragma unroll
-        for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
-                Xt [(64 + 16 * jj + lk + 4 * r) * TU_LDX + wave * 16 + lr] = -xt [jj][r] ;
-    }
-    __syncthreads () ;                      // (also: s_last is visible)
-    if (s_last)
-    {
-#pragma unroll
-        for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++) B [t0row + (i64) (16 * jj + lk + 4 * r) * lda] = xt [jj][r] ;
-    }
-#pragma unroll
-    for (int i = 0 ; i < 4 ; i++)
-#pragma unroll
-        for (int s4 = 0 ; s4 < 4 ; s4++)
-#pragma unroll
-            for (int jt = 0 ; jt < 4 ; jt++)
-            {
-                double bv = Xt [(16 * i + 4 * s4 + lk) * TU_LDX + 16 * jt + lr] ;
-                c0 [jt] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, pj [i][s4], c0 [jt], 0, 0, 0) ;
-                double bw = Xt [(64 + 16 * i + 4 * s4 + lk) * TU_LDX + 16 * jt + lr] ;
-                c0 [jt] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bw, xr [i][s4], c0 [jt], 0, 0, 0) ;
-            }
-    // ---- tile column 1: -X_T1 into the same region (nobody of this workgroup reads the old one any more)
-    if (blk == 1)
-    {
-#pragma unroll
-        for (int j = 0 ; j < 4 ; j++) xt [j] = xr [j] ;
-    }
-    else trsm_solve_rows<false> (bt1, 4, Ls, ldl, Wd, lane, nvalid, false, 64, B, t1row, lda, tick, xt) ;
-    __syncthreads () ;
-    {
-        const int j = tid & 63 ;
-#pragma unroll
-        for (int q = 0 ; q < 16 ; q++)
-        {
-            const int k = (tid >> 6) + 4 * q ;
-            Xt [k * TU_LDX + j] = -Bp [64 + j + (i64) k * lda] ;
-        }
-#pragma unroll
-        for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++)
-                Xt [(64 + 16 * jj + lk + 4 * r) * TU_LDX + wave * 16 + lr] = -xt [jj][r] ;
-    }
-    __syncthreads () ;
-    if (s_last)
-    {
-#pragma unroll
-        for (int jj = 0 ; jj < 4 ; jj++)
-#pragma unroll
-            for (int r = 0 ; r < 4 ; r++) B [t1row + (i64) (16 * jj + lk + 4 * r) * lda] = xt [jj][r] ;
-    }
-    if (blk >= 1)
-    {
-#pragma unroll
-        for (int i = 0 ; i < 4 ; i++)
-#pragma unroll
-            for (int s4 = 0 ; s4 < 4 ; s4++)
-#pragma unroll
-                for (int jt = 0 ; jt < 4 ; jt++)
-                {
-                    double bv = Xt [(16 * i + 4 * s4 + lk) * TU_LDX + 16 * jt + lr] ;
-                    c1 [jt] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bv, pj [i][s4], c1 [jt], 0, 0, 0) ;
-                    double bw = Xt [(64 + 16 * i + 4 * s4 + lk) * TU_LDX + 16 * jt + lr] ;
-                    c1 [jt] = __builtin_amdgcn_mfma_f64_16x16x4f64 (bw, xr [i][s4], c1 [jt], 0, 0, 0) ;
-                }
-        if (rok)
-        {
-#pragma unroll
-            for (int jt = 0 ; jt < 4 ; jt++)
-#pragma unroll
-                for (int r = 0 ; r < 4 ; r++)
-                {
-                    const int j = 16 * jt + lk + 4 * r ;
-                    C0 [brow + (i64) j * lda] = c0 [jt][r] ;
-                    // (workgroup 1's second tile is the diagonal block (T1, T1): its strictly upper triangle stays zero)
-                    if (blk >= 2 || wave * 16 + lr >= j) C1 [brow + (i64) j * lda] = c1 [jt][r] ;
-                }
-        }
-        return ;
-    }
-    // workgroup 0: its tile of column 0 is the next diagonal block
-    double *A = C0 ;
-    if (inf != 0)
-    {
-        // an earlier pivot of this front failed: its remaining columns are zero
-        for (int k = wave ; k < PF_NB ; k += 4)
-            if (lane >= k) A [lane + (i64) k * lda] = 0.0 ;
-        return ;
-    }
-    double *T = Ls ;                                // T [k * PF2_LD + i] = A (i, k), zero above the diagonal
-    __syncthreads () ;                              // (every wave is done with Ls / Wd: its solves of T1 are above)
-#pragma unroll
-    for (int jt = 0 ; jt < 4 ; jt++)
-#pragma unroll
-        for (int r = 0 ; r < 4 ; r++)
-        {
-            const int i = wave * 16 + lr, j = 16 * jt + lk + 4 * r ;
-            T [j * PF2_LD + i] = (i >= j) ? c0 [jt][r] : 0.0 ;
-        }
-    __syncthreads () ;
-    pf_eliminate<false> (T, PF_NB / 16, &s_fail, tid, tick) ;
-    const int fail = s_fail ;
-    if (fail >= 0 && tid == 0) info [G.front] = G.col0 + 64 + fail + 1 ;
-    pf_store<false> (A, lda, T, PF_NB, fail, lane, wave) ;
-}
-
 // ---- multi-GPU: packing of a shared front's block column for the row-split exchange ----
 // A block column [b0, b0+w) of a front shared by g ranks holds per-rank partial sums in
 // its live rows (>= b0).  It is summed with ONE reduce-scatter whose segment q carries

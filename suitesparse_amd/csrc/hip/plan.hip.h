@@ -76,7 +76,7 @@ static inline int window_count (const FrontD &f, int ob) { return f.nscol > ob ?
 // K_XCHG_RS / K_XCHG_AG: the exchange of a shared front's block column (multi-GPU): reduce-scatter of
 // the partial sums by row chunks before its panel chain, all-gathers of the solved chunks after it (near rows in line,
 // far rows on the exchange stream, awaited by a K_JOIN ahead of the outer update)
-enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_CHAINF, K_TRSM_UPD2, K_NKIND } ;
+enum Kind { K_ZERO = 0, K_EA, K_POTRF, K_TRSM, K_UPD_BIG, K_UPD_SMALL, K_JOIN, K_XCHG_RS, K_SMALL, K_UPD_PF, K_TRSM_UPD, K_XCHG_AG, K_UPD_W, K_DIAG, K_ROWSOLVE, K_WIN, K_CHAINF, K_NKIND } ;
 
 struct Launch {
     int kind ;

@@ -68,7 +68,7 @@ struct DenseScheduler
     bool xla ;                      // exchange look-ahead (several ranks)
     bool chain256 = false ;         // the 256-column chain instead of the 64-column one
     bool fused256 = true ;          // ... as ONE launch per sub-block (k_chainf) rather than k_diag + k_rowsolve
-    bool fuse_potrf = false, fuse_trsm = false, fuse_upd2 = false ;
+    bool fuse_potrf = false, fuse_trsm = false ;
     bool balance_cb ;
     // ---- state of the batch
     std::vector<GemmGroup> big, small ;     // regions collected for the next flush: 128 x 128 tiles (opt-in) / 64 x 64
@@ -720,7 +720,6 @@ struct DenseScheduler
         fused256 = !getenv ("CHOLMOD_HIP_NO_CHAINF") ;
         fuse_potrf = !(flags & CHOLMOD_HIP_NO_FUSED_POTRF) && !chain256 ;     // (the 256-column chain has no separate dpotrf launches to fuse)
         fuse_trsm = fuse_potrf && !(flags & CHOLMOD_HIP_NO_FUSED_TRSM) ;
-        fuse_upd2 = fuse_trsm && !getenv ("CHOLMOD_HIP_NO_TRSM_UPD2") ;
     }
 
     // ---- the panel chain in 256-column sub-blocks (kernels.hip.h: k_chainf, or k_diag / k_rowsolve) -----------------------
@@ -856,39 +855,6 @@ struct DenseScheduler
         Lf_.ng = (int) (S.tg.size () - Lf_.goff) ; Lf_.grid = fblocks ; Lf_.aux = NB ;
         if (Lf_.ng) S.launches.push_back (Lf_) ;
     }
-    // The even steps with p = 2 (the second block of a pair: e = 2 mod 4): dtrsm of the rows below it, the K = 128 update of
-    // the next two blocks with the pair, the dpotrf of the first of them -- one launch (k_trsm_upd2) instead of k_trsm_mfma +
-    // k_update2f.  Both target blocks full and inside the same outer block column, the front not shared, a real plan.
-    void emit_trsm_upd2 (int i0, std::vector<char> &fused)
-    {
-        if (!fuse_trsm || !fuse_upd2 || cx || twin) return ;
-        Launch Lf_ {K_TRSM_UPD2, 0, 0, S.tg.size (), 0, 0} ;
-        int fblocks = 0 ;
-        for (int q = 0 ; q < nf ; q++)
-        {
-            const FrontD &f = fr [ids [q]] ;
-            if (fused [q] || f.nscol < i0 + 3 * NB || is_shared (ids [q])) continue ;
-            int OBq = ob_of (f) ;
-            int o0 = (i0 / OBq) * OBq ;
-            int o1 = std::min (o0 + OBq, (int) f.nscol) ;
-            if (i0 + 3 * NB > o1) continue ;             // both target blocks inside this outer block column
-            int e = (i0 - o0) / NB + 1 ;
-            if ((e & -e) != 2) continue ;               // p = 2 steps only
-            const int t0 = i0 + NB ;
-            int m = f.nsrow - t0 ;
-            TrGroup G {f.psx + i0 + co (i0, f.nsrow),
-                       f.psx + t0 + co (i0, f.nsrow), f.nsrow, m, NB,
-                       ids [q], i0, fblocks} ;
-            fblocks += (m + TRM_ROWS - 1) / TRM_ROWS ;
-            S.tg.push_back (G) ;
-            Lf_.flops += (double) m * NB * NB + 2.0 * ((double) m * 2 * NB - (double) (2 * NB) * (2 * NB - 1) / 2) * (2.0 * NB) + (double) NB * NB * NB / 3.0 ;
-            Lf_.bytes += 8.0 * (6.0 * m * NB) ;
-            fused [q] = 2 ;
-            pf_done [q] = t0 ;
-        }
-        Lf_.ng = (int) (S.tg.size () - Lf_.goff) ; Lf_.grid = fblocks ; Lf_.aux = NB ;
-        if (Lf_.ng) S.launches.push_back (Lf_) ;
-    }
     // dtrsm of the rows below the diagonal block -- of a shared front, whose block column has been dealt to the ranks by row
     // chunks: the rest of the 512-wide diagonal block (every rank of the group) and this rank's chunk below it
     void emit_trsm (int i0, const std::vector<char> &fused)
@@ -926,7 +892,6 @@ struct DenseScheduler
             emit_potrf (i0) ;
             std::vector<char> fused (nf, 0) ;
             emit_trsm_upd (i0, fused) ;
-            emit_trsm_upd2 (i0, fused) ;
             emit_trsm (i0, fused) ;
             leave_sub_block (i0, NB) ;
             push_doubling_steps (i0, NB, &fused) ;
