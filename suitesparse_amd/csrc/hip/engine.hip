@@ -594,6 +594,9 @@ static int factorize_prologue (cholmod_hip_plan *P)
         if (P->lx_local > P->lx_fronts) HIPCHK (hipMemsetAsync (P->d_Lx + P->lx_fronts, 0xFF, (size_t) (P->lx_local - P->lx_fronts) * sizeof (double), st)) ;
         if (P->d_ag) HIPCHK (hipMemsetAsync (P->d_ag, 0xFF, (size_t) P->ag_len * sizeof (double), st)) ;
         if (P->d_agf) HIPCHK (hipMemsetAsync (P->d_agf, 0xFF, (size_t) P->agf_len * sizeof (double), st)) ;
+        // (... and the padding behind L that partial tiles of k_update3 may read -- into accumulators nobody stores: a NaN
+        // that reaches the factor from there shows in every poisoned parity test; round-5 advisor)
+        HIPCHK (hipMemsetAsync (P->d_Lx + std::max<i64> (P->lx_local, 1), 0xFF, (size_t) UPD3_LX_PAD * sizeof (double), st)) ;
     }
     HIPCHK (hipMemsetAsync (P->d_Lx, 0, std::max<i64> (poison ? P->lx_fronts : P->lx_local, 1) * sizeof (double), st)) ;
     HIPCHK (hipMemsetAsync (P->d_info, 0, std::max<i64> (P->nsuper, 1) * sizeof (i32), st)) ;

@@ -49,7 +49,7 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     // top fronts of a big factor sit deep inside the one Lx allocation): does the rate depend on it?
     i64 skip = 0 ;
     if (const char *e = getenv ("CHOLMOD_PROBE_OFFSET_GB")) skip = (i64) (atof (e) * 1e9 / 8.0) ;
-    if (hipMalloc ((void **) &d, (total + skip) * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    if (hipMalloc ((void **) &d, (total + skip + UPD3_LX_PAD) * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;    // (partial tiles of k_update3 read up to 63 rows past an operand, kernels.hip.h)
     double *d_base = d ;
     d += skip ;
     // operands filled on the device (full-mantissa pseudo-random values in [-0.5, 0.5)): regions of
@@ -142,7 +142,7 @@ double cholmod_hip_bench_update_pair (int64_t m1, int64_t n1, int64_t m2, int64_
     const i64 c2_off = c1_off + ld * n1 + 1 ;                   // C of the square: m2 x m2
     const i64 total = c2_off + m2 * m2 ;
     double *d = nullptr ;
-    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    if (hipMalloc ((void **) &d, (total + UPD3_LX_PAD) * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     hipLaunchKernelGGL (k_fill_random, dim3 (4096), dim3 (256), 0, 0, d, total) ;
     if (hipDeviceSynchronize () != hipSuccess) { (void) hipFree (d) ; return CHOLMOD_HIP_GPU_PROBLEM ; }
     auto region = [&] (i64 rows0, i64 m, i64 n, i64 c_off, i64 ldc)
@@ -487,7 +487,7 @@ double cholmod_hip_debug_update_diff (int64_t m, int64_t n, int64_t k, int tri, 
         h [q] = (double) (sdd >> 11) / 9007199254740992.0 - 0.5 ;
     }
     double *d = nullptr ; GemmGroup *dg = nullptr ;
-    if (hipMalloc ((void **) &d, total * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
+    if (hipMalloc ((void **) &d, (total + UPD3_LX_PAD) * sizeof (double)) != hipSuccess) return CHOLMOD_HIP_OUT_OF_MEMORY ;
     HIPCHK (hipMalloc ((void **) &dg, sizeof (GemmGroup))) ;
     GemmGroup G ;
     memset (&G, 0, sizeof (G)) ;

@@ -120,8 +120,15 @@ int ssamd_solve_subset (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_sp
     Int ysetlen ;
     if (!need_values)
     {
-        for (Int p = 0 ; p < blen ; p++) Yseti [p] = IPerm ? IPerm [Bseti [p]] : Bseti [p] ;
-        ysetlen = blen ;
+        /* (an index listed twice enters once, as in the reach below: Xset has n slots, a Bset with duplicates may be longer) */
+        ysetlen = 0 ;
+        for (Int p = 0 ; p < blen ; p++)
+        {
+            const Int i = IPerm ? IPerm [Bseti [p]] : Bseti [p] ;
+            if (Flag [i] == mark) continue ;
+            Flag [i] = mark ;
+            Yseti [ysetlen++] = i ;
+        }
     }
     else
     {

@@ -84,6 +84,27 @@ def test_subset_solve_matches_the_full_solve_on_the_reach(case):
     assert S.cm.malloc_count == 0 if hasattr(S.cm, "malloc_count") else True
 
 
+def test_subset_solve_with_an_index_listed_many_times():
+    """A Bset longer than n (every index several times): Xset holds each index once for every system -- the P / Pt / D
+    systems copied Bset as it came, into n slots (round-5 advisor)."""
+    n, Ap, Ai, Ax = G.poisson2d(6)
+    perm = G.geometric_nd(6, 6, 1, 2)
+    S = ch.Session(use_gpu=0)
+    A, Lf = _factor(S, n, Ap, Ai, Ax, perm)
+    rng = np.random.default_rng(2)
+    base = rng.choice(n, size=5, replace=False)
+    bset = np.concatenate([base] * 9)                   # 45 entries for n = 36
+    assert len(bset) > n
+    b = np.zeros(n); b[base] = rng.standard_normal(len(base))
+    for sys in (ch.SYS_P, ch.SYS_Pt, ch.SYS_D, ch.SYS_A, ch.SYS_L):
+        x, xset = S.solve_subset(Lf, b, bset, sys=sys)
+        assert len(set(xset.tolist())) == len(xset) <= n, sys
+        full = S.solve(Lf, b, sys=sys)
+        assert np.allclose(x[xset], full[xset], rtol=1e-12, atol=1e-13), sys
+    S.free_factor(Lf); S.free_sparse(A); S.finish()
+    assert S.cm.malloc_count == 0
+
+
 def test_subset_solve_of_a_complex_factor():
     n, Ap, Ai, Ax = G.poisson2d(16)
     rng = np.random.default_rng(2)
