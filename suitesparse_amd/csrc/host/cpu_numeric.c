@@ -61,26 +61,45 @@ static void *sym2 (void *h, const char *prefix, const char *name)
 static int lp64_probe (dgemm_fn g, dpotrf_fn p)
 {
     double M [9] = {4, 2, 2,  0, 5, 3,  0, 0, 6} ;          /* lower triangle, column-major */
-    int n3 [2] = {3, -1}, info [2] = {-1, -1} ;
-    p ("L", n3, M, n3, info) ;
+    int n3 = 3, info = -1 ;
+    p ("L", &n3, M, &n3, &info) ;
     double Aa [6] = {1, 2, 3,  4, 5, 6}, Bb [4] = {1, 0,  0, 1}, Cc [6] = {0, 0, 0, 0, 0, 0} ;
-    int m3 [2] = {3, -1}, n2 [2] = {2, -1}, k2 [2] = {2, -1} ;
+    int m3 = 3, n2 = 2, k2 = 2 ;
     double one = 1.0, zero = 0.0 ;
-    g ("N", "N", m3, n2, k2, &one, Aa, m3, Bb, k2, &zero, Cc, m3) ;
-    int okp = (info [0] == 0 && fabs (M [0] - 2.0) < 1e-14 && fabs (M [1] - 1.0) < 1e-14 && fabs (M [4] - 2.0) < 1e-14
+    g ("N", "N", &m3, &n2, &k2, &one, Aa, &m3, Bb, &k2, &zero, Cc, &m3) ;
+    int okp = (info == 0 && fabs (M [0] - 2.0) < 1e-14 && fabs (M [1] - 1.0) < 1e-14 && fabs (M [4] - 2.0) < 1e-14
         && fabs (M [5] - 1.0) < 1e-14 && fabs (M [8] - 2.0) < 1e-14) ;
     int okg = 1 ;
     for (int q = 0 ; q < 6 ; q++) if (Cc [q] != Aa [q]) okg = 0 ;
     return okp && okg ;
 }
 
-/* In this process, behind the negative second words (round-4 advisor item: no fork () inside a library -- the host process
- * may be multi-threaded with the HIP runtime, RCCL and OpenMP loaded, and a child that runs BLAS code after fork can
- * deadlock on a lock whose owner no longer exists).  An ILP64 library reads (n, -1) as a negative 64-bit dimension and
- * leaves through its argument check. */
-static int lp64_self_check (dgemm_fn g, dpotrf_fn p)
+/* The width of the library's integers, found WITHOUT handing it an invalid argument (round-5 advisor: the negative
+ * dimension of the earlier probe sends an ILP64 library into xerbla, and reference LAPACK's xerbla STOPs -- the host
+ * application with it).  ilaver_ (major, minor, patch) only WRITES three integers: an LP64 library leaves the words
+ * between them alone, an ILP64 one writes eight bytes each.  OpenBLAS also says so in its configuration string, and
+ * MKL's single dynamic library takes its interface from MKL_INTERFACE_LAYER.  1 = 32-bit integers as far as can be told,
+ * 0 = 64-bit (the library is not used); the known-answer calls above run only after that, with valid arguments. */
+typedef void (*ilaver_fn) (int *, int *, int *) ;
+typedef char *(*get_config_fn) (void) ;
+static int lp64_by_inspection (void *h, const char *prefix)
 {
-    return lp64_probe (g, p) ;
+    get_config_fn gc = (get_config_fn) sym2 (h, prefix, "openblas_get_config") ;
+    if (!gc) gc = (get_config_fn) dlsym (h, "openblas_get_config") ;
+    if (gc) { const char *c = gc () ; if (c && strstr (c, "USE64BITINT")) return 0 ; }
+    if (dlsym (h, "MKL_Set_Num_Threads"))
+    {
+        const char *e = getenv ("MKL_INTERFACE_LAYER") ;
+        if (e && (strstr (e, "ILP64") || strstr (e, "ilp64"))) return 0 ;
+    }
+    ilaver_fn iv = (ilaver_fn) sym2 (h, prefix, "ilaver_") ;
+    if (iv)
+    {
+        int v [8] = {-7, -7, -7, -7, -7, -7, -7, -7} ;
+        iv (&v [0], &v [2], &v [4]) ;
+        if (v [1] != -7 || v [3] != -7 || v [5] != -7) return 0 ;       /* the high words of 64-bit integers */
+    }
+    return 1 ;
 }
 
 static int try_blas (const char *path, const char *prefix)
@@ -92,12 +111,9 @@ static int try_blas (const char *path, const char *prefix)
     dtrsm_fn t = (dtrsm_fn) sym2 (h, prefix, "dtrsm_") ;
     dpotrf_fn p = (dpotrf_fn) sym2 (h, prefix, "dpotrf_") ;
     if (!g || !s || !t || !p) { dlclose (h) ; return 0 ; }
-    /* self-check before trusting it: the arguments are 32-bit ints (LP64 interface); an ILP64 build
-     * found under the same soname reads 8 bytes from each.  Every size therefore sits in a two-word
-     * array whose second word is -1: an ILP64 library sees a NEGATIVE dimension and leaves through
-     * its argument check (info < 0 / xerbla) instead of running over the 9- and 6-element arrays
-     * with whatever the stack held next to a lone int (lp64_self_check). */
-    if (!lp64_self_check (g, p))
+    /* before trusting it: the arguments are 32-bit ints (LP64 interface).  The integer width is read off the library
+     * without calling anything with an argument it could reject (lp64_by_inspection); then two known-answer calls. */
+    if (!lp64_by_inspection (h, prefix) || !lp64_probe (g, p))
     {
         fprintf (stderr, "cholmod (CPU path): %s fails the LP64 self-check (an ILP64 build?): not used\n", path) ;
         dlclose (h) ;
