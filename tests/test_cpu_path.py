@@ -206,6 +206,40 @@ def test_cpu_path_on_several_threads(blas, threads, grid):
     assert out.strip().endswith("ok")
 
 
+def test_a_blas_with_64_bit_integers_is_refused_without_being_called(tmp_path):
+    """An ILP64 library found under the LP64 names is recognised by inspection -- ilaver_ writes eight bytes per integer --
+    and not used: none of its compute entry points may be called (here they abort the process, as a reference xerbla
+    that STOPs would), the factorization falls back to the built-in kernels (round-5 advisor)."""
+    src = tmp_path / "fake_ilp64.c"
+    src.write_text(r'''
+#include <stdlib.h>
+void ilaver_ (long *a, long *b, long *c) { *a = 3 ; *b = 12 ; *c = 0 ; }
+void dgemm_ (void) { abort () ; }
+void dsyrk_ (void) { abort () ; }
+void dtrsm_ (void) { abort () ; }
+void dpotrf_ (void) { abort () ; }
+''')
+    so = tmp_path / "libfake_ilp64.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    code = r'''
+import sys, ctypes
+sys.path.insert(0, ".")
+from suitesparse_amd import cholmod as ch, generators as G
+n, Ap, Ai, Ax = G.poisson2d(12)
+S = ch.Session(use_gpu=0)
+A = S.sparse(n, Ap, Ai, Ax, -1)
+Lf = S.analyze(A)
+assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
+S.L.ssamd_cpu_blas_name.restype = ctypes.c_char_p
+print("blas:", S.L.ssamd_cpu_blas_name().decode())
+'''
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, CHOLMOD_BLAS_LIBRARY=str(so)),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fails the LP64 self-check" in out.stderr
+    assert "libfake_ilp64" not in out.stdout.split("blas:")[1]
+
+
 def test_env_default_is_cpu_like_the_reference(monkeypatch):
     """Common->useGPU == -1 (cholmod_l_start): CHOLMOD_USE_GPU unset selects the CPU
     (CHOLMOD/Supernodal/cholmod_super_symbolic.c:286-291), =1 the GPU."""
