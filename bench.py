@@ -70,6 +70,10 @@ sys.path.insert(0, os.environ["BENCH_ROOT"])
 from suitesparse_amd import cholmod as ch, generators as G
 m = int(os.environ["BENCH_CPU_M"])
 counts = [int(v) for v in os.environ["BENCH_CPU_COUNTS"].split(",")]
+L0 = ch.lib()
+cap = int(L0.ssamd_cpu_max_threads())          # (OpenBLAS: its compile-time MAX_THREADS; 0 = none)
+if cap > 0:
+    counts = sorted({min(c, cap) for c in counts})
 budget = float(os.environ.get("BENCH_CPU_BUDGET_S", "30"))
 gomp = ctypes.CDLL("libgomp.so.1")
 n, Ap, Ai, Ax = G.poisson3d(m)
@@ -94,7 +98,7 @@ for t in sorted(counts, reverse=True):          # widest first: should the budge
     spent += dt
     pts.append({"threads": t, "seconds": dt})
 S.L.ssamd_cpu_blas_name.restype = ctypes.c_char_p
-print(json.dumps({"fl": S.cm.fl, "points": pts, "first_seconds": first, "blas": S.L.ssamd_cpu_blas_name().decode()}))
+print(json.dumps({"fl": S.cm.fl, "points": pts, "first_seconds": first, "blas": S.L.ssamd_cpu_blas_name().decode(), "blas_max_threads": cap}))
 """
 
 
@@ -126,7 +130,12 @@ def cpu_baseline(sample_m):
         out = subprocess.run([sys.executable, "-c", CPU_CHILD], env=env, capture_output=True, text=True, timeout=900)
         r = json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:      # report, never fail the bench line
-        return {"value": None, "unit": "GFLOP/s", "cores": 0, "host_cores": cores, "kind": "port", "sample": f"failed: {e!r}"[:200]}
+        tail = ""
+        try:
+            tail = " | " + " ".join((out.stderr or "").strip().splitlines()[-3:])
+        except Exception:
+            pass
+        return {"value": None, "unit": "GFLOP/s", "cores": 0, "host_cores": cores, "kind": "port", "sample": (f"failed: {e!r}" + tail)[:300]}
     leg = time.perf_counter() - t0
     fl, blas = r["fl"], r["blas"]
     pts = sorted(({"threads": q["threads"], "GFLOPs": fl / q["seconds"] / 1e9, "seconds_best": q["seconds"]} for q in r["points"]),
@@ -136,6 +145,7 @@ def cpu_baseline(sample_m):
             "sample_short": f"poisson3d {sample_m}^3 ND, whole factorization, {top['seconds_best']:.1f} s",
             "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
             "by_threads": pts, "first_factorization_seconds": r["first_seconds"], "leg_seconds": leg,
+            "blas_max_threads": r.get("blas_max_threads"),
             "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)),
             "sample": f"poisson3d {sample_m}^3 geometric ND" + (" (BASELINE configs[1], the whole factorization)" if sample_m == 100 else "")
                       + f", one factorization per thread count ({', '.join(str(q['threads']) for q in pts)}) after one untimed, "

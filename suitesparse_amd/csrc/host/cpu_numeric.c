@@ -47,6 +47,7 @@ static struct
     set_threads_fn set_threads ;    /* openblas_set_num_threads / MKL_Set_Num_Threads, or NULL */
     get_threads_fn0 get_threads ;   /* openblas_get_num_threads / MKL_Get_Max_Threads, or NULL */
     int max_threads, cur_threads ;
+    int max_callers ;               /* most threads that may be inside the library at once (OpenBLAS: its MAX_THREADS), 0 = no limit known */
     char name [256] ;
 } g_blas ;
 
@@ -129,6 +130,16 @@ static int try_blas (const char *path, const char *prefix)
     if (!g_blas.set_threads) { g_blas.set_threads = (set_threads_fn) dlsym (h, "MKL_Set_Num_Threads") ; g_blas.get_threads = (get_threads_fn0) dlsym (h, "MKL_Get_Max_Threads") ; }
     g_blas.max_threads = ssamd_host_threads_uncapped () ;
     g_blas.cur_threads = -1 ;
+    {
+        /* OpenBLAS hands every caller a buffer out of a pool sized by its compile-time MAX_THREADS and terminates the
+         * program when the pool runs out ("too many memory regions"): scipy's build says MAX_THREADS=64, and 256 OpenMP
+         * threads calling dgemm at once on the 256-thread host of the GPU box ended the CPU baseline's process (round 6).
+         * The factorization therefore never runs more threads than that. */
+        get_config_fn gc = (get_config_fn) sym2 (h, prefix, "openblas_get_config") ;
+        if (!gc) gc = (get_config_fn) dlsym (h, "openblas_get_config") ;
+        const char *c = gc ? gc () : NULL, *m = c ? strstr (c, "MAX_THREADS=") : NULL ;
+        g_blas.max_callers = (m && atoi (m + 12) > 0) ? atoi (m + 12) : 0 ;
+    }
     snprintf (g_blas.name, sizeof (g_blas.name), "%s%s%s", path, prefix [0] ? " prefix " : "", prefix) ;
     g_blas.handle = h ;         /* (last: everything above is in place when a reader sees the handle) */
     return 1 ;
@@ -162,6 +173,13 @@ static void bind_blas_impl (void)
 
 static pthread_once_t g_blas_once = PTHREAD_ONCE_INIT ;
 static void bind_blas_once (void) { (void) pthread_once (&g_blas_once, bind_blas_impl) ; }
+
+/* most OpenMP threads the CPU factorization will use with the bound BLAS (0: no limit but the caller's) */
+int ssamd_cpu_max_threads (void)
+{
+    bind_blas_once () ;
+    return g_blas.handle ? g_blas.max_callers : 0 ;
+}
 
 const char *ssamd_cpu_blas_name (void)
 {
@@ -709,6 +727,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
     int nth = ssamd_host_threads_uncapped () ;
     { const char *e = getenv ("CHOLMOD_CPU_SUBTREES") ; if (e && !strcmp (e, "0")) nth = 1 ; }
     if (X.have_blas && !g_blas.set_threads) nth = 1 ;
+    if (X.have_blas && g_blas.max_callers > 0 && nth > g_blas.max_callers) nth = g_blas.max_callers ;
     if (n >= ((Int) 1 << 31) - 1) nth = 1 ;
     if (nsuper < 2) nth = 1 ;
     int blas_entry_threads = -1 ;
