@@ -102,6 +102,22 @@ print(json.dumps({"fl": S.cm.fl, "points": pts, "first_seconds": first, "blas": 
 """
 
 
+def cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None: the GPU boxes show 256
+    hardware threads and a quota of 16 -- threads beyond it are throttled, not added."""
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if a == "max" else max(1, -(-int(a) // int(b)))
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return max(1, -(-q // p_)) if q > 0 and p_ > 0 else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(sample_m):
     """The build's own CPU supernodal path (Common->useGPU = 0: suitesparse_amd/csrc/host/cpu_numeric.c, the reference's
     left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU supernodal path") timed on the host
@@ -119,10 +135,14 @@ def cpu_baseline(sample_m):
         b = _scipy_openblas()
         if b:
             base["CHOLMOD_BLAS_LIBRARY"] = b
+    quota = cpu_quota()
+    usable = min(cores, quota) if quota else cores
     if "OMP_NUM_THREADS" in os.environ:
         counts = [int(os.environ["OMP_NUM_THREADS"])]
     else:
-        counts = sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)})
+        # up to what the container may use: every hardware thread without a quota, the quota's worth of threads with one
+        # (and one point at twice the quota, to show what oversubscribing it costs)
+        counts = sorted({min(usable, c) for c in (4, 8, 16, 32, 64, 128, usable)} | ({min(cores, 2 * usable)} if quota else set()))
     base["BENCH_CPU_COUNTS"] = ",".join(str(c) for c in counts)
     env = dict(base, OMP_NUM_THREADS=str(max(counts)), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", OMP_PROC_BIND="false")
     t0 = time.perf_counter()
@@ -141,15 +161,17 @@ def cpu_baseline(sample_m):
     pts = sorted(({"threads": q["threads"], "GFLOPs": fl / q["seconds"] / 1e9, "seconds_best": q["seconds"]} for q in r["points"]),
                  key=lambda q: q["threads"])
     top = max(pts, key=lambda q: q["GFLOPs"])
-    return {"value": top["GFLOPs"], "unit": "GFLOP/s", "cores": top["threads"], "host_cores": cores, "kind": "port",
+    return {"value": top["GFLOPs"], "unit": "GFLOP/s", "cores": top["threads"], "host_cores": cores, "cpu_quota": quota, "kind": "port",
             "sample_short": f"poisson3d {sample_m}^3 ND, whole factorization, {top['seconds_best']:.1f} s",
             "path": "product CPU path (cholmod_l_factorize with Common->useGPU = 0, host/cpu_numeric.c)",
             "by_threads": pts, "first_factorization_seconds": r["first_seconds"], "leg_seconds": leg,
             "blas_max_threads": r.get("blas_max_threads"),
-            "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)),
+            "monotone_in_threads": all(pts[i + 1]["GFLOPs"] >= 0.97 * pts[i]["GFLOPs"] for i in range(len(pts) - 1)
+                                       if pts[i + 1]["threads"] <= usable),
             "sample": f"poisson3d {sample_m}^3 geometric ND" + (" (BASELINE configs[1], the whole factorization)" if sample_m == 100 else "")
                       + f", one factorization per thread count ({', '.join(str(q['threads']) for q in pts)}) after one untimed, "
-                      f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas} (one thread per call), host cores {cores}"}
+                      f"fl={fl:.3e}, {top['seconds_best']:.2f} s at {top['threads']} threads, BLAS={blas} (one thread per call), host cores {cores}"
+                      + (f", container CPU quota {quota}" if quota else "")}
 
 
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r05k_pmc_summary_poisson200_top48.json"}
@@ -629,7 +651,7 @@ def compact_line(full):
     cb = g("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"),
-                                "host_cores": cb.get("host_cores"), "kind": cb.get("kind"),
+                                "host_cores": cb.get("host_cores"), "cpu_quota": cb.get("cpu_quota"), "kind": cb.get("kind"),
                                 "sample": (cb.get("sample_short") or (cb.get("sample") or "")[:60])}
         if cb.get("by_threads"):
             line["cpu_baseline"]["by_threads"] = {str(q["threads"]): _r(q["GFLOPs"], 4) for q in cb["by_threads"]}

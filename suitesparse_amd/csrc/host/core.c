@@ -336,25 +336,57 @@ cholmod_sparse *cholmod_l_copy_sparse (cholmod_sparse *A, cholmod_common *Common
  * short columns): they stop scaling at a few dozen and lose beyond a socket
  * (EPYC 9575F x 2, 256 hardware threads: 4x slower than with 32), so the OpenMP
  * default is capped; CHOLMOD_HOST_THREADS overrides. */
-int ssamd_host_threads (void)
+/* CPUs' worth of time the container may use (cgroup v2 cpu.max, v1 cfs quota), 0 = no quota.  The GPU boxes of this
+ * project show 256 hardware threads and a quota of 16: every thread beyond the quota is a thread that gets throttled --
+ * which is why, for five rounds, every host loop of this library measured best at 16 threads and worse beyond (round 6). */
+int ssamd_cpu_quota (void)
+{
+    static int cached = -1 ;
+    if (cached >= 0) return cached ;
+    int q = 0 ;
+    FILE *f = fopen ("/sys/fs/cgroup/cpu.max", "r") ;
+    if (f)
+    {
+        char a [64] = {0} ; double per = 0 ;
+        if (fscanf (f, "%63s %lf", a, &per) == 2 && strcmp (a, "max") != 0 && per > 0) q = (int) ceil (atof (a) / per) ;
+        fclose (f) ;
+    }
+    else
+    {
+        double qu = -1, pe = 0 ;
+        FILE *g = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *h = fopen ("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r") ;
+        if (g && h && fscanf (g, "%lf", &qu) == 1 && fscanf (h, "%lf", &pe) == 1 && qu > 0 && pe > 0) q = (int) ceil (qu / pe) ;
+        if (g) fclose (g) ;
+        if (h) fclose (h) ;
+    }
+    cached = q > 0 ? q : 0 ;
+    return cached ;
+}
+
+/* the OpenMP default, not beyond the container's CPU quota unless the caller asked for a number (OMP_NUM_THREADS) */
+static int omp_threads_within_quota (void)
 {
     int nt = 1 ;
 #ifdef _OPENMP
     nt = omp_get_max_threads () ;
 #endif
+    const int q = ssamd_cpu_quota () ;
+    if (q > 0 && nt > q && !getenv ("OMP_NUM_THREADS")) nt = q ;
+    return nt > 0 ? nt : 1 ;
+}
+
+int ssamd_host_threads (void)
+{
     const char *e = getenv ("CHOLMOD_HOST_THREADS") ;
     if (e && atoi (e) > 0) return atoi (e) ;
+    const int nt = omp_threads_within_quota () ;
     return nt > 32 ? 32 : nt ;
 }
 
 /* threads the caller allows (OMP_NUM_THREADS / the OpenMP default), not capped: the dense calls of the CPU path */
 int ssamd_host_threads_uncapped (void)
 {
-    int nt = 1 ;
-#ifdef _OPENMP
-    nt = omp_get_max_threads () ;
-#endif
-    return nt > 0 ? nt : 1 ;
+    return omp_threads_within_quota () ;
 }
 
 /* Symmetric permutation C = P A P' (Perm may be NULL), upper_out selects the

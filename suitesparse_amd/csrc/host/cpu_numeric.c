@@ -339,6 +339,47 @@ typedef struct
     size_t n_syrk, n_gemm, n_potrf, n_trsm ;
 } cpu_ws ;
 
+/* C (n2 x n1, ld n2, lower trapezoid) = Ld (n2 x dk, ld) * Ld (first n1 rows)': the update of a SMALL descendant, without a
+ * BLAS call.  97 % of the updates of a 3D problem have at most 16 columns, and a call into the bound library costs
+ * more than their arithmetic -- with OpenBLAS also a turn at the global lock of its buffer pool, which is what made 64 threads
+ * slower than 16 on the 256-thread host (round 6: 868 / 657 / 373 GFLOP/s at 16 / 32 / 64 threads with every update a dsyrk +
+ * dgemm).  Column by column, the inner loop contiguous in both arrays. */
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2,fma", "default")))
+static void small_update (Int n1, Int n2, Int dk, const double *restrict Ld, Int ld, double *restrict C)
+{
+    for (Int j = 0 ; j < n1 ; j++)
+    {
+        double *restrict cj = C + j * n2 ;
+        for (Int i = j ; i < n2 ; i++) cj [i] = 0.0 ;
+        for (Int p = 0 ; p < dk ; p++)
+        {
+            const double b = Ld [j + p * ld] ;
+            const double *restrict a = Ld + p * ld ;
+            for (Int i = j ; i < n2 ; i++) cj [i] += a [i] * b ;
+        }
+    }
+}
+
+/* C (M x N, ld M) = A (M x K, lda) * B (N x K, ldb)': a descendant's share of one target tile (phase B), small */
+__attribute__((optimize("O3"), target_clones("avx512f", "avx2,fma", "default")))
+static void small_gemm_nt (Int M, Int N, Int K, const double *restrict A, Int lda, const double *restrict B, Int ldb, double *restrict C)
+{
+    for (Int j = 0 ; j < N ; j++)
+    {
+        double *restrict cj = C + j * M ;
+        for (Int i = 0 ; i < M ; i++) cj [i] = 0.0 ;
+        for (Int p = 0 ; p < K ; p++)
+        {
+            const double b = B [j + p * ldb] ;
+            const double *restrict a = A + p * lda ;
+            for (Int i = 0 ; i < M ; i++) cj [i] += a [i] * b ;
+        }
+    }
+}
+
+/* flops (n1 n2 dk) below which an update stays out of the BLAS */
+#define CPU_SMALL_UPDATE 40000.0
+
 static void assemble_columns (const cpu_ctx *X, const int32_t *where, Int s, Int c0, Int c1)
 {
     const Int k1 = X->Super [s], psi = X->Lpi [s], nsrow = X->Lpi [s+1] - psi ;
@@ -391,7 +432,18 @@ static Int factor_supernode_seq (const cpu_ctx *X, cpu_ws *W, Int s, Int *info_o
             const Int n1 = q2 - q1, n2 = drows - q1 ;               /* rows inside s / from there down */
             const double *Ld = Lx + Lpx [d] + q1 ;                  /* ld = drows */
             for (Int r = 0 ; r < n2 ; r++) relpos [r] = where [Ls [dpi + q1 + r]] ;
-            if (X->have_blas)
+            if (X->have_blas && (double) n1 * (double) n2 * (double) dk < CPU_SMALL_UPDATE)
+            {
+                small_update (n1, n2, dk, Ld, drows, C) ;
+                W->n_syrk++ ;
+                for (Int j = 0 ; j < n1 ; j++)
+                {
+                    double *dst = Fs + relpos [j] * nsrow ;
+                    const double *cj = C + j * n2 ;
+                    for (Int i = j ; i < n2 ; i++) dst [relpos [i]] -= cj [i] ;
+                }
+            }
+            else if (X->have_blas)
             {
                 const double one = 1.0, zero = 0.0 ;
                 int in1 = (int) n1, idk = (int) dk, ild = (int) drows, ildc = (int) n2, in3 = (int) (n2 - n1) ;
@@ -429,13 +481,13 @@ static Int factor_supernode_seq (const cpu_ctx *X, cpu_ws *W, Int s, Int *info_o
         /* diagonal block: the first `good` columns */
         Int info = 0 ;
         t0 = now_s () ;
-        if (X->have_blas)
+        if (X->have_blas && good > 24)
         {
             int in = (int) good, ild = (int) nsrow, iinfo = 0 ;
             g_blas.potrf ("L", &in, Fs, &ild, &iinfo) ;
             info = iinfo ;
         }
-        else info = k_potrf (good, Fs, nsrow) ;
+        else info = k_potrf (good, Fs, nsrow) ;         /* (small diagonal blocks: the built-in kernel, no library call) */
         W->t_potrf += now_s () - t0 ; W->n_potrf++ ;
         if (info > 0 && pass == 0)
         {
@@ -450,7 +502,7 @@ static Int factor_supernode_seq (const cpu_ctx *X, cpu_ws *W, Int s, Int *info_o
         /* rows below the factored block (after a failed pivot that includes the remaining rows of the diagonal block, as
          * in the reference) */
         t0 = now_s () ;
-        if (X->have_blas)
+        if (X->have_blas && (double) (nsrow - good) * (double) good * (double) good >= CPU_SMALL_UPDATE)
         {
             const double one = 1.0 ;
             int im = (int) (nsrow - good), in = (int) good, ild = (int) nsrow ;
@@ -610,7 +662,8 @@ static Int factor_supernode_tiled (const cpu_ctx *X, cpu_ws *WS, int nth, Int s,
                         {
                             const double one = 1.0, zero = 0.0 ;
                             int im = (int) M, in = (int) N, ik = (int) dk, ild = (int) drows ;
-                            g_blas.gemm ("N", "C", &im, &in, &ik, &one, Ai_, &ild, Aj_, &ild, &zero, C, &im) ;
+                            if ((double) M * (double) N * (double) dk < CPU_SMALL_UPDATE) small_gemm_nt (M, N, dk, Ai_, drows, Aj_, drows, C) ;
+                            else g_blas.gemm ("N", "C", &im, &in, &ik, &one, Ai_, &ild, Aj_, &ild, &zero, C, &im) ;
                             for (Int jj = 0 ; jj < N ; jj++)
                             {
                                 double *dst = Fs + (Int) where [Ls [base + j0 + jj]] * nsrow ;
@@ -869,6 +922,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
     }
     else if (ok)
     {
+        const double tA0 = now_s () ;
         /* ---- phase A: the subtrees, heaviest first ---- */
         Int *sfail_sub = order ;            /* per subtree: failing supernode or EMPTY (order [] is free again) */
         Int *info_sub = sparent ;           /* per subtree: its info (sparent [] is not needed any more) */
@@ -925,6 +979,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
                     d = dnext ;
                 }
             cholmod_l_free ((size_t) (nsub > 0 ? nsub : 1), sizeof (Int), by_weight, Common) ;
+            const double tB0 = now_s () ;
             /* ---- phase B: the top part in index order (everything below a top supernode is complete); a failure below
              * ends it at the first failing index: what lies beyond is zeroed anyway ---- */
             for (Int p = sub_ptr [nsub] ; p < sub_ptr [nsub + 1] ; p++)
@@ -956,6 +1011,9 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
                 }
                 advance_descendants (&X, s, -1, NULL, NULL) ;
             }
+            if (getenv ("CHOLMOD_CPU_TIMING"))
+                fprintf (stderr, "cholmod (CPU path): %d threads, %ld subtrees %.3f s, %ld top supernodes %.3f s\n", nth, (long) nsub, tB0 - tA0,
+                    (long) ntop, now_s () - tB0) ;
         }
     }
     if (ok && sfail != EMPTY && Lpx [sfail+1] < (Int) L->xsize)

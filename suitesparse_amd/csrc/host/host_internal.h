@@ -63,6 +63,7 @@ int ssamd_cpu_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, 
 void ssamd_cpu_super_solve (int which, const cholmod_factor *L, double *X, Int nrhs, Int ldx) ;
 const char *ssamd_cpu_blas_name (void) ;
 int ssamd_cpu_max_threads (void) ;
+int ssamd_cpu_quota (void) ;
 int ssamd_factor_has_cholesky_sizes (const cholmod_factor *L) ;
 /* subset_solve.c: cholmod_l_solve2 with Bset */
 int ssamd_solve_subset (int sys, cholmod_factor *L, cholmod_dense *B, cholmod_sparse *Bset, cholmod_dense *X,
