@@ -74,7 +74,7 @@ L0 = ch.lib()
 cap = int(L0.ssamd_cpu_max_threads())          # (OpenBLAS: its compile-time MAX_THREADS; 0 = none)
 if cap > 0:
     counts = sorted({min(c, cap) for c in counts})
-budget = float(os.environ.get("BENCH_CPU_BUDGET_S", "30"))
+budget = float(os.environ.get("BENCH_CPU_BUDGET_S", "18"))
 gomp = ctypes.CDLL("libgomp.so.1")
 n, Ap, Ai, Ax = G.poisson3d(m)
 perm = G.geometric_nd(m, m, m, 4)
@@ -87,7 +87,8 @@ ok = S.factorize(A, Lf)
 first = time.perf_counter() - t0
 assert ok == 1 and S.cm.status == 0
 pts, spent = [], 0.0
-for t in sorted(counts, reverse=True):          # widest first: should the budget run out, the narrow points are the ones missing
+order = [int(v) for v in os.environ.get("BENCH_CPU_ORDER", "").split(",") if v] or sorted(counts, reverse=True)
+for t in [c for c in order if c in counts]:      # the usable width first: should the budget run out, the side points are the ones missing
     if spent > budget:
         break
     gomp.omp_set_num_threads(t)
@@ -123,9 +124,9 @@ def cpu_baseline(sample_m):
     left-looking loop with a BLAS bound at run time -- SURVEY 8d's "the build's CPU supernodal path") timed on the host
     cores on a bounded sample of the same workload family, in ONE child process (the BLAS binding is per process).  Not the
     oracle: nothing under oracle/ is timed.  The sample is BASELINE configs[1] itself (Poisson 100^3, fl = 6.3e12); after
-    one untimed factorization (first touch of L->x) the child times one factorization per thread count -- 8, 16, 32, 64, 128
-    and every hardware thread of the box, widest first, until 30 s are spent; `value` is the best, `cores` the thread count
-    that gave it, `host_cores` what the box has.  Round 6: the path runs independent subtrees on one thread each and the top
+    one untimed factorization (first touch of L->x) the child times one factorization per thread count -- what the container
+    may use (its cgroup CPU quota: 16 on the GPU boxes, whose 256 hardware threads are `host_cores`), half of that, and twice
+    the quota if 18 s have not been spent by then; `value` is the best, `cores` the thread count that gave it.  Round 6: the path runs independent subtrees on one thread each and the top
     supernodes by tiles, the BLAS on one thread per call (rounds 3-5: a threaded BLAS under a serial loop, best at 16
     threads and slower beyond)."""
     import subprocess
@@ -142,8 +143,10 @@ def cpu_baseline(sample_m):
     else:
         # up to what the container may use: every hardware thread without a quota, the quota's worth of threads with one
         # (and one point at twice the quota, to show what oversubscribing it costs)
-        counts = sorted({min(usable, c) for c in (4, 8, 16, 32, 64, 128, usable)} | ({min(cores, 2 * usable)} if quota else set()))
+        counts = sorted({max(1, usable // 2), usable} | ({min(cores, 2 * usable)} if quota else set()))
     base["BENCH_CPU_COUNTS"] = ",".join(str(c) for c in counts)
+    # (what the container may use first, half of it next, twice the quota -- what oversubscribing it costs -- if time is left)
+    base["BENCH_CPU_ORDER"] = ",".join(str(c) for c in ([usable, max(1, usable // 2)] + ([min(cores, 2 * usable)] if quota else [])))
     env = dict(base, OMP_NUM_THREADS=str(max(counts)), OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", OMP_PROC_BIND="false")
     t0 = time.perf_counter()
     try:
