@@ -471,8 +471,7 @@ int cholmod_l_factorize_p (cholmod_sparse *A, double beta [2], SuiteSparse_long 
         double tq0 = timing ? api_now () : 0, tq1 = 0, tq2 = 0 ;
         int rc = cholmod_hip_values_staging (plan, &stage, &cap) ;
         const int nth = api_threads () ;
-        static int overlap = -1 ;
-        if (overlap < 0) { const char *e = getenv ("CHOLMOD_API_OVERLAP") ; overlap = (e && !strcmp (e, "0")) ? 0 : 1 ; }
+        const int overlap = 1 ;
         const int64_t *gidx = NULL ;
         int64_t glen = 0, gcount = 0 ;
         if (rc == CHOLMOD_HIP_OK && (size_t) cap == annz && nth >= 3 && overlap
