@@ -77,12 +77,14 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
             return
-        if case in ("p3d_64", "p3d_32_notposdef_root") or (case == "p3d_48" and world >= 8):
+        if case in ("p3d_64", "p3d_32_notposdef_root") or (case in ("p3d_48", "p3d_40") and world >= 8):
             bind_blas()                 # (the oracle's dense kernels through a BLAS: 64^3 in seconds instead of minutes)
         if case == "p3d_20":
             n, Ap, Ai, Ax = G.poisson3d(20); perm = G.geometric_nd(20, 20, 20, 4)
         elif case == "p3d_32":
             n, Ap, Ai, Ax = G.poisson3d(32); perm = G.geometric_nd(32, 32, 32, 4)
+        elif case == "p3d_40":
+            n, Ap, Ai, Ax = G.poisson3d(40); perm = G.geometric_nd(40, 40, 40, 4)
         elif case == "p3d_48":
             n, Ap, Ai, Ax = G.poisson3d(48); perm = G.geometric_nd(48, 48, 48, 4)
         elif case == "p3d_64":

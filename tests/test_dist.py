@@ -471,9 +471,9 @@ JIT8 = dict(CHOLMOD_HIP_TEST_POISON_ARENA="1", CHOLMOD_HIP_TEST_JITTER="11:1200"
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["p3d_48", pytest.param("p3d_64", marks=pytest.mark.slow)])
+@pytest.mark.parametrize("case", ["p3d_40", pytest.param("p3d_64", marks=pytest.mark.slow)])
 def test_world8_on_one_gpu_matches_oracle(case):
-    """(48^3 in the default -m gpu set; 64^3 -- eight oracle factorizations beside the eight peers, 100 s -- under
+    """(40^3 in the default -m gpu set; 64^3 -- eight oracle factorizations beside the eight peers, 100 s -- under
     -m "gpu and slow")"""
     res = _run_ranks(8, "gpu", case, timeout=1500, extra_env=dict(NATIVE, **JIT8))
     sizes = set()
