@@ -16,8 +16,8 @@ OUT = os.path.join(ROOT, "tests", "golden", "schedule_fingerprints.json")
 
 KNOBS = ["CHOLMOD_HIP_SHARE_AS_WORLD", "CHOLMOD_HIP_ARENA_BUDGET_MB", "CHOLMOD_HIP_OB1024_ROWS", "CHOLMOD_HIP_OB2048_ROWS",
          "CHOLMOD_HIP_OB4096_ROWS", "CHOLMOD_HIP_NO_CB_PASSTHROUGH", "CHOLMOD_HIP_NO_DISTRIBUTED_FRONTS", "CHOLMOD_HIP_OWN_W",
-         "CHOLMOD_HIP_SHARED_CHAIN64", "CHOLMOD_HIP_CHAINF_AUTO", "CHOLMOD_HIP_UPD3_MIN_TILES", "CHOLMOD_HIP_UPD3_BY_LAUNCH",
-         "CHOLMOD_HIP_NO_CHAINF", "CHOLMOD_HIP_NO_SUBGROUPS", "CHOLMOD_HIP_NO_CB_BALANCE", "CHOLMOD_HIP_EA_TW_BIG",
+         "CHOLMOD_HIP_SHARED_CHAIN64", "CHOLMOD_HIP_CHAINF_AUTO", "CHOLMOD_HIP_UPD3_MIN_TILES",
+         "CHOLMOD_HIP_NO_CHAINF", "CHOLMOD_HIP_NO_SUBGROUPS", "CHOLMOD_HIP_NO_CB_BALANCE",
          "CHOLMOD_HIP_UPD3_HALF_MAX"]
 
 
@@ -35,7 +35,6 @@ def cases():
     for fl in (128, 512, 1024, 512 | 1024, 8192, 4, 2048):
         base.append((1, [0], fl, {}))
     base.append((1, [0], 0, {"CHOLMOD_HIP_UPD3_MIN_TILES": "16"}))
-    base.append((1, [0], 0, {"CHOLMOD_HIP_UPD3_MIN_TILES": "16", "CHOLMOD_HIP_UPD3_BY_LAUNCH": "0"}))
     base.append((1, [0], 0, {"CHOLMOD_HIP_UPD3_HALF_MAX": "0"}))                                            # whole tiles only
     base.append((1, [0], 0, {"CHOLMOD_HIP_OB1024_ROWS": "300", "CHOLMOD_HIP_OB2048_ROWS": "900", "CHOLMOD_HIP_OB4096_ROWS": "100000"}))
     base.append((1, [0], 0, {"CHOLMOD_HIP_ARENA_BUDGET_MB": "3"}))
