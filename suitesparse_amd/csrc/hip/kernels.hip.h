@@ -385,6 +385,7 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
 {
     const int lane = tid & 63, wave = tid >> 6 ;
     int lr = lane & 15, lk = lane >> 4 ;
+    __shared__ __attribute__((aligned(16))) double bc [128] ;        // wave 0's broadcast scratch (real panels)
     for (int jb = 0 ; jb < nblk ; jb++)
     {
         int c0 = 16 * jb ;
@@ -447,24 +448,35 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
             for (int c = 0 ; c < 16 ; c++) a [c] = T [(c0 + c) * PF2_LD + rr] ;
             int fail = -1 ;
             double dv = 1.0 ;                   // lane c keeps the pivot of column c
+            // Round 6: pivot and multipliers of a column travel through a 128-double LDS scratch of the wave, as in the
+            // thin-front kernel (tf_panel) since round 2 -- every lane writes its entry of the column (one ds_write_b64; the
+            // panel's diagonal rows are lanes 0 .. 15), everybody reads them back as broadcast ds_read_b128 pairs: (15 - c) / 2
+            // + (15 - c) + 8 vector instructions per column where a v_readlane pair per value cost 3 (15 - c) + 10.  LDS
+            // operations of one wave execute in order: the read behind the write needs no barrier.  The LDS round trip of the
+            // multipliers runs beside the reciprocal's chain (v_rcp_f64 + one Newton step on the pivot, which arrives the
+            // same way).
+            typedef double pf_d2 __attribute__((ext_vector_type(2))) ;
 #pragma unroll
             for (int c = 0 ; c < 16 ; c++)
             {
-                double d = readlane_f64 (a [c], c) ;
+                bc [lane] = a [c] ;
+                asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+                double u [16] ;
+#pragma unroll
+                for (int c2 = c & ~1 ; c2 < 16 ; c2 += 2)
+                {
+                    pf_d2 v = *(const pf_d2 *) (bc + c2) ;
+                    u [c2] = v.x ; u [c2 + 1] = v.y ;
+                }
+                asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
+                const double d = u [c] ;
                 if (fail < 0 && d <= 0.0) fail = c0 + c ;
                 // (past a failed pivot the columns carry garbage; they are
                 // zeroed below, and nothing flows back into earlier columns)
                 double x = __builtin_amdgcn_rcp (d) ;
                 double e = __builtin_fma (-d, x, 1.0) ;
                 double t0 = a [c] * x ;             // beside e, off the chain: t = a x (1 + e)
-                // the column's multipliers leave for the scalar registers together, next to
-                // the reciprocal: (read-lane, read-lane, fma) triples one behind the other
-                // through one scalar pair cost ~70 cycles each
-                double u [16] ;
-#pragma unroll
-                for (int c2 = c + 1 ; c2 < 16 ; c2++) u [c2] = readlane_f64 (a [c], c2) ;
-                __builtin_amdgcn_sched_barrier (0) ;
-                double t = __builtin_fma (t0, e, t0) ;      // u(row,c) / d: rcp -> e -> t -> fma, one multiply less on the chain
+                double t = __builtin_fma (t0, e, t0) ;      // u(row,c) / d
 #pragma unroll
                 for (int c2 = c + 1 ; c2 < 16 ; c2++) a [c2] = __builtin_fma (-t, u [c2], a [c2]) ;
                 if (lane == c) dv = d ;
@@ -475,13 +487,18 @@ __device__ __forceinline__ void pf_eliminate (double *T, int nblk, int *s_fail, 
             // 0..15, then the stored columns l = u * rsqrt(d)
             double r, ri ;
             sqrt_rsqrt (dv, r, ri) ;
+            bc [lane] = r ; bc [64 + lane] = ri ;
+            asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
 #pragma unroll
-            for (int c = 0 ; c < 16 ; c++)
+            for (int c = 0 ; c < 16 ; c += 2)
             {
-                double rc = readlane_f64 (r, c), ric = readlane_f64 (ri, c) ;
-                a [c] = (lane == c) ? rc : a [c] * ric ;
+                pf_d2 rv = *(const pf_d2 *) (bc + c), iv = *(const pf_d2 *) (bc + 64 + c) ;
+                a [c] = (lane == c) ? rv.x : a [c] * iv.x ;
+                a [c + 1] = (lane == c + 1) ? rv.y : a [c + 1] * iv.y ;
                 if (fail >= 0 && c0 + c >= fail) a [c] = 0.0 ;
+                if (fail >= 0 && c0 + c + 1 >= fail) a [c + 1] = 0.0 ;
             }
+            asm volatile ("" ::: "memory") ; __builtin_amdgcn_wave_barrier () ;
             // (entries above the diagonal of the 16x16 block are never read again)
             if (row < PF_NB)
             {
