@@ -11,7 +11,12 @@
  * and an external BLAS/LAPACK), so this restatement is pinned against the
  * reference outputs recorded in SURVEY.md section 8c/8d (bcsstk01 maps, leading
  * Lx values, Frobenius norm, BLAS call counts, fl/lnz; ND Poisson nsuper /
- * update counts) -- see tests/golden/ and tests/test_oracle_golden.py.
+ * update counts) -- see tests/golden/ and tests/test_oracle_golden.py -- and,
+ * for the elimination tree and the column counts (lnz, fl), against the
+ * reference-HELD record LDL/Demo/ldlmain.out (48 pairs "Nz in L / Flop count"
+ * over LDL/Matrix/A01..A24; tests/test_ldl_recorded.py).  No reference-held
+ * vector exists for the supernodal maps or for L: numeric parity stays
+ * "unpinned" in the sense of the project rules.
  *
  * Every routine cites the reference file:line whose behaviour it follows
  * (paths relative to the reference root, CHOLMOD/...).  Index type is int64

@@ -41,8 +41,13 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     // flag 131072: the layout of a real front -- an odd leading dimension and operand offsets that are
     // only 8-byte aligned (packed supernodes start anywhere, nsrow is any number)
     const bool odd = (flags & 131072) != 0 ;
-    i64 ld = std::max (m, n) + (odd ? 1 + (std::max (m, n) & 1 ? 0 : 0) + ((std::max (m, n) + 1) % 2 == 0 ? 1 : 0) : 0) ;
-    i64 a_off = odd ? 1 : 0, b_off = a_off + ld * k + (odd ? 2 : 0), c_off = b_off + ld * k + (odd ? 1 : 0) ;
+    // CHOLMOD_PROBE_ODD_PARTS (with flag 131072): 1 = only the operands A / B in the odd layout, 2 = only the target C, 3 = both (default)
+    int parts = 3 ;
+    if (const char *e = getenv ("CHOLMOD_PROBE_ODD_PARTS")) parts = atoi (e) & 3 ;
+    const bool odd_ab = odd && (parts & 1), odd_c = odd && (parts & 2) ;
+    i64 ld = std::max (m, n) + (odd_ab ? 1 + ((std::max (m, n) + 1) % 2 == 0 ? 1 : 0) : 0) ;
+    i64 a_off = odd_ab ? 1 : 0, b_off = a_off + ld * k + (odd_ab ? 2 : 0), c_off = b_off + ld * k ;
+    c_off = (c_off + 15) / 16 * 16 + (odd_c ? 1 : 0) ;
     i64 total = c_off + (m + 3) * n ;
     double *d = nullptr ;
     // CHOLMOD_PROBE_OFFSET_GB=g: the operands sit g GB into ONE allocation of g GB + their own size (as the
@@ -60,7 +65,7 @@ double cholmod_hip_bench_update_kernel (int64_t m, int64_t n, int64_t k, int ite
     int T = small ? SMALL : BIG ;
     GemmGroup G ;
     memset (&G, 0, sizeof (G)) ;
-    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) (m + (odd ? 3 : 0)) ;
+    G.a_off = a_off ; G.b_off = b_off ; G.c_off = c_off ; G.lda = (i32) ld ; G.ldc = (i32) (m + (odd_c ? 3 : 0)) ;
     G.m = (i32) m ; G.n = (i32) n ; G.k = (i32) k ; G.tri = (flags & 65536) ? 1 : 0 ; G.tile_mul = 1 ; G.tile_add = 0 ;
     if (G.tri) { G.b_off = a_off ; if (m < n) { (void) hipFree (d_base) ; return CHOLMOD_HIP_INVALID ; } }    // a syrk-shaped region: B = A, only tiles on / below the diagonal
     int TM = T, TN = T ;

@@ -377,21 +377,54 @@ int cholmod_l_check_factor (cholmod_factor *L, cholmod_common *Common)
     return TRUE ;
 }
 
+/* reference: Check/cholmod_check.c:652-960 (check_sparse), the conditions only -- nothing is printed here */
 int cholmod_l_check_sparse (cholmod_sparse *A, cholmod_common *Common)
 {
     RETURN_IF_NULL_COMMON (FALSE) ;
-    RETURN_IF_NULL (A, FALSE) ;
     Common->status = CHOLMOD_OK ;
+#define BAD(msg) { ERROR (CHOLMOD_INVALID, msg) ; free (Wi) ; return FALSE ; }
+    Int *Wi = NULL ;
+    if (!A) BAD ("null") ;
     const Int *Ap = A->p, *Ai = A->i, *Anz = A->nz ;
-    if (!Ap || !Ai || (!A->packed && !Anz)) { ERROR (CHOLMOD_INVALID, "invalid") ; return FALSE ; }
-    if (A->stype != 0 && A->nrow != A->ncol) { ERROR (CHOLMOD_INVALID, "invalid") ; return FALSE ; }
-    for (size_t j = 0 ; j < A->ncol ; j++)
+    const Int nrow = (Int) A->nrow, ncol = (Int) A->ncol, nzmax = (Int) A->nzmax ;
+    if (A->itype != CHOLMOD_LONG) BAD ("integer type must match routine") ;
+    if (A->xtype < CHOLMOD_PATTERN || A->xtype > CHOLMOD_ZOMPLEX) BAD ("unknown xtype") ;
+    if (A->dtype != CHOLMOD_DOUBLE) BAD ("real type must match routine") ;
+    if (A->stype != 0 && nrow != ncol) BAD ("symmetric but not square") ;
+    if (!Ap) BAD ("p array not present") ;
+    if (!Ai) BAD ("i array not present") ;
+    if (!A->packed && !Anz) BAD ("nz array not present") ;
+    if (A->xtype != CHOLMOD_PATTERN && !A->x) BAD ("x array not present") ;
+    if (A->xtype == CHOLMOD_ZOMPLEX && !A->z) BAD ("z array not present") ;
+    if (A->packed && Ap [0] != 0) BAD ("p [0] must be zero") ;
+    if (A->packed && (Ap [ncol] < Ap [0] || Ap [ncol] > nzmax)) BAD ("p [ncol] invalid") ;
+    if (!A->sorted && nrow > 0)
     {
-        Int p = Ap [j], pend = A->packed ? Ap [j+1] : p + Anz [j] ;
-        if (p < 0 || pend > (Int) A->nzmax || p > pend) { ERROR (CHOLMOD_INVALID, "invalid") ; return FALSE ; }
-        for ( ; p < pend ; p++)
-            if (Ai [p] < 0 || Ai [p] >= (Int) A->nrow) { ERROR (CHOLMOD_INVALID, "invalid") ; return FALSE ; }
+        // (unsorted columns: duplicates are found with a mark per row, as the reference does with Common->Iwork)
+        Wi = malloc ((size_t) nrow * sizeof (Int)) ;
+        if (!Wi) { ERROR (CHOLMOD_OUT_OF_MEMORY, "out of memory") ; return FALSE ; }
+        for (Int i = 0 ; i < nrow ; i++) Wi [i] = EMPTY ;
     }
+    for (Int j = 0 ; j < ncol ; j++)
+    {
+        Int p = Ap [j], pend, nz ;
+        if (A->packed) { pend = Ap [j+1] ; nz = pend - p ; }
+        else { nz = Anz [j] < 0 ? 0 : Anz [j] ; pend = p + nz ; }       // (Anz [j] < 0 is treated as zero)
+        if (p < 0 || pend > nzmax) BAD ("pointer invalid") ;
+        if (nz < 0 || nz > nrow) BAD ("nz invalid") ;
+        Int ilast = EMPTY ;
+        for ( ; p < pend ; p++)
+        {
+            Int i = Ai [p] ;
+            if (i < 0 || i >= nrow) BAD ("row index out of range") ;
+            if (A->sorted && i <= ilast) BAD ("row indices out of order") ;
+            if (!A->sorted && Wi [i] == j) BAD ("duplicate row index") ;
+            ilast = i ;
+            if (!A->sorted) Wi [i] = j ;
+        }
+    }
+    free (Wi) ;
+#undef BAD
     return TRUE ;
 }
 
