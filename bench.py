@@ -180,7 +180,7 @@ def cpu_baseline(sample_m):
 PMC_BY_WORKLOAD = {"poisson3d_200^3_geometricND_leaf4": "r05k_pmc_summary_poisson200_top48.json"}
 # counters of EVERY launch of one refactorization of the mid-size workloads, summed per kernel (tools/pmc_workload.sh: three
 # separate rocprofv3 --pmc passes; round-4 review, item 3) -- matched by the start of the workload name
-PMC_BY_KERNEL = {"poisson3d_100^3": "r05k_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r06z_pmc_by_kernel_box42r3.json",
+PMC_BY_KERNEL = {"poisson3d_100^3": "r05k_pmc_by_kernel_p100.json", "box_stencil_r3_42^3": "r06p_pmc_by_kernel_box42r3.json",
                  "poisson2d_1259^2": "r05k_pmc_by_kernel_p2d1259.json"}
 CHAIN_KERNELS = ("k_update2f", "k_trsm_upd", "k_trsm_mfma", "k_potrf_mfma", "k_extend_add", "k_update2", "k_update3", "k_thin_front",
                  "k_leaf_pair")
