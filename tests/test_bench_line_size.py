@@ -1,6 +1,6 @@
 """The ONE stdout line of bench.py stays small enough for the driver to parse (round-5 review: 25.9 KB of counter tables and
 notes in the line left BENCH_r05.json.parsed = null).  No GPU: the line is rebuilt from a committed full record of the DEFAULT
-workload set (200^3 headline + the four secondary workloads + CPU baseline + roofline with counters)."""
+workload set (200^3 headline + the secondary workloads + CPU baseline + roofline with counters)."""
 import json
 import os
 import sys
@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-RECORDS = ["r05g_bench_line.json", "r04zq_poisson200_bench_line.json", "r04y_poisson200_exchange_selftest_share_as_world8_bench_line.json"]
+RECORDS = ["r06p_bench_detail.json", "r05g_bench_line.json", "r04zq_poisson200_bench_line.json", "r04y_poisson200_exchange_selftest_share_as_world8_bench_line.json"]
 
 
 @pytest.mark.parametrize("rec", RECORDS)
@@ -57,3 +57,12 @@ def test_compact_line_survives_non_finite_and_errors():
     d = json.loads(bench.compact_line(full))
     assert "residual_2norm" not in d or d["residual_2norm"] is None
     assert d["roofline"]["traffic"] is None and len(d["error"]) <= 160
+
+
+def test_the_committed_line_is_what_the_full_record_compacts_to():
+    """profiles/r06p_bench_line.json is the stdout of the run whose full record is r06p_bench_detail.json"""
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06p_bench_detail.json")))
+    line = open(os.path.join(ROOT, "profiles", "r06p_bench_line.json")).read().strip()
+    assert len(line) < 4096 and json.loads(line) == json.loads(bench.compact_line(full))
+    assert len(json.loads(line)["secondary"]) == 5
