@@ -171,3 +171,58 @@ def test_factorize_rejects_a_factor_analysed_for_spqr():
         S.free_factor(Lf)
         S.free_sparse(A)
         S.finish()
+
+
+def test_check_sparse_refuses_what_the_reference_refuses():
+    """cholmod_l_check_sparse, condition by condition (reference Check/cholmod_check.c:652-960): a valid matrix passes; every
+    single defect makes it return FALSE with CHOLMOD_INVALID and leaves the matrix alone."""
+    S = ch.Session(use_gpu=0)
+    Ap = np.array([0, 2, 3, 5], dtype=np.int64)
+    Ai = np.array([0, 2, 1, 0, 2], dtype=np.int64)
+    Ax = np.arange(1.0, 6.0)
+
+    def fresh(stype=0):
+        return S.sparse(3, Ap, Ai, Ax, stype)
+
+    def refused(A):
+        ok = S.L.cholmod_l_check_sparse(A, C.byref(S.cm))
+        st = S.cm.status
+        return ok == 0 and st == ch.INVALID
+
+    A = fresh()
+    assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1 and S.cm.status == ch.OK
+    a = A.contents
+    p = ch._view(a.p, 4, C.c_int64, np.int64)
+    i = ch._view(a.i, 5, C.c_int64, np.int64)
+    p[0] = 1 ; assert refused(A) ; p[0] = 0                         # p [0] must be zero
+    p[3] = 7 ; assert refused(A) ; p[3] = 5                         # p [ncol] beyond nzmax
+    p[1] = 4 ; p[2] = 3 ; assert refused(A) ; p[1] = 2               # a column that ends before it starts
+    i[1] = 3 ; assert refused(A) ; i[1] = 2                         # row index out of range
+    i[1] = -1 ; assert refused(A) ; i[1] = 2
+    i[0], i[1] = 2, 0 ; assert refused(A)                           # sorted flag set, indices out of order
+    a.sorted = 0
+    assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1       # ... fine for an unsorted matrix
+    i[0], i[1] = 2, 2 ; assert refused(A)                           # duplicate row index in an unsorted column
+    a.sorted = 1 ; assert refused(A)                                # (and "out of order" for a sorted one)
+    i[0], i[1] = 0, 2
+    assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1
+    a.itype = 0 ; assert refused(A) ; a.itype = 2                   # CHOLMOD_INT matrix handed to the _l_ routine
+    a.dtype = 1 ; assert refused(A) ; a.dtype = 0                   # single precision
+    a.xtype = 7 ; assert refused(A) ; a.xtype = ch.REAL
+    keep = a.x ; a.x = None ; assert refused(A)                     # values missing for a real matrix
+    a.xtype = 0 ; assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1      # ... a pattern has none
+    a.xtype = ch.REAL ; a.x = keep
+    a.stype = 1 ; a.ncol = 2 ; assert refused(A) ; a.ncol = 3 ; a.stype = 0     # symmetric but not square
+    # unpacked: counts per column, a negative count is an empty column, a count beyond nrow is refused
+    nz = np.array([2, 1, 2], dtype=np.int64)
+    a.packed = 0 ; a.nz = nz.ctypes.data
+    assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1
+    nz[1] = -3 ; assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1
+    nz[2] = 4 ; assert refused(A)
+    a.nz = None ; assert refused(A)                                 # nz array not present
+    a.packed = 1
+    assert S.L.cholmod_l_check_sparse(A, C.byref(S.cm)) == 1
+    assert S.L.cholmod_l_check_sparse(None, C.byref(S.cm)) == 0 and S.cm.status == ch.INVALID
+    S.free_sparse(A)
+    assert S.cm.malloc_count == 0
+    S.finish()
