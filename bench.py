@@ -983,6 +983,10 @@ def main():
         t0 = time.perf_counter()
         Lf = S.analyze(A, perm)
         t_analyze = time.perf_counter() - t0
+        # (one GPU: the engine's plan -- schedule, maps, the HBM reservation -- is built inside cholmod_l_analyze, as the
+        # reference cuts its device pools there; several ranks: by cholmod_l_hip_prepare below)
+        plan_in_analyze = bool(ch.FactorView(Lf).hip_plan)
+        t_plan = float(S.cm.hip_plan_seconds) if plan_in_analyze else 0.0
         fl = S.cm.fl
         fv = ch.FactorView(Lf)
         # reserve HBM for L and the contribution blocks (no collective in here)
@@ -1253,7 +1257,8 @@ def main():
                         "checked on every call): H2D of A->x, gather into the resident S on the device, factorization on the "
                         "cached plan, L left in HBM; a new pattern takes the host permutation + full upload again",
             "roofline": roof, "cpu_baseline": cpu,
-            "host_seconds": {"generate": t_gen, "analyze": t_analyze, "first_factorize_incl_plan_h2d": t_first},
+            "host_seconds": {"generate": t_gen, "analyze": t_analyze, "plan_inside_analyze": t_plan,
+                             "first_factorize_incl_plan_h2d": t_first, "analyze_plus_first_factorize": t_analyze + t_first},
         }
         if resid is not None:
             line["residual_2norm"] = resid

@@ -196,6 +196,15 @@ typedef struct cholmod_common_struct
                                      * (reference cholmod_core.h, Cholesky/cholmod_solve.c:1112) */
     int prefer_binary ;             /* cholmod_l_read_*: a symmetric pattern-only file keeps all-one values instead of
                                      * diagonal = 1 + degree, off-diagonal = -1 (cholmod_core.h:545-560) */
+    int hip_lazy_plan ;             /* 0 (default): cholmod_l_analyze of a real matrix with Common->useGPU on builds the
+                                     * engine's plan -- schedule, maps, the HBM reservation for L and the contribution
+                                     * blocks -- as the reference cuts its device pools inside the analysis
+                                     * (cholmod_super_symbolic.c:243-327); a failure there is not an error of the analysis,
+                                     * the first factorization tries again and reports.  1: at the first factorization
+                                     * (or cholmod_l_hip_prepare), as until round 5 -- for callers that analyse more
+                                     * patterns than the device could hold factors of */
+    double hip_plan_seconds ;       /* out: what the last creation of an engine plan took (inside cholmod_l_analyze, the
+                                     * first factorization or cholmod_l_hip_prepare) */
 } cholmod_common ;
 
 typedef struct cholmod_sparse_struct
@@ -251,6 +260,7 @@ typedef struct cholmod_factor_struct
                                  * full twin (x: 4 xsize doubles), 2 = engine-only, complex storage (px = 2 x the
                                  * complex px; CHOLMOD_HIP_CX_STORAGE) */
     void *bset_work ;           /* cholmod_l_solve2 with Bset: column -> supernode, flags (2n + 1 integers, built by the first call) */
+    int hip_plan_ahead ;        /* != 0: hip_plan was built inside cholmod_l_analyze and no factorization has used it yet (plan flags + 1) */
 } cholmod_factor ;
 
 /* ---- Core ---------------------------------------------------------------- */

@@ -77,6 +77,7 @@ class Common(C.Structure):
         ("hip_rank", C.c_int), ("hip_world", C.c_int),
         ("hip_allreduce", C.c_void_p), ("hip_allreduce_user", C.c_void_p),
         ("hip_cpu_fallback", C.c_int), ("prefer_zomplex", C.c_int), ("prefer_binary", C.c_int),
+        ("hip_lazy_plan", C.c_int), ("hip_plan_seconds", C.c_double),
     ]
 
 
@@ -114,7 +115,7 @@ class Factor(C.Structure):
                 ("hip_plan", C.c_void_p), ("hip_on_device", C.c_int), ("hip_host_valid", C.c_int),
                 ("cx_twin", C.c_void_p), ("hip_apat_hash", C.c_uint64), ("hip_apat_nnz", C.c_size_t),
                 ("hip_apat_valid", C.c_int), ("hip_apat_hash2", C.c_uint64), ("hip_is_twin", C.c_int),
-                ("bset_work", C.c_void_p)]
+                ("bset_work", C.c_void_p), ("hip_plan_ahead", C.c_int)]
 
 
 # every symbol include/cholmod.h and include/cholmod_hip.h declare

@@ -812,6 +812,15 @@ cholmod_factor *cholmod_l_analyze_p2 (int for_whom, cholmod_sparse *A, SuiteSpar
         cholmod_l_free_factor (&L, Common) ;
         return NULL ;
     }
+    /* the engine's plan, as the reference cuts its device pools inside the analysis (cholmod_super_symbolic.c:243-327);
+     * real matrices: a complex one is factorized through a twin factor that owns the plan (complex.c) */
+    if (for_whom == CHOLMOD_ANALYZE_FOR_CHOLESKY && A->xtype == CHOLMOD_REAL && !Common->hip_lazy_plan)
+    {
+        double tp = ssamd_now () ;
+        ssamd_plan_ahead (L, Common) ;
+        if (timing) fprintf (stderr, "cholmod_l_analyze: engine plan (schedule, maps, HBM reservation) %.3f s%s\n", ssamd_now () - tp,
+            L->hip_plan ? "" : " -- none built") ;
+    }
     return L ;
 }
 

@@ -52,6 +52,7 @@ void ssamd_colcounts (Int n, const Int *Lp, const Int *Li, const Int *Parent, co
 int ssamd_nested_dissection (Int n, const Int *Ap, const Int *Ai, Int *Perm, cholmod_common *Common) ;
 int ssamd_resolve_use_gpu (cholmod_common *Common) ;
 int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common) ;
+void ssamd_plan_ahead (cholmod_factor *L, cholmod_common *Common) ;
 
 /* complex.c: complex / zomplex input through the real embedding */
 int ssamd_complex_super_numeric (cholmod_sparse *A, double beta, cholmod_factor *L, cholmod_common *Common) ;

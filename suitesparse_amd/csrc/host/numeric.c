@@ -102,13 +102,9 @@ int ssamd_factor_has_cholesky_sizes (const cholmod_factor *L)
     return (size_t) px [L->nsuper] <= L->xsize ;
 }
 
-int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
+/* the plan flags a factorization of L would ask for now */
+static int plan_flags_of (const cholmod_factor *L, const cholmod_common *Common)
 {
-    if (!ssamd_factor_has_cholesky_sizes (L))
-    { ERROR (CHOLMOD_INVALID, "L was analysed for SPQR (no Cholesky sizes)") ; return FALSE ; }
-    if (L->hip_plan) return TRUE ;
-    int st = 0 ;
-    int world = Common->hip_world > 1 ? Common->hip_world : 1 ;
     int flags = Common->hip_flags ;
     /* the real twin of a complex factor (complex.c): the update kernels contract over the even
      * panel columns only -- the complex multiply-add as four real ones (zherk / zgemm,
@@ -119,8 +115,28 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
         const char *e = getenv ("CHOLMOD_HIP_TWIN_FULL_K") ;
         if (!(e && atoi (e) != 0)) flags |= CHOLMOD_HIP_PHI_TWIN ;
     }
+    return flags ;
+}
+
+int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
+{
+    if (!ssamd_factor_has_cholesky_sizes (L))
+    { ERROR (CHOLMOD_INVALID, "L was analysed for SPQR (no Cholesky sizes)") ; return FALSE ; }
+    int st = 0 ;
+    int world = Common->hip_world > 1 ? Common->hip_world : 1 ;
+    const int flags = plan_flags_of (L, Common) ;
+    if (L->hip_plan && L->hip_plan_ahead && !L->hip_on_device && (L->hip_plan_ahead - 1 != flags || world > 1))
+    {
+        /* a plan built inside the analysis, and Common->hip_flags / hip_world have changed since: build it again */
+        cholmod_hip_plan_destroy ((cholmod_hip_plan *) L->hip_plan) ;
+        L->hip_plan = NULL ;
+    }
+    L->hip_plan_ahead = 0 ;
+    if (L->hip_plan) return TRUE ;
+    const double t_plan = omp_get_wtime () ;
     cholmod_hip_plan *P = cholmod_hip_plan_create_dist ((int64_t) L->n, (int64_t) L->nsuper,
         L->super, L->pi, L->px, L->s, flags, world > 1 ? Common->hip_rank : 0, world, &st) ;
+    Common->hip_plan_seconds = omp_get_wtime () - t_plan ;
     if (!P) return map_hip_status (st ? st : CHOLMOD_HIP_GPU_PROBLEM, Common, "HIP plan creation failed") ;
     /* (several ranks need an exchange: the Common->hip_allreduce callback, or the
      * native RCCL path attached to L->hip_plan with cholmod_hip_rccl_attach after
@@ -129,6 +145,20 @@ int ssamd_ensure_plan (cholmod_factor *L, cholmod_common *Common)
         cholmod_hip_set_allreduce (P, Common->hip_allreduce, Common->hip_allreduce_user) ;
     L->hip_plan = P ;
     return TRUE ;
+}
+
+/* The plan at the end of cholmod_l_analyze (Common->hip_lazy_plan == 0; one GPU -- the ranks of a multi-GPU run attach their
+ * exchange to the plan after cholmod_l_hip_prepare).  Not an error of the analysis when it cannot be built: L stays without
+ * a plan, the first factorization tries again and reports. */
+void ssamd_plan_ahead (cholmod_factor *L, cholmod_common *Common)
+{
+    if (!L || !L->is_super || !L->useGPU || L->hip_plan || Common->useGPU != 1) return ;
+    if (Common->hip_world > 1 || Common->hip_allreduce) return ;
+    if (!ssamd_factor_has_cholesky_sizes (L) || !cholmod_hip_probe ()) return ;
+    const int st = Common->status, tc = Common->try_catch ;
+    Common->try_catch = TRUE ;
+    if (ssamd_ensure_plan (L, Common)) L->hip_plan_ahead = plan_flags_of (L, Common) + 1 ;
+    Common->try_catch = tc ; Common->status = st ;
 }
 
 static void absorb_stats (cholmod_factor *L, cholmod_common *Common)

@@ -31,4 +31,5 @@ assert S.refactorize_resident(Lf) == 1
 t7 = time.perf_counter()
 print("%s: generate %.2f s, copy in %.2f, analyze %.2f (plan inside: %s), prepare %.2f, FIRST factorize %.2f, second (values only) %.2f, resident %.2f"
       % (name, t1 - t0, t2 - t1, t3 - t2, have_plan, t4 - t3, t5 - t4, t6 - t5, t7 - t6))
-print("first factorization incl. plan: %.2f s; analyze + that: %.2f s" % (t5 - t3, t5 - t2))
+print("plan creation %.2f s (%s); everything between the end of the analysis and a numeric factor: %.2f s; analyze + that: %.2f s"
+      % (S.cm.hip_plan_seconds, "inside cholmod_l_analyze" if have_plan else "cholmod_l_hip_prepare", t5 - t3, t5 - t2))
