@@ -6,17 +6,21 @@
  * for the HIP engine: only tests/, __graft_entry__.smoke() and the cpu_baseline
  * leg of bench.py may load it.  The product library never links or calls it.
  *
- * Pinning: the reference itself cannot be compiled in this image under the
- * project rules (it needs the CMake-generated cholmod_export.h / cholmod_config.h
- * and an external BLAS/LAPACK), so this restatement is pinned against the
- * reference outputs recorded in SURVEY.md section 8c/8d (bcsstk01 maps, leading
- * Lx values, Frobenius norm, BLAS call counts, fl/lnz; ND Poisson nsuper /
- * update counts) -- see tests/golden/ and tests/test_oracle_golden.py -- and,
- * for the elimination tree and the column counts (lnz, fl), against the
- * reference-HELD record LDL/Demo/ldlmain.out (48 pairs "Nz in L / Flop count"
- * over LDL/Matrix/A01..A24; tests/test_ldl_recorded.py).  No reference-held
- * vector exists for the supernodal maps or for L: numeric parity stays
- * "unpinned" in the sense of the project rules.
+ * Pinning: CHOLMOD itself cannot be compiled in this image under the project
+ * rules (it needs the CMake-generated cholmod_export.h / cholmod_config.h and an
+ * external BLAS/LAPACK).  This restatement is pinned
+ *  - against REFERENCE CODE COMPILED HERE: the reference tree's CSparse
+ *    (oracle/Makefile target `ref`, oracle/csref.py): etree and column counts
+ *    identical, the pattern of L contained in / equal to the supernodal structure,
+ *    the values of L to 1e-12 (tests/test_csparse_reference.py);
+ *  - against the reference-HELD record LDL/Demo/ldlmain.out (48 pairs "Nz in L /
+ *    Flop count": lnz, fl; tests/test_ldl_recorded.py);
+ *  - against the outputs of the compiled CHOLMOD recorded in SURVEY.md 8c/8d
+ *    (bcsstk01 maps, BLAS call counts, ND Poisson nsuper / update counts;
+ *    tests/golden/reference_recorded.json, tests/test_oracle_golden.py) for what
+ *    CSparse has no notion of: the relaxed supernode partition, maxcsize /
+ *    maxesize, the descendant lists.
+ * See DESIGN.md section 5 for what each of them constrains.
  *
  * Every routine cites the reference file:line whose behaviour it follows
  * (paths relative to the reference root, CHOLMOD/...).  Index type is int64
