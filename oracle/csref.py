@@ -64,6 +64,12 @@ def lib():
         L.cs_nfree.argtypes = [C.POINTER(CSN)]
         L.cs_free.restype = C.c_void_p
         L.cs_free.argtypes = [C.c_void_p]
+        for f in ("cs_ipvec", "cs_pvec"):
+            getattr(L, f).restype = csi
+            getattr(L, f).argtypes = [_p, _d, _d, csi]
+        for f in ("cs_lsolve", "cs_ltsolve"):
+            getattr(L, f).restype = csi
+            getattr(L, f).argtypes = [C.POINTER(CS), _d]
         _lib = L
     return _lib
 
@@ -81,10 +87,11 @@ def _upper(n, Ap, Ai, Ax, stype):
     return A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
 
 
-def reference_cholesky(n, Ap, Ai, Ax, stype, perm=None, numeric=True):
-    """-> dict(parent, colcount, lnz, Lp, Li, Lx, ok): etree and column counts of P A P' (perm: new -> old, as L->Perm),
+def reference_cholesky(n, Ap, Ai, Ax, stype, perm=None, numeric=True, b=None):
+    """-> dict(parent, colcount, lnz, Lp, Li, Lx, ok[, x]): etree and column counts of P A P' (perm: new -> old, as L->Perm),
     and -- numeric -- its Cholesky factor in CSC, all computed by the reference's CSparse.  ok = False: not positive
-    definite (cs_chol returned NULL)."""
+    definite (cs_chol returned NULL).  b (n or n x k, column-major columns): also x = A \\ b by the steps of cs_cholsol.c --
+    cs_ipvec, cs_lsolve, cs_ltsolve, cs_pvec."""
     L = lib()
     Up, Ui, Ux = _upper(n, Ap, Ai, Ax, stype)
     A = CS(len(Ui), n, n, Up.ctypes.data_as(_p), Ui.ctypes.data_as(_p), Ux.ctypes.data_as(_d), -1)
@@ -113,6 +120,16 @@ def reference_cholesky(n, Ap, Ai, Ax, stype, perm=None, numeric=True):
                 out["Lp"] = np.ctypeslib.as_array(Lm.p, shape=(n + 1,)).copy()
                 out["Li"] = np.ctypeslib.as_array(Lm.i, shape=(max(nz, 1),))[:nz].copy()
                 out["Lx"] = np.ctypeslib.as_array(Lm.x, shape=(max(nz, 1),))[:nz].copy()
+                if b is not None:
+                    B = np.atleast_2d(np.asarray(b, dtype=np.float64).T).copy()        # rows = right-hand sides
+                    X = np.empty_like(B)
+                    w = np.empty(n)
+                    for r in range(B.shape[0]):
+                        L.cs_ipvec(pinv, B[r].ctypes.data_as(_d), w.ctypes.data_as(_d), n)      # x = P*b
+                        L.cs_lsolve(N.contents.L, w.ctypes.data_as(_d))                         # x = L\\x
+                        L.cs_ltsolve(N.contents.L, w.ctypes.data_as(_d))                        # x = L'\\x
+                        L.cs_pvec(pinv, w.ctypes.data_as(_d), X[r].ctypes.data_as(_d), n)       # b = P'*x
+                    out["x"] = X[0] if np.ndim(b) == 1 else X.T.copy()
                 L.cs_nfree(N)
     finally:
         for q in (pinv, parent, post, cnt):

@@ -8,7 +8,8 @@ permutation,
   * every entry of cs_chol's pattern of L lies inside the supernodal structure (super, pi, s), and with
     nrelax = zrelax = 0 (fundamental supernodes) the two patterns are the same set,
   * the values agree entry for entry (1e-12 of ||L||_F; measured 1e-16 .. 1e-15), the explicit zeros that relaxed
-    amalgamation stores are exact zeros.
+    amalgamation stores are exact zeros,
+  * cholmod_l_solve returns what the reference's cs_cholsol steps (cs_ipvec, cs_lsolve, cs_ltsolve, cs_pvec) return.
 
 The library is prebuilt (it is never built from anything but /root/reference/CSparse and travels to the GPU box as a file);
 without it the module is skipped."""
@@ -145,9 +146,16 @@ def _product(case, relax, postorder, use_gpu):
     Lf = S.analyze(A, perm)
     assert S.factorize(A, Lf) == 1 and S.cm.status == ch.OK
     fv = ch.FactorView(Lf)
-    R = check_against_reference(case, fv.Perm, None, fv.ColCount, fv.super, fv.pi, fv.px, fv.s, fv.x, relax,
-                                "HIP path" if use_gpu else "CPU path")
+    what = "HIP path" if use_gpu else "CPU path"
+    R = check_against_reference(case, fv.Perm, None, fv.ColCount, fv.super, fv.pi, fv.px, fv.s, fv.x, relax, what)
     assert int(S.cm.lnz) == R["lnz"]
+    # the solve (cholmod_l_solve: super_lsolve / ltsolve under the permutation) against the reference's cs_cholsol steps
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, 3))
+    Xr = csref.reference_cholesky(n, Ap, Ai, Ax, stype, perm=fv.Perm, b=B)["x"]
+    for k in range(3):
+        x = S.solve(Lf, B[:, k].copy())
+        assert np.linalg.norm(x - Xr[:, k]) <= 1e-9 * np.linalg.norm(Xr[:, k]), what + ": solve"
     S.free_factor(Lf)
     S.free_sparse(A)
     assert S.cm.malloc_count == 0
