@@ -237,3 +237,47 @@ def test_oracle_on_poisson_32_cubed_against_the_compiled_reference():
 @pytest.mark.gpu
 def test_hip_path_on_poisson_32_cubed_against_the_compiled_reference():
     _product(_grid("p3d", 32, 4), "default", True, 1)
+
+
+# ---- seeded random matrices: patterns no grid has (dense rows, isolated vertices, chains), random permutations ---------------
+def _random_spd(seed):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 260))
+    density = float(rng.choice([0.01, 0.03, 0.08, 0.2]))
+    Bm = sp.random(n, n, density=density, random_state=np.random.RandomState(seed), format="csc")
+    if rng.random() < 0.3:                                 # a dense row / column
+        k = int(rng.integers(0, n))
+        Bm = Bm.tolil()
+        Bm[k, :] = rng.standard_normal(n) * (rng.random(n) < 0.6)
+        Bm = Bm.tocsc()
+    Am = (Bm + Bm.T).tocsc()
+    Am.setdiag(0)
+    Am.eliminate_zeros()
+    rowsum = np.asarray(abs(Am).sum(axis=1)).ravel()
+    Am = (Am + sp.diags(rowsum + rng.random(n) + 0.1)).tocsc()          # strictly diagonally dominant: positive definite
+    L = sp.tril(Am, format="csc")
+    L.sort_indices()
+    perm = rng.permutation(n).astype(np.int64) if rng.random() < 0.7 else None
+    return n, L.indptr.astype(np.int64), L.indices.astype(np.int64), L.data.astype(np.float64), -1, perm
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_matrices_oracle_and_cpu_path_against_the_compiled_reference(seed):
+    case = _random_spd(1000 + seed)
+    n, Ap, Ai, Ax, stype, perm = case
+    relax = "norelax" if seed % 3 == 0 else "default"
+    postorder = seed % 2 == 0
+    kw = {"nrelax": [0, 0, 0], "zrelax": [0.0, 0.0, 0.0]} if relax == "norelax" else {}
+    O = OracleFactor(n, Ap, Ai, stype, perm=perm, postorder=postorder, **kw)
+    assert O.factorize(Ax) == 0
+    x = O.x.copy()
+    x[~O.lower_mask()] = 0.0
+    check_against_reference(case, O.Perm, O.Parent, O.ColCount, O.super, O.pi, O.px, O.s, x, relax, "oracle")
+    _product(case, relax, postorder, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_random_matrices_hip_path_against_the_compiled_reference(seed):
+    _product(_random_spd(1000 + seed), "norelax" if seed % 3 == 0 else "default", seed % 2 == 0, 1)
