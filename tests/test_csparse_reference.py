@@ -281,3 +281,10 @@ def test_random_matrices_oracle_and_cpu_path_against_the_compiled_reference(seed
 @pytest.mark.parametrize("seed", range(40))
 def test_random_matrices_hip_path_against_the_compiled_reference(seed):
     _product(_random_spd(1000 + seed), "norelax" if seed % 3 == 0 else "default", seed % 2 == 0, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_hip_path_on_poisson_40_cubed_against_the_compiled_reference():
+    """(-m "gpu and slow": 32 s of cs_chol + the entry-by-entry comparison of 2.2e7 entries)"""
+    _product(_grid("p3d", 40, 4), "default", True, 1)
