@@ -59,6 +59,12 @@ cholmod_factor *ssamd_complex_twin (cholmod_factor *L, cholmod_common *Common)
         cholmod_l_free_factor ((cholmod_factor **) &L->cx_twin, Common) ;
         L->hip_on_device = FALSE ;
     }
+    /* a plan built by the analysis of a REAL matrix of this pattern and never used: the twin brings its own */
+    if (L->hip_plan && L->hip_plan_ahead && !L->hip_on_device)
+    {
+        cholmod_hip_plan_destroy ((cholmod_hip_plan *) L->hip_plan) ;
+        L->hip_plan = NULL ; L->hip_plan_ahead = 0 ;
+    }
     size_t n = L->n, nsuper = L->nsuper ;
     cholmod_factor *T = cholmod_l_calloc (1, sizeof (cholmod_factor), Common) ;
     if (!T) return NULL ;

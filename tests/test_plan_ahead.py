@@ -135,3 +135,31 @@ def test_a_failed_reservation_inside_the_analysis_is_reported_by_the_factorizati
     S.free_factor(Lf)
     S.free_sparse(A)
     S.finish()
+
+
+@pytest.mark.gpu
+def test_a_complex_factorization_after_a_real_analysis_drops_the_unused_plan():
+    """analyze sees a real matrix (plan built ahead), factorize gets Hermitian values on the same pattern: the twin factor
+    brings its own plan, the unused one must not keep its HBM"""
+    n, Ap, Ai, Ax, perm, O = _problem(6)
+    Az = Ax.astype(np.complex128)
+    off = Ai != np.repeat(np.arange(n), np.diff(Ap))
+    Az[off] *= np.exp(0.3j)
+    S = ch.Session()
+    A = S.sparse(n, Ap, Ai, Ax, -1)
+    Lf = S.analyze(A, perm)
+    assert Lf.contents.hip_plan and Lf.contents.hip_plan_ahead != 0
+    Ac = S.sparse(n, Ap, Ai, Az, -1)
+    assert S.factorize(Ac, Lf) == 1 and S.cm.status == ch.OK
+    assert Lf.contents.cx_twin and not Lf.contents.hip_plan and Lf.contents.hip_plan_ahead == 0
+    b = G.demo_rhs(n).astype(np.complex128)
+    x = S.solve(Lf, b)
+    import scipy.sparse as sp
+    Lo = sp.csc_matrix((Az, Ai, Ap), shape=(n, n))
+    Af = Lo + sp.tril(Lo, -1).conj().T
+    assert np.linalg.norm(Af @ x - b) <= 1e-11 * np.linalg.norm(b)
+    S.free_factor(Lf)
+    S.free_sparse(A)
+    S.free_sparse(Ac)
+    assert S.cm.malloc_count == 0
+    S.finish()
